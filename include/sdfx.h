@@ -1,0 +1,188 @@
+/*
+ * sdfx.h — C ABI of libsdfx_hip.so, the MI355X (gfx950) implementation of the Instant-NGP
+ * volumetric hot path of ashawkey/stable-dreamfusion.
+ *
+ * One entry point per function of the reference's pybind `_backend` modules (19 of them):
+ *   raymarching  — raymarching/src/raymarching.h:7-18   (bindings.cpp:5-18)
+ *   gridencoder  — gridencoder/src/gridencoder.h:11-15  (bindings.cpp:5-8)
+ *   shencoder    — shencoder/src/shencoder.h:8-9        (bindings.cpp:5-6)
+ *   freqencoder  — freqencoder/src/freqencoder.h:7-10   (bindings.cpp:5-6)
+ * plus a small number of extensions the reference realises in Python (stable ray
+ * compaction, nerf/renderer.py:791) or that remove a copy at the boundary.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer (HBM) unless the name ends in `_host`.
+ *   - The caller allocates everything; the library never allocates, frees or retains
+ *     memory.  Kernels that need working memory take an explicit `scratch` pointer and
+ *     report the size they need through the matching `*_scratch_bytes` function.
+ *   - `stream` is a hipStream_t (passed as void* so the header needs no HIP include).
+ *     All work is enqueued on it; no entry point synchronises the device.
+ *   - Return value: 0 on success, a negative SDFX_E_* code otherwise; the message is
+ *     available from sdfx_last_error() (thread-local).
+ *   - `is_half` selects the table element type of the grid encoder: 0 = float32,
+ *     1 = IEEE float16 (what torch autocast feeds the reference, gridencoder/grid.py:46-47).
+ *   - Zero-initialisation contracts are the reference's: outputs documented as
+ *     "pre-zeroed" are only partially written (raymarching/raymarching.py:249-251,284,
+ *     309-310; gridencoder/grid.py:84).
+ */
+#ifndef SDFX_H_
+#define SDFX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sdfx_stream_t; /* hipStream_t */
+
+enum {
+    SDFX_OK = 0,
+    SDFX_E_INVALID = -1,     /* bad argument (unsupported D / C / degree, null pointer, ...) */
+    SDFX_E_LAUNCH = -2,      /* HIP reported a launch error                                  */
+    SDFX_E_UNSUPPORTED = -3  /* combination the reference also rejects                       */
+};
+
+const char* sdfx_last_error(void);
+/* version / build info string (arch, git-less) */
+const char* sdfx_build_info(void);
+
+/* ------------------------------------------------------------------ raymarching: utils */
+
+/* raymarching.cu:148-156 near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars) */
+int sdfx_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
+                            float* nears, float* fars, sdfx_stream_t stream);
+
+/* raymarching.cu:201-209 sph_from_ray(rays_o, rays_d, radius, N, coords[N,2]) */
+int sdfx_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                      sdfx_stream_t stream);
+
+/* raymarching.cu:229-232 morton3D(coords[N,3] i32, N, indices[N] i32) */
+int sdfx_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, sdfx_stream_t stream);
+
+/* raymarching.cu:257-260 morton3D_invert(indices[N], N, coords[N,3]) */
+int sdfx_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, sdfx_stream_t stream);
+
+/* raymarching.cu:292-300 packbits(grid[C*H^3] f32, N = C*H^3/8, density_thresh, bitfield[N] u8) */
+int sdfx_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, sdfx_stream_t stream);
+
+/* raymarching.cu:321-326 flatten_rays(rays[N,2], N, M, res[M] pre-zeroed) */
+int sdfx_flatten_rays(const int32_t* rays, uint32_t N, uint32_t M, int32_t* res, sdfx_stream_t stream);
+
+/* ---------------------------------------------------------------- raymarching: training */
+
+/*
+ * raymarching.cu:477-489 march_rays_train.  Same two-call protocol as the reference
+ * (raymarching/raymarching.py:240-254):
+ *   pass 1: xyzs == dirs == ts == NULL — counts the occupied samples of every ray (at most
+ *           max_steps), writes rays[n] = (offset, count) and adds the total to counter[0].
+ *           Offsets are the exclusive prefix sum of the counts in ray order (the reference
+ *           hands them out with atomicAdd in completion order; any consumer addresses
+ *           samples through `rays`, so only the assignment differs, deterministically).
+ *   pass 2: xyzs/dirs/ts [M,3],[M,3],[M,2] pre-zeroed — writes the samples.
+ * `scratch` (optional, may be NULL): N*max_steps floats. When the same scratch is given to
+ * both passes, pass 1 records the sample positions and pass 2 becomes a coalesced,
+ * sample-parallel write instead of a second serial march.
+ */
+int sdfx_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, int contract,
+                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
+                          const float* fars, float* xyzs, float* dirs, float* ts, int32_t* rays, int32_t* counter,
+                          const float* noises, float* scratch, sdfx_stream_t stream);
+uint64_t sdfx_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps);
+
+/* raymarching.cu:582-590 composite_rays_train_forward (weights [M] pre-zeroed) */
+int sdfx_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays,
+                                      uint32_t M, uint32_t N, float T_thresh, int binarize, float* weights,
+                                      float* weights_sum, float* depth, float* image, sdfx_stream_t stream);
+
+/* raymarching.cu:698-706 composite_rays_train_backward (grad_sigmas [M], grad_rgbs [M,3] pre-zeroed) */
+int sdfx_composite_rays_train_backward(const float* grad_weights, const float* grad_weights_sum, const float* grad_depth,
+                                       const float* grad_image, const float* sigmas, const float* rgbs, const float* ts,
+                                       const int32_t* rays, const float* weights_sum, const float* depth,
+                                       const float* image, uint32_t M, uint32_t N, float T_thresh, int binarize,
+                                       float* grad_sigmas, float* grad_rgbs, sdfx_stream_t stream);
+
+/* --------------------------------------------------------------- raymarching: inference */
+
+/* raymarching.cu:832-839 march_rays (xyzs/dirs/ts [n_alive*n_step, ...] pre-zeroed) */
+int sdfx_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                    const float* rays_o, const float* rays_d, float bound, int contract, float dt_gamma,
+                    uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
+                    const float* fars, float* xyzs, float* dirs, float* ts, const float* noises, sdfx_stream_t stream);
+
+/* raymarching.cu:928-934 composite_rays (mutates rays_alive, rays_t, weights_sum, depth, image) */
+int sdfx_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int binarize, int32_t* rays_alive,
+                        float* rays_t, const float* sigmas, const float* rgbs, const float* ts, float* weights_sum,
+                        float* depth, float* image, sdfx_stream_t stream);
+
+/*
+ * Extension — stable compaction of the alive-ray list.  The reference does this with a
+ * boolean mask in Python, `rays_alive = rays_alive[rays_alive >= 0]` (nerf/renderer.py:791).
+ * out[0..count) = the entries of in[0..n) that are >= 0, order preserved; count_out[0] = count.
+ * scratch: sdfx_compact_rays_scratch_bytes(n) bytes.
+ */
+int sdfx_compact_rays(const int32_t* rays_alive_in, uint32_t n, int32_t* rays_alive_out, int32_t* count_out,
+                      void* scratch, sdfx_stream_t stream);
+uint64_t sdfx_compact_rays_scratch_bytes(uint32_t n);
+
+/* ------------------------------------------------------------------------- gridencoder */
+
+/*
+ * gridencoder.cu:467-490 grid_encode_forward.
+ *   inputs [B,D] f32 in [0,1]; embeddings [sum, C] f32|f16; offsets [L+1] i32 (device);
+ *   offsets_host: the same L+1 values in host memory (the launch plan needs the level sizes;
+ *   passing them avoids a device->host copy and keeps the call asynchronous);
+ *   outputs [L,B,C] (out_layout 0, the reference's) or [B,L*C] (out_layout 1, the permute of
+ *   gridencoder/grid.py:64 folded into the store); dy_dx [B, L*D*C] or NULL.
+ *   S = log2(per_level_scale); H = base resolution; gridtype 0 hash / 1 tiled; interp 0 linear / 1 smoothstep.
+ */
+int sdfx_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
+                             const int32_t* offsets_host, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                             uint32_t max_level, float S, uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners,
+                             uint32_t interp, int is_half, int out_layout, sdfx_stream_t stream);
+
+/*
+ * gridencoder.cu:492-522 grid_encode_backward.  grad [L,B,C] (grad_layout 0) or [B,L*C]
+ * (grad_layout 1); grad_embeddings pre-zeroed, same type as the table; dy_dx / grad_inputs
+ * NULL unless the forward saved dy_dx.
+ */
+int sdfx_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                              const int32_t* offsets_host, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                              uint32_t L, uint32_t max_level, float S, uint32_t H, const void* dy_dx, void* grad_inputs,
+                              uint32_t gridtype, int align_corners, uint32_t interp, int is_half, int grad_layout,
+                              sdfx_stream_t stream);
+
+/* gridencoder.cu:662-668 grad_total_variation (adds into grad; f32 or f16 by is_half) */
+int sdfx_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,
+                              const int32_t* offsets_host, float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                              float S, uint32_t H, uint32_t gridtype, int align_corners, int is_half,
+                              sdfx_stream_t stream);
+
+/* gridencoder.cu:705-713 grad_weight_decay (B = table rows; adds into grad) */
+int sdfx_grad_weight_decay(const void* embeddings, void* grad, const int32_t* offsets, float weight, uint32_t B,
+                           uint32_t C, uint32_t L, int is_half, sdfx_stream_t stream);
+
+/* -------------------------------------------------------------------------- freqencoder */
+
+/* freqencoder.cu:97-110 freq_encode_forward(inputs[B,D], B, D, deg, C = D + 2*D*deg, outputs[B,C]) */
+int sdfx_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs,
+                             sdfx_stream_t stream);
+
+/* freqencoder.cu:113-129 freq_encode_backward(grad[B,C], outputs[B,C], ..., grad_inputs[B,D]) */
+int sdfx_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                              float* grad_inputs, sdfx_stream_t stream);
+
+/* ---------------------------------------------------------------------------- shencoder */
+
+/* shencoder.cu:399-417 sh_encode_forward(inputs[B,3], outputs[B,C*C], B, D=3, C=degree<=8, dy_dx[B,3*C*C]|NULL) */
+int sdfx_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, float* dy_dx,
+                           sdfx_stream_t stream);
+
+/* shencoder.cu:419-439 sh_encode_backward(grad[B,C*C], inputs, B, D, C, dy_dx, grad_inputs[B,3] pre-zeroed, accumulated into) */
+int sdfx_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
+                            const float* dy_dx, float* grad_inputs, sdfx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFX_H_ */

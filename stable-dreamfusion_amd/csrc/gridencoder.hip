@@ -1,0 +1,652 @@
+// gridencoder.hip — gfx950 kernels for the multi-resolution hash / tiled grid encoder
+// (forward, table-gradient scatter, input gradient, TV and weight-decay regularisers)
+// behind the C ABI of include/sdfx.h.
+//
+// Behavioural reference: gridencoder/src/gridencoder.cu (line citations at each kernel).
+// What is different by design, for CDNA4:
+//   * work is a level-major list of (level, 256-point tile) items, cut into 8 contiguous
+//     cost-balanced ranges, one per XCD (workgroup b runs on XCD b % 8): each XCD's 4 MiB L2
+//     then holds the one or two table levels it is gathering from instead of all sixteen;
+//   * per-level resolutions are computed once on the host (same float32 formula as the
+//     reference kernel, gridencoder.cu:133) and travel in the kernel arguments, so device
+//     and CPU oracle agree on every level by construction;
+//   * each vertex row (C channels) is fetched with one 4/8/16-byte load and all 2^D rows of
+//     a sample are issued before the first use;
+//   * the fp16 table gradient uses the packed global_atomic_pk_add_f16 of gfx950.
+#include "sdfx_common.h"
+
+#include <math.h>
+
+using namespace sdfx;
+
+namespace {
+
+constexpr uint32_t kMaxLevels = 32;
+constexpr uint32_t kXcds = 8;
+constexpr uint32_t kTile = 256;  // work items per workgroup
+
+struct GridPlan {
+    uint32_t res[kMaxLevels];      // per-level resolution
+    uint32_t off[kMaxLevels + 1];  // per-level first row (host copy of `offsets`)
+    uint32_t start[kXcds];         // [start, end) item range of each XCD in the level-major list
+    uint32_t end[kXcds];
+    uint32_t tiles;                // tiles per level
+};
+
+// (uint32_t)ceil(exp2f(level * S) * H) in float32 — gridencoder.cu:133
+inline uint32_t level_resolution(uint32_t level, float S, uint32_t H) {
+    return (uint32_t)ceilf(exp2f((float)level * S) * (float)H);
+}
+
+// Build the plan: resolutions, offsets, and the per-XCD ranges of the level-major item list.
+// Levels whose table slice is small enough to live in L1/L2 next to anything else cost less
+// per tile than the multi-MiB hashed levels; ranges are balanced on that estimate.
+GridPlan make_plan(const int32_t* offsets_host, uint32_t levels, float S, uint32_t H, uint32_t C, uint32_t elem_bytes,
+                   uint64_t items_per_level) {
+    GridPlan p;
+    memset(&p, 0, sizeof(p));
+    for (uint32_t l = 0; l < levels; l++) {
+        p.res[l] = level_resolution(l, S, H);
+        p.off[l] = (uint32_t)offsets_host[l];
+    }
+    p.off[levels] = (uint32_t)offsets_host[levels];
+    p.tiles = div_up(items_per_level, kTile);
+    double cost[kMaxLevels];
+    double total = 0;
+    for (uint32_t l = 0; l < levels; l++) {
+        const double bytes = (double)(p.off[l + 1] - p.off[l]) * C * elem_bytes;
+        cost[l] = bytes > 512.0 * 1024.0 ? 1.0 : 0.4;
+        total += cost[l] * p.tiles;
+    }
+    // boundary k sits where the cumulative cost reaches k * total / 8
+    uint32_t bound[kXcds + 1];
+    bound[0] = 0;
+    bound[kXcds] = levels * p.tiles;
+    uint32_t l = 0;
+    double cum = 0;  // cost of all complete levels before l
+    for (uint32_t k = 1; k < kXcds; k++) {
+        const double target = total * k / kXcds;
+        while (l < levels && cum + cost[l] * p.tiles <= target) {
+            cum += cost[l] * p.tiles;
+            l++;
+        }
+        uint32_t item = l * p.tiles;
+        if (l < levels) {
+            uint32_t within = (uint32_t)((target - cum) / cost[l]);
+            if (within > p.tiles) within = p.tiles;
+            item += within;
+        }
+        if (item < bound[k - 1]) item = bound[k - 1];
+        bound[k] = item;
+    }
+    for (uint32_t k = 0; k < kXcds; k++) {
+        p.start[k] = bound[k];
+        p.end[k] = bound[k + 1];
+    }
+    return p;
+}
+
+inline uint32_t plan_grid_size(const GridPlan& p) {
+    uint32_t longest = 0;
+    for (uint32_t k = 0; k < kXcds; k++) {
+        const uint32_t len = p.end[k] - p.start[k];
+        if (len > longest) longest = len;
+    }
+    return longest * kXcds;
+}
+
+// workgroup -> (level, tile); false when this workgroup has no item
+__device__ __forceinline__ bool plan_item(const GridPlan& p, uint32_t& level, uint32_t& tile) {
+    const uint32_t xcd = blockIdx.x % kXcds;
+    const uint32_t item = p.start[xcd] + blockIdx.x / kXcds;
+    if (item >= p.end[xcd]) return false;
+    level = item / p.tiles;
+    tile = item - level * p.tiles;
+    return true;
+}
+
+// ---- table element types ----------------------------------------------------------------
+template <bool HALF> struct Elem;
+template <> struct Elem<false> {
+    using type = float;
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+    // value as the reference's scalar_t would hold it
+    static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <> struct Elem<true> {
+    using type = __half;
+    static __device__ __forceinline__ float load(const __half* p) { return __half2float(*p); }
+    static __device__ __forceinline__ void store(__half* p, float v) { *p = __float2half_rn(v); }
+    static __device__ __forceinline__ float round(float v) { return __half2float(__float2half_rn(v)); }
+};
+
+// One vertex row = C elements. Rows are loaded / stored as a few wide words.
+template <typename T, uint32_t C>
+struct Row {
+    static constexpr uint32_t kBytes = sizeof(T) * C;
+    static constexpr uint32_t kWord = kBytes >= 16 ? 16 : kBytes;  // bytes per access (2..16)
+    static constexpr uint32_t kWords = kBytes / kWord;
+    T v[C];
+
+    __device__ __forceinline__ void load(const T* p) {
+        if constexpr (kWord == 16) {
+#pragma unroll
+            for (uint32_t i = 0; i < kWords; i++) reinterpret_cast<uint4*>(v)[i] = reinterpret_cast<const uint4*>(p)[i];
+        } else if constexpr (kWord == 8) {
+            *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(p);
+        } else if constexpr (kWord == 4) {
+            *reinterpret_cast<uint32_t*>(v) = *reinterpret_cast<const uint32_t*>(p);
+        } else {
+            v[0] = p[0];
+        }
+    }
+    __device__ __forceinline__ void store(T* p) const {
+        if constexpr (kWord == 16) {
+#pragma unroll
+            for (uint32_t i = 0; i < kWords; i++) reinterpret_cast<uint4*>(p)[i] = reinterpret_cast<const uint4*>(v)[i];
+        } else if constexpr (kWord == 8) {
+            *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(v);
+        } else if constexpr (kWord == 4) {
+            *reinterpret_cast<uint32_t*>(p) = *reinterpret_cast<const uint32_t*>(v);
+        } else {
+            p[0] = v[0];
+        }
+    }
+};
+
+// corner `idx` of the cell: weight and vertex coordinates (gridencoder.cu:171-184)
+template <uint32_t D>
+__device__ __forceinline__ float corner(uint32_t idx, const float pos[D], const uint32_t pos_grid[D], uint32_t resolution,
+                                        uint32_t pgl[D]) {
+    float w = 1;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if ((idx & (1u << d)) == 0) {
+            w *= 1 - pos[d];
+            pgl[d] = pos_grid[d];
+        } else {
+            w *= pos[d];
+            pgl[d] = min(pos_grid[d] + 1, resolution - 1);
+        }
+    }
+    return w;
+}
+
+// =========================================================================================
+// forward — gridencoder.cu:82-249
+// =========================================================================================
+template <uint32_t D, uint32_t C, bool HALF>
+__global__ __launch_bounds__(kTile) void k_grid_forward(const float* __restrict__ inputs,
+                                                         const typename Elem<HALF>::type* __restrict__ table,
+                                                         typename Elem<HALF>::type* __restrict__ outputs, uint32_t B,
+                                                         uint32_t L, GridPlan plan,
+                                                         typename Elem<HALF>::type* __restrict__ dy_dx,
+                                                         uint32_t gridtype, int align_corners, uint32_t interp,
+                                                         int out_layout) {
+    using T = typename Elem<HALF>::type;
+    using E = Elem<HALF>;
+    uint32_t level, tile;
+    if (!plan_item(plan, level, tile)) return;
+    const uint32_t b = tile * kTile + threadIdx.x;
+    if (b >= B) return;
+
+    T* out = out_layout == 0 ? outputs + ((size_t)level * B + b) * C : outputs + ((size_t)b * L + level) * C;
+
+    float in[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        if (in[d] < 0 || in[d] > 1) oob = true;
+    }
+    if (oob) {  // gridencoder.cu:105-130
+        Row<T, C> z;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) E::store(&z.v[ch], 0.0f);
+        z.store(out);
+        if (dy_dx) {
+            T* dy = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
+#pragma unroll
+            for (uint32_t i = 0; i < D; i++) z.store(dy + i * C);
+        }
+        return;
+    }
+
+    const uint32_t resolution = plan.res[level];
+    const uint32_t row0 = plan.off[level];
+    const uint32_t hashmap_size = plan.off[level + 1] - row0;
+    const T* tab = table + (size_t)row0 * C;
+
+    float pos[D], pos_deriv[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) grid_locate_axis(in[d], resolution, align_corners != 0, interp, pos[d], pos_deriv[d], pos_grid[d]);
+
+    // issue a batch of row gathers (all 2^D of them when they fit in registers), then
+    // accumulate in corner order (gridencoder.cu:168-195; `results` has the table's type
+    // there, so the half path rounds after every corner)
+    constexpr uint32_t NC = 1u << D;
+    constexpr uint32_t kBatch = (NC * C <= 64) ? NC : (C >= 64 ? 1 : (64 / C));
+    float results[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) results[ch] = 0;
+#pragma unroll
+    for (uint32_t base = 0; base < NC; base += kBatch) {
+        float w[kBatch];
+        Row<T, C> rows[kBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; k++) {
+            uint32_t pgl[D];
+            w[k] = corner<D>(base + k, pos, pos_grid, resolution, pgl);
+            const uint32_t row = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+            rows[k].load(tab + (size_t)row * C);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; k++) {
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) results[ch] = E::round(results[ch] + w[k] * E::load(&rows[k].v[ch]));
+        }
+    }
+    Row<T, C> o;
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) E::store(&o.v[ch], results[ch]);
+    o.store(out);
+
+    // d(features)/d(inputs) for this level (gridencoder.cu:203-248)
+    if (dy_dx) {
+        T* dy = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
+#pragma unroll
+        for (uint32_t gd = 0; gd < D; gd++) {
+            float rg[C];
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) rg[ch] = 0;
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float wg = (float)(align_corners ? resolution - 1 : resolution);
+                uint32_t pgl[D];
+#pragma unroll
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                    if ((idx & (1u << nd)) == 0) {
+                        wg *= 1 - pos[d];
+                        pgl[d] = pos_grid[d];
+                    } else {
+                        wg *= pos[d];
+                        pgl[d] = min(pos_grid[d] + 1, resolution - 1);
+                    }
+                }
+                pgl[gd] = pos_grid[gd];
+                const uint32_t rl = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+                pgl[gd] = min(pos_grid[gd] + 1, resolution - 1);
+                const uint32_t rr = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+                Row<T, C> left, right;
+                left.load(tab + (size_t)rl * C);
+                right.load(tab + (size_t)rr * C);
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    const float diff = E::round(E::load(&right.v[ch]) - E::load(&left.v[ch]));
+                    rg[ch] = E::round(rg[ch] + wg * diff * pos_deriv[gd]);
+                }
+            }
+            Row<T, C> og;
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) E::store(&og.v[ch], rg[ch]);
+            og.store(dy + gd * C);
+        }
+    }
+}
+
+// =========================================================================================
+// backward: scatter-add into the table gradient — gridencoder.cu:252-349
+// One work item = (sample, channel pair) of one level, as in the reference (N_C = min(2, C)).
+// =========================================================================================
+template <uint32_t D, uint32_t C, bool HALF>
+__global__ __launch_bounds__(kTile) void k_grid_backward(const typename Elem<HALF>::type* __restrict__ grad,
+                                                          const float* __restrict__ inputs,
+                                                          typename Elem<HALF>::type* __restrict__ grad_table,
+                                                          uint32_t B, uint32_t L, GridPlan plan, uint32_t gridtype,
+                                                          int align_corners, uint32_t interp, int grad_layout) {
+    using T = typename Elem<HALF>::type;
+    using E = Elem<HALF>;
+    constexpr uint32_t N_C = C < 2 ? C : 2;
+    uint32_t level, tile;
+    if (!plan_item(plan, level, tile)) return;
+    const uint32_t gid = tile * kTile + threadIdx.x;
+    const uint32_t b = gid * N_C / C;
+    if (b >= B) return;
+    const uint32_t ch = gid * N_C - b * C;
+
+    float in[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        if (in[d] < 0 || in[d] > 1) return;  // gridencoder.cu:279-284
+    }
+
+    const uint32_t resolution = plan.res[level];
+    const uint32_t row0 = plan.off[level];
+    const uint32_t hashmap_size = plan.off[level + 1] - row0;
+    T* gtab = grad_table + (size_t)row0 * C + ch;
+
+    float pos[D], pos_deriv[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) grid_locate_axis(in[d], resolution, align_corners != 0, interp, pos[d], pos_deriv[d], pos_grid[d]);
+
+    const T* g = grad_layout == 0 ? grad + ((size_t)level * B + b) * C + ch : grad + ((size_t)b * L + level) * C + ch;
+    float grad_cur[N_C];
+#pragma unroll
+    for (uint32_t c = 0; c < N_C; c++) grad_cur[c] = E::load(g + c);
+
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        uint32_t pgl[D];
+        const float w = corner<D>(idx, pos, pos_grid, resolution, pgl);
+        const uint32_t row = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+        T* dst = gtab + (size_t)row * C;
+        if constexpr (HALF) {
+            static_assert(N_C == 2, "the fp16 table gradient needs an even channel count (grid.py:46)");
+            // each contribution is rounded to half, then added in half: gridencoder.cu:338-339
+            const __half2 v = __halves2half2(__float2half_rn(w * grad_cur[0]), __float2half_rn(w * grad_cur[1]));
+            unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), v);  // global_atomic_pk_add_f16
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < N_C; c++) unsafeAtomicAdd(dst + c, w * grad_cur[c]);  // global_atomic_add_f32
+        }
+    }
+}
+
+// grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c] — gridencoder.cu:352-378
+template <uint32_t D, uint32_t C, bool HALF>
+__global__ __launch_bounds__(256) void k_grid_input_backward(const typename Elem<HALF>::type* __restrict__ grad,
+                                                              const typename Elem<HALF>::type* __restrict__ dy_dx,
+                                                              typename Elem<HALF>::type* __restrict__ grad_inputs,
+                                                              uint32_t B, uint32_t L, uint32_t levels, int grad_layout) {
+    using E = Elem<HALF>;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D;
+    const uint32_t d = t - b * D;
+    const auto* dy = dy_dx + (size_t)b * L * D * C;
+    float result = 0;
+    for (uint32_t l = 0; l < levels; l++) {
+        const auto* g = grad_layout == 0 ? grad + ((size_t)l * B + b) * C : grad + ((size_t)b * L + l) * C;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) {
+            const float prod = E::round(E::load(g + ch) * E::load(dy + (size_t)l * D * C + d * C + ch));
+            result = E::round(result + prod);
+        }
+    }
+    E::store(grad_inputs + t, result);
+}
+
+// =========================================================================================
+// regularisers (float32 tables) — gridencoder.cu:525-631 and :670-703
+// =========================================================================================
+template <uint32_t D, uint32_t C>
+__global__ __launch_bounds__(kTile) void k_grad_tv(const float* __restrict__ inputs, const float* __restrict__ table,
+                                                    float* __restrict__ grad, float weight, uint32_t B, GridPlan plan,
+                                                    uint32_t gridtype, int align_corners) {
+    uint32_t level, tile;
+    if (!plan_item(plan, level, tile)) return;
+    const uint32_t b = tile * kTile + threadIdx.x;
+    if (b >= B) return;
+    float in[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        if (in[d] < 0 || in[d] > 1) return;
+    }
+    const uint32_t resolution = plan.res[level];
+    const uint32_t row0 = plan.off[level];
+    const uint32_t hashmap_size = plan.off[level + 1] - row0;
+    const float* tab = table + (size_t)row0 * C;
+    float* gtab = grad + (size_t)row0 * C;
+
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        float pos, deriv;
+        grid_locate_axis(in[d], resolution, align_corners != 0, 0u, pos, deriv, pos_grid[d]);
+    }
+    float results[C], idelta[C], centre[C];
+    const uint32_t row = grid_row<D>(gridtype, hashmap_size, resolution, pos_grid);
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) {
+        results[ch] = 0; idelta[ch] = 0;
+        centre[ch] = tab[(size_t)row * C + ch];
+    }
+    const float w = weight / (2 * D);
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const uint32_t cur = pos_grid[d];
+        if (cur < resolution) {  // always true in the reference as well (gridencoder.cu:595)
+            pos_grid[d] = cur + 1;
+            const uint32_t rr = grid_row<D>(gridtype, hashmap_size, resolution, pos_grid);
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) {
+                const float gv = centre[ch] - tab[(size_t)rr * C + ch];
+                results[ch] += gv;
+                idelta[ch] += gv * gv;
+            }
+        }
+        if (cur > 0) {
+            pos_grid[d] = cur - 1;
+            const uint32_t rl = grid_row<D>(gridtype, hashmap_size, resolution, pos_grid);
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) {
+                const float gv = centre[ch] - tab[(size_t)rl * C + ch];
+                results[ch] += gv;
+                idelta[ch] += gv * gv;
+            }
+        }
+        pos_grid[d] = cur;
+    }
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++)
+        unsafeAtomicAdd(gtab + (size_t)row * C + ch, w * results[ch] * rsqrtf(idelta[ch] + 1e-9f));
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_grad_wd(const typename Elem<HALF>::type* __restrict__ table,
+                                                  typename Elem<HALF>::type* __restrict__ grad,
+                                                  const int32_t* __restrict__ offsets, float weight, uint32_t B,
+                                                  uint32_t C, uint32_t L) {
+    using E = Elem<HALF>;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B * C) return;
+    const uint32_t n = b / C;
+    uint32_t level = 0, l = 0, r = L;
+    while (l < r) {  // binary search of the row in `offsets` (gridencoder.cu:686-699)
+        const uint32_t m = (l + r) / 2;
+        if ((uint32_t)offsets[m] <= n) { level = m; l = m + 1; } else { r = m; }
+    }
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const float g = E::load(grad + b) + 2 * weight * E::load(table + b) / (float)hashmap_size;
+    E::store(grad + b, g);
+}
+
+// ---- dispatch ---------------------------------------------------------------------------
+#define SDFX_DISPATCH_C(D_, HALF_, FN, ...)                                   \
+    switch (C) {                                                              \
+        case 1: FN<D_, 1, HALF_>(__VA_ARGS__); break;                         \
+        case 2: FN<D_, 2, HALF_>(__VA_ARGS__); break;                         \
+        case 4: FN<D_, 4, HALF_>(__VA_ARGS__); break;                         \
+        case 8: FN<D_, 8, HALF_>(__VA_ARGS__); break;                         \
+        case 16: FN<D_, 16, HALF_>(__VA_ARGS__); break;                       \
+        case 32: FN<D_, 32, HALF_>(__VA_ARGS__); break;                       \
+        default: break;                                                       \
+    }
+
+#define SDFX_DISPATCH_DC(HALF_, FN, ...)                                      \
+    switch (D) {                                                              \
+        case 2: SDFX_DISPATCH_C(2, HALF_, FN, __VA_ARGS__) break;             \
+        case 3: SDFX_DISPATCH_C(3, HALF_, FN, __VA_ARGS__) break;             \
+        case 4: SDFX_DISPATCH_C(4, HALF_, FN, __VA_ARGS__) break;             \
+        case 5: SDFX_DISPATCH_C(5, HALF_, FN, __VA_ARGS__) break;             \
+        default: break;                                                       \
+    }
+
+struct FwdArgs {
+    const float* inputs; const void* table; void* outputs; uint32_t B, L; GridPlan plan; void* dy_dx;
+    uint32_t gridtype; int align_corners; uint32_t interp; int out_layout; hipStream_t st; uint32_t grid;
+};
+template <uint32_t D, uint32_t C, bool HALF>
+void launch_forward(const FwdArgs& a) {
+    using T = typename Elem<HALF>::type;
+    hipLaunchKernelGGL((k_grid_forward<D, C, HALF>), dim3(a.grid), dim3(kTile), 0, a.st, a.inputs,
+                       static_cast<const T*>(a.table), static_cast<T*>(a.outputs), a.B, a.L, a.plan,
+                       static_cast<T*>(a.dy_dx), a.gridtype, a.align_corners, a.interp, a.out_layout);
+}
+
+struct BwdArgs {
+    const void* grad; const float* inputs; void* grad_table; uint32_t B, L, levels; GridPlan plan; uint32_t gridtype;
+    int align_corners; uint32_t interp; int grad_layout; const void* dy_dx; void* grad_inputs; hipStream_t st;
+    uint32_t grid;
+};
+template <uint32_t D, uint32_t C, bool HALF>
+void launch_backward(const BwdArgs& a) {
+    using T = typename Elem<HALF>::type;
+    if constexpr (HALF && C == 1) {
+        return;  // rejected by the caller: the reference forces float when C is odd (grid.py:45-47)
+    } else {
+        hipLaunchKernelGGL((k_grid_backward<D, C, HALF>), dim3(a.grid), dim3(kTile), 0, a.st,
+                           static_cast<const T*>(a.grad), a.inputs, static_cast<T*>(a.grad_table), a.B, a.L, a.plan,
+                           a.gridtype, a.align_corners, a.interp, a.grad_layout);
+        if (a.dy_dx && a.grad_inputs) {
+            hipLaunchKernelGGL((k_grid_input_backward<D, C, HALF>), dim3(div_up((uint64_t)a.B * D, 256)), dim3(256), 0,
+                               a.st, static_cast<const T*>(a.grad), static_cast<const T*>(a.dy_dx),
+                               static_cast<T*>(a.grad_inputs), a.B, a.L, a.levels, a.grad_layout);
+        }
+    }
+}
+
+struct TvArgs {
+    const float* inputs; const float* table; float* grad; float weight; uint32_t B; GridPlan plan; uint32_t gridtype;
+    int align_corners; hipStream_t st; uint32_t grid;
+};
+template <uint32_t D, uint32_t C, bool HALF>
+void launch_tv(const TvArgs& a) {
+    hipLaunchKernelGGL((k_grad_tv<D, C>), dim3(a.grid), dim3(kTile), 0, a.st, a.inputs, a.table, a.grad, a.weight, a.B,
+                       a.plan, a.gridtype, a.align_corners);
+}
+
+bool supported_dc(uint32_t D, uint32_t C) {
+    const bool d_ok = D >= 2 && D <= 5;
+    const bool c_ok = C == 1 || C == 2 || C == 4 || C == 8 || C == 16 || C == 32;
+    return d_ok && c_ok;
+}
+
+bool aligned_for(const void* p, uint32_t C, uint32_t elem_bytes) {
+    uint32_t a = C * elem_bytes;
+    if (a > 16) a = 16;
+    return (reinterpret_cast<uintptr_t>(p) % a) == 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+int sdfx_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
+                             const int32_t* offsets_host, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                             uint32_t max_level, float S, uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners,
+                             uint32_t interp, int is_half, int out_layout, sdfx_stream_t stream) {
+    (void)offsets;
+    SDFX_REQUIRE(inputs && embeddings && offsets_host && outputs, "grid_encode_forward: null pointer");
+    if (!supported_dc(D, C)) {  // gridencoder.cu:392,409 throw std::runtime_error here
+        set_error("GridEncoding: D must be 2, 3, 4 or 5 and C must be 1, 2, 4, 8, 16 or 32 (got D=%u C=%u)", D, C);
+        return SDFX_E_UNSUPPORTED;
+    }
+    SDFX_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward: L must be in [1, %u]", kMaxLevels);
+    SDFX_REQUIRE(max_level >= 1 && max_level <= L, "grid_encode_forward: max_level must be in [1, L]");
+    SDFX_REQUIRE(gridtype <= 1 && interp <= 1 && (out_layout == 0 || out_layout == 1), "grid_encode_forward: bad enum");
+    const uint32_t eb = is_half ? 2 : 4;
+    SDFX_REQUIRE(aligned_for(embeddings, C, eb) && aligned_for(outputs, C, eb) && (!dy_dx || aligned_for(dy_dx, C, eb)),
+                 "grid_encode_forward: embeddings/outputs/dy_dx must be aligned to min(16, C*sizeof(elem)) bytes");
+    if (B == 0) return SDFX_OK;
+    FwdArgs a;
+    a.inputs = inputs; a.table = embeddings; a.outputs = outputs; a.B = B; a.L = L;
+    a.plan = make_plan(offsets_host, max_level, S, H, C, eb, B);
+    a.dy_dx = dy_dx; a.gridtype = gridtype; a.align_corners = align_corners; a.interp = interp;
+    a.out_layout = out_layout; a.st = as_stream(stream); a.grid = plan_grid_size(a.plan);
+    if (is_half) { SDFX_DISPATCH_DC(true, launch_forward, a) } else { SDFX_DISPATCH_DC(false, launch_forward, a) }
+    return check_launch("grid_encode_forward");
+}
+
+int sdfx_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                              const int32_t* offsets_host, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                              uint32_t L, uint32_t max_level, float S, uint32_t H, const void* dy_dx, void* grad_inputs,
+                              uint32_t gridtype, int align_corners, uint32_t interp, int is_half, int grad_layout,
+                              sdfx_stream_t stream) {
+    (void)offsets; (void)embeddings;
+    SDFX_REQUIRE(grad && inputs && offsets_host && grad_embeddings, "grid_encode_backward: null pointer");
+    if (!supported_dc(D, C)) {
+        set_error("GridEncoding: D must be 2, 3, 4 or 5 and C must be 1, 2, 4, 8, 16 or 32 (got D=%u C=%u)", D, C);
+        return SDFX_E_UNSUPPORTED;
+    }
+    if (is_half && C == 1) {
+        set_error("grid_encode_backward: a float16 table needs an even C (the reference forces float32, grid.py:45-47)");
+        return SDFX_E_UNSUPPORTED;
+    }
+    SDFX_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L must be in [1, %u]", kMaxLevels);
+    SDFX_REQUIRE(max_level >= 1 && max_level <= L, "grid_encode_backward: max_level must be in [1, L]");
+    SDFX_REQUIRE(gridtype <= 1 && interp <= 1 && (grad_layout == 0 || grad_layout == 1), "grid_encode_backward: bad enum");
+    const uint32_t eb = is_half ? 2 : 4;
+    SDFX_REQUIRE(!is_half || (reinterpret_cast<uintptr_t>(grad_embeddings) % 4) == 0,
+                 "grid_encode_backward: float16 grad_embeddings must be 4-byte aligned");
+    if (B == 0) return SDFX_OK;
+    const uint32_t N_C = C < 2 ? C : 2;
+    BwdArgs a;
+    a.grad = grad; a.inputs = inputs; a.grad_table = grad_embeddings; a.B = B; a.L = L; a.levels = max_level;
+    a.plan = make_plan(offsets_host, max_level, S, H, C, eb, (uint64_t)B * C / N_C);
+    a.gridtype = gridtype; a.align_corners = align_corners; a.interp = interp; a.grad_layout = grad_layout;
+    a.dy_dx = dy_dx; a.grad_inputs = grad_inputs; a.st = as_stream(stream); a.grid = plan_grid_size(a.plan);
+    if (is_half) { SDFX_DISPATCH_DC(true, launch_backward, a) } else { SDFX_DISPATCH_DC(false, launch_backward, a) }
+    return check_launch("grid_encode_backward");
+}
+
+int sdfx_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,
+                              const int32_t* offsets_host, float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                              float S, uint32_t H, uint32_t gridtype, int align_corners, int is_half,
+                              sdfx_stream_t stream) {
+    (void)offsets;
+    SDFX_REQUIRE(inputs && embeddings && grad && offsets_host, "grad_total_variation: null pointer");
+    if (!supported_dc(D, C)) {
+        set_error("GridEncoding: D must be 2, 3, 4 or 5 and C must be 1, 2, 4, 8, 16 or 32 (got D=%u C=%u)", D, C);
+        return SDFX_E_UNSUPPORTED;
+    }
+    if (is_half) {
+        set_error("grad_total_variation: float32 tables only (the reference runs it with autocast disabled, grid.py:172)");
+        return SDFX_E_UNSUPPORTED;
+    }
+    SDFX_REQUIRE(L >= 1 && L <= kMaxLevels, "grad_total_variation: L must be in [1, %u]", kMaxLevels);
+    if (B == 0) return SDFX_OK;
+    TvArgs a;
+    a.inputs = static_cast<const float*>(inputs); a.table = static_cast<const float*>(embeddings);
+    a.grad = static_cast<float*>(grad); a.weight = weight; a.B = B;
+    a.plan = make_plan(offsets_host, L, S, H, C, 4, B);
+    a.gridtype = gridtype; a.align_corners = align_corners; a.st = as_stream(stream); a.grid = plan_grid_size(a.plan);
+    SDFX_DISPATCH_DC(false, launch_tv, a)
+    return check_launch("grad_total_variation");
+}
+
+int sdfx_grad_weight_decay(const void* embeddings, void* grad, const int32_t* offsets, float weight, uint32_t B,
+                           uint32_t C, uint32_t L, int is_half, sdfx_stream_t stream) {
+    SDFX_REQUIRE(embeddings && grad && offsets, "grad_weight_decay: null pointer");
+    if ((uint64_t)B * C == 0) return SDFX_OK;
+    const dim3 grid(div_up((uint64_t)B * C, 256));
+    if (is_half) {
+        hipLaunchKernelGGL(k_grad_wd<true>, grid, dim3(256), 0, as_stream(stream), static_cast<const __half*>(embeddings),
+                           static_cast<__half*>(grad), offsets, weight, B, C, L);
+    } else {
+        hipLaunchKernelGGL(k_grad_wd<false>, grid, dim3(256), 0, as_stream(stream), static_cast<const float*>(embeddings),
+                           static_cast<float*>(grad), offsets, weight, B, C, L);
+    }
+    return check_launch("grad_weight_decay");
+}
+
+}  // extern "C"
