@@ -1,0 +1,92 @@
+"""`_gridencoder` — drop-in for the reference's pybind module (gridencoder/src/bindings.cpp:5-8;
+gridencoder/grid.py:10-13 tries `import _gridencoder as _backend` first)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+import _sdfx as S
+
+_FLOATS = (torch.float32, torch.float16)
+_OFFSETS_HOST = {}
+
+
+def offsets_host(offsets: torch.Tensor):
+    """Host copy of the level offsets (cached per device buffer; the launch plan needs the
+    level sizes on the host, and the buffer never changes after GridEncoder.__init__)."""
+    key = (offsets.data_ptr(), offsets.numel())
+    hit = _OFFSETS_HOST.get(key)
+    if hit is None:
+        vals = [int(v) for v in offsets.detach().cpu().tolist()]
+        hit = (C.c_int32 * len(vals))(*vals)
+        if len(_OFFSETS_HOST) > 64:
+            _OFFSETS_HOST.clear()
+        _OFFSETS_HOST[key] = hit
+    return hit
+
+
+def _table(t, name):
+    S.check_tensor(t, name, *_FLOATS)
+    return t
+
+
+def _same(a, b, na, nb):
+    if a.dtype != b.dtype:
+        raise RuntimeError(f"{na} and {nb} must have the same dtype ({a.dtype} vs {b.dtype})")
+
+
+def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C_, L, max_level, S_, H, dy_dx, gridtype,
+                        align_corners, interp, out_layout=0):
+    S.check_tensor(inputs, "inputs", torch.float32)
+    _table(embeddings, "embeddings")
+    S.check_tensor(offsets, "offsets", torch.int32)
+    _table(outputs, "outputs")
+    _same(embeddings, outputs, "embeddings", "outputs")
+    if dy_dx is not None:
+        _table(dy_dx, "dy_dx")
+        _same(embeddings, dy_dx, "embeddings", "dy_dx")
+    S.call("sdfx_grid_encode_forward", S.ptr(inputs), S.ptr(embeddings), S.ptr(offsets), offsets_host(offsets),
+           S.ptr(outputs), B, D, C_, L, max_level, float(S_), H, S.ptr(dy_dx), gridtype, int(bool(align_corners)), interp,
+           int(embeddings.dtype == torch.float16), out_layout, S.stream())
+
+
+def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C_, L, max_level, S_, H, dy_dx,
+                         grad_inputs, gridtype, align_corners, interp, grad_layout=0):
+    _table(grad, "grad")
+    S.check_tensor(inputs, "inputs", torch.float32)
+    _table(embeddings, "embeddings")
+    S.check_tensor(offsets, "offsets", torch.int32)
+    _table(grad_embeddings, "grad_embeddings")
+    _same(grad, grad_embeddings, "grad", "grad_embeddings")
+    if dy_dx is not None:
+        _table(dy_dx, "dy_dx")
+        _same(grad, dy_dx, "grad", "dy_dx")
+    if grad_inputs is not None:
+        _table(grad_inputs, "grad_inputs")
+        _same(grad, grad_inputs, "grad", "grad_inputs")
+    S.call("sdfx_grid_encode_backward", S.ptr(grad), S.ptr(inputs), S.ptr(embeddings), S.ptr(offsets),
+           offsets_host(offsets), S.ptr(grad_embeddings), B, D, C_, L, max_level, float(S_), H, S.ptr(dy_dx),
+           S.ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, int(grad.dtype == torch.float16), grad_layout,
+           S.stream())
+
+
+def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C_, L, S_, H, gridtype, align_corners):
+    _table(inputs, "inputs")
+    _table(embeddings, "embeddings")
+    _table(grad, "grad")
+    _same(embeddings, grad, "embeddings", "grad")
+    _same(embeddings, inputs, "embeddings", "inputs")
+    S.check_tensor(offsets, "offsets", torch.int32)
+    S.call("sdfx_grad_total_variation", S.ptr(inputs), S.ptr(embeddings), S.ptr(grad), S.ptr(offsets),
+           offsets_host(offsets), float(weight), B, D, C_, L, float(S_), H, gridtype, int(bool(align_corners)),
+           int(embeddings.dtype == torch.float16), S.stream())
+
+
+def grad_weight_decay(embeddings, grad, offsets, weight, B, C_, L):
+    _table(embeddings, "embeddings")
+    _table(grad, "grad")
+    _same(embeddings, grad, "embeddings", "grad")
+    S.check_tensor(offsets, "offsets", torch.int32)
+    S.call("sdfx_grad_weight_decay", S.ptr(embeddings), S.ptr(grad), S.ptr(offsets), float(weight), B, C_, L,
+           int(embeddings.dtype == torch.float16), S.stream())

@@ -1,0 +1,127 @@
+"""ctypes binding of libsdfx_hip.so (C ABI declared in include/sdfx.h).
+
+This is the only place the shared library is opened.  There is no fallback: if the HIP
+library has not been built, or an entry point reports an error, a RuntimeError is raised —
+nothing in the shipped path routes around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsdfx_hip.so")
+
+_u32, _f32, _int, _ptr, _u64 = C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_uint64
+
+# name -> argtypes (every entry point returns int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "sdfx_near_far_from_aabb": [_ptr, _ptr, _ptr, _u32, _f32, _ptr, _ptr, _ptr],
+    "sdfx_sph_from_ray": [_ptr, _ptr, _f32, _u32, _ptr, _ptr],
+    "sdfx_morton3D": [_ptr, _u32, _ptr, _ptr],
+    "sdfx_morton3D_invert": [_ptr, _u32, _ptr, _ptr],
+    "sdfx_packbits": [_ptr, _u32, _f32, _ptr, _ptr],
+    "sdfx_flatten_rays": [_ptr, _u32, _u32, _ptr, _ptr],
+    "sdfx_march_rays_train": [_ptr, _ptr, _ptr, _f32, _int, _f32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr,
+                              _ptr, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_march_rays_train_scratch_bytes": [_u32, _u32],
+    "sdfx_composite_rays_train_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _f32, _int, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_composite_rays_train_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32,
+                                           _f32, _int, _ptr, _ptr, _ptr],
+    "sdfx_march_rays": [_u32, _u32, _ptr, _ptr, _ptr, _ptr, _f32, _int, _f32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr,
+                        _ptr, _ptr, _ptr, _ptr],
+    "sdfx_composite_rays": [_u32, _u32, _f32, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_compact_rays": [_ptr, _u32, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_compact_rays_scratch_bytes": [_u32],
+    "sdfx_grid_encode_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32,
+                                 _int, _u32, _int, _int, _ptr],
+    "sdfx_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _ptr,
+                                  _ptr, _u32, _int, _u32, _int, _int, _ptr],
+    "sdfx_grad_total_variation": [_ptr, _ptr, _ptr, _ptr, _ptr, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int,
+                                  _int, _ptr],
+    "sdfx_grad_weight_decay": [_ptr, _ptr, _ptr, _f32, _u32, _u32, _u32, _int, _ptr],
+    "sdfx_freq_encode_forward": [_ptr, _u32, _u32, _u32, _u32, _ptr, _ptr],
+    "sdfx_freq_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _u32, _ptr, _ptr],
+    "sdfx_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
+    "sdfx_sh_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
+}
+_RESTYPES = {
+    "sdfx_march_rays_train_scratch_bytes": _u64,
+    "sdfx_compact_rays_scratch_bytes": _u64,
+}
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    """Open libsdfx_hip.so (once). Fails loudly when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libsdfx_hip.so not found at {LIB_PATH}: build it with "
+                "`python stable-dreamfusion_amd/build.py` (or __graft_entry__.build()). "
+                "There is no CPU or PyTorch fallback for these operators.")
+        handle = C.CDLL(LIB_PATH)
+        handle.sdfx_last_error.restype = C.c_char_p
+        handle.sdfx_last_error.argtypes = []
+        handle.sdfx_build_info.restype = C.c_char_p
+        handle.sdfx_build_info.argtypes = []
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name, None)
+            if fn is None:
+                continue  # optional entry points are checked where they are used
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, _int)
+        _LIB = handle
+    return _LIB
+
+
+def exported_symbols():
+    """Names declared for binding (used by the CPU test that checks the ABI surface)."""
+    return ["sdfx_last_error", "sdfx_build_info"] + list(_SIGNATURES)
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().sdfx_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"sdfx error {rc}: {msg}")
+
+
+def stream() -> C.c_void_p:
+    """hipStream_t of torch's current stream on the current device."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> C.c_void_p | None:
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ---- argument checks: a superset of the reference's CHECK_CUDA / CHECK_CONTIGUOUS / CHECK_IS_* ----
+def check_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+
+
+def check_contiguous(t: torch.Tensor, name: str) -> None:
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+def check_dtype(t: torch.Tensor, name: str, *dtypes) -> None:
+    if t.dtype not in dtypes:
+        raise RuntimeError(f"{name} must be one of {tuple(str(d) for d in dtypes)}, got {t.dtype}")
+
+
+def check_tensor(t: torch.Tensor, name: str, *dtypes) -> torch.Tensor:
+    check_cuda(t, name)
+    check_contiguous(t, name)
+    if dtypes:
+        check_dtype(t, name, *dtypes)
+    return t
+
+
+def call(name: str, *args) -> None:
+    check(getattr(lib(), name)(*args))

@@ -1,0 +1,135 @@
+"""NeRFNetwork — the `-O` field of nerf/network_grid.py: 16x2 hash grid -> MLP 32-64-64-4,
+density blob, finite-difference normals, Lambertian shading, frequency-encoded background MLP."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.amp import custom_bwd, custom_fwd
+from torch.autograd import Function
+
+from freqencoder import FreqEncoder
+from gridencoder import GridEncoder
+
+from .renderer import NeRFRenderer, safe_normalize
+
+
+class _trunc_exp(Function):
+    """exp with the backward argument clamped at 15 (activation.py:5-18)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float)
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x = ctx.saved_tensors[0]
+        return g * torch.exp(x.clamp(max=15))
+
+
+trunc_exp = _trunc_exp.apply
+
+
+def biased_softplus(x, bias=0):
+    return F.softplus(x - bias)
+
+
+class MLP(nn.Module):
+    """nerf/network_grid.py:13-32"""
+
+    def __init__(self, dim_in, dim_out, dim_hidden, num_layers, bias=True):
+        super().__init__()
+        self.dim_in, self.dim_out, self.dim_hidden, self.num_layers = dim_in, dim_out, dim_hidden, num_layers
+        self.net = nn.ModuleList([
+            nn.Linear(dim_in if l == 0 else dim_hidden, dim_out if l == num_layers - 1 else dim_hidden, bias=bias)
+            for l in range(num_layers)])
+
+    def forward(self, x):
+        for l in range(self.num_layers):
+            x = self.net[l](x)
+            if l != self.num_layers - 1:
+                x = F.relu(x, inplace=True)
+        return x
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, opt, num_layers=3, hidden_dim=64, num_layers_bg=2, hidden_dim_bg=32):
+        super().__init__(opt)
+        self.num_layers = num_layers
+        self.hidden_dim = hidden_dim
+        # get_encoder('hashgrid', input_dim=3, log2_hashmap_size=19, desired_resolution=2048 * bound,
+        #             interpolation='smoothstep')  (network_grid.py:49, encoding.py:74-76)
+        self.encoder = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                                   desired_resolution=2048 * self.bound, gridtype="hash", align_corners=False,
+                                   interpolation="smoothstep")
+        self.in_dim = self.encoder.output_dim
+        self.sigma_net = MLP(self.in_dim, 4, hidden_dim, num_layers, bias=True)
+        self.density_activation = trunc_exp if self.opt.density_activation == "exp" else biased_softplus
+
+        if self.opt.bg_radius > 0:
+            self.num_layers_bg = num_layers_bg
+            self.hidden_dim_bg = hidden_dim_bg
+            self.encoder_bg = FreqEncoder(input_dim=3, degree=6)  # get_encoder('frequency', multires=6)
+            self.in_dim_bg = self.encoder_bg.output_dim
+            self.bg_net = MLP(self.in_dim_bg, 3, hidden_dim_bg, num_layers_bg, bias=True)
+        else:
+            self.bg_net = None
+
+    def common_forward(self, x):
+        enc = self.encoder(x, bound=self.bound, max_level=self.max_level)
+        h = self.sigma_net(enc)
+        sigma = self.density_activation(h[..., 0] + self.density_blob(x))
+        albedo = torch.sigmoid(h[..., 1:])
+        return sigma, albedo
+
+    def finite_difference_normal(self, x, epsilon=1e-2):
+        """Six more field evaluations at x +- eps along each axis (network_grid.py:81-96)."""
+        def sig(dx, dy, dz):
+            off = torch.tensor([[dx, dy, dz]], device=x.device)
+            return self.common_forward((x + off).clamp(-self.bound, self.bound))[0]
+        dx_pos, dx_neg = sig(epsilon, 0.0, 0.0), sig(-epsilon, 0.0, 0.0)
+        dy_pos, dy_neg = sig(0.0, epsilon, 0.0), sig(0.0, -epsilon, 0.0)
+        dz_pos, dz_neg = sig(0.0, 0.0, epsilon), sig(0.0, 0.0, -epsilon)
+        normal = torch.stack([0.5 * (dx_pos - dx_neg) / epsilon, 0.5 * (dy_pos - dy_neg) / epsilon,
+                              0.5 * (dz_pos - dz_neg) / epsilon], dim=-1)
+        return -normal
+
+    def normal(self, x):
+        normal = self.finite_difference_normal(x)
+        normal = safe_normalize(normal)
+        return torch.nan_to_num(normal)
+
+    def forward(self, x, d, l=None, ratio=1, shading="albedo"):
+        sigma, albedo = self.common_forward(x)
+        if shading == "albedo":
+            normal = None
+            color = albedo
+        else:
+            normal = self.normal(x)
+            lambertian = ratio + (1 - ratio) * (normal * l).sum(-1).clamp(min=0)
+            if shading == "textureless":
+                color = lambertian.unsqueeze(-1).repeat(1, 3)
+            elif shading == "normal":
+                color = (normal + 1) / 2
+            else:
+                color = albedo * lambertian.unsqueeze(-1)
+        return sigma, color, normal
+
+    def density(self, x):
+        sigma, albedo = self.common_forward(x)
+        return {"sigma": sigma, "albedo": albedo}
+
+    def background(self, d):
+        h = self.encoder_bg(d)
+        h = self.bg_net(h)
+        return torch.sigmoid(h)
+
+    def get_params(self, lr):
+        params = [{"params": self.encoder.parameters(), "lr": lr * 10},
+                  {"params": self.sigma_net.parameters(), "lr": lr}]
+        if self.opt.bg_radius > 0:
+            params.append({"params": self.bg_net.parameters(), "lr": lr})
+        return params

@@ -1,0 +1,171 @@
+"""NeRFRenderer — the `cuda_ray` renderer of nerf/renderer.py driven by the HIP operators.
+
+Restates the control flow of `run_cuda` (nerf/renderer.py:709-816), `update_extra_state`
+(:1102-1149), `density_blob` (:338-349) and `render` (:1154-1190, cuda_ray branch). Buffer names,
+shapes and dtypes (`aabb_train`, `aabb_infer`, `density_grid`, `density_bitfield`) are the
+reference's, so its checkpoints load.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+import raymarching
+
+
+def safe_normalize(x, eps=1e-20):
+    """nerf/utils.py:109-110"""
+    return x / torch.sqrt(torch.clamp(torch.sum(x * x, -1, keepdim=True), min=eps))
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.bound = opt.bound
+        self.cascade = 1 + math.ceil(math.log2(opt.bound))
+        self.grid_size = 128
+        self.max_level = None
+        self.cuda_ray = opt.cuda_ray
+        self.min_near = opt.min_near
+        self.density_thresh = opt.density_thresh
+
+        aabb_train = torch.FloatTensor([-opt.bound, -opt.bound, -opt.bound, opt.bound, opt.bound, opt.bound])
+        self.register_buffer("aabb_train", aabb_train)
+        self.register_buffer("aabb_infer", aabb_train.clone())
+
+        density_grid = torch.zeros([self.cascade, self.grid_size ** 3])
+        density_bitfield = torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8)
+        self.register_buffer("density_grid", density_grid)
+        self.register_buffer("density_bitfield", density_bitfield)
+        self.mean_density = 0
+        self.iter_density = 0
+        self._grid_coords = None  # (morton indices, cell-centre coords), built once per device
+
+    @torch.no_grad()
+    def density_blob(self, x):
+        d = (x ** 2).sum(-1)
+        if self.opt.density_activation == "exp":
+            return self.opt.blob_density * torch.exp(-d / (2 * self.opt.blob_radius ** 2))
+        return self.opt.blob_density * (1 - torch.sqrt(d) / self.opt.blob_radius)
+
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def density(self, x):
+        raise NotImplementedError()
+
+    def reset_extra_state(self):
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+
+    # --------------------------------------------------------------------------- run_cuda
+    def run_cuda(self, rays_o, rays_d, light_d=None, ambient_ratio=1.0, shading="albedo", bg_color=None, perturb=False,
+                 T_thresh=1e-4, binarize=False, **kwargs):
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        device = rays_o.device
+
+        # NOTE: min_near is not forwarded (the reference does not either), so the op's 0.2 default applies
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer)
+
+        if light_d is None:
+            light_d = safe_normalize(rays_o + torch.randn(3, device=device))
+
+        results = {}
+        if self.training:
+            xyzs, dirs, ts, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield,
+                                                                self.cascade, self.grid_size, nears, fars, perturb,
+                                                                self.opt.dt_gamma, self.opt.max_steps)
+            dirs = safe_normalize(dirs)
+            if light_d.shape[0] > 1:
+                flatten_rays = raymarching.flatten_rays(rays, xyzs.shape[0]).long()
+                light_d = light_d[flatten_rays]
+
+            sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
+            weights, weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ts, rays, T_thresh, binarize)
+
+            if self.opt.lambda_orient > 0 and normals is not None:
+                loss_orient = weights.detach() * (normals * dirs).sum(-1).clamp(min=0) ** 2
+                results["loss_orient"] = loss_orient.mean()
+            if self.opt.lambda_3d_normal_smooth > 0 and normals is not None:
+                normals_perturb = self.normal(xyzs + torch.randn_like(xyzs) * 1e-2)
+                results["loss_normal_perturb"] = (normals - normals_perturb).abs().mean()
+            if (self.opt.lambda_2d_normal_smooth > 0 or self.opt.lambda_normal > 0) and normals is not None:
+                _, _, _, normal_image = raymarching.composite_rays_train(sigmas.detach(), (normals + 1) / 2, ts, rays,
+                                                                         T_thresh, binarize)
+                results["normal_image"] = normal_image
+            results["weights"] = weights
+            results["num_samples"] = xyzs.shape[0]
+        else:
+            dtype = torch.float32
+            weights_sum = torch.zeros(N, dtype=dtype, device=device)
+            depth = torch.zeros(N, dtype=dtype, device=device)
+            image = torch.zeros(N, 3, dtype=dtype, device=device)
+            n_alive = N
+            rays_alive = torch.arange(n_alive, dtype=torch.int32, device=device)
+            rays_t = nears.clone()
+            step = 0
+            while step < self.opt.max_steps:
+                n_alive = rays_alive.shape[0]
+                if n_alive <= 0:
+                    break
+                n_step = max(min(N // n_alive, 8), 1)
+                xyzs, dirs, ts = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
+                                                        self.density_bitfield, self.cascade, self.grid_size, nears, fars,
+                                                        perturb if step == 0 else False, self.opt.dt_gamma,
+                                                        self.opt.max_steps)
+                dirs = safe_normalize(dirs)
+                sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
+                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, ts, weights_sum, depth, image,
+                                           T_thresh, binarize)
+                rays_alive = raymarching.compact_rays(rays_alive)  # the reference: rays_alive[rays_alive >= 0]
+                step += n_step
+
+        if bg_color is None:
+            bg_color = self.background(rays_d) if self.opt.bg_radius > 0 else 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        results["image"] = image.view(*prefix, 3)
+        results["depth"] = depth.view(*prefix)
+        results["weights_sum"] = weights_sum.reshape(*prefix)
+        return results
+
+    # ----------------------------------------------------------------- update_extra_state
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        """Refresh density_grid (EMA-max of jittered field samples, Morton order) and repack the
+        occupancy bitfield; called every opt.update_extra_interval iterations."""
+        device = self.aabb_train.device
+        tmp_grid = -torch.ones_like(self.density_grid)
+        if self._grid_coords is None or self._grid_coords[0].device != device:
+            ar = torch.arange(self.grid_size, dtype=torch.int32, device=device)
+            xx, yy, zz = torch.meshgrid(ar, ar, ar, indexing="ij")
+            coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+            indices = raymarching.morton3D(coords).long()
+            xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
+            self._grid_coords = (indices, xyzs)
+        indices, xyzs = self._grid_coords
+
+        for cas in range(self.cascade):
+            bound = min(2 ** cas, self.bound)
+            half_grid_size = bound / self.grid_size
+            cas_xyzs = xyzs * (bound - half_grid_size)
+            cas_xyzs = cas_xyzs + (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
+            sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach()
+            tmp_grid[cas, indices] = sigmas.to(tmp_grid.dtype)
+
+        valid_mask = self.density_grid >= 0
+        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
+        self.mean_density = torch.mean(self.density_grid[valid_mask]).item()
+        self.iter_density += 1
+
+        density_thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+
+    def render(self, rays_o, rays_d, mvp=None, h=None, w=None, staged=False, max_ray_batch=4096, **kwargs):
+        return self.run_cuda(rays_o, rays_d, **kwargs)

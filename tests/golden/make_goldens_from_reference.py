@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own Python code and CUDA source text.
+
+Runs only in the build container (needs /root/reference; the GPU box does not have it), the
+.npz outputs are committed. Nothing is written into /root/reference (bytecode disabled).
+
+  cams_ref.npz   16 training cameras from nerf/provider.py NeRFDataset.collate (seeds 0..15) and the
+                 rays nerf/utils.py get_rays makes for view 0 -> pins tests/synth.py's numpy restatement.
+  freq_ref.npz   encoding.py FreqEncoder_torch(deg 6) on random inputs -> pins the freq oracle/kernel layout.
+  field_ref.npz  nerf/network_grid.py MLP(32,4,64,3) + activation.trunc_exp + NeRFRenderer.density_blob
+                 + sigmoid on random features -> pins oracle.field_forward and the fused field kernel.
+  run_composite_ref.npz  the cumprod compositing of NeRFRenderer.run (nerf/renderer.py:648-672)
+                 -> pins composite_rays_train (same maths without the early stop).
+  sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
+                 text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
+"""
+import os
+import random
+import re
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+import numpy as np
+import torch
+
+
+def stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return self
+        def __getattr__(self, k): return _Any()
+    for n in ["cv2", "trimesh", "mcubes", "pymeshlab", "imageio", "xatlas", "nvdiffrast", "tensorboardX", "torchvision",
+              "torchmetrics", "torch_ema", "nvdiffrast.torch", "torchvision.transforms", "torchvision.transforms.functional",
+              "torchvision.utils"]:
+        stub(n)
+    sys.modules["nvdiffrast"].torch = sys.modules["nvdiffrast.torch"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.modules["torchvision.utils"].save_image = _Any()
+    sys.modules["torchmetrics"].PearsonCorrCoef = _Any
+    sys.modules["torch_ema"].ExponentialMovingAverage = _Any
+    sys.modules["tensorboardX"].SummaryWriter = _Any
+
+
+def make_cams():
+    from nerf.provider import NeRFDataset
+    from nerf.utils import get_rays
+    import argparse
+    opt = argparse.Namespace(
+        radius_range=[3.0, 3.5], theta_range=[45, 105], phi_range=[-180, 180], fovy_range=[10, 30], default_radius=3.2,
+        default_polar=90, default_azimuth=0, default_fovy=20, angle_overhead=30, angle_front=60, jitter_pose=False,
+        jitter_center=0.2, jitter_target=0.2, jitter_up=0.02, uniform_sphere_rate=0, min_near=0.01, images=None,
+        known_view_scale=1.5, ref_radii=[], ref_polars=[], ref_azimuths=[], batch_size=1, dataset_size_train=100,
+        dataset_size_valid=8, dataset_size_test=100, progressive_view=False, progressive_view_init_ratio=0.2,
+        progressive_level=False, w=64, h=64)
+    ds = NeRFDataset(opt, device="cpu", type="train", H=64, W=64, size=100)
+    poses, fovys, radii, polars, azims = [], [], [], [], []
+    rays0 = None
+    for seed in range(16):
+        random.seed(seed)
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        data = ds.collate([0])
+        rays_o, rays_d = data["rays_o"], data["rays_d"]
+        # recover the pose: origin + the rotation from three pixel directions is overkill; re-run rand_poses instead
+        random.seed(seed); torch.manual_seed(seed); np.random.seed(seed)
+        from nerf.provider import rand_poses
+        p, dirs, th, ph, rad = rand_poses(1, "cpu", opt, radius_range=opt.radius_range, theta_range=opt.theta_range,
+                                          phi_range=opt.phi_range, return_dirs=True, angle_overhead=opt.angle_overhead,
+                                          angle_front=opt.angle_front, uniform_sphere_rate=opt.uniform_sphere_rate)
+        fov = random.random() * (opt.fovy_range[1] - opt.fovy_range[0]) + opt.fovy_range[0]
+        focal = 64 / (2 * np.tan(np.deg2rad(fov) / 2))
+        rr = get_rays(p, np.array([focal, focal, 32, 32]), 64, 64, -1)
+        assert torch.equal(rr["rays_o"], rays_o) and torch.equal(rr["rays_d"], rays_d), "pose replay diverged"
+        poses.append(p[0].numpy()); fovys.append(fov)
+        if seed == 0:
+            rays0 = (rays_o[0].numpy().copy(), rays_d[0].numpy().copy())
+    np.savez_compressed(os.path.join(OUT, "cams_ref.npz"), poses=np.stack(poses).astype(np.float32),
+                        fovy=np.array(fovys, np.float64), rays_o0=rays0[0], rays_d0=rays0[1])
+    print("cams_ref.npz", np.stack(poses).shape)
+
+
+def make_freq():
+    from encoding import FreqEncoder_torch
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(257, 3, generator=g) * 2 - 1)
+    enc = FreqEncoder_torch(input_dim=3, max_freq_log2=5, N_freqs=6, log_sampling=True)
+    y = enc(x.double()).float()  # float64 evaluation = the exact layout/value target
+    np.savez_compressed(os.path.join(OUT, "freq_ref.npz"), x=x.numpy(), y=y.numpy(), degree=6)
+    print("freq_ref.npz", tuple(y.shape))
+
+
+def make_field():
+    from nerf.network_grid import MLP
+    from activation import trunc_exp
+    import argparse
+    torch.manual_seed(5)
+    mlp = MLP(32, 4, 64, 3, bias=True)
+    g = torch.Generator().manual_seed(12)
+    enc = torch.randn(1031, 32, generator=g) * 0.5
+    x = torch.rand(1031, 3, generator=g) * 2 - 1
+    # NeRFRenderer.density_blob (nerf/renderer.py:338-349), 'exp' branch, called unbound with a stub self
+    from nerf.renderer import NeRFRenderer
+    fake = types.SimpleNamespace(opt=argparse.Namespace(density_activation="exp", blob_density=5, blob_radius=0.2))
+    blob = NeRFRenderer.density_blob(fake, x)
+    h = mlp(enc)
+    sigma = trunc_exp(h[..., 0] + blob)
+    albedo = torch.sigmoid(h[..., 1:])
+    np.savez_compressed(os.path.join(OUT, "field_ref.npz"), enc=enc.numpy(), x=x.numpy(),
+                        **{f"w{i}": l.weight.detach().numpy() for i, l in enumerate(mlp.net)},
+                        **{f"b{i}": l.bias.detach().numpy() for i, l in enumerate(mlp.net)},
+                        h=h.detach().numpy(), sigma=sigma.detach().numpy(), albedo=albedo.detach().numpy(),
+                        blob=blob.numpy())
+    print("field_ref.npz", tuple(h.shape))
+
+
+def make_run_composite():
+    # nerf/renderer.py:648-672 restated with the same torch ops on synthetic per-ray samples
+    g = torch.Generator().manual_seed(13)
+    N, T = 37, 96
+    z_vals, _ = torch.sort(torch.rand(N, T, generator=g) * 2 + 2, dim=-1)
+    deltas = z_vals[..., 1:] - z_vals[..., :-1]
+    deltas = torch.cat([deltas, 0.05 * torch.ones_like(deltas[..., :1])], dim=-1)
+    sigmas = torch.exp(torch.randn(N, T, generator=g) * 1.5)
+    rgbs = torch.rand(N, T, 3, generator=g)
+    alphas = 1 - torch.exp(-deltas * sigmas)
+    alphas_shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
+    weights = alphas * torch.cumprod(alphas_shifted, dim=-1)[..., :-1]
+    weights_sum = weights.sum(dim=-1)
+    depth = torch.sum(weights * z_vals, dim=-1)
+    image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
+    np.savez_compressed(os.path.join(OUT, "run_composite_ref.npz"), z_vals=z_vals.numpy(), deltas=deltas.numpy(),
+                        sigmas=sigmas.numpy(), rgbs=rgbs.numpy(), weights=weights.numpy(),
+                        weights_sum=weights_sum.numpy(), depth=depth.numpy(), image=image.numpy())
+    print("run_composite_ref.npz", N, T)
+
+
+def make_sh():
+    src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
+    body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
+
+    def collect(var):
+        exprs = {}
+        for m in re.finditer(r"\b%s\[(\d+)\]\s*=\s*([^;]+);" % var, body):
+            exprs[int(m.group(1))] = m.group(2)
+        return exprs
+
+    tabs = {v: collect(v) for v in ("outputs", "dx", "dy", "dz")}
+    assert all(len(t) == 64 for t in tabs.values()), {k: len(v) for k, v in tabs.items()}
+    rng = np.random.default_rng(14)
+    pts = rng.uniform(-1, 1, size=(129, 3))
+    pts[:3] = [[0, 0, 1], [0, 0, -1], [1, 0, 0]]  # poles and an equator point
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    env = dict(x=x, y=y, z=z, xy=x * y, xz=x * z, yz=y * z, x2=x * x, y2=y * y, z2=z * z, xyz=x * y * z)
+    env.update(x4=env["x2"] ** 2, y4=env["y2"] ** 2, z4=env["z2"] ** 2)
+    env.update(x6=env["x4"] * env["x2"], y6=env["y4"] * env["y2"], z6=env["z4"] * env["z2"], pow=np.power)
+    out = {}
+    for name, tab in tabs.items():
+        arr = np.zeros((pts.shape[0], 64))
+        for i in range(64):
+            expr = re.sub(r"(\d+\.\d*(?:[eE][-+]?\d+)?|\d+[eE][-+]?\d+)f", r"\1", tab[i])  # strip float suffixes
+            arr[:, i] = eval(expr, {"__builtins__": {}}, env) + np.zeros_like(x)
+        out[name] = arr
+    np.savez_compressed(os.path.join(OUT, "sh_ref.npz"), pts=pts, y=out["outputs"], dx=out["dx"], dy=out["dy"], dz=out["dz"])
+    print("sh_ref.npz", out["outputs"].shape)
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "reference checkout not mounted"
+    sys.path.insert(0, REF)
+    install_stubs()
+    make_sh()
+    make_freq()
+    make_run_composite()
+    make_field()
+    make_cams()

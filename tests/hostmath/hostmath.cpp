@@ -1,0 +1,86 @@
+// hostmath.cpp — TEST HARNESS ONLY. Builds the per-sample device arithmetic of
+// stable-dreamfusion_amd/csrc/sdfx_math.h for the host (g++, -ffp-contract=off) so the
+// not-gpu test suite can compare it with the independent C oracle without a GPU. The loops
+// below mirror the thread bodies of k_march_count / k_grid_forward; nothing here ships.
+#include <cstdint>
+#include <cmath>
+#include <cstring>
+
+#include "../../stable-dreamfusion_amd/csrc/sdfx_math.h"
+
+using namespace sdfx;
+
+extern "C" {
+
+// body of k_march_count for every ray, plus tbuf recording
+void hm_march_count(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, int contract,
+                    float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
+                    const float* fars, const float* noises, int32_t* counts, float* tbuf) {
+    const MarchParams p = make_march_params(bound, contract, dt_gamma, max_steps, C, H);
+    for (uint32_t n = 0; n < N; n++) {
+        const MarchRay r = make_march_ray(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3);
+        const float far = fars[n];
+        float t = nears[n];
+        t += clampf_(t * p.dt_gamma, p.dt_min, p.dt_max) * noises[n];
+        uint32_t step = 0;
+        while (t < far && step < max_steps) {
+            float dt, cx, cy, cz;
+            if (march_probe(r, p, grid, t, dt, cx, cy, cz)) {
+                if (tbuf) tbuf[(size_t)n * max_steps + step] = t;
+                step++;
+                t += dt;
+            }
+        }
+        counts[n] = (int32_t)step;
+    }
+}
+
+// body of k_march_write_tbuf for one ray
+void hm_march_write(const float* rays_o, const float* rays_d, float bound, int contract, float dt_gamma,
+                    uint32_t max_steps, uint32_t C, uint32_t H, uint32_t n, uint32_t count, const float* tbuf,
+                    float* xyzs, float* ts) {
+    const MarchParams p = make_march_params(bound, contract, dt_gamma, max_steps, C, H);
+    const MarchRay r = make_march_ray(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3);
+    for (uint32_t i = 0; i < count; i++) {
+        const float t = tbuf[(size_t)n * max_steps + i];
+        float cx, cy, cz;
+        march_position(r, p, t, cx, cy, cz);
+        const float dt = march_dt(p, t);
+        xyzs[i * 3 + 0] = cx; xyzs[i * 3 + 1] = cy; xyzs[i * 3 + 2] = cz;
+        ts[i * 2 + 0] = t + dt; ts[i * 2 + 1] = dt;
+    }
+}
+
+// float32 forward of k_grid_forward<3, C=2> for one level (features only)
+void hm_grid_forward_d3c2(const float* inputs, const float* table, uint32_t B, uint32_t row0, uint32_t hashmap_size,
+                          uint32_t resolution, uint32_t gridtype, int align_corners, uint32_t interp, float* out) {
+    for (uint32_t b = 0; b < B; b++) {
+        float pos[3], deriv[3];
+        uint32_t pg[3];
+        bool oob = false;
+        for (int d = 0; d < 3; d++) {
+            const float v = inputs[(size_t)b * 3 + d];
+            if (v < 0 || v > 1) oob = true;
+        }
+        if (oob) { out[b * 2] = out[b * 2 + 1] = 0; continue; }
+        for (int d = 0; d < 3; d++) grid_locate_axis(inputs[(size_t)b * 3 + d], resolution, align_corners != 0, interp, pos[d], deriv[d], pg[d]);
+        float res[2] = {0, 0};
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            float w = 1;
+            uint32_t pgl[3];
+            for (uint32_t d = 0; d < 3; d++) {
+                if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pg[d]; }
+                else { w *= pos[d]; pgl[d] = pg[d] + 1 < resolution - 1 ? pg[d] + 1 : resolution - 1; }
+            }
+            const uint32_t row = grid_row<3>(gridtype, hashmap_size, resolution, pgl);
+            res[0] += w * table[(size_t)(row0 + row) * 2 + 0];
+            res[1] += w * table[(size_t)(row0 + row) * 2 + 1];
+        }
+        out[b * 2] = res[0]; out[b * 2 + 1] = res[1];
+    }
+}
+
+uint32_t hm_morton3D(uint32_t x, uint32_t y, uint32_t z) { return morton3D(x, y, z); }
+uint32_t hm_morton3D_invert(uint32_t v) { return morton3D_invert(v); }
+
+}  // extern "C"

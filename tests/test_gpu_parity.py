@@ -1,0 +1,402 @@
+"""-m gpu: the HIP path (Python operator packages -> ctypes -> C ABI -> gfx950 kernels) against the
+CPU oracle on identical seeded inputs. Integer / index outputs and fp32 grid features are compared
+bit-exactly; compositing and fp16 / atomic paths within the stated tolerances."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+AABB = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def test_library_is_the_hip_build(dev):
+    import _sdfx
+    info = _sdfx.lib().sdfx_build_info().decode()
+    assert "gfx950" in info
+    maps = open("/proc/self/maps").read()
+    assert "libsdfx_hip.so" in maps
+
+
+# ------------------------------------------------------------------------------------ utils
+def test_near_far_morton_packbits_flatten_sph(oracle, dev):
+    import raymarching
+    o, d = synth.s_rays(4)
+    o[:3] += 5.0  # a few misses
+    n_ref, f_ref = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    n, f = raymarching.near_far_from_aabb(T(o, dev), T(d, dev), T(AABB, dev))
+    assert np.array_equal(N_(n), n_ref) and np.array_equal(N_(f), f_ref)
+    n2, _ = raymarching.near_far_from_aabb(T(o, dev), T(d, dev), T(AABB, dev), 0.05)
+    assert np.array_equal(N_(n2), oracle.near_far_from_aabb(o, d, AABB, 0.05)[0])
+
+    coords = np.random.default_rng(0).integers(0, 128, (100003, 3)).astype(np.int32)
+    m = raymarching.morton3D(T(coords, dev))
+    assert np.array_equal(N_(m), oracle.morton3D(coords))
+    assert np.array_equal(N_(raymarching.morton3D_invert(m)), coords)
+
+    grid, thresh, bf_ref = synth.s_grid_init()
+    bf = raymarching.packbits(T(grid, dev), thresh)
+    assert np.array_equal(N_(bf), bf_ref) and np.array_equal(bf_ref, oracle.packbits(grid, thresh))
+    # unaligned view + reuse of a passed-in bitfield
+    g2 = T(np.concatenate([[0.0], grid[0]]).astype(np.float32), dev)[1:].view(1, -1)
+    out = torch.zeros_like(bf)
+    assert raymarching.packbits(g2, thresh, out) is out and np.array_equal(N_(out), bf_ref)
+
+    rays = np.array([[0, 3], [3, 0], [3, 70], [73, 1]], np.int32)
+    assert np.array_equal(N_(raymarching.flatten_rays(T(rays, dev), 74)), oracle.flatten_rays(rays, 74))
+
+    oo = np.random.default_rng(1).uniform(-0.3, 0.3, (1000, 3)).astype(np.float32)
+    dd = np.random.default_rng(2).normal(size=(1000, 3)).astype(np.float32)
+    sph = raymarching.sph_from_ray(T(oo, dev), T(dd, dev), 1.4)
+    assert np.abs(N_(sph) - oracle.sph_from_ray(oo, dd, 1.4)).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------- train march
+@pytest.mark.parametrize("gridname,view", [("init", 0), ("init", 9), ("blobs", 3), ("full", 1)])
+def test_march_rays_train_bit_exact(oracle, dev, gridname, view):
+    import raymarching
+    bf = {"init": lambda: synth.s_grid_init()[2], "blobs": synth.s_grid_blobs, "full": synth.s_grid_full}[gridname]()
+    o, d = synth.s_rays(view)
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    noises = synth.s_noises(4096, seed=7 + view)
+    x_ref, d_ref, t_ref, r_ref = oracle.march_rays_train(o, d, 1.0, bf, 1, 128, nears, fars, noises)
+    xyzs, dirs, ts, rays = raymarching.march_rays_train(T(o, dev), T(d, dev), 1.0, T(bf, dev), 1, 128, T(nears, dev),
+                                                        T(fars, dev), True, 0, 1024, False, T(noises, dev))
+    assert np.array_equal(N_(rays), r_ref)          # counts AND prefix-sum offsets, bit-exact
+    assert np.array_equal(N_(xyzs), x_ref) and np.array_equal(N_(dirs), d_ref) and np.array_equal(N_(ts), t_ref)
+
+
+def test_march_rays_train_literal_two_pass_protocol(oracle, dev):
+    """The pybind-level protocol of raymarching.py:240-254, with and without scratch hand-over."""
+    import _raymarching as B
+    bf = synth.s_grid_blobs(cascade=2, seed=5)
+    o, d = synth.s_rays(2)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-2, -2, -2, 2, 2, 2], np.float32), 0.2)
+    noises = synth.s_noises(4096, seed=3)
+    for contract, dt_gamma in ((False, 0.0), (False, 1.0 / 128), (True, 0.0)):
+        x_ref, d_ref, t_ref, r_ref = oracle.march_rays_train(o, d, 2.0, bf, 2, 128, nears, fars, noises, dt_gamma=dt_gamma,
+                                                             max_steps=512, contract=contract)
+        for use_scratch in (True, False):
+            args = (T(o, dev), T(d, dev), T(bf, dev), 2.0, contract, dt_gamma, 512, 4096, 2, 128, T(nears, dev), T(fars, dev))
+            rays = torch.empty(4096, 2, dtype=torch.int32, device=dev)
+            counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            nz = T(noises, dev)
+            B.march_rays_train(*args, None, None, None, rays, counter, nz)
+            if not use_scratch:
+                B._MARCH_SCRATCH.clear()       # force the replay kernel
+            M = int(counter.item())
+            assert M == x_ref.shape[0]
+            xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); ts = torch.zeros(M, 2, device=dev)
+            B.march_rays_train(*args, xyzs, dirs, ts, rays, counter, nz)
+            assert np.array_equal(N_(rays), r_ref)
+            assert np.array_equal(N_(xyzs), x_ref) and np.array_equal(N_(ts), t_ref) and np.array_equal(N_(dirs), d_ref)
+
+
+def test_march_empty_and_ragged(oracle, dev):
+    import raymarching
+    bf = np.zeros(128 ** 3 // 8, np.uint8)            # nothing occupied -> M = 0
+    o, d = synth.s_rays(0)
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    xyzs, dirs, ts, rays = raymarching.march_rays_train(T(o, dev), T(d, dev), 1.0, T(bf, dev), 1, 128, T(nears, dev),
+                                                        T(fars, dev))
+    assert xyzs.shape == (0, 3) and ts.shape == (0, 2) and int(rays[:, 1].sum()) == 0
+    w, ws, dep, img = raymarching.composite_rays_train(torch.zeros(0, device=dev), torch.zeros(0, 3, device=dev), ts, rays)
+    assert w.numel() == 0 and float(ws.abs().sum()) == 0 and float(img.abs().sum()) == 0
+    # N not a multiple of 64
+    o5, d5 = o[:77], d[:77]
+    bf2 = synth.s_grid_init()[2]
+    r_ref = oracle.march_rays_train(o5, d5, 1.0, bf2, 1, 128, nears[:77], fars[:77], np.zeros(77, np.float32))[3]
+    rays5 = raymarching.march_rays_train(T(o5, dev), T(d5, dev), 1.0, T(bf2, dev), 1, 128, T(nears[:77], dev), T(fars[:77], dev))[3]
+    assert np.array_equal(N_(rays5), r_ref)
+
+
+# --------------------------------------------------------------------------------- composite
+def _composite_case(oracle, grid="init", view=0, seed=6):
+    bf = synth.s_grid_init()[2] if grid == "init" else synth.s_grid_full()
+    o, d = synth.s_rays(view)
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    xyzs, dirs, ts, rays = oracle.march_rays_train(o, d, 1.0, bf, 1, 128, nears, fars, synth.s_noises(4096))
+    sig, rgb = synth.s_sigma_rgb(xyzs.shape[0], seed)
+    return sig, rgb, ts, rays
+
+
+@pytest.mark.parametrize("grid,scale,binarize", [("init", 1.0, False), ("full", 30.0, False), ("init", 100.0, True)])
+def test_composite_train_forward_backward(oracle, dev, grid, scale, binarize):
+    """North-star tolerance: 1e-4 relative on composited RGB / weights_sum / depth."""
+    import raymarching
+    sig, rgb, ts, rays = _composite_case(oracle, grid)
+    sig = (sig * scale).astype(np.float32)   # scale > 1 exercises the T < 1e-4 early stop
+    w_ref, ws_ref, d_ref, im_ref = oracle.composite_rays_train_forward(sig, rgb, ts, rays, 1e-4, binarize)
+    st, ct = T(sig, dev).requires_grad_(), T(rgb, dev).requires_grad_()
+    w, ws, dep, img = raymarching.composite_rays_train(st, ct, T(ts, dev), T(rays, dev), 1e-4, binarize)
+
+    def close(a, b, rtol=1e-4, atol=2e-6):
+        a = N_(a)
+        assert np.abs(a - b).max() <= atol + rtol * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
+        assert np.allclose(a, b, rtol=rtol, atol=2e-5)
+
+    close(ws, ws_ref); close(dep, d_ref); close(img, im_ref); close(w, w_ref)
+    # samples past the cut have exactly zero weight on both sides, except where the cut moved by one
+    # sample because the scan associates the transmittance product differently (weight < T_thresh there)
+    mism = (N_(w) == 0) != (w_ref == 0)
+    assert mism.mean() < 1e-3 and (np.abs(w_ref[mism]).max(initial=0) < 2e-4) and (np.abs(N_(w)[mism]).max(initial=0) < 2e-4)
+
+    rng = np.random.default_rng(8)
+    gw = rng.normal(size=w_ref.shape).astype(np.float32) * 0.1
+    gws, gd, gi = (rng.normal(size=ws_ref.shape).astype(np.float32), rng.normal(size=d_ref.shape).astype(np.float32),
+                   rng.normal(size=im_ref.shape).astype(np.float32))
+    gs_ref, gc_ref = oracle.composite_rays_train_backward(gw, gws, gd, gi, sig, rgb, ts, rays, ws_ref, d_ref, im_ref, 1e-4,
+                                                          binarize)
+    torch.autograd.backward([w, ws, dep, img], [T(gw, dev), T(gws, dev), T(gd, dev), T(gi, dev)])
+    gs, gc = N_(st.grad), N_(ct.grad)
+    assert np.abs(gc - gc_ref).max() <= 1e-4 * np.abs(gc_ref).max() + 1e-6
+    # grad_sigma is a difference of O(1) prefix sums: absolute error scales with the ray's accumulated magnitude
+    assert np.abs(gs - gs_ref).max() <= 2e-4 * np.abs(gs_ref).max() + 1e-5
+    assert np.median(np.abs(gs - gs_ref) / (np.abs(gs_ref) + 1e-3)) < 1e-4
+
+
+def test_composite_overflow_ray_is_zeroed(oracle, dev):
+    """offset + count > M -> outputs zero, no gradient (raymarching.cu:521-528, 630)."""
+    import _raymarching as B
+    rays = np.array([[0, 4], [4, 10]], np.int32)      # second ray overruns M = 8
+    sig, rgb = synth.s_sigma_rgb(8)
+    ts = np.stack([np.linspace(0.3, 1, 8), np.full(8, 0.01)], -1).astype(np.float32)
+    ref = oracle.composite_rays_train_forward(sig, rgb, ts, rays)
+    w = torch.zeros(8, device=dev); ws = torch.empty(2, device=dev); dep = torch.empty(2, device=dev); img = torch.empty(2, 3, device=dev)
+    B.composite_rays_train_forward(T(sig, dev), T(rgb, dev), T(ts, dev), T(rays, dev), 8, 2, 1e-4, False, w, ws, dep, img)
+    assert np.allclose(N_(w), ref[0], atol=1e-6) and float(ws[1]) == 0 and float(img[1].abs().sum()) == 0
+    assert np.all(N_(w)[4:] == 0)
+
+
+# --------------------------------------------------------------------------------- inference
+def test_inference_march_composite_loop_and_compaction(oracle, dev):
+    """The eval-time loop of nerf/renderer.py:759-794 run with the HIP ops (and the ballot/prefix-sum
+    compaction) against the same loop run with the oracle (and a numpy boolean mask)."""
+    import raymarching
+    bf = synth.s_grid_init()[2]
+    o, d = synth.s_rays(7)
+    N = o.shape[0]
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+
+    def sigma_rgb(xyzs):   # a fixed analytic field, float32 on both sides
+        r2 = (xyzs.astype(np.float32) ** 2).sum(-1)
+        return (40 * np.exp(-r2 / np.float32(0.08))).astype(np.float32), (0.5 + 0.5 * np.sin(7 * xyzs)).astype(np.float32)
+
+    # oracle loop
+    ws_r = np.zeros(N, np.float32); dp_r = np.zeros(N, np.float32); im_r = np.zeros((N, 3), np.float32)
+    alive_r = np.arange(N, dtype=np.int32); t_r = nears.copy()
+    # HIP loop
+    ws = torch.zeros(N, device=dev); dp = torch.zeros(N, device=dev); im = torch.zeros(N, 3, device=dev)
+    alive = torch.arange(N, dtype=torch.int32, device=dev); rt = T(nears, dev).clone()
+    od, dd, bfd, nd, fd = T(o, dev), T(d, dev), T(bf, dev), T(nears, dev), T(fars, dev)
+    step = 0
+    while step < 1024:
+        n_alive = alive_r.shape[0]
+        assert alive.shape[0] == n_alive
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        x_r, _, ts_r = oracle.march_rays(n_alive, n_step, alive_r, t_r, o, d, 1.0, bf, 1, 128, nears, fars,
+                                         np.zeros(n_alive, np.float32))
+        x, _, ts = raymarching.march_rays(n_alive, n_step, alive, rt, od, dd, 1.0, bfd, 1, 128, nd, fd)
+        assert np.array_equal(N_(x), x_r) and np.array_equal(N_(ts), ts_r)
+        s_r, c_r = sigma_rgb(x_r)
+        oracle.composite_rays(n_alive, n_step, alive_r, t_r, s_r, c_r, ts_r, ws_r, dp_r, im_r, 1e-2)
+        raymarching.composite_rays(n_alive, n_step, alive, rt, T(s_r, dev), T(c_r, dev), ts, ws, dp, im, 1e-2)
+        assert np.array_equal(N_(alive), alive_r)       # same rays killed
+        alive_r = alive_r[alive_r >= 0]
+        alive = raymarching.compact_rays(alive)
+        assert np.array_equal(N_(alive), alive_r)       # stable order preserved
+        step += n_step
+    assert np.allclose(N_(ws), ws_r, rtol=1e-5, atol=1e-6) and np.allclose(N_(im), im_r, rtol=1e-5, atol=1e-6)
+    assert np.allclose(N_(dp), dp_r, rtol=1e-5, atol=1e-6) and ws_r.max() > 0.5
+
+
+def test_compact_rays_edge_cases(dev):
+    import raymarching
+    for n in (0, 1, 63, 64, 65, 255, 256, 257, 100003):
+        a = torch.from_numpy(np.random.default_rng(n).integers(-1, 5, n).astype(np.int32)).to(dev)
+        a = torch.where(a >= 0, torch.arange(n, dtype=torch.int32, device=dev), a) if n else a
+        assert torch.equal(raymarching.compact_rays(a), a[a >= 0])
+    assert raymarching.compact_rays(torch.full((1000,), -1, dtype=torch.int32, device=dev)).numel() == 0
+
+
+# ------------------------------------------------------------------------------ grid encoder
+def _grid_setup(oracle, kind="trained", dtype=np.float32, **kw):
+    offsets, pls = oracle.grid_offsets(**kw)
+    return offsets, pls, synth.s_table(int(offsets[-1]), kw.get("level_dim", 2), kind, dtype)
+
+
+@pytest.mark.parametrize("interp,gridtype,align", [(1, 0, False), (0, 0, False), (0, 1, True)])
+def test_grid_forward_fp32_bit_exact(oracle, dev, interp, gridtype, align):
+    import _gridencoder as B
+    offsets, pls, table = _grid_setup(oracle, desired_resolution=2048)
+    x = synth.s_points_uniform(20011, seed=21)
+    x[:5] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1.0, 0.0, 0.999999], [1.5, 0.2, 0.2]]
+    out_ref, lbc_ref, dy_ref = oracle.grid_encode_forward(x, table, offsets, pls, 16, True, gridtype, align, interp)
+    Bn, L, C = x.shape[0], 16, 2
+    S = np.log2(pls)
+    for layout in (0, 1):
+        out = torch.empty((L, Bn, C) if layout == 0 else (Bn, L * C), device=dev)
+        dy = torch.empty(Bn, L * 3 * C, device=dev)
+        B.grid_encode_forward(T(x, dev), T(table, dev), T(offsets, dev), out, Bn, 3, C, L, L, S, 16, dy, gridtype, align,
+                              interp, layout)
+        assert np.array_equal(N_(out), lbc_ref if layout == 0 else out_ref)
+        assert np.array_equal(N_(dy), dy_ref)
+
+
+def test_grid_module_forward_backward_fp32(oracle, dev):
+    """GridEncoder module (the encoding.py / network_grid.py call surface): forward bit-exact,
+    table gradient within float-atomic reordering noise, input gradient bit-exact."""
+    from gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                      desired_resolution=2048, interpolation="smoothstep").to(dev)
+    offsets, pls, table = _grid_setup(oracle, desired_resolution=2048)
+    assert np.array_equal(N_(enc.offsets), offsets) and enc.embeddings.shape == table.shape
+    with torch.no_grad():
+        enc.embeddings.copy_(T(table, dev))
+    xw = (synth.s_points_uniform(30000, seed=22) * 2 - 1).astype(np.float32)     # world coords in [-1, 1]
+    x01 = ((xw + np.float32(1)) / np.float32(2)).astype(np.float32)
+    xt = T(xw, dev).requires_grad_()
+    out = enc(xt, bound=1)
+    out_ref, _, dy_ref = oracle.grid_encode_forward(x01, table, offsets, pls, 16, True, 0, False, 1)
+    assert np.array_equal(N_(out), out_ref)
+    gr = np.random.default_rng(5).normal(size=out_ref.shape).astype(np.float32)
+    out.backward(T(gr, dev))
+    gi_ref, gt_ref = oracle.grid_encode_backward(gr, x01, table, offsets, pls, 16, dy_ref, 0, False, 1)
+    gt = N_(enc.embeddings.grad)
+    assert np.abs(gt - gt_ref).max() <= 1e-5 * np.abs(gt_ref).max() + 1e-6
+    assert np.array_equal((gt != 0), (gt_ref != 0))
+    assert np.allclose(N_(xt.grad), gi_ref * np.float32(0.5), rtol=1e-6, atol=1e-7)   # chain rule of (x + 1) / 2
+
+
+def test_grid_autocast_half_path(oracle, dev):
+    """-O path: autocast -> fp16 table, fp16 features (half accumulation as gridencoder.cu:168,191),
+    packed-half atomics for the table gradient (gridencoder.cu:334-340)."""
+    from gridencoder import GridEncoder
+    enc = GridEncoder(desired_resolution=2048, interpolation="smoothstep").to(dev)
+    offsets, pls, table = _grid_setup(oracle, desired_resolution=2048)
+    with torch.no_grad():
+        enc.embeddings.copy_(T(table, dev))
+    x01 = synth.s_points_uniform(20000, seed=23)
+    xw = (x01 * 2 - 1).astype(np.float32)
+    x01 = ((xw + np.float32(1)) / np.float32(2)).astype(np.float32)
+    th = table.astype(np.float16)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = enc(T(xw, dev))
+        assert out.dtype == torch.float16
+        out_ref, _, _ = oracle.grid_encode_forward(x01, th, offsets, pls, 16, False, 0, False, 1)
+        assert np.array_equal(N_(out).view(np.uint16), out_ref.view(np.uint16))       # bit-exact incl. half rounding order
+        gr = (np.random.default_rng(6).normal(size=out_ref.shape) * 0.01).astype(np.float16)
+        out.backward(T(gr, dev))
+    g = N_(enc.embeddings.grad)
+    assert g.dtype == np.float32      # autograd casts the half table gradient back to the fp32 parameter
+    _, gt_ref = oracle.grid_encode_backward(gr, x01, th, offsets, pls, 16, None, 0, False, 1)
+    gt_ref = gt_ref.astype(np.float32)
+    # half accumulation in a different (atomic) order: compare against the fp32-accumulated truth too
+    _, gt32 = oracle.grid_encode_backward(gr.astype(np.float32), x01, table, offsets, pls, 16, None, 0, False, 1)
+    scale = np.abs(gt32).max()
+    assert np.abs(g - gt32).max() < 2e-2 * scale
+    assert np.abs(g - gt32).mean() < 1.5 * np.abs(gt_ref - gt32).mean() + 1e-6 * scale
+
+
+@pytest.mark.parametrize("D,C", [(2, 1), (2, 8), (3, 4), (4, 2), (5, 2), (3, 32), (3, 16)])
+def test_grid_other_dims_fp32(oracle, dev, D, C):
+    import _gridencoder as B
+    offsets, pls = oracle.grid_offsets(input_dim=D, num_levels=6, level_dim=C, log2_hashmap_size=14, desired_resolution=256)
+    table = synth.s_table(int(offsets[-1]), C, "trained")
+    x = synth.s_points_uniform(3001, D, seed=30 + D)
+    out_ref, lbc_ref, dy_ref = oracle.grid_encode_forward(x, table, offsets, pls, 16, True, 0, False, 0)
+    out = torch.empty(6, 3001, C, device=dev); dy = torch.empty(3001, 6 * D * C, device=dev)
+    B.grid_encode_forward(T(x, dev), T(table, dev), T(offsets, dev), out, 3001, D, C, 6, 6, np.log2(pls), 16, dy, 0, False, 0)
+    assert np.array_equal(N_(out), lbc_ref) and np.array_equal(N_(dy), dy_ref)
+    gr = np.random.default_rng(1).normal(size=(3001, 6 * C)).astype(np.float32)
+    gi_ref, gt_ref = oracle.grid_encode_backward(gr, x, table, offsets, pls, 16, dy_ref, 0, False, 0)
+    gt = torch.zeros_like(T(table, dev)); gi = torch.zeros(3001, D, device=dev)
+    B.grid_encode_backward(T(gr, dev), T(x, dev), T(table, dev), T(offsets, dev), gt, 3001, D, C, 6, 6, np.log2(pls), 16, dy,
+                           gi, 0, False, 0, 1)
+    assert np.abs(N_(gt) - gt_ref).max() <= 1e-5 * np.abs(gt_ref).max() + 1e-6
+    assert np.allclose(N_(gi), gi_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_grid_max_level_and_errors(oracle, dev):
+    from gridencoder import GridEncoder
+    import _gridencoder as B
+    enc = GridEncoder(desired_resolution=2048).to(dev)
+    x = T(synth.s_points_uniform(100) * 2 - 1, dev)
+    out = enc(x, max_level=0.5)
+    assert float(out[:, 16:].abs().sum()) == 0 and float(out[:, :16].abs().sum()) > 0
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        B.grid_encode_forward(x.cpu(), enc.embeddings, enc.offsets, torch.empty(16, 100, 2, device=dev), 100, 3, 2, 16, 16, 0.46, 16, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        B.grid_encode_forward(x.t().contiguous().t(), enc.embeddings, enc.offsets, torch.empty(16, 100, 2, device=dev), 100, 3, 2, 16, 16, 0.46, 16, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="C must be"):
+        B.grid_encode_forward(x, torch.zeros(enc.embeddings.shape[0], 3, device=dev), enc.offsets, torch.empty(16, 100, 3, device=dev), 100, 3, 3, 16, 16, 0.46, 16, None, 0, False, 0)
+
+
+def test_grid_tv_and_weight_decay(oracle, dev):
+    from gridencoder import GridEncoder
+    enc = GridEncoder(num_levels=8, log2_hashmap_size=15, desired_resolution=512).to(dev)
+    offsets, pls = oracle.grid_offsets(num_levels=8, log2_hashmap_size=15, desired_resolution=512)
+    table = synth.s_table(int(offsets[-1]), 2, "trained")
+    with torch.no_grad():
+        enc.embeddings.copy_(T(table, dev))
+    with pytest.raises(ValueError):
+        enc.grad_weight_decay(0.1)
+    g0 = np.random.default_rng(2).normal(size=table.shape).astype(np.float32)
+    enc.embeddings.grad = T(g0, dev).clone()
+    enc.grad_weight_decay(0.1)
+    ref = g0.copy(); oracle.grad_weight_decay(table, ref, offsets, 0.1)
+    assert np.array_equal(N_(enc.embeddings.grad), ref)
+    xw = (synth.s_points_uniform(5000, seed=40) * 2 - 1).astype(np.float32)
+    enc.embeddings.grad = T(g0, dev).clone()
+    enc.grad_total_variation(1e-3, T(xw, dev), bound=1)
+    ref = g0.copy()
+    oracle.grad_total_variation(((xw + np.float32(1)) / np.float32(2)).astype(np.float32), table, ref, offsets, 1e-3, pls, 16)
+    assert np.abs(N_(enc.embeddings.grad) - ref).max() < 1e-5 * np.abs(ref).max() + 1e-7
+
+
+# ------------------------------------------------------------------------------- freq / SH
+def test_freq_encoder(oracle, dev):
+    from freqencoder import FreqEncoder
+    enc = FreqEncoder(input_dim=3, degree=6)
+    g = np.load(os.path.join(synth.GOLDEN, "freq_ref.npz"))
+    xt = T(g["x"], dev).requires_grad_()
+    y = enc(xt)
+    assert y.shape == (257, 39) and np.abs(N_(y) - g["y"]).max() < 2e-6      # reference FreqEncoder_torch fixture
+    gr = np.random.default_rng(3).normal(size=(257, 39)).astype(np.float32)
+    y.backward(T(gr, dev))
+    assert np.allclose(N_(xt.grad), oracle.freq_encode_backward(gr, oracle.freq_encode_forward(g["x"], 6), 3, 6), rtol=1e-5, atol=1e-5)
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert enc(T(g["x"], dev).half()).dtype == torch.float32             # cast_inputs=float32
+
+
+def test_sh_encoder(oracle, dev):
+    from shencoder import SHEncoder
+    g = np.load(os.path.join(synth.GOLDEN, "sh_ref.npz"))
+    pts = g["pts"].astype(np.float32)
+    for deg in (1, 2, 4, 8):
+        enc = SHEncoder(degree=deg)
+        xt = T(pts, dev).requires_grad_()
+        y = enc(xt)
+        n = deg * deg
+        assert np.abs(N_(y) - g["y"][:, :n]).max() < 3e-5                    # literal shencoder.cu expressions fixture
+        ref, dy_ref = oracle.sh_encode_forward(pts, deg, True)
+        gr = np.random.default_rng(deg).normal(size=(pts.shape[0], n)).astype(np.float32)
+        y.backward(T(gr, dev))
+        gi_ref = oracle.sh_encode_backward(gr, pts, deg, dy_ref)
+        assert np.allclose(N_(xt.grad), gi_ref, rtol=1e-4, atol=1e-4)
+    with pytest.raises(AssertionError):
+        SHEncoder(degree=9)

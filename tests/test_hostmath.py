@@ -1,0 +1,81 @@
+"""CPU: the per-sample DEVICE arithmetic (stable-dreamfusion_amd/csrc/sdfx_math.h, built for
+the host by tests/hostmath) against the independent C oracle — bit-exact. This is the part of
+the HIP kernels that decides ray counts and hash indices; the wave-level structure around it
+is covered by the -m gpu tests."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import synth
+
+u32, f32, i32 = C.c_uint32, C.c_float, C.c_int
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _march_host(hostmath, o, d, bf, nears, fars, noises, bound=1.0, contract=0, dt_gamma=0.0, max_steps=1024, Cc=1, H=128):
+    N = o.shape[0]
+    counts = np.zeros(N, np.int32)
+    tbuf = np.zeros((N, max_steps), np.float32)
+    hostmath.hm_march_count(_p(o), _p(d), _p(bf), f32(bound), i32(contract), f32(dt_gamma), u32(max_steps), u32(N),
+                            u32(Cc), u32(H), _p(nears), _p(fars), _p(noises), _p(counts), _p(tbuf))
+    return counts, tbuf
+
+
+@pytest.mark.parametrize("gridname,view", [("init", 0), ("init", 5), ("blobs", 3), ("full", 1)])
+def test_march_bit_exact_vs_oracle(oracle, hostmath, gridname, view):
+    bf = {"init": lambda: synth.s_grid_init()[2], "blobs": synth.s_grid_blobs, "full": synth.s_grid_full}[gridname]()
+    o, d = synth.s_rays(view)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
+    noises = synth.s_noises(4096, seed=7 + view)
+    xyzs, dirs, ts, rays = oracle.march_rays_train(o, d, 1.0, bf, 1, 128, nears, fars, noises)
+    counts, tbuf = _march_host(hostmath, o, d, bf, nears, fars, noises)
+    assert np.array_equal(counts, rays[:, 1])
+    # replay the write pass for a few rays: positions and (t, dt) bit-exact
+    for n in np.argsort(-counts)[:4].tolist() + [int(np.argmax(counts > 0))]:
+        cnt = int(counts[n])
+        if cnt == 0:
+            continue
+        xs = np.zeros((cnt, 3), np.float32)
+        tt = np.zeros((cnt, 2), np.float32)
+        hostmath.hm_march_write(_p(o), _p(d), f32(1.0), i32(0), f32(0.0), u32(1024), u32(1), u32(128), u32(n), u32(cnt),
+                                _p(tbuf), _p(xs), _p(tt))
+        off = int(rays[n, 0])
+        assert np.array_equal(xs, xyzs[off:off + cnt])
+        assert np.array_equal(tt, ts[off:off + cnt])
+
+
+def test_march_cascades_contract_and_dt_gamma(oracle, hostmath):
+    """bound = 2 (two cascades), cone-angle stepping and L-inf contraction, bit-exact counts."""
+    bf = synth.s_grid_blobs(cascade=2, seed=5)
+    o, d = synth.s_rays(2)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-2, -2, -2, 2, 2, 2], np.float32), 0.2)
+    noises = synth.s_noises(4096, seed=3)
+    for contract, dt_gamma in ((0, 0.0), (0, 1.0 / 128), (1, 0.0)):
+        _, _, _, rays = oracle.march_rays_train(o, d, 2.0, bf, 2, 128, nears, fars, noises, dt_gamma=dt_gamma,
+                                                max_steps=512, contract=bool(contract))
+        counts, _ = _march_host(hostmath, o, d, bf, nears, fars, noises, bound=2.0, contract=contract, dt_gamma=dt_gamma,
+                                max_steps=512, Cc=2)
+        assert np.array_equal(counts, rays[:, 1]), (contract, dt_gamma)
+        assert counts.sum() > 0
+
+
+@pytest.mark.parametrize("gridtype,interp,align", [(0, 1, 0), (0, 0, 0), (1, 0, 1)])
+def test_grid_forward_bit_exact_vs_oracle(oracle, hostmath, gridtype, interp, align):
+    offsets, pls = oracle.grid_offsets(desired_resolution=2048)
+    table = synth.s_table(int(offsets[-1]), 2, "trained")
+    x = synth.s_points_uniform(2000, seed=21)
+    x[:5] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1.0, 0.0, 0.999999], [1.5, 0.2, 0.2]]
+    _, lbc, _ = oracle.grid_encode_forward(x, table, offsets, pls, 16, gridtype=gridtype, align_corners=bool(align),
+                                           interpolation=interp)
+    S = np.float32(np.log2(pls))
+    for level in range(16):
+        res = oracle.grid_resolution(level, S, 16)
+        out = np.zeros((x.shape[0], 2), np.float32)
+        hostmath.hm_grid_forward_d3c2(_p(x), _p(table), u32(x.shape[0]), u32(int(offsets[level])),
+                                      u32(int(offsets[level + 1] - offsets[level])), u32(res), u32(gridtype), i32(align),
+                                      u32(interp), _p(out))
+        assert np.array_equal(out, lbc[level]), level
