@@ -18,9 +18,10 @@ echo "bench exit: $?" | tee -a $OUT/summary.txt
 tail -3 $OUT/bench.err | tee -a $OUT/summary.txt
 cat $OUT/bench.json | tee -a $OUT/summary.txt
 if [ "${PROFILE:-1}" = "1" ]; then
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-bench > $OLDPWD/$OUT/prof.log 2>&1 )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-bench > $OLDPWD/$OUT/prof.log 2>&1 )
   echo "rocprof exit: $?" | tee -a $OUT/summary.txt
   find $OUT/prof -name "*kernel_stats*" | head -3 | tee -a $OUT/summary.txt
-  # keep the small summaries, drop the big traces
-  find $OUT/prof -name "*kernel_trace*" -size +8M -delete 2>/dev/null
+  # keep the small summaries, drop everything big (gpurun_out is capped at 64 MiB)
+  find $OUT/prof -type f -size +2M -delete 2>/dev/null
+  du -sh $OUT | tee -a $OUT/summary.txt
 fi
