@@ -152,6 +152,21 @@ int sdfx_grid_encode_backward(const void* grad, const float* inputs, const void*
                               uint32_t gridtype, int align_corners, uint32_t interp, int is_half, int grad_layout,
                               sdfx_stream_t stream);
 
+/*
+ * Extension — the same table gradient as sdfx_grid_encode_backward for D = 3, C = 2 (no dy_dx), computed
+ * by binning contributions per 2048-row bucket and reducing each bucket in LDS instead of issuing one
+ * device-scope atomic per (sample, level, corner). `scratch`: device memory of `scratch_bytes` bytes,
+ * 16-byte aligned; samples are processed in chunks that fit it (see *_scratch_bytes for sizing).
+ * Returns SDFX_E_UNSUPPORTED for other D / C so the caller can use sdfx_grid_encode_backward.
+ */
+int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, const int32_t* offsets_host,
+                                     void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                     uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                     uint32_t interp, int is_half, int grad_layout, void* scratch, uint64_t scratch_bytes,
+                                     sdfx_stream_t stream);
+uint64_t sdfx_grid_encode_backward_binned_scratch_bytes(const int32_t* offsets_host, uint32_t L, uint32_t max_level, float S,
+                                                         uint32_t H, uint32_t chunk_points, int is_half);
+
 /* gridencoder.cu:662-668 grad_total_variation (adds into grad; f32 or f16 by is_half) */
 int sdfx_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,
                               const int32_t* offsets_host, float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
@@ -181,6 +196,36 @@ int sdfx_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint
 /* shencoder.cu:419-439 sh_encode_backward(grad[B,C*C], inputs, B, D, C, dy_dx, grad_inputs[B,3] pre-zeroed, accumulated into) */
 int sdfx_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
                             const float* dy_dx, float* grad_inputs, sdfx_stream_t stream);
+
+/* ------------------------------------------------------------------------------- field */
+
+/*
+ * Extension — the field's "tiny MLP" fused into one kernel pair. Replaces, for the fp16-autocast -O
+ * configuration, nerf/network_grid.py:13-32 (sigma_net: Linear(32,64) ReLU Linear(64,64) ReLU Linear(64,4))
+ * plus the output activations of common_forward (:68-78): sigma = exp(h0 + density_blob(x)),
+ * albedo = sigmoid(h1..3); density_blob = nerf/renderer.py:338-349 ('exp' branch); the backward of the
+ * exp clamps its argument at 15 (activation.py:13-16). fp16 inputs and weights, float32 accumulation,
+ * layer outputs rounded to fp16 — the arithmetic of the autocast GEMMs it stands in for.
+ *
+ *   enc        fp16 features, enc_layout 0: [16, B, 2] (the encoder's level-major layout), 1: [B, 32]
+ *   x          [B, 3] float32 sample positions (world coordinates, for the density blob)
+ *   packed     sdfx_field_packed_words() 32-bit words written by sdfx_field_pack from the six float32
+ *              torch parameters (w1 [64,32], b1 [64], w2 [64,64], b2 [64], w3 [4,64], b3 [4])
+ *   sigma [B], albedo [B,3] float32 outputs; dsigma / dalbedo their gradients
+ *   denc       gradient of the features, fp16, same layout as enc
+ *   scratch    sdfx_field_backward_scratch_bytes(B) bytes (per-workgroup weight-gradient partial sums)
+ *   dw1..db3   float32 parameter gradients (overwritten)
+ */
+uint32_t sdfx_field_packed_words(void);
+uint64_t sdfx_field_backward_scratch_bytes(uint32_t B);
+int sdfx_field_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                    uint32_t* packed, sdfx_stream_t stream);
+int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const uint32_t* packed, uint32_t B,
+                       float blob_density, float blob_radius, float* sigma, float* albedo, sdfx_stream_t stream);
+int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const uint32_t* packed, uint32_t B,
+                        float blob_density, float blob_radius, const float* dsigma, const float* dalbedo, void* denc,
+                        float* scratch, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                        sdfx_stream_t stream);
 
 #ifdef __cplusplus
 }

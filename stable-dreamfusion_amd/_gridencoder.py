@@ -3,6 +3,7 @@ gridencoder/grid.py:10-13 tries `import _gridencoder as _backend` first)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -51,6 +52,27 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C_, L, max_l
            int(embeddings.dtype == torch.float16), out_layout, S.stream())
 
 
+# ---- binned scatter (D = 3, C = 2): persistent scratch per device -----------------------------------
+_BINNED = int(os.environ.get("SDFX_GRID_BWD_BINNED", "1"))
+_BINNED_CHUNK_POINTS = int(os.environ.get("SDFX_GRID_BWD_CHUNK", str(1 << 20)))
+_BINNED_SCRATCH = {}
+
+
+def _binned_scratch(device, offsets, L, max_level, S_, H, is_half):
+    key = (device.index, offsets.data_ptr(), max_level, is_half)
+    hit = _BINNED_SCRATCH.get(key)
+    if hit is None:
+        nbytes = int(S.lib().sdfx_grid_encode_backward_binned_scratch_bytes(offsets_host(offsets), L, max_level, float(S_), H,
+                                                                           _BINNED_CHUNK_POINTS, is_half))
+        if nbytes <= 0:
+            return None
+        hit = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if len(_BINNED_SCRATCH) > 8:
+            _BINNED_SCRATCH.clear()
+        _BINNED_SCRATCH[key] = hit
+    return hit
+
+
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C_, L, max_level, S_, H, dy_dx,
                          grad_inputs, gridtype, align_corners, interp, grad_layout=0):
     _table(grad, "grad")
@@ -65,6 +87,14 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
     if grad_inputs is not None:
         _table(grad_inputs, "grad_inputs")
         _same(grad, grad_inputs, "grad", "grad_inputs")
+    if _BINNED and D == 3 and C_ == 2 and dy_dx is None and B > 0:
+        is_half = int(grad.dtype == torch.float16)
+        scratch = _binned_scratch(grad.device, offsets, L, max_level, S_, H, is_half)
+        if scratch is not None:
+            S.call("sdfx_grid_encode_backward_binned", S.ptr(grad), S.ptr(inputs), offsets_host(offsets),
+                   S.ptr(grad_embeddings), B, D, C_, L, max_level, float(S_), H, gridtype, int(bool(align_corners)), interp,
+                   is_half, grad_layout, S.ptr(scratch), scratch.numel(), S.stream())
+            return
     S.call("sdfx_grid_encode_backward", S.ptr(grad), S.ptr(inputs), S.ptr(embeddings), S.ptr(offsets),
            offsets_host(offsets), S.ptr(grad_embeddings), B, D, C_, L, max_level, float(S_), H, S.ptr(dy_dx),
            S.ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, int(grad.dtype == torch.float16), grad_layout,

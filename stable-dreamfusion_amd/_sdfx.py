@@ -39,6 +39,9 @@ _SIGNATURES = {
                                  _int, _u32, _int, _int, _ptr],
     "sdfx_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _ptr,
                                   _ptr, _u32, _int, _u32, _int, _int, _ptr],
+    "sdfx_grid_encode_backward_binned": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
+                                         _int, _int, _ptr, _u64, _ptr],
+    "sdfx_grid_encode_backward_binned_scratch_bytes": [_ptr, _u32, _u32, _f32, _u32, _u32, _int],
     "sdfx_grad_total_variation": [_ptr, _ptr, _ptr, _ptr, _ptr, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int,
                                   _int, _ptr],
     "sdfx_grad_weight_decay": [_ptr, _ptr, _ptr, _f32, _u32, _u32, _u32, _int, _ptr],
@@ -46,10 +49,19 @@ _SIGNATURES = {
     "sdfx_freq_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _u32, _ptr, _ptr],
     "sdfx_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "sdfx_sh_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
+    "sdfx_field_packed_words": [],
+    "sdfx_field_backward_scratch_bytes": [_u32],
+    "sdfx_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_field_forward": [_ptr, _int, _ptr, _ptr, _u32, _f32, _f32, _ptr, _ptr, _ptr],
+    "sdfx_field_backward": [_ptr, _int, _ptr, _ptr, _u32, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                            _ptr, _ptr],
 }
 _RESTYPES = {
     "sdfx_march_rays_train_scratch_bytes": _u64,
     "sdfx_compact_rays_scratch_bytes": _u64,
+    "sdfx_grid_encode_backward_binned_scratch_bytes": _u64,
+    "sdfx_field_packed_words": _u32,
+    "sdfx_field_backward_scratch_bytes": _u64,
 }
 
 _LIB = None

@@ -1,0 +1,416 @@
+// field.hip — the "tiny MLP" of the Instant-NGP field as one fused gfx950 kernel pair.
+//
+// What it replaces: nerf/network_grid.py:13-32,68-78 — sigma_net = Linear(32,64) ReLU Linear(64,64) ReLU
+// Linear(64,4) run by torch under fp16 autocast (three skinny GEMMs + bias/ReLU/exp/sigmoid kernels
+// forward, six GEMMs backward — the weight-gradient GEMMs alone were ~30 % of an iteration on MI355X,
+// profiles/r01_v1_*), followed by sigma = trunc_exp(h0 + density_blob(x)), albedo = sigmoid(h1..3)
+// (activation.py:5-18, nerf/renderer.py:338-349). There is no native reference for this op; the
+// oracle is that torch module (tests/golden/field_ref.npz is generated from the reference's own MLP).
+//
+// Design (no MFMA: 12.8 kFLOP per sample next to ~600 B of gathers — this path is not a dense GEMM):
+//   * one thread per sample; activations live in registers as packed half2;
+//   * weights are wave-uniform, so they are fetched with scalar loads (s_load_dwordxN through the
+//     scalar cache) and feed v_dot2_f32_f16 directly as SGPR operands: 2 MACs per instruction with
+//     float32 accumulation — the arithmetic autocast GEMMs do (fp16 inputs, fp32 accumulate, fp16 out);
+//   * the backward recomputes the activations (nothing but the 64-byte feature row is re-read), forms
+//     d(features) per thread, and reduces the weight gradient inside the workgroup through an LDS
+//     staging tile ([sample][feature] halves) with each thread owning a 4x4 / 4x2 block of a weight
+//     matrix; per-workgroup partial sums are combined by a second tiny kernel (deterministic, no atomics);
+//   * features are read, and d(features) written, directly in the encoder's level-major [L, B, 2]
+//     layout (or [B, 32]), so the permute copies of gridencoder/grid.py:64,82 disappear on this path.
+#include "sdfx_common.h"
+
+using namespace sdfx;
+
+namespace {
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t kIn = 32, kHid = 64, kOut = 4;
+// packed parameter block (32-bit words)
+constexpr uint32_t kW1 = 0;                          // [64][16]  half2 over input pairs
+constexpr uint32_t kW2 = kW1 + kHid * kIn / 2;       // [64][32]
+constexpr uint32_t kW3 = kW2 + kHid * kHid / 2;      // [4][32]
+constexpr uint32_t kW3T = kW3 + kOut * kHid / 2;     // [64][2]   half2 over output pairs (transposed, for d-activations)
+constexpr uint32_t kW2T = kW3T + kHid * kOut / 2;    // [64][32]
+constexpr uint32_t kW1T = kW2T + kHid * kHid / 2;    // [32][32]
+constexpr uint32_t kB1 = kW1T + kIn * kHid / 2;      // [64] float (rounded to half)
+constexpr uint32_t kB2 = kB1 + kHid;
+constexpr uint32_t kB3 = kB2 + kHid;
+constexpr uint32_t kPackedWords = kB3 + kOut;        // 6532
+
+// gradient block (floats), same order as the torch parameters
+constexpr uint32_t gW1 = 0, gB1 = gW1 + kHid * kIn, gW2 = gB1 + kHid, gB2 = gW2 + kHid * kHid, gW3 = gB2 + kHid,
+                   gB3 = gW3 + kOut * kHid, kGradWords = gB3 + kOut;  // 6532
+
+constexpr uint32_t kThreads = 256;
+constexpr uint32_t kMaxBlocks = 512;
+
+__device__ __forceinline__ h2 as_h2(uint32_t w) { return __builtin_bit_cast(h2, w); }
+__device__ __forceinline__ uint32_t as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ h2 pack(float a, float b) { return h2{(_Float16)a, (_Float16)b}; }  // round-to-nearest-even
+__device__ __forceinline__ float dot2(uint32_t w, h2 v, float acc) { return __builtin_amdgcn_fdot2(as_h2(w), v, acc, false); }
+
+// ---- parameter packing -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_field_pack(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     const float* __restrict__ w3, const float* __restrict__ b3,
+                                                     uint32_t* __restrict__ packed) {
+    for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < kPackedWords; i += blockDim.x * gridDim.x) {
+        uint32_t v;
+        if (i < kW2) {  // W1[o][2kp, 2kp+1]
+            const uint32_t j = i - kW1, o = j / (kIn / 2), kp = j % (kIn / 2);
+            v = as_u32(pack(w1[o * kIn + 2 * kp], w1[o * kIn + 2 * kp + 1]));
+        } else if (i < kW3) {
+            const uint32_t j = i - kW2, o = j / (kHid / 2), kp = j % (kHid / 2);
+            v = as_u32(pack(w2[o * kHid + 2 * kp], w2[o * kHid + 2 * kp + 1]));
+        } else if (i < kW3T) {
+            const uint32_t j = i - kW3, o = j / (kHid / 2), kp = j % (kHid / 2);
+            v = as_u32(pack(w3[o * kHid + 2 * kp], w3[o * kHid + 2 * kp + 1]));
+        } else if (i < kW2T) {  // W3^T[k][2op, 2op+1]
+            const uint32_t j = i - kW3T, k = j / (kOut / 2), op = j % (kOut / 2);
+            v = as_u32(pack(w3[(2 * op) * kHid + k], w3[(2 * op + 1) * kHid + k]));
+        } else if (i < kW1T) {  // W2^T[k][2op, 2op+1]
+            const uint32_t j = i - kW2T, k = j / (kHid / 2), op = j % (kHid / 2);
+            v = as_u32(pack(w2[(2 * op) * kHid + k], w2[(2 * op + 1) * kHid + k]));
+        } else if (i < kB1) {   // W1^T[k][2op, 2op+1]
+            const uint32_t j = i - kW1T, k = j / (kHid / 2), op = j % (kHid / 2);
+            v = as_u32(pack(w1[(2 * op) * kIn + k], w1[(2 * op + 1) * kIn + k]));
+        } else {                // biases: float value of the half-rounded parameter
+            const uint32_t j = i - kB1;
+            const float b = j < kHid ? b1[j] : (j < 2 * kHid ? b2[j - kHid] : b3[j - 2 * kHid]);
+            v = __builtin_bit_cast(uint32_t, (float)(_Float16)b);
+        }
+        packed[i] = v;
+    }
+}
+
+// ---- per-sample forward pieces ---------------------------------------------------------------
+struct Acts {
+    h2 enc[kIn / 2];
+    h2 h1[kHid / 2];
+    h2 h2_[kHid / 2];
+    float h3[kOut];  // float value of the half-rounded layer output
+};
+
+// features of sample b as 16 half2 (one per level). layout 0: [L, B, 2]; 1: [B, 32]
+__device__ __forceinline__ void load_enc(const uint32_t* __restrict__ enc, int layout, uint32_t B, uint32_t b, h2 (&e)[kIn / 2]) {
+    if (layout == 0) {
+#pragma unroll
+        for (uint32_t l = 0; l < kIn / 2; l++) e[l] = as_h2(enc[(size_t)l * B + b]);
+    } else {
+        const uint4* row = reinterpret_cast<const uint4*>(enc + (size_t)b * (kIn / 2));
+#pragma unroll
+        for (uint32_t q = 0; q < kIn / 8; q++) {
+            const uint4 v = row[q];
+            e[q * 4 + 0] = as_h2(v.x); e[q * 4 + 1] = as_h2(v.y); e[q * 4 + 2] = as_h2(v.z); e[q * 4 + 3] = as_h2(v.w);
+        }
+    }
+}
+
+__device__ __forceinline__ void mlp_forward(const uint32_t* __restrict__ P, Acts& a) {
+    const float* bias = reinterpret_cast<const float*>(P);
+    // layer 1: 32 -> 64, ReLU, rounded to half as an autocast Linear output is
+#pragma unroll
+    for (uint32_t op = 0; op < kHid / 2; op++) {
+        float acc0 = bias[kB1 + 2 * op], acc1 = bias[kB1 + 2 * op + 1];
+#pragma unroll
+        for (uint32_t kp = 0; kp < kIn / 2; kp++) {
+            acc0 = dot2(P[kW1 + (2 * op) * (kIn / 2) + kp], a.enc[kp], acc0);
+            acc1 = dot2(P[kW1 + (2 * op + 1) * (kIn / 2) + kp], a.enc[kp], acc1);
+        }
+        a.h1[op] = pack(fmaxf(acc0, 0.f), fmaxf(acc1, 0.f));
+    }
+    // layer 2: 64 -> 64, ReLU
+#pragma unroll
+    for (uint32_t op = 0; op < kHid / 2; op++) {
+        float acc0 = bias[kB2 + 2 * op], acc1 = bias[kB2 + 2 * op + 1];
+#pragma unroll
+        for (uint32_t kp = 0; kp < kHid / 2; kp++) {
+            acc0 = dot2(P[kW2 + (2 * op) * (kHid / 2) + kp], a.h1[kp], acc0);
+            acc1 = dot2(P[kW2 + (2 * op + 1) * (kHid / 2) + kp], a.h1[kp], acc1);
+        }
+        a.h2_[op] = pack(fmaxf(acc0, 0.f), fmaxf(acc1, 0.f));
+    }
+    // layer 3: 64 -> 4
+#pragma unroll
+    for (uint32_t o = 0; o < kOut; o++) {
+        float acc = bias[kB3 + o];
+#pragma unroll
+        for (uint32_t kp = 0; kp < kHid / 2; kp++) acc = dot2(P[kW3 + o * (kHid / 2) + kp], a.h2_[kp], acc);
+        a.h3[o] = (float)(_Float16)acc;
+    }
+}
+
+// density blob of nerf/renderer.py:345: blob_density * exp(-|x|^2 / (2 r^2))
+__device__ __forceinline__ float density_blob(const float* __restrict__ x, uint32_t b, float blob_density, float inv_2r2) {
+    const float px = x[(size_t)b * 3], py = x[(size_t)b * 3 + 1], pz = x[(size_t)b * 3 + 2];
+    const float d = px * px + py * py + pz * pz;
+    return blob_density * expf(-d * inv_2r2);
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// =========================================================================================
+// forward: features -> (sigma, albedo)
+// =========================================================================================
+__global__ __launch_bounds__(kThreads) void k_field_forward(const uint32_t* __restrict__ enc, int enc_layout,
+                                                             const float* __restrict__ x,
+                                                             const uint32_t* __restrict__ P, uint32_t B,
+                                                             float blob_density, float inv_2r2,
+                                                             float* __restrict__ sigma, float* __restrict__ albedo) {
+    const uint32_t b = blockIdx.x * kThreads + threadIdx.x;
+    if (b >= B) return;
+    Acts a;
+    load_enc(enc, enc_layout, B, b, a.enc);
+    mlp_forward(P, a);
+    const float z = a.h3[0] + density_blob(x, b, blob_density, inv_2r2);
+    sigma[b] = expf(z);  // trunc_exp forward (activation.py:9-11)
+    albedo[(size_t)b * 3 + 0] = sigmoidf_(a.h3[1]);
+    albedo[(size_t)b * 3 + 1] = sigmoidf_(a.h3[2]);
+    albedo[(size_t)b * 3 + 2] = sigmoidf_(a.h3[3]);
+}
+
+// =========================================================================================
+// backward: (d sigma, d albedo) -> d features, per-workgroup weight-gradient partial sums
+// =========================================================================================
+constexpr uint32_t kStageStride = 64;  // words per staged sample; word i of sample p lives at (i + p) & 63 (bank rotation)
+#define STG(p, i) (((i) + (p)) & 63u)
+
+__global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __restrict__ enc, int enc_layout,
+                                                              const float* __restrict__ x,
+                                                              const uint32_t* __restrict__ P, uint32_t B,
+                                                              float blob_density, float inv_2r2,
+                                                              const float* __restrict__ dsigma,
+                                                              const float* __restrict__ dalbedo,
+                                                              uint32_t* __restrict__ denc,
+                                                              float* __restrict__ partials) {
+    __shared__ uint32_t stage[kThreads * kStageStride];
+    const uint32_t t = threadIdx.x;
+    // this thread's share of the weight gradient
+    const uint32_t o4 = (t >> 4) * 4;   // 4 output rows   (W2, W1)
+    const uint32_t k4 = (t & 15) * 4;   // 4 input columns (W2)
+    const uint32_t k2 = (t & 15) * 2;   // 2 input columns (W1)
+    const uint32_t o3 = t >> 6, k3 = t & 63;  // one entry of W3
+    float gw2[4][4], gw1[4][2], gw3 = 0.f, gb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) gw2[i][j] = 0.f;
+        gw1[i][0] = 0.f; gw1[i][1] = 0.f;
+    }
+
+    const uint32_t ntiles = (B + kThreads - 1) / kThreads;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t b = tile * kThreads + t;
+        const bool valid = b < B;
+        Acts a;
+        h2 dh1[kHid / 2], dh2[kHid / 2], dh3[kOut / 2];
+        if (valid) {
+            load_enc(enc, enc_layout, B, b, a.enc);
+            mlp_forward(P, a);
+            // output activations: d sigma / d z = exp(min(z, 15)) (activation.py:13-16); d sigmoid = a (1 - a)
+            const float z = a.h3[0] + density_blob(x, b, blob_density, inv_2r2);
+            const float g0 = dsigma[b] * expf(fminf(z, 15.0f));
+            float g[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float s = sigmoidf_(a.h3[1 + c]);
+                g[c] = dalbedo[(size_t)b * 3 + c] * s * (1.0f - s);
+            }
+            dh3[0] = pack(g0, g[0]);
+            dh3[1] = pack(g[1], g[2]);
+            // d h2 = relu'(h2) * W3^T d h3
+#pragma unroll
+            for (uint32_t kp = 0; kp < kHid / 2; kp++) {
+                float v0 = dot2(P[kW3T + (2 * kp) * 2], dh3[0], 0.f);
+                v0 = dot2(P[kW3T + (2 * kp) * 2 + 1], dh3[1], v0);
+                float v1 = dot2(P[kW3T + (2 * kp + 1) * 2], dh3[0], 0.f);
+                v1 = dot2(P[kW3T + (2 * kp + 1) * 2 + 1], dh3[1], v1);
+                const h2 act = a.h2_[kp];
+                dh2[kp] = pack(act.x > (_Float16)0 ? v0 : 0.f, act.y > (_Float16)0 ? v1 : 0.f);
+            }
+            // d h1 = relu'(h1) * W2^T d h2
+#pragma unroll
+            for (uint32_t kp = 0; kp < kHid / 2; kp++) {
+                float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+                for (uint32_t op = 0; op < kHid / 2; op++) {
+                    v0 = dot2(P[kW2T + (2 * kp) * (kHid / 2) + op], dh2[op], v0);
+                    v1 = dot2(P[kW2T + (2 * kp + 1) * (kHid / 2) + op], dh2[op], v1);
+                }
+                const h2 act = a.h1[kp];
+                dh1[kp] = pack(act.x > (_Float16)0 ? v0 : 0.f, act.y > (_Float16)0 ? v1 : 0.f);
+            }
+            // d features = W1^T d h1, written in the layout the features came in
+#pragma unroll
+            for (uint32_t kp = 0; kp < kIn / 2; kp++) {
+                float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+                for (uint32_t op = 0; op < kHid / 2; op++) {
+                    v0 = dot2(P[kW1T + (2 * kp) * (kHid / 2) + op], dh1[op], v0);
+                    v1 = dot2(P[kW1T + (2 * kp + 1) * (kHid / 2) + op], dh1[op], v1);
+                }
+                const uint32_t w = as_u32(pack(v0, v1));
+                if (enc_layout == 0) denc[(size_t)kp * B + b] = w;
+                else denc[(size_t)b * (kIn / 2) + kp] = w;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < kHid / 2; i++) { a.h1[i] = h2{0, 0}; a.h2_[i] = h2{0, 0}; dh1[i] = h2{0, 0}; dh2[i] = h2{0, 0}; }
+#pragma unroll
+            for (uint32_t i = 0; i < kIn / 2; i++) a.enc[i] = h2{0, 0};
+            dh3[0] = h2{0, 0}; dh3[1] = h2{0, 0};
+        }
+
+        uint32_t* row = stage + t * kStageStride;
+        // ---- dW2 += dh2 (x) h1 ; db2 += dh2 --------------------------------------------------
+        __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < kHid / 2; i++) { row[STG(t, i)] = as_u32(a.h1[i]); row[STG(t, 32 + i)] = as_u32(dh2[i]); }
+        __syncthreads();
+        for (uint32_t p = 0; p < kThreads; p++) {
+            const uint32_t* r = stage + p * kStageStride;
+            const h2 i0 = as_h2(r[STG(p, k4 / 2)]), i1 = as_h2(r[STG(p, k4 / 2 + 1)]);
+            const h2 d0 = as_h2(r[STG(p, 32 + o4 / 2)]), d1 = as_h2(r[STG(p, 32 + o4 / 2 + 1)]);
+            const float in[4] = {(float)i0.x, (float)i0.y, (float)i1.x, (float)i1.y};
+            const float dd[4] = {(float)d0.x, (float)d0.y, (float)d1.x, (float)d1.y};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) gw2[i][j] = fmaf(dd[i], in[j], gw2[i][j]);
+            if (t < 64) {            // db2[t]
+                const h2 v = as_h2(r[STG(p, 32 + t / 2)]);
+                gb += (t & 1) ? (float)v.y : (float)v.x;
+            }
+        }
+        // ---- dW1 += dh1 (x) enc ; db1 += dh1 -------------------------------------------------
+        __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < kIn / 2; i++) row[STG(t, i)] = as_u32(a.enc[i]);
+#pragma unroll
+        for (uint32_t i = 0; i < kHid / 2; i++) row[STG(t, 32 + i)] = as_u32(dh1[i]);
+        __syncthreads();
+        for (uint32_t p = 0; p < kThreads; p++) {
+            const uint32_t* r = stage + p * kStageStride;
+            const h2 i0 = as_h2(r[STG(p, k2 / 2)]);
+            const h2 d0 = as_h2(r[STG(p, 32 + o4 / 2)]), d1 = as_h2(r[STG(p, 32 + o4 / 2 + 1)]);
+            const float dd[4] = {(float)d0.x, (float)d0.y, (float)d1.x, (float)d1.y};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                gw1[i][0] = fmaf(dd[i], (float)i0.x, gw1[i][0]);
+                gw1[i][1] = fmaf(dd[i], (float)i0.y, gw1[i][1]);
+            }
+            if (t >= 64 && t < 128) {  // db1[t - 64]
+                const h2 v = as_h2(r[STG(p, 32 + (t - 64) / 2)]);
+                gb += (t & 1) ? (float)v.y : (float)v.x;
+            }
+        }
+        // ---- dW3 += dh3 (x) h2 ; db3 += dh3 --------------------------------------------------
+        __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < kHid / 2; i++) row[STG(t, i)] = as_u32(a.h2_[i]);
+        row[STG(t, 32)] = as_u32(dh3[0]);
+        row[STG(t, 33)] = as_u32(dh3[1]);
+        __syncthreads();
+        for (uint32_t p = 0; p < kThreads; p++) {
+            const uint32_t* r = stage + p * kStageStride;
+            const h2 iv = as_h2(r[STG(p, k3 / 2)]);
+            const h2 dv = as_h2(r[STG(p, 32 + o3 / 2)]);
+            const float in = (k3 & 1) ? (float)iv.y : (float)iv.x;
+            const float dd = (o3 & 1) ? (float)dv.y : (float)dv.x;
+            gw3 = fmaf(dd, in, gw3);
+            if (t >= 128 && t < 132) {  // db3[t - 128]
+                const h2 v = as_h2(r[STG(p, 32 + (t - 128) / 2)]);
+                gb += (t & 1) ? (float)v.y : (float)v.x;
+            }
+        }
+    }
+
+    // per-workgroup partial sums, laid out like the torch parameters
+    float* out = partials + (size_t)blockIdx.x * kGradWords;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) out[gW2 + (o4 + i) * kHid + k4 + j] = gw2[i][j];
+        out[gW1 + (o4 + i) * kIn + k2] = gw1[i][0];
+        out[gW1 + (o4 + i) * kIn + k2 + 1] = gw1[i][1];
+    }
+    out[gW3 + o3 * kHid + k3] = gw3;
+    if (t < 64) out[gB2 + t] = gb;
+    else if (t < 128) out[gB1 + (t - 64)] = gb;
+    else if (t < 132) out[gB3 + (t - 128)] = gb;
+}
+
+// sum the per-workgroup partials into the six parameter gradients
+__global__ __launch_bounds__(256) void k_field_wgrad_reduce(const float* __restrict__ partials, uint32_t nblocks,
+                                                             float* __restrict__ dw1, float* __restrict__ db1,
+                                                             float* __restrict__ dw2, float* __restrict__ db2,
+                                                             float* __restrict__ dw3, float* __restrict__ db3) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kGradWords) return;
+    float s = 0.f;
+    for (uint32_t k = 0; k < nblocks; k++) s += partials[(size_t)k * kGradWords + i];
+    if (i < gB1) dw1[i - gW1] = s;
+    else if (i < gW2) db1[i - gB1] = s;
+    else if (i < gB2) dw2[i - gW2] = s;
+    else if (i < gW3) db2[i - gB2] = s;
+    else if (i < gB3) dw3[i - gW3] = s;
+    else db3[i - gB3] = s;
+}
+
+uint32_t backward_blocks(uint32_t B) {
+    const uint32_t tiles = div_up(B, kThreads);
+    return tiles < kMaxBlocks ? tiles : kMaxBlocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t sdfx_field_packed_words(void) { return kPackedWords; }
+
+uint64_t sdfx_field_backward_scratch_bytes(uint32_t B) { return (uint64_t)backward_blocks(B ? B : 1) * kGradWords * sizeof(float); }
+
+int sdfx_field_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                    uint32_t* packed, sdfx_stream_t stream) {
+    SDFX_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && packed, "field_pack: null pointer");
+    hipLaunchKernelGGL(k_field_pack, dim3(8), dim3(256), 0, as_stream(stream), w1, b1, w2, b2, w3, b3, packed);
+    return check_launch("field_pack");
+}
+
+int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const uint32_t* packed, uint32_t B,
+                       float blob_density, float blob_radius, float* sigma, float* albedo, sdfx_stream_t stream) {
+    SDFX_REQUIRE(enc && x && packed && sigma && albedo, "field_forward: null pointer");
+    SDFX_REQUIRE(enc_layout == 0 || enc_layout == 1, "field_forward: enc_layout must be 0 ([L,B,2]) or 1 ([B,32])");
+    SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_forward: features misaligned");
+    SDFX_REQUIRE(blob_radius > 0, "field_forward: blob_radius must be positive");
+    if (B == 0) return SDFX_OK;
+    hipLaunchKernelGGL(k_field_forward, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                       static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
+                       1.0f / (2 * blob_radius * blob_radius), sigma, albedo);
+    return check_launch("field_forward");
+}
+
+int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const uint32_t* packed, uint32_t B,
+                        float blob_density, float blob_radius, const float* dsigma, const float* dalbedo, void* denc,
+                        float* scratch, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                        sdfx_stream_t stream) {
+    SDFX_REQUIRE(enc && x && packed && dsigma && dalbedo && denc && scratch && dw1 && db1 && dw2 && db2 && dw3 && db3,
+                 "field_backward: null pointer");
+    SDFX_REQUIRE(enc_layout == 0 || enc_layout == 1, "field_backward: enc_layout must be 0 ([L,B,2]) or 1 ([B,32])");
+    SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_backward: features misaligned");
+    SDFX_REQUIRE(blob_radius > 0, "field_backward: blob_radius must be positive");
+    hipStream_t st = as_stream(stream);
+    const uint32_t nblocks = B ? backward_blocks(B) : 0;
+    if (B) {
+        hipLaunchKernelGGL(k_field_backward, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
+                           enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
+                           static_cast<uint32_t*>(denc), scratch);
+    }
+    hipLaunchKernelGGL(k_field_wgrad_reduce, dim3(div_up(kGradWords, 256)), dim3(256), 0, st, scratch, nblocks, dw1, db1,
+                       dw2, db2, dw3, db3);
+    return check_launch("field_backward");
+}
+
+}  // extern "C"

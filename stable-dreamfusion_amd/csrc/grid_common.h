@@ -1,0 +1,166 @@
+// grid_common.h — launch plan, table element types and per-corner arithmetic shared by the
+// grid-encoder translation units (gridencoder.hip, gridencoder_bwd_binned.hip).
+#pragma once
+
+#include "sdfx_common.h"
+
+#include <math.h>
+
+namespace sdfx {
+namespace grid {
+
+constexpr uint32_t kMaxLevels = 32;
+constexpr uint32_t kXcds = 8;
+constexpr uint32_t kTile = 256;  // work items per workgroup
+
+struct GridPlan {
+    uint32_t res[kMaxLevels];      // per-level resolution
+    uint32_t off[kMaxLevels + 1];  // per-level first row (host copy of `offsets`)
+    uint32_t start[kXcds];         // [start, end) item range of each XCD in the level-major list
+    uint32_t end[kXcds];
+    uint32_t tiles;                // tiles per level
+};
+
+// (uint32_t)ceil(exp2f(level * S) * H) in float32 — gridencoder.cu:133
+inline uint32_t level_resolution(uint32_t level, float S, uint32_t H) {
+    return (uint32_t)ceilf(exp2f((float)level * S) * (float)H);
+}
+
+// Build the plan: resolutions, offsets, and the per-XCD ranges of the level-major item list.
+// Levels whose table slice is small enough to live in L1/L2 next to anything else cost less
+// per tile than the multi-MiB hashed levels; ranges are balanced on that estimate.
+inline GridPlan make_plan(const int32_t* offsets_host, uint32_t levels, float S, uint32_t H, uint32_t C, uint32_t elem_bytes,
+                   uint64_t items_per_level) {
+    GridPlan p;
+    memset(&p, 0, sizeof(p));
+    for (uint32_t l = 0; l < levels; l++) {
+        p.res[l] = level_resolution(l, S, H);
+        p.off[l] = (uint32_t)offsets_host[l];
+    }
+    p.off[levels] = (uint32_t)offsets_host[levels];
+    p.tiles = div_up(items_per_level, kTile);
+    double cost[kMaxLevels];
+    double total = 0;
+    for (uint32_t l = 0; l < levels; l++) {
+        const double bytes = (double)(p.off[l + 1] - p.off[l]) * C * elem_bytes;
+        cost[l] = bytes > 512.0 * 1024.0 ? 1.0 : 0.4;
+        total += cost[l] * p.tiles;
+    }
+    // boundary k sits where the cumulative cost reaches k * total / 8
+    uint32_t bound[kXcds + 1];
+    bound[0] = 0;
+    bound[kXcds] = levels * p.tiles;
+    uint32_t l = 0;
+    double cum = 0;  // cost of all complete levels before l
+    for (uint32_t k = 1; k < kXcds; k++) {
+        const double target = total * k / kXcds;
+        while (l < levels && cum + cost[l] * p.tiles <= target) {
+            cum += cost[l] * p.tiles;
+            l++;
+        }
+        uint32_t item = l * p.tiles;
+        if (l < levels) {
+            uint32_t within = (uint32_t)((target - cum) / cost[l]);
+            if (within > p.tiles) within = p.tiles;
+            item += within;
+        }
+        if (item < bound[k - 1]) item = bound[k - 1];
+        bound[k] = item;
+    }
+    for (uint32_t k = 0; k < kXcds; k++) {
+        p.start[k] = bound[k];
+        p.end[k] = bound[k + 1];
+    }
+    return p;
+}
+
+inline uint32_t plan_grid_size(const GridPlan& p) {
+    uint32_t longest = 0;
+    for (uint32_t k = 0; k < kXcds; k++) {
+        const uint32_t len = p.end[k] - p.start[k];
+        if (len > longest) longest = len;
+    }
+    return longest * kXcds;
+}
+
+// workgroup -> (level, tile); false when this workgroup has no item
+__device__ __forceinline__ bool plan_item(const GridPlan& p, uint32_t& level, uint32_t& tile) {
+    const uint32_t xcd = blockIdx.x % kXcds;
+    const uint32_t item = p.start[xcd] + blockIdx.x / kXcds;
+    if (item >= p.end[xcd]) return false;
+    level = item / p.tiles;
+    tile = item - level * p.tiles;
+    return true;
+}
+
+// ---- table element types ----------------------------------------------------------------
+template <bool HALF> struct Elem;
+template <> struct Elem<false> {
+    using type = float;
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+    // value as the reference's scalar_t would hold it
+    static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <> struct Elem<true> {
+    using type = __half;
+    static __device__ __forceinline__ float load(const __half* p) { return __half2float(*p); }
+    static __device__ __forceinline__ void store(__half* p, float v) { *p = __float2half_rn(v); }
+    static __device__ __forceinline__ float round(float v) { return __half2float(__float2half_rn(v)); }
+};
+
+// One vertex row = C elements. Rows are loaded / stored as a few wide words.
+template <typename T, uint32_t C>
+struct Row {
+    static constexpr uint32_t kBytes = sizeof(T) * C;
+    static constexpr uint32_t kWord = kBytes >= 16 ? 16 : kBytes;  // bytes per access (2..16)
+    static constexpr uint32_t kWords = kBytes / kWord;
+    T v[C];
+
+    __device__ __forceinline__ void load(const T* p) {
+        if constexpr (kWord == 16) {
+#pragma unroll
+            for (uint32_t i = 0; i < kWords; i++) reinterpret_cast<uint4*>(v)[i] = reinterpret_cast<const uint4*>(p)[i];
+        } else if constexpr (kWord == 8) {
+            *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(p);
+        } else if constexpr (kWord == 4) {
+            *reinterpret_cast<uint32_t*>(v) = *reinterpret_cast<const uint32_t*>(p);
+        } else {
+            v[0] = p[0];
+        }
+    }
+    __device__ __forceinline__ void store(T* p) const {
+        if constexpr (kWord == 16) {
+#pragma unroll
+            for (uint32_t i = 0; i < kWords; i++) reinterpret_cast<uint4*>(p)[i] = reinterpret_cast<const uint4*>(v)[i];
+        } else if constexpr (kWord == 8) {
+            *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(v);
+        } else if constexpr (kWord == 4) {
+            *reinterpret_cast<uint32_t*>(p) = *reinterpret_cast<const uint32_t*>(v);
+        } else {
+            p[0] = v[0];
+        }
+    }
+};
+
+// corner `idx` of the cell: weight and vertex coordinates (gridencoder.cu:171-184)
+template <uint32_t D>
+__device__ __forceinline__ float corner(uint32_t idx, const float pos[D], const uint32_t pos_grid[D], uint32_t resolution,
+                                        uint32_t pgl[D]) {
+    float w = 1;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if ((idx & (1u << d)) == 0) {
+            w *= 1 - pos[d];
+            pgl[d] = pos_grid[d];
+        } else {
+            w *= pos[d];
+            pgl[d] = min(pos_grid[d] + 1, resolution - 1);
+        }
+    }
+    return w;
+}
+
+
+}  // namespace grid
+}  // namespace sdfx

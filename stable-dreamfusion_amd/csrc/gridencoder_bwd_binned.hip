@@ -1,0 +1,406 @@
+// gridencoder_bwd_binned.hip — table-gradient scatter of the hash-grid encoder without a global
+// atomic per contribution (D = 3, C = 2: the configuration the -O path trains).
+//
+// Why: on MI355X a device-scope atomic is executed at the memory side of the fabric (the per-XCD
+// L2s are not coherent with each other), at ~18 G atomics/s for random addresses and far less when
+// neighbouring samples of a ray hammer the same coarse cell. The reference's scheme — one atomic per
+// (sample, level, corner), gridencoder.cu:252-349 — needs 128 atomics per sample and took 9.9 ms per
+// call at 4.2e5 samples (rocprof, profiles/r01_v1_*). This file replaces it by a two-kernel
+// "bin, then reduce in LDS" scatter:
+//
+//   K1 bin     every (sample, level, corner) contribution becomes an 8/12-byte item {row, value}.
+//              Lanes hold consecutive samples of a ray, so at coarse and middle levels runs of lanes
+//              hit the same table row: a wave-level segmented scan folds each run into one item.
+//              Items are binned by row range (2048 rows per bucket) with an LDS histogram and ONE
+//              global atomic per (workgroup, bucket) that reserves a slice of the bucket's item list.
+//   K2 reduce  one workgroup per bucket (several for over-full coarse buckets) sums its items into a
+//              2048 x 2 float accumulator in LDS and adds it to the table gradient with plain,
+//              coalesced read-modify-writes (the workgroup owns those rows).
+//
+// Items that do not fit a bucket's reserved capacity fall back to a direct global atomic in K1, so
+// the result is complete for any input distribution. Sums are formed in float32 and rounded to the
+// table type once (the reference rounds every contribution to half before adding, gridencoder.cu:338).
+#include "grid_common.h"
+
+using namespace sdfx;
+using namespace sdfx::grid;
+
+namespace {
+
+constexpr uint32_t kBucketRowsLog2 = 11;
+constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;  // rows per bucket (16 KiB of float2 accumulators)
+constexpr uint32_t kMaxBucketsPerLevel = 512;            // levels up to 2^20 rows
+constexpr uint32_t kBinThreads = 256;
+constexpr uint32_t kPointsPerThread = 2;
+constexpr uint32_t kReduceThreads = 256;
+constexpr uint32_t kItemsPerSplit = 32768;               // target items per K2 workgroup
+constexpr uint32_t kMaxSplits = 64;
+
+struct BinPlan {
+    uint32_t bucket_first[kMaxLevels + 1];  // first bucket id of each level (prefix sum)
+    uint32_t split_first[kMaxLevels + 1];   // first K2 workgroup id of each level
+    uint32_t splits[kMaxLevels];            // K2 workgroups per bucket of this level
+    uint32_t cap[kMaxLevels];               // item capacity of one bucket of this level
+    uint32_t item_first[kMaxLevels];        // first item slot (in units of 1024 items) of the level's bucket 0
+    uint32_t merge_mask;                    // bit l: fold lane runs at level l before binning
+    uint32_t levels;
+};
+
+template <bool HALF> struct Item;
+template <> struct Item<true> {   // {row in level, half2 contribution}
+    uint32_t row;
+    uint32_t val;
+    static __device__ __forceinline__ Item make(uint32_t row, float a, float b) {
+        Item it;
+        it.row = row;
+        const __half2 h = __halves2half2(__float2half_rn(a), __float2half_rn(b));
+        it.val = *reinterpret_cast<const uint32_t*>(&h);
+        return it;
+    }
+    __device__ __forceinline__ float2 value() const {
+        const __half2 h = *reinterpret_cast<const __half2*>(&val);
+        return make_float2(__low2float(h), __high2float(h));
+    }
+};
+template <> struct Item<false> {  // {row in level, float2 contribution}
+    uint32_t row;
+    float a, b;
+    static __device__ __forceinline__ Item make(uint32_t row, float a, float b) {
+        Item it;
+        it.row = row; it.a = a; it.b = b;
+        return it;
+    }
+    __device__ __forceinline__ float2 value() const { return make_float2(a, b); }
+};
+
+// fold runs of equal `key` among neighbouring lanes: after the call the LAST lane of every run holds
+// the run's sums and returns true; the other lanes return false.
+__device__ __forceinline__ bool fold_lane_runs(uint32_t key, bool active, float& a, float& b, int lane) {
+    // inactive lanes get a key no active lane can have, so they break runs and are never emitted
+    const uint32_t k = active ? key : (0xFFFFFFFFu - (uint32_t)lane);
+    const uint32_t prev = __shfl_up(k, 1, kWave);
+    bool head = (lane == 0) || (prev != k);
+    bool f = head;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const float au = __shfl_up(a, o, kWave);
+        const float bu = __shfl_up(b, o, kWave);
+        const int fu = __shfl_up((int)f, o, kWave);
+        if (lane >= o && !f) {
+            a += au;
+            b += bu;
+            f = fu != 0;
+        }
+    }
+    const int next_head = __shfl_down((int)head, 1, kWave);
+    const bool tail = (lane == kWave - 1) || (next_head != 0);
+    return active && tail;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: contributions -> binned items
+// ---------------------------------------------------------------------------------------------
+template <bool HALF>
+__global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,
+                                                               const float* __restrict__ inputs,
+                                                               typename Elem<HALF>::type* __restrict__ grad_table,
+                                                               uint32_t B, uint32_t L, uint32_t b0, uint32_t b1,
+                                                               GridPlan plan, BinPlan bin, uint32_t gridtype,
+                                                               int align_corners, uint32_t interp, int grad_layout,
+                                                               uint32_t* __restrict__ cursors,
+                                                               Item<HALF>* __restrict__ items) {
+    using T = typename Elem<HALF>::type;
+    using E = Elem<HALF>;
+    constexpr uint32_t D = 3, C = 2, NCORN = 8, NITEM = NCORN * kPointsPerThread;
+    __shared__ uint32_t hist[kMaxBucketsPerLevel];
+    __shared__ uint32_t gbase[kMaxBucketsPerLevel];
+
+    uint32_t level, tile;
+    const bool has_item = plan_item(plan, level, tile);  // wave-uniform (depends on blockIdx only)
+    if (!has_item) return;
+    const int lane = lane_id();
+    const uint32_t nb = bin.bucket_first[level + 1] - bin.bucket_first[level];
+    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) hist[i] = 0;
+    __syncthreads();
+
+    const uint32_t resolution = plan.res[level];
+    const uint32_t row0 = plan.off[level];
+    const uint32_t hashmap_size = plan.off[level + 1] - row0;
+    const bool merge = (bin.merge_mask >> level) & 1u;
+
+    uint32_t rows[NITEM];
+    float va[NITEM], vb[NITEM];
+    uint32_t rank[NITEM];
+    uint32_t alive = 0;  // bit i: item i is emitted by this lane
+
+#pragma unroll
+    for (uint32_t k = 0; k < kPointsPerThread; k++) {
+        const uint32_t b = b0 + tile * (kBinThreads * kPointsPerThread) + k * kBinThreads + threadIdx.x;
+        bool valid = b < b1;
+        float in[D] = {0.f, 0.f, 0.f};
+        if (valid) {
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                in[d] = inputs[(size_t)b * D + d];
+                if (in[d] < 0 || in[d] > 1) valid = false;  // gridencoder.cu:279-284
+            }
+        }
+        float pos[D], pos_deriv[D];
+        uint32_t pos_grid[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++)
+            grid_locate_axis(valid ? in[d] : 0.f, resolution, align_corners != 0, interp, pos[d], pos_deriv[d], pos_grid[d]);
+        float g0 = 0.f, g1 = 0.f;
+        if (valid) {
+            const T* g = grad_layout == 0 ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * L + level) * C;
+            g0 = E::load(g);
+            g1 = E::load(g + 1);
+        }
+#pragma unroll
+        for (uint32_t idx = 0; idx < NCORN; idx++) {
+            const uint32_t i = k * NCORN + idx;
+            uint32_t pgl[D];
+            const float w = corner<D>(idx, pos, pos_grid, resolution, pgl);
+            rows[i] = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+            va[i] = w * g0;
+            vb[i] = w * g1;
+            bool emit = valid;
+            if (merge) emit = fold_lane_runs(rows[i], valid, va[i], vb[i], lane);  // all lanes participate
+            if (emit) {
+                alive |= 1u << i;
+                rank[i] = atomicAdd(&hist[rows[i] >> kBucketRowsLog2], 1u);  // LDS
+            }
+        }
+    }
+    __syncthreads();
+    // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's item list
+    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) {
+        const uint32_t cnt = hist[i];
+        gbase[i] = cnt ? atomicAdd(&cursors[bin.bucket_first[level] + i], cnt) : 0u;
+    }
+    __syncthreads();
+
+    const uint32_t cap = bin.cap[level];
+    Item<HALF>* level_items = items + (size_t)bin.item_first[level] * 1024u;
+    T* gtab = grad_table + (size_t)row0 * C;
+#pragma unroll
+    for (uint32_t i = 0; i < NITEM; i++) {
+        if (!((alive >> i) & 1u)) continue;
+        const uint32_t bucket = rows[i] >> kBucketRowsLog2;
+        const uint32_t slot = gbase[bucket] + rank[i];
+        if (slot < cap) {
+            level_items[(size_t)bucket * cap + slot] = Item<HALF>::make(rows[i], va[i], vb[i]);
+        } else {  // bucket over capacity: add directly (complete for any input distribution)
+            T* dst = gtab + (size_t)rows[i] * C;
+            if constexpr (HALF) {
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), __halves2half2(__float2half_rn(va[i]), __float2half_rn(vb[i])));
+            } else {
+                unsafeAtomicAdd(dst, va[i]);
+                unsafeAtomicAdd(dst + 1, vb[i]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: per-bucket reduction in LDS, then one read-modify-write per touched table row
+// ---------------------------------------------------------------------------------------------
+template <bool HALF>
+__global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce(typename Elem<HALF>::type* __restrict__ grad_table,
+                                                                     GridPlan plan, BinPlan bin,
+                                                                     const uint32_t* __restrict__ cursors,
+                                                                     const Item<HALF>* __restrict__ items) {
+    using T = typename Elem<HALF>::type;
+    __shared__ float acc[kBucketRows * 2];
+
+    // workgroup -> (level, bucket, split)
+    uint32_t level = 0;
+    while (level + 1 < bin.levels && blockIdx.x >= bin.split_first[level + 1]) level++;
+    const uint32_t splits = bin.splits[level];
+    const uint32_t local = blockIdx.x - bin.split_first[level];
+    const uint32_t bucket = local / splits;
+    const uint32_t split = local - bucket * splits;
+
+    const uint32_t cap = bin.cap[level];
+    uint32_t n = cursors[bin.bucket_first[level] + bucket];
+    if (n > cap) n = cap;
+    // this split's slice of the item list
+    const uint32_t per = (n + splits - 1) / splits;
+    const uint32_t begin = split * per;
+    const uint32_t end = begin + per < n ? begin + per : n;
+    if (begin >= end) return;
+
+    for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreads) acc[i] = 0.f;
+    __syncthreads();
+
+    const Item<HALF>* src = items + (size_t)bin.item_first[level] * 1024u + (size_t)bucket * cap;
+    for (uint32_t i = begin + threadIdx.x; i < end; i += kReduceThreads) {
+        const Item<HALF> it = src[i];
+        const float2 v = it.value();
+        const uint32_t r = (it.row & (kBucketRows - 1)) * 2;
+        atomicAdd(&acc[r], v.x);      // ds_add_f32
+        atomicAdd(&acc[r + 1], v.y);
+    }
+    __syncthreads();
+
+    const uint32_t row0 = plan.off[level];
+    const uint32_t level_rows = plan.off[level + 1] - row0;
+    const uint32_t first_row = bucket << kBucketRowsLog2;
+    for (uint32_t r = threadIdx.x; r < kBucketRows; r += kReduceThreads) {
+        const float a = acc[r * 2], b = acc[r * 2 + 1];
+        if (a == 0.f && b == 0.f) continue;
+        const uint32_t row = first_row + r;
+        if (row >= level_rows) continue;
+        T* dst = grad_table + ((size_t)row0 + row) * 2;
+        if (splits == 1) {  // sole owner of these rows: plain read-modify-write
+            if constexpr (HALF) {
+                const __half2 o = *reinterpret_cast<const __half2*>(dst);
+                *reinterpret_cast<__half2*>(dst) =
+                    __halves2half2(__float2half_rn(__low2float(o) + a), __float2half_rn(__high2float(o) + b));
+            } else {
+                float2 o = *reinterpret_cast<const float2*>(dst);
+                o.x += a; o.y += b;
+                *reinterpret_cast<float2*>(dst) = o;
+            }
+        } else {
+            if constexpr (HALF) {
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), __halves2half2(__float2half_rn(a), __float2half_rn(b)));
+            } else {
+                unsafeAtomicAdd(dst, a);
+                unsafeAtomicAdd(dst + 1, b);
+            }
+        }
+    }
+}
+
+// host: bucket geometry for a chunk of `chunk` samples
+BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uint64_t* total_items_1024, uint32_t* total_buckets,
+                      uint32_t* total_splits) {
+    BinPlan b;
+    memset(&b, 0, sizeof(b));
+    b.levels = levels;
+    uint64_t items = 0;
+    uint32_t buckets = 0, wgs = 0;
+    for (uint32_t l = 0; l < levels; l++) {
+        const uint32_t rows = plan.off[l + 1] - plan.off[l];
+        const uint32_t nb = (rows + kBucketRows - 1) >> kBucketRowsLog2;
+        b.bucket_first[l] = buckets;
+        b.split_first[l] = wgs;
+        const uint64_t worst = (uint64_t)8 * chunk;  // every contribution of the chunk lands in this level
+        // uniform share + 25 % + slack; coarse levels rely on the run folding, and on the atomic fallback beyond that
+        uint64_t cap = (worst + nb - 1) / nb;
+        cap = cap + cap / 4 + 256;
+        b.cap[l] = (uint32_t)cap;
+        uint32_t splits = (uint32_t)((cap + kItemsPerSplit - 1) / kItemsPerSplit);
+        if (splits < 1) splits = 1;
+        if (splits > kMaxSplits) splits = kMaxSplits;
+        b.splits[l] = splits;
+        b.item_first[l] = (uint32_t)items;
+        items += ((uint64_t)nb * cap + 1023) / 1024;
+        buckets += nb;
+        wgs += nb * splits;
+        // fold lane runs where neighbouring samples (~1/600 of the unit cube apart) usually share a cell
+        if (plan.res[l] <= 640) b.merge_mask |= 1u << l;
+    }
+    b.bucket_first[levels] = buckets;
+    b.split_first[levels] = wgs;
+    *total_items_1024 = items;
+    *total_buckets = buckets;
+    *total_splits = wgs;
+    return b;
+}
+
+bool binned_supported(uint32_t D, uint32_t C, uint32_t L, const int32_t* offsets_host) {
+    if (D != 3 || C != 2 || L < 1 || L > kMaxLevels) return false;
+    for (uint32_t l = 0; l < L; l++) {
+        const uint32_t rows = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        if (((rows + kBucketRows - 1) >> kBucketRowsLog2) > kMaxBucketsPerLevel) return false;
+    }
+    return true;
+}
+
+constexpr uint64_t kCursorBytes = (uint64_t)kMaxLevels * kMaxBucketsPerLevel * sizeof(uint32_t);
+
+uint64_t scratch_bytes_for(const GridPlan& plan, uint32_t levels, uint32_t chunk, bool half) {
+    uint64_t items;
+    uint32_t nb, wg;
+    make_bin_plan(plan, levels, chunk, &items, &nb, &wg);
+    return kCursorBytes + items * 1024u * (half ? sizeof(Item<true>) : sizeof(Item<false>));
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of scratch that let `chunk_points` samples be processed per pass (more samples are chunked)
+uint64_t sdfx_grid_encode_backward_binned_scratch_bytes(const int32_t* offsets_host, uint32_t L, uint32_t max_level, float S,
+                                                         uint32_t H, uint32_t chunk_points, int is_half) {
+    if (!offsets_host || L < 1 || L > kMaxLevels || max_level < 1 || max_level > L) return 0;
+    const GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, is_half ? 2 : 4, chunk_points);
+    return scratch_bytes_for(plan, max_level, chunk_points, is_half != 0);
+}
+
+// Same contract as sdfx_grid_encode_backward (table gradient only: D = 3, C = 2, no dy_dx), plus scratch.
+// Returns SDFX_E_UNSUPPORTED for other shapes so the caller can take the atomic path.
+int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, const int32_t* offsets_host,
+                                     void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                     uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                     uint32_t interp, int is_half, int grad_layout, void* scratch, uint64_t scratch_bytes,
+                                     sdfx_stream_t stream) {
+    SDFX_REQUIRE(grad && inputs && offsets_host && grad_embeddings && scratch, "grid_encode_backward_binned: null pointer");
+    if (!binned_supported(D, C, L, offsets_host)) {
+        set_error("grid_encode_backward_binned: only D=3, C=2, levels of at most %u rows", kMaxBucketsPerLevel * kBucketRows);
+        return SDFX_E_UNSUPPORTED;
+    }
+    SDFX_REQUIRE(max_level >= 1 && max_level <= L, "grid_encode_backward_binned: max_level must be in [1, L]");
+    SDFX_REQUIRE(gridtype <= 1 && interp <= 1 && (grad_layout == 0 || grad_layout == 1), "grid_encode_backward_binned: bad enum");
+    SDFX_REQUIRE((reinterpret_cast<uintptr_t>(grad_embeddings) % (is_half ? 4 : 8)) == 0 &&
+                     (reinterpret_cast<uintptr_t>(scratch) % 16) == 0,
+                 "grid_encode_backward_binned: grad_embeddings / scratch misaligned");
+    if (B == 0) return SDFX_OK;
+    hipStream_t st = as_stream(stream);
+    const uint32_t eb = is_half ? 2 : 4;
+
+    // largest chunk (multiple of 512 samples) whose item lists fit the scratch
+    uint32_t chunk = B;
+    {
+        const uint32_t gran = kBinThreads * kPointsPerThread;
+        chunk = ((chunk + gran - 1) / gran) * gran;
+        for (;;) {
+            const GridPlan p = make_plan(offsets_host, max_level, S, H, 2, eb, chunk);
+            if (scratch_bytes_for(p, max_level, chunk, is_half != 0) <= scratch_bytes) break;
+            SDFX_REQUIRE(chunk > gran, "grid_encode_backward_binned: scratch too small (%llu bytes)",
+                         (unsigned long long)scratch_bytes);
+            chunk = ((chunk / 2 + gran - 1) / gran) * gran;
+        }
+    }
+    uint32_t* cursors = static_cast<uint32_t*>(scratch);
+    void* items = static_cast<char*>(scratch) + kCursorBytes;
+
+    for (uint32_t b0 = 0; b0 < B; b0 += chunk) {
+        const uint32_t b1 = b0 + chunk < B ? b0 + chunk : B;
+        const uint32_t n = b1 - b0;
+        const GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, eb, (n + kPointsPerThread - 1) / kPointsPerThread);
+        uint64_t items_1024;
+        uint32_t nbuckets, nsplits;
+        const BinPlan bin = make_bin_plan(plan, max_level, chunk, &items_1024, &nbuckets, &nsplits);
+        (void)hipMemsetAsync(cursors, 0, (size_t)nbuckets * sizeof(uint32_t), st);
+        const uint32_t grid1 = plan_grid_size(plan);
+        if (is_half) {
+            hipLaunchKernelGGL(k_grid_bwd_bin<true>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const __half*>(grad),
+                               inputs, static_cast<__half*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
+                               interp, grad_layout, cursors, static_cast<Item<true>*>(items));
+            hipLaunchKernelGGL(k_grid_bwd_reduce<true>, dim3(nsplits), dim3(kReduceThreads), 0, st,
+                               static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items));
+        } else {
+            hipLaunchKernelGGL(k_grid_bwd_bin<false>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const float*>(grad),
+                               inputs, static_cast<float*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
+                               interp, grad_layout, cursors, static_cast<Item<false>*>(items));
+            hipLaunchKernelGGL(k_grid_bwd_reduce<false>, dim3(nsplits), dim3(kReduceThreads), 0, st,
+                               static_cast<float*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<false>*>(items));
+        }
+    }
+    return check_launch("grid_encode_backward_binned");
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+"""Fused field evaluation for the fp16-autocast `-O` configuration:
+
+    sigma, albedo = fused_field(x, encoder, sigma_net, bound, blob_density, blob_radius)
+
+== NeRFNetwork.common_forward (nerf/network_grid.py:68-78) with the hash-grid encode, the 32-64-64-4
+MLP and the output activations run by three HIP kernels (encode, field forward; field backward +
+binned table-gradient scatter in the backward). The features stay in the encoder's level-major
+[16, B, 2] layout end to end, so neither the forward nor the backward permutes them.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+import _field
+import _gridencoder
+
+
+class _fused_field(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, x, embeddings, offsets, w1, b1, w2, b2, w3, b3, bound, per_level_scale, base_resolution, gridtype,
+                align_corners, interp, blob_density, blob_radius):
+        x = x.float().contiguous()
+        B = x.shape[0]
+        inputs = ((x + bound) / (2 * bound)).contiguous()       # GridEncoder.forward's map to [0, 1] (grid.py:157)
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = np.log2(per_level_scale)
+        emb = embeddings.to(torch.half).contiguous()             # autocast: fp16 table (grid.py:46-47)
+        enc = torch.empty(L, B, C, device=x.device, dtype=torch.half)
+        _gridencoder.grid_encode_forward(inputs, emb, offsets, enc, B, 3, C, L, L, S, base_resolution, None, gridtype,
+                                         align_corners, interp, 0)
+        packed = torch.empty(_field.packed_words(), dtype=torch.int32, device=x.device)
+        _field.pack(w1.detach().float().contiguous(), b1.detach().float().contiguous(), w2.detach().float().contiguous(),
+                    b2.detach().float().contiguous(), w3.detach().float().contiguous(), b3.detach().float().contiguous(), packed)
+        sigma = torch.empty(B, dtype=torch.float32, device=x.device)
+        albedo = torch.empty(B, 3, dtype=torch.float32, device=x.device)
+        _field.forward(enc, 0, x, packed, B, blob_density, blob_radius, sigma, albedo)
+        ctx.save_for_backward(x, inputs, offsets, enc, packed)
+        ctx.meta = (B, C, L, S, base_resolution, gridtype, align_corners, interp, blob_density, blob_radius, tuple(emb.shape))
+        return sigma, albedo
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, dsigma, dalbedo):
+        x, inputs, offsets, enc, packed = ctx.saved_tensors
+        B, C, L, S, H, gridtype, align_corners, interp, blob_density, blob_radius, emb_shape = ctx.meta
+        dev = x.device
+        dsigma = dsigma.float().contiguous()
+        dalbedo = dalbedo.float().contiguous()
+        denc = torch.empty_like(enc)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dw1, db1 = torch.empty(64, 32, **f32), torch.empty(64, **f32)
+        dw2, db2 = torch.empty(64, 64, **f32), torch.empty(64, **f32)
+        dw3, db3 = torch.empty(4, 64, **f32), torch.empty(4, **f32)
+        _field.backward(enc, 0, x, packed, B, blob_density, blob_radius, dsigma, dalbedo, denc, dw1, db1, dw2, db2, dw3, db3)
+        grad_emb = torch.zeros(emb_shape, dtype=torch.half, device=dev)
+        _gridencoder.grid_encode_backward(denc, inputs, grad_emb, offsets, grad_emb, B, 3, C, L, L, S, H, None, None, gridtype,
+                                          align_corners, interp, 0)
+        return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 8
+
+
+def supported(encoder, sigma_net, x, density_activation, max_level) -> bool:
+    return (x.is_cuda and torch.is_autocast_enabled("cuda") and density_activation == "exp" and max_level is None
+            and encoder.input_dim == 3 and encoder.level_dim == 2 and encoder.num_levels == 16
+            and sigma_net.num_layers == 3 and sigma_net.dim_hidden == 64 and sigma_net.dim_in == 32 and sigma_net.dim_out == 4
+            and sigma_net.net[0].bias is not None)
+
+
+def fused_field(x, encoder, sigma_net, bound, blob_density, blob_radius):
+    n = sigma_net.net
+    return _fused_field.apply(x, encoder.embeddings, encoder.offsets, n[0].weight, n[0].bias, n[1].weight, n[1].bias,
+                              n[2].weight, n[2].bias, bound, encoder.per_level_scale, encoder.base_resolution,
+                              encoder.gridtype_id, encoder.align_corners, encoder.interp_id, blob_density, blob_radius)

@@ -2,6 +2,8 @@
 density blob, finite-difference normals, Lambertian shading, frequency-encoded background MLP."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -11,7 +13,12 @@ from torch.autograd import Function
 from freqencoder import FreqEncoder
 from gridencoder import GridEncoder
 
+from . import fused_field as _ff
 from .renderer import NeRFRenderer, safe_normalize
+
+# fused encode -> MLP -> activation kernels for the fp16-autocast path (SDFX_FUSED_FIELD=0 keeps the
+# reference's module-by-module evaluation: GridEncoder -> nn.Linear stack -> torch activations)
+_FUSED = int(os.environ.get("SDFX_FUSED_FIELD", "1"))
 
 
 class _trunc_exp(Function):
@@ -79,6 +86,11 @@ class NeRFNetwork(NeRFRenderer):
             self.bg_net = None
 
     def common_forward(self, x):
+        if _FUSED and _ff.supported(self.encoder, self.sigma_net, x, self.opt.density_activation, self.max_level):
+            shape = x.shape[:-1]
+            sigma, albedo = _ff.fused_field(x.reshape(-1, 3), self.encoder, self.sigma_net, self.bound,
+                                            self.opt.blob_density, self.opt.blob_radius)
+            return sigma.view(*shape), albedo.view(*shape, 3)
         enc = self.encoder(x, bound=self.bound, max_level=self.max_level)
         h = self.sigma_net(enc)
         sigma = self.density_activation(h[..., 0] + self.density_blob(x))
