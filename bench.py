@@ -226,6 +226,31 @@ def cpu_baseline(n_rays):
     return {"rays": n_rays, "samples": int(M), "seconds": dt, "rays_per_s": n_rays / dt, "iters_per_s": n_rays / dt / 4096.0}
 
 
+# ---- multi-GPU control path (independent prompts, one process per GPU) ------------------------------
+def rank_seed(rank: int) -> int:
+    """Every rank optimises its own prompt/seed."""
+    return 1000 * rank
+
+
+def rank_view(rank: int, step: int, n_views: int) -> int:
+    """Camera used by `rank` at `step`: ranks walk the reference sampler's 16 cameras with a rank offset."""
+    return (step + rank) % n_views
+
+
+def job_elapsed(local_elapsed: float, dist, device) -> float:
+    """Wall time of the whole job = MAX over ranks of the barrier-bracketed local time."""
+    if dist is None:
+        return float(local_elapsed)
+    t = torch.tensor([local_elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_throughput(world: int, steps: int, elapsed: float) -> float:
+    """Whole-job iterations per second: every rank does `steps` iterations of its own scene in `elapsed`."""
+    return world * steps / elapsed
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -251,7 +276,7 @@ def main():
     install_timers(timer)
 
     # independent prompt/seed per rank
-    seed = 1000 * rank
+    seed = rank_seed(rank)
     torch.manual_seed(seed)
     np.random.seed(seed)
     opt = default_opt()
@@ -284,12 +309,12 @@ def main():
     poses, fovy = synth.reference_cameras()
     views = []
     for v in range(len(poses)):
-        o, d = synth.get_rays(poses[(v + rank) % len(poses)], float(fovy[(v + rank) % len(poses)]))
+        o, d = synth.get_rays(poses[v], float(fovy[v]))
         az = float(np.degrees(np.arctan2(poses[v][0, 3], poses[v][2, 3])))
         views.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), az))
 
     def one_step(i):
-        ro, rd, az = views[i % len(views)]
+        ro, rd, az = views[rank_view(rank, i, len(views))]
         return step.step(ro, rd, azimuth=az)
 
     for i in range(args.warmup):
@@ -310,10 +335,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = job_elapsed(elapsed, dist, dev)
 
     if rank != 0:
         if dist is not None:
@@ -323,7 +345,7 @@ def main():
 
     ksum = timer.summary()
     enc = ksum.get("grid_encode_forward", {"GBps": 0.0, "avg_us": 0.0, "launches": 0, "bytes": 0})
-    iters_per_s = world * args.steps / elapsed
+    iters_per_s = job_throughput(world, args.steps, elapsed)
     result = {
         "metric": "sds_iters_per_sec", "value": iters_per_s, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",

@@ -11,7 +11,7 @@ import os
 
 import torch
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
+_HERE = os.path.dirname(os.path.realpath(__file__))  # realpath: backends_only/ holds symlinks to these files
 LIB_PATH = os.path.join(_HERE, "csrc", "libsdfx_hip.so")
 
 _u32, _f32, _int, _ptr, _u64 = C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_uint64

@@ -110,35 +110,47 @@ __device__ __forceinline__ void load_enc(const uint32_t* __restrict__ enc, int l
 
 __device__ __forceinline__ void mlp_forward(const uint32_t* __restrict__ P, Acts& a) {
     const float* bias = reinterpret_cast<const float*>(P);
-    // layer 1: 32 -> 64, ReLU, rounded to half as an autocast Linear output is
+    // layer 1: 32 -> 64, ReLU, rounded to half as an autocast Linear output is. Four outputs are
+    // accumulated at a time so that four independent v_dot2 chains are in flight per lane.
 #pragma unroll
-    for (uint32_t op = 0; op < kHid / 2; op++) {
-        float acc0 = bias[kB1 + 2 * op], acc1 = bias[kB1 + 2 * op + 1];
+    for (uint32_t oq = 0; oq < kHid / 4; oq++) {
+        float acc[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) acc[j] = bias[kB1 + 4 * oq + j];
 #pragma unroll
         for (uint32_t kp = 0; kp < kIn / 2; kp++) {
-            acc0 = dot2(P[kW1 + (2 * op) * (kIn / 2) + kp], a.enc[kp], acc0);
-            acc1 = dot2(P[kW1 + (2 * op + 1) * (kIn / 2) + kp], a.enc[kp], acc1);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) acc[j] = dot2(P[kW1 + (4 * oq + j) * (kIn / 2) + kp], a.enc[kp], acc[j]);
         }
-        a.h1[op] = pack(fmaxf(acc0, 0.f), fmaxf(acc1, 0.f));
+        a.h1[2 * oq] = pack(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f));
+        a.h1[2 * oq + 1] = pack(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
     }
     // layer 2: 64 -> 64, ReLU
 #pragma unroll
-    for (uint32_t op = 0; op < kHid / 2; op++) {
-        float acc0 = bias[kB2 + 2 * op], acc1 = bias[kB2 + 2 * op + 1];
+    for (uint32_t oq = 0; oq < kHid / 4; oq++) {
+        float acc[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) acc[j] = bias[kB2 + 4 * oq + j];
 #pragma unroll
         for (uint32_t kp = 0; kp < kHid / 2; kp++) {
-            acc0 = dot2(P[kW2 + (2 * op) * (kHid / 2) + kp], a.h1[kp], acc0);
-            acc1 = dot2(P[kW2 + (2 * op + 1) * (kHid / 2) + kp], a.h1[kp], acc1);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) acc[j] = dot2(P[kW2 + (4 * oq + j) * (kHid / 2) + kp], a.h1[kp], acc[j]);
         }
-        a.h2_[op] = pack(fmaxf(acc0, 0.f), fmaxf(acc1, 0.f));
+        a.h2_[2 * oq] = pack(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f));
+        a.h2_[2 * oq + 1] = pack(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
     }
-    // layer 3: 64 -> 4
+    // layer 3: 64 -> 4 (the four outputs are the four chains)
+    {
+        float acc[4];
 #pragma unroll
-    for (uint32_t o = 0; o < kOut; o++) {
-        float acc = bias[kB3 + o];
+        for (uint32_t o = 0; o < kOut; o++) acc[o] = bias[kB3 + o];
 #pragma unroll
-        for (uint32_t kp = 0; kp < kHid / 2; kp++) acc = dot2(P[kW3 + o * (kHid / 2) + kp], a.h2_[kp], acc);
-        a.h3[o] = (float)(_Float16)acc;
+        for (uint32_t kp = 0; kp < kHid / 2; kp++) {
+#pragma unroll
+            for (uint32_t o = 0; o < kOut; o++) acc[o] = dot2(P[kW3 + o * (kHid / 2) + kp], a.h2_[kp], acc[o]);
+        }
+#pragma unroll
+        for (uint32_t o = 0; o < kOut; o++) a.h3[o] = (float)(_Float16)acc[o];
     }
 }
 
@@ -232,28 +244,34 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
             }
             // d h1 = relu'(h1) * W2^T d h2
 #pragma unroll
-            for (uint32_t kp = 0; kp < kHid / 2; kp++) {
-                float v0 = 0.f, v1 = 0.f;
+            for (uint32_t kq = 0; kq < kHid / 4; kq++) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (uint32_t op = 0; op < kHid / 2; op++) {
-                    v0 = dot2(P[kW2T + (2 * kp) * (kHid / 2) + op], dh2[op], v0);
-                    v1 = dot2(P[kW2T + (2 * kp + 1) * (kHid / 2) + op], dh2[op], v1);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) v[j] = dot2(P[kW2T + (4 * kq + j) * (kHid / 2) + op], dh2[op], v[j]);
                 }
-                const h2 act = a.h1[kp];
-                dh1[kp] = pack(act.x > (_Float16)0 ? v0 : 0.f, act.y > (_Float16)0 ? v1 : 0.f);
+                const h2 act0 = a.h1[2 * kq], act1 = a.h1[2 * kq + 1];
+                dh1[2 * kq] = pack(act0.x > (_Float16)0 ? v[0] : 0.f, act0.y > (_Float16)0 ? v[1] : 0.f);
+                dh1[2 * kq + 1] = pack(act1.x > (_Float16)0 ? v[2] : 0.f, act1.y > (_Float16)0 ? v[3] : 0.f);
             }
             // d features = W1^T d h1, written in the layout the features came in
 #pragma unroll
-            for (uint32_t kp = 0; kp < kIn / 2; kp++) {
-                float v0 = 0.f, v1 = 0.f;
+            for (uint32_t kq = 0; kq < kIn / 4; kq++) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (uint32_t op = 0; op < kHid / 2; op++) {
-                    v0 = dot2(P[kW1T + (2 * kp) * (kHid / 2) + op], dh1[op], v0);
-                    v1 = dot2(P[kW1T + (2 * kp + 1) * (kHid / 2) + op], dh1[op], v1);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) v[j] = dot2(P[kW1T + (4 * kq + j) * (kHid / 2) + op], dh1[op], v[j]);
                 }
-                const uint32_t w = as_u32(pack(v0, v1));
-                if (enc_layout == 0) denc[(size_t)kp * B + b] = w;
-                else denc[(size_t)b * (kIn / 2) + kp] = w;
+                const uint32_t w0 = as_u32(pack(v[0], v[1])), w1 = as_u32(pack(v[2], v[3]));
+                if (enc_layout == 0) {
+                    denc[(size_t)(2 * kq) * B + b] = w0;
+                    denc[(size_t)(2 * kq + 1) * B + b] = w1;
+                } else {
+                    denc[(size_t)b * (kIn / 2) + 2 * kq] = w0;
+                    denc[(size_t)b * (kIn / 2) + 2 * kq + 1] = w1;
+                }
             }
         } else {
 #pragma unroll
@@ -269,6 +287,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
 #pragma unroll
         for (uint32_t i = 0; i < kHid / 2; i++) { row[STG(t, i)] = as_u32(a.h1[i]); row[STG(t, 32 + i)] = as_u32(dh2[i]); }
         __syncthreads();
+#pragma unroll 8
         for (uint32_t p = 0; p < kThreads; p++) {
             const uint32_t* r = stage + p * kStageStride;
             const h2 i0 = as_h2(r[STG(p, k4 / 2)]), i1 = as_h2(r[STG(p, k4 / 2 + 1)]);
@@ -291,6 +310,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
 #pragma unroll
         for (uint32_t i = 0; i < kHid / 2; i++) row[STG(t, 32 + i)] = as_u32(dh1[i]);
         __syncthreads();
+#pragma unroll 8
         for (uint32_t p = 0; p < kThreads; p++) {
             const uint32_t* r = stage + p * kStageStride;
             const h2 i0 = as_h2(r[STG(p, k2 / 2)]);
@@ -313,6 +333,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
         row[STG(t, 32)] = as_u32(dh3[0]);
         row[STG(t, 33)] = as_u32(dh3[1]);
         __syncthreads();
+#pragma unroll 8
         for (uint32_t p = 0; p < kThreads; p++) {
             const uint32_t* r = stage + p * kStageStride;
             const h2 iv = as_h2(r[STG(p, k3 / 2)]);
@@ -343,14 +364,22 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
 }
 
 // sum the per-workgroup partials into the six parameter gradients
-__global__ __launch_bounds__(256) void k_field_wgrad_reduce(const float* __restrict__ partials, uint32_t nblocks,
+__global__ __launch_bounds__(64) void k_field_wgrad_reduce(const float* __restrict__ partials, uint32_t nblocks,
                                                              float* __restrict__ dw1, float* __restrict__ db1,
                                                              float* __restrict__ dw2, float* __restrict__ db2,
                                                              float* __restrict__ dw3, float* __restrict__ db3) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= kGradWords) return;
-    float s = 0.f;
-    for (uint32_t k = 0; k < nblocks; k++) s += partials[(size_t)k * kGradWords + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent load/add chains
+    uint32_t k = 0;
+    for (; k + 4 <= nblocks; k += 4) {
+        s0 += partials[(size_t)(k + 0) * kGradWords + i];
+        s1 += partials[(size_t)(k + 1) * kGradWords + i];
+        s2 += partials[(size_t)(k + 2) * kGradWords + i];
+        s3 += partials[(size_t)(k + 3) * kGradWords + i];
+    }
+    for (; k < nblocks; k++) s0 += partials[(size_t)k * kGradWords + i];
+    const float s = (s0 + s1) + (s2 + s3);
     if (i < gB1) dw1[i - gW1] = s;
     else if (i < gW2) db1[i - gB1] = s;
     else if (i < gB2) dw2[i - gW2] = s;
@@ -408,7 +437,7 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
                            enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
                            static_cast<uint32_t*>(denc), scratch);
     }
-    hipLaunchKernelGGL(k_field_wgrad_reduce, dim3(div_up(kGradWords, 256)), dim3(256), 0, st, scratch, nblocks, dw1, db1,
+    hipLaunchKernelGGL(k_field_wgrad_reduce, dim3(div_up(kGradWords, 64)), dim3(64), 0, st, scratch, nblocks, dw1, db1,
                        dw2, db2, dw3, db3);
     return check_launch("field_backward");
 }

@@ -16,9 +16,11 @@ constexpr uint32_t kTile = 256;  // work items per workgroup
 struct GridPlan {
     uint32_t res[kMaxLevels];      // per-level resolution
     uint32_t off[kMaxLevels + 1];  // per-level first row (host copy of `offsets`)
-    uint32_t start[kXcds];         // [start, end) item range of each XCD in the level-major list
+    uint32_t start[kXcds];         // [start, end) item range of each XCD in the virtual-level-major list
     uint32_t end[kXcds];
+    uint32_t order[kMaxLevels];    // virtual level -> level (fine and coarse levels interleaved)
     uint32_t tiles;                // tiles per level
+    uint32_t vec16;                // table base is 16-byte aligned: paired 16-byte gathers allowed
 };
 
 // (uint32_t)ceil(exp2f(level * S) * H) in float32 — gridencoder.cu:133
@@ -26,11 +28,18 @@ inline uint32_t level_resolution(uint32_t level, float S, uint32_t H) {
     return (uint32_t)ceilf(exp2f((float)level * S) * (float)H);
 }
 
-// Build the plan: resolutions, offsets, and the per-XCD ranges of the level-major item list.
-// Levels whose table slice is small enough to live in L1/L2 next to anything else cost less
-// per tile than the multi-MiB hashed levels; ranges are balanced on that estimate.
+// Build the plan: resolutions, offsets, and the per-XCD ranges of the item list.
+//
+// Items are (virtual level, tile) pairs in virtual-level-major order, cut into 8 equal contiguous ranges, one
+// per XCD. The virtual order interleaves the levels from both ends — [L-1, 0, L-2, 1, ...] — because the
+// cost of a level is the number of distinct 128-byte table lines a wave touches (measured: ~2.4 CU-cycles per
+// line, independent of the access width; tools/ubench/gather_width.hip): fine levels cost 4 lines per sample,
+// coarse levels a fraction of one when neighbouring lanes are neighbouring samples. Pairing a fine with a
+// coarse level gives every XCD the same load (and, with 16 levels, exactly two levels = at most 4 MiB of fp16
+// table in its 4 MiB L2).
 inline GridPlan make_plan(const int32_t* offsets_host, uint32_t levels, float S, uint32_t H, uint32_t C, uint32_t elem_bytes,
                    uint64_t items_per_level) {
+    (void)C; (void)elem_bytes;
     GridPlan p;
     memset(&p, 0, sizeof(p));
     for (uint32_t l = 0; l < levels; l++) {
@@ -39,37 +48,11 @@ inline GridPlan make_plan(const int32_t* offsets_host, uint32_t levels, float S,
     }
     p.off[levels] = (uint32_t)offsets_host[levels];
     p.tiles = div_up(items_per_level, kTile);
-    double cost[kMaxLevels];
-    double total = 0;
-    for (uint32_t l = 0; l < levels; l++) {
-        const double bytes = (double)(p.off[l + 1] - p.off[l]) * C * elem_bytes;
-        cost[l] = bytes > 512.0 * 1024.0 ? 1.0 : 0.4;
-        total += cost[l] * p.tiles;
-    }
-    // boundary k sits where the cumulative cost reaches k * total / 8
-    uint32_t bound[kXcds + 1];
-    bound[0] = 0;
-    bound[kXcds] = levels * p.tiles;
-    uint32_t l = 0;
-    double cum = 0;  // cost of all complete levels before l
-    for (uint32_t k = 1; k < kXcds; k++) {
-        const double target = total * k / kXcds;
-        while (l < levels && cum + cost[l] * p.tiles <= target) {
-            cum += cost[l] * p.tiles;
-            l++;
-        }
-        uint32_t item = l * p.tiles;
-        if (l < levels) {
-            uint32_t within = (uint32_t)((target - cum) / cost[l]);
-            if (within > p.tiles) within = p.tiles;
-            item += within;
-        }
-        if (item < bound[k - 1]) item = bound[k - 1];
-        bound[k] = item;
-    }
+    for (uint32_t v = 0, lo = 0, hi = levels; v < levels; v++) p.order[v] = (v & 1u) ? lo++ : --hi;
+    const uint64_t total = (uint64_t)levels * p.tiles;
     for (uint32_t k = 0; k < kXcds; k++) {
-        p.start[k] = bound[k];
-        p.end[k] = bound[k + 1];
+        p.start[k] = (uint32_t)(total * k / kXcds);
+        p.end[k] = (uint32_t)(total * (k + 1) / kXcds);
     }
     return p;
 }
@@ -88,8 +71,9 @@ __device__ __forceinline__ bool plan_item(const GridPlan& p, uint32_t& level, ui
     const uint32_t xcd = blockIdx.x % kXcds;
     const uint32_t item = p.start[xcd] + blockIdx.x / kXcds;
     if (item >= p.end[xcd]) return false;
-    level = item / p.tiles;
-    tile = item - level * p.tiles;
+    const uint32_t virt = item / p.tiles;
+    level = p.order[virt];
+    tile = item - virt * p.tiles;
     return true;
 }
 

@@ -4,9 +4,10 @@
 //
 // Behavioural reference: gridencoder/src/gridencoder.cu (line citations at each kernel).
 // What is different by design, for CDNA4:
-//   * work is a level-major list of (level, 256-point tile) items, cut into 8 contiguous
-//     cost-balanced ranges, one per XCD (workgroup b runs on XCD b % 8): each XCD's 4 MiB L2
-//     then holds the one or two table levels it is gathering from instead of all sixteen;
+//   * work is a list of (level, 256-point tile) items cut into 8 contiguous ranges, one per XCD
+//     (workgroup b runs on XCD b % 8), with fine and coarse levels paired so that the ranges
+//     cost the same: each XCD's 4 MiB L2 then holds the two table levels it is gathering from
+//     instead of all sixteen;
 //   * per-level resolutions are computed once on the host (same float32 formula as the
 //     reference kernel, gridencoder.cu:133) and travel in the kernel arguments, so device
 //     and CPU oracle agree on every level by construction;
@@ -83,12 +84,50 @@ __global__ __launch_bounds__(kTile) void k_grid_forward(const float* __restrict_
     for (uint32_t base = 0; base < NC; base += kBatch) {
         float w[kBatch];
         Row<T, C> rows[kBatch];
+        // The two corners of an x-pair (idx, idx+1) are the rows r0 and r1 = row(x+1, ...). The x prime of
+        // the spatial hash is 1 and dense levels are x-major, so r0 ^ r1 is almost always a low-bit mask:
+        // both rows then sit in one aligned 16-byte block of the table and ONE 16-byte gather serves both
+        // (the L1 cost of a divergent gather is per lane, not per byte). Values are unchanged.
+        constexpr uint32_t RB = (sizeof(T) * C <= 8) ? 16u / (sizeof(T) * C) : 1u;  // rows per 16-byte block
+        if constexpr (RB > 1 && (kBatch % 2 == 0)) {
+            if (plan.vec16) {
 #pragma unroll
-        for (uint32_t k = 0; k < kBatch; k++) {
-            uint32_t pgl[D];
-            w[k] = corner<D>(base + k, pos, pos_grid, resolution, pgl);
-            const uint32_t row = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
-            rows[k].load(tab + (size_t)row * C);
+                for (uint32_t k = 0; k < kBatch; k += 2) {
+                    uint32_t pgl[D];
+                    w[k] = corner<D>(base + k, pos, pos_grid, resolution, pgl);
+                    const uint32_t r0 = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+                    w[k + 1] = corner<D>(base + k + 1, pos, pos_grid, resolution, pgl);
+                    const uint32_t r1 = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+                    Row<T, C> blk[RB];
+                    *reinterpret_cast<uint4*>(blk) = *reinterpret_cast<const uint4*>(tab + (size_t)(r0 & ~(RB - 1)) * C);
+                    rows[k] = blk[0];
+#pragma unroll
+                    for (uint32_t j = 1; j < RB; j++) if ((r0 & (RB - 1)) == j) rows[k] = blk[j];
+                    if ((r0 ^ r1) < RB) {
+                        rows[k + 1] = blk[0];
+#pragma unroll
+                        for (uint32_t j = 1; j < RB; j++) if ((r1 & (RB - 1)) == j) rows[k + 1] = blk[j];
+                    } else {
+                        rows[k + 1].load(tab + (size_t)r1 * C);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < kBatch; k++) {
+                    uint32_t pgl[D];
+                    w[k] = corner<D>(base + k, pos, pos_grid, resolution, pgl);
+                    const uint32_t row = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+                    rows[k].load(tab + (size_t)row * C);
+                }
+            }
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < kBatch; k++) {
+                uint32_t pgl[D];
+                w[k] = corner<D>(base + k, pos, pos_grid, resolution, pgl);
+                const uint32_t row = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+                rows[k].load(tab + (size_t)row * C);
+            }
         }
 #pragma unroll
         for (uint32_t k = 0; k < kBatch; k++) {
@@ -419,6 +458,7 @@ int sdfx_grid_encode_forward(const float* inputs, const void* embeddings, const 
     FwdArgs a;
     a.inputs = inputs; a.table = embeddings; a.outputs = outputs; a.B = B; a.L = L;
     a.plan = make_plan(offsets_host, max_level, S, H, C, eb, B);
+    a.plan.vec16 = (reinterpret_cast<uintptr_t>(embeddings) % 16) == 0 ? 1u : 0u;
     a.dy_dx = dy_dx; a.gridtype = gridtype; a.align_corners = align_corners; a.interp = interp;
     a.out_layout = out_layout; a.st = as_stream(stream); a.grid = plan_grid_size(a.plan);
     if (is_half) { SDFX_DISPATCH_DC(true, launch_forward, a) } else { SDFX_DISPATCH_DC(false, launch_forward, a) }

@@ -30,8 +30,8 @@ namespace {
 constexpr uint32_t kBucketRowsLog2 = 11;
 constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;  // rows per bucket (16 KiB of float2 accumulators)
 constexpr uint32_t kMaxBucketsPerLevel = 512;            // levels up to 2^20 rows
-constexpr uint32_t kBinThreads = 256;
-constexpr uint32_t kPointsPerThread = 2;
+constexpr uint32_t kBinThreads = 512;
+constexpr uint32_t kPointsPerThread = 1;
 constexpr uint32_t kReduceThreads = 256;
 constexpr uint32_t kItemsPerSplit = 32768;               // target items per K2 workgroup
 constexpr uint32_t kMaxSplits = 64;
@@ -380,7 +380,9 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
     for (uint32_t b0 = 0; b0 < B; b0 += chunk) {
         const uint32_t b1 = b0 + chunk < B ? b0 + chunk : B;
         const uint32_t n = b1 - b0;
-        const GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, eb, (n + kPointsPerThread - 1) / kPointsPerThread);
+        // one plan tile = one K1 workgroup = kBinThreads * kPointsPerThread samples
+        const GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, eb,
+                                        (uint64_t)div_up(n, kBinThreads * kPointsPerThread) * kTile);
         uint64_t items_1024;
         uint32_t nbuckets, nsplits;
         const BinPlan bin = make_bin_plan(plan, max_level, chunk, &items_1024, &nbuckets, &nsplits);

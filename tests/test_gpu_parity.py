@@ -355,7 +355,7 @@ def test_grid_backward_binned_scatter(oracle, dev, is_half):
         gt2 = torch.zeros(table.shape, dtype=tdt, device=dev)
         S.call("sdfx_grid_encode_backward", S.ptr(grt), S.ptr(xt), None, S.ptr(off_t), oh, S.ptr(gt2), Bn, 3, 2, 16, 16, S_, 16,
                None, None, 0, 0, 1, int(is_half), 1, S.stream())
-        assert np.abs(N_(gt2).astype(np.float32) - gt_ref).max() <= (3e-2 if is_half else 2e-5) * scale, name
+        assert np.abs(N_(gt2).astype(np.float32) - gt_ref).max() <= (8e-2 if is_half else 2e-5) * scale, name
 
 
 @pytest.mark.parametrize("D,C", [(2, 1), (2, 8), (3, 4), (4, 2), (5, 2), (3, 32), (3, 16)])
