@@ -604,7 +604,9 @@ static inline void grid_locate(const float* in, uint32_t D, uint32_t resolution,
 /*
  * gridencoder.cu:82-249 (kernel_grid) — outputs [L, B, C]; dy_dx [B, L, D, C] or NULL.
  * is_half selects scalar_t = at::Half: the 8-corner sum is then accumulated in half
- * (`results[ch] += w * grid[...]` with results of type scalar_t, :168,191).
+ * (`results[ch] += w * grid[...]` with results of type scalar_t, :168,191): each product is rounded to half
+ * (implicit float -> at::Half conversion of the right-hand side) and each partial sum is rounded to half.
+ * Verified bit for bit against the reference kernel itself (tests/test_gpu_vs_reference_kernels.py).
  */
 void orc_grid_encode_forward(const float* inputs, const void* embeddings, const int* offsets, void* outputs,
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level, float S, uint32_t H,
@@ -646,7 +648,9 @@ void orc_grid_encode_forward(const float* inputs, const void* embeddings, const 
                 }
                 const uint32_t index = get_grid_index(gridtype, D, C, 0, hashmap_size, resolution, pgl);
                 for (uint32_t ch = 0; ch < C; ch++)
-                    results[ch] = as_scalar(results[ch] + w * tab_ld(embeddings, tab0 + index + ch, is_half), is_half);
+                    /* `results[ch] += w * grid[...]` with results of type at::Half resolves to operator+=(Half&, const Half&):
+                       the float product is converted (rounded) to Half first, then the two halves are added and rounded */
+                    results[ch] = as_scalar(results[ch] + as_scalar(w * tab_ld(embeddings, tab0 + index + ch, is_half), is_half), is_half);
             }
             for (uint32_t ch = 0; ch < C; ch++) tab_st(outputs, out0 + ch, results[ch], is_half);
 
@@ -675,7 +679,7 @@ void orc_grid_encode_forward(const float* inputs, const void* embeddings, const 
                         for (uint32_t ch = 0; ch < C; ch++) {
                             /* (grid[r] - grid[l]) is a scalar_t subtraction (:239) */
                             const float diff = as_scalar(tab_ld(embeddings, tab0 + ir + ch, is_half) - tab_ld(embeddings, tab0 + il + ch, is_half), is_half);
-                            rg[ch] = as_scalar(rg[ch] + w * diff * pos_deriv[gd], is_half);
+                            rg[ch] = as_scalar(rg[ch] + as_scalar(w * diff * pos_deriv[gd], is_half), is_half);  /* same double rounding */
                         }
                     }
                     for (uint32_t ch = 0; ch < C; ch++) tab_st(dy_dx, dy0 + (size_t)gd * C + ch, rg[ch], is_half);

@@ -90,7 +90,15 @@ template <> struct Elem<true> {
     using type = __half;
     static __device__ __forceinline__ float load(const __half* p) { return __half2float(*p); }
     static __device__ __forceinline__ void store(__half* p, float v) { *p = __float2half_rn(v); }
-    static __device__ __forceinline__ float round(float v) { return __half2float(__float2half_rn(v)); }
+    // float -> half -> float with the conversion kept opaque to the optimiser: written as plain casts,
+    // hipcc folds `half(w * float(g))` into v_fma_mixlo_f16, which rounds the exact product ONCE, whereas the
+    // reference's at::Half arithmetic rounds the product to float32 first and then to half (a 1-ulp
+    // difference in ~0.1 % of features; found by running the reference kernel itself, oracle/_ref).
+    static __device__ __forceinline__ float round(float v) {
+        _Float16 h;
+        asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(v));
+        return (float)h;
+    }
 };
 
 // One vertex row = C elements. Rows are loaded / stored as a few wide words.

@@ -16,6 +16,8 @@
 //   * the fp16 table gradient uses the packed global_atomic_pk_add_f16 of gfx950.
 #include "grid_common.h"
 
+#include <stdlib.h>
+
 using namespace sdfx;
 
 using namespace sdfx::grid;
@@ -73,8 +75,9 @@ __global__ __launch_bounds__(kTile) void k_grid_forward(const float* __restrict_
     for (uint32_t d = 0; d < D; d++) grid_locate_axis(in[d], resolution, align_corners != 0, interp, pos[d], pos_deriv[d], pos_grid[d]);
 
     // issue a batch of row gathers (all 2^D of them when they fit in registers), then
-    // accumulate in corner order (gridencoder.cu:168-195; `results` has the table's type
-    // there, so the half path rounds after every corner)
+    // accumulate in corner order (gridencoder.cu:168-195; `results` has the table's type there:
+    // `results[ch] += w * grid[...]` converts the float product to at::Half, then adds two halves —
+    // so the half path rounds the product AND the partial sum at every corner)
     constexpr uint32_t NC = 1u << D;
     constexpr uint32_t kBatch = (NC * C <= 64) ? NC : (C >= 64 ? 1 : (64 / C));
     float results[C];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(kTile) void k_grid_forward(const float* __restrict_
 #pragma unroll
         for (uint32_t k = 0; k < kBatch; k++) {
 #pragma unroll
-            for (uint32_t ch = 0; ch < C; ch++) results[ch] = E::round(results[ch] + w[k] * E::load(&rows[k].v[ch]));
+            for (uint32_t ch = 0; ch < C; ch++) results[ch] = E::round(results[ch] + E::round(w[k] * E::load(&rows[k].v[ch])));
         }
     }
     Row<T, C> o;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(kTile) void k_grid_forward(const float* __restrict_
 #pragma unroll
                 for (uint32_t ch = 0; ch < C; ch++) {
                     const float diff = E::round(E::load(&right.v[ch]) - E::load(&left.v[ch]));
-                    rg[ch] = E::round(rg[ch] + wg * diff * pos_deriv[gd]);
+                    rg[ch] = E::round(rg[ch] + E::round(wg * diff * pos_deriv[gd]));
                 }
             }
             Row<T, C> og;
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void k_grad_wd(const typename Elem<HALF>::type
         if ((uint32_t)offsets[m] <= n) { level = m; l = m + 1; } else { r = m; }
     }
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
-    const float g = E::load(grad + b) + 2 * weight * E::load(table + b) / (float)hashmap_size;
+    const float g = E::load(grad + b) + E::round(2 * weight * E::load(table + b) / (float)hashmap_size);
     E::store(grad + b, g);
 }
 
@@ -459,6 +462,7 @@ int sdfx_grid_encode_forward(const float* inputs, const void* embeddings, const 
     a.inputs = inputs; a.table = embeddings; a.outputs = outputs; a.B = B; a.L = L;
     a.plan = make_plan(offsets_host, max_level, S, H, C, eb, B);
     a.plan.vec16 = (reinterpret_cast<uintptr_t>(embeddings) % 16) == 0 ? 1u : 0u;
+    if (getenv("SDFX_GRID_NOVEC16")) a.plan.vec16 = 0;  // debugging aid: force the one-gather-per-corner path
     a.dy_dx = dy_dx; a.gridtype = gridtype; a.align_corners = align_corners; a.interp = interp;
     a.out_layout = out_layout; a.st = as_stream(stream); a.grid = plan_grid_size(a.plan);
     if (is_half) { SDFX_DISPATCH_DC(true, launch_forward, a) } else { SDFX_DISPATCH_DC(false, launch_forward, a) }
