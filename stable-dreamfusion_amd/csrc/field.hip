@@ -12,10 +12,12 @@
 //   * weights are wave-uniform, so they are fetched with scalar loads (s_load_dwordxN through the
 //     scalar cache) and feed v_dot2_f32_f16 directly as SGPR operands: 2 MACs per instruction with
 //     float32 accumulation — the arithmetic autocast GEMMs do (fp16 inputs, fp32 accumulate, fp16 out);
-//   * the backward recomputes the activations (nothing but the 64-byte feature row is re-read), forms
-//     d(features) per thread, and reduces the weight gradient inside the workgroup through an LDS
-//     staging tile ([sample][feature] halves) with each thread owning a 4x4 / 4x2 block of a weight
-//     matrix; per-workgroup partial sums are combined by a second tiny kernel (deterministic, no atomics);
+//   * the backward recomputes the activations (nothing but the 64-byte feature row is re-read) and forms
+//     d(features) per thread, also on v_dot2. The WEIGHT gradient is the one genuinely dense contraction
+//     of this path — dW2[64x64] = dh2[64 x P] . h1[64 x P]^T over the P samples of a tile — so it goes to the
+//     matrix cores: activations and their gradients are staged in LDS as [feature][sample] halves and each
+//     wave accumulates 32x32 blocks with v_mfma_f32_32x32x16_f16 (sample axis = K). Per-workgroup partial
+//     sums are combined by a second tiny kernel (deterministic, no atomics);
 //   * features are read, and d(features) written, directly in the encoder's level-major [L, B, 2]
 //     layout (or [B, 32]), so the permute copies of gridencoder/grid.py:64,82 disappear on this path.
 #include "sdfx_common.h"
@@ -186,8 +188,51 @@ __global__ __launch_bounds__(kThreads) void k_field_forward(const uint32_t* __re
 // =========================================================================================
 // backward: (d sigma, d albedo) -> d features, per-workgroup weight-gradient partial sums
 // =========================================================================================
-constexpr uint32_t kStageStride = 64;  // words per staged sample; word i of sample p lives at (i + p) & 63 (bank rotation)
-#define STG(p, i) (((i) + (p)) & 63u)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// LDS staging tile for the weight-gradient contractions: row = one feature, 256 samples (+8 halves of padding
+// so that the 16-byte fragment reads of 32 consecutive rows fall on different banks).
+constexpr uint32_t kRowHalves = kThreads + 8;
+constexpr uint32_t kStageRows = 2 * kHid;  // the largest phase stages 64 inputs + 64 output gradients
+
+// fragment of v_mfma_f32_32x32x16_f16: lane l holds 8 consecutive K elements (samples) of row (l & 31),
+// starting at K = 8 * (l >> 5) within the 16-sample step. A and B use the same sample mapping, and the
+// contraction runs over the samples, so the result does not depend on how K is numbered.
+__device__ __forceinline__ h8 frag(const _Float16* stage, uint32_t row, uint32_t step, int lane) {
+    return *reinterpret_cast<const h8*>(stage + (size_t)(row + (lane & 31)) * kRowHalves + step * 16 + 8 * (lane >> 5));
+}
+
+// acc[32x32 block] += sum over the 256 staged samples of a_rows (x) b_rows
+__device__ __forceinline__ f32x16 contract(const _Float16* stage, uint32_t a_row0, uint32_t b_row0, f32x16 acc, int lane,
+                                           bool a_valid = true) {
+#pragma unroll 4
+    for (uint32_t step = 0; step < kThreads / 16; step++) {
+        h8 a = frag(stage, a_row0, step, lane);
+        if (!a_valid) a = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        const h8 b = frag(stage, b_row0, step, lane);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// sum of one staged row over the samples (bias gradient)
+__device__ __forceinline__ float row_sum(const _Float16* stage, uint32_t row) {
+    const h8* r = reinterpret_cast<const h8*>(stage + (size_t)row * kRowHalves);
+    float s = 0.f;
+#pragma unroll 4
+    for (uint32_t i = 0; i < kThreads / 8; i++) {
+        const h8 v = r[i];
+        s += ((float)v[0] + (float)v[1]) + ((float)v[2] + (float)v[3]) + (((float)v[4] + (float)v[5]) + ((float)v[6] + (float)v[7]));
+    }
+    return s;
+}
+
+// store feature pair (2i, 2i+1) of this thread's sample into rows row0 + 2i, row0 + 2i + 1
+__device__ __forceinline__ void stage_pair(_Float16* stage, uint32_t row0, uint32_t i, uint32_t t, h2 v) {
+    stage[(size_t)(row0 + 2 * i) * kRowHalves + t] = v.x;
+    stage[(size_t)(row0 + 2 * i + 1) * kRowHalves + t] = v.y;
+}
 
 __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __restrict__ enc, int enc_layout,
                                                               const float* __restrict__ x,
@@ -197,20 +242,14 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
                                                               const float* __restrict__ dalbedo,
                                                               uint32_t* __restrict__ denc,
                                                               float* __restrict__ partials) {
-    __shared__ uint32_t stage[kThreads * kStageStride];
+    __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * kRowHalves];
     const uint32_t t = threadIdx.x;
-    // this thread's share of the weight gradient
-    const uint32_t o4 = (t >> 4) * 4;   // 4 output rows   (W2, W1)
-    const uint32_t k4 = (t & 15) * 4;   // 4 input columns (W2)
-    const uint32_t k2 = (t & 15) * 2;   // 2 input columns (W1)
-    const uint32_t o3 = t >> 6, k3 = t & 63;  // one entry of W3
-    float gw2[4][4], gw1[4][2], gw3 = 0.f, gb = 0.f;
+    const int lane = (int)(t & 63);
+    const uint32_t wave = t >> 6;            // 4 waves: each owns one 32x32 block of dW2 and one of dW1 / dW3
+    f32x16 acc2, accx;                       // dW2 block (wave >> 1, wave & 1); dW1 block (waves 0,1) or dW3 block (waves 2,3)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) gw2[i][j] = 0.f;
-        gw1[i][0] = 0.f; gw1[i][1] = 0.f;
-    }
+    for (int i = 0; i < 16; i++) { acc2[i] = 0.f; accx[i] = 0.f; }
+    float gb = 0.f;                          // bias gradient owned by this thread (t < 64: b2, 64..127: b1, 128..131: b3)
 
     const uint32_t ntiles = (B + kThreads - 1) / kThreads;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -281,83 +320,44 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
             dh3[0] = h2{0, 0}; dh3[1] = h2{0, 0};
         }
 
-        uint32_t* row = stage + t * kStageStride;
-        // ---- dW2 += dh2 (x) h1 ; db2 += dh2 --------------------------------------------------
+        // ---- dW2 += dh2 . h1^T ; db2 += sum dh2 : rows [0,64) = h1, [64,128) = dh2 ------------------------
         __syncthreads();
 #pragma unroll
-        for (uint32_t i = 0; i < kHid / 2; i++) { row[STG(t, i)] = as_u32(a.h1[i]); row[STG(t, 32 + i)] = as_u32(dh2[i]); }
+        for (uint32_t i = 0; i < kHid / 2; i++) { stage_pair(stage, 0, i, t, a.h1[i]); stage_pair(stage, kHid, i, t, dh2[i]); }
         __syncthreads();
-#pragma unroll 8
-        for (uint32_t p = 0; p < kThreads; p++) {
-            const uint32_t* r = stage + p * kStageStride;
-            const h2 i0 = as_h2(r[STG(p, k4 / 2)]), i1 = as_h2(r[STG(p, k4 / 2 + 1)]);
-            const h2 d0 = as_h2(r[STG(p, 32 + o4 / 2)]), d1 = as_h2(r[STG(p, 32 + o4 / 2 + 1)]);
-            const float in[4] = {(float)i0.x, (float)i0.y, (float)i1.x, (float)i1.y};
-            const float dd[4] = {(float)d0.x, (float)d0.y, (float)d1.x, (float)d1.y};
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) gw2[i][j] = fmaf(dd[i], in[j], gw2[i][j]);
-            if (t < 64) {            // db2[t]
-                const h2 v = as_h2(r[STG(p, 32 + t / 2)]);
-                gb += (t & 1) ? (float)v.y : (float)v.x;
-            }
-        }
-        // ---- dW1 += dh1 (x) enc ; db1 += dh1 -------------------------------------------------
+        acc2 = contract(stage, kHid + 32 * (wave >> 1), 32 * (wave & 1), acc2, lane);
+        if (t < kHid) gb += row_sum(stage, kHid + t);
+        // ---- dW1 += dh1 . enc^T ; db1 += sum dh1 : rows [0,32) = enc, [32,96) = dh1 ------------------------
         __syncthreads();
 #pragma unroll
-        for (uint32_t i = 0; i < kIn / 2; i++) row[STG(t, i)] = as_u32(a.enc[i]);
+        for (uint32_t i = 0; i < kIn / 2; i++) stage_pair(stage, 0, i, t, a.enc[i]);
 #pragma unroll
-        for (uint32_t i = 0; i < kHid / 2; i++) row[STG(t, 32 + i)] = as_u32(dh1[i]);
+        for (uint32_t i = 0; i < kHid / 2; i++) stage_pair(stage, kIn, i, t, dh1[i]);
         __syncthreads();
-#pragma unroll 8
-        for (uint32_t p = 0; p < kThreads; p++) {
-            const uint32_t* r = stage + p * kStageStride;
-            const h2 i0 = as_h2(r[STG(p, k2 / 2)]);
-            const h2 d0 = as_h2(r[STG(p, 32 + o4 / 2)]), d1 = as_h2(r[STG(p, 32 + o4 / 2 + 1)]);
-            const float dd[4] = {(float)d0.x, (float)d0.y, (float)d1.x, (float)d1.y};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                gw1[i][0] = fmaf(dd[i], (float)i0.x, gw1[i][0]);
-                gw1[i][1] = fmaf(dd[i], (float)i0.y, gw1[i][1]);
-            }
-            if (t >= 64 && t < 128) {  // db1[t - 64]
-                const h2 v = as_h2(r[STG(p, 32 + (t - 64) / 2)]);
-                gb += (t & 1) ? (float)v.y : (float)v.x;
-            }
-        }
-        // ---- dW3 += dh3 (x) h2 ; db3 += dh3 --------------------------------------------------
+        if (wave < 2) accx = contract(stage, kIn + 32 * wave, 0, accx, lane);
+        if (t >= 64 && t < 64 + kHid) gb += row_sum(stage, kIn + (t - 64));
+        // ---- dW3 += dh3 . h2^T ; db3 += sum dh3 : rows [0,64) = h2, [64,68) = dh3 --------------------------
         __syncthreads();
 #pragma unroll
-        for (uint32_t i = 0; i < kHid / 2; i++) row[STG(t, i)] = as_u32(a.h2_[i]);
-        row[STG(t, 32)] = as_u32(dh3[0]);
-        row[STG(t, 33)] = as_u32(dh3[1]);
+        for (uint32_t i = 0; i < kHid / 2; i++) stage_pair(stage, 0, i, t, a.h2_[i]);
+        stage_pair(stage, kHid, 0, t, dh3[0]);
+        stage_pair(stage, kHid, 1, t, dh3[1]);
         __syncthreads();
-#pragma unroll 8
-        for (uint32_t p = 0; p < kThreads; p++) {
-            const uint32_t* r = stage + p * kStageStride;
-            const h2 iv = as_h2(r[STG(p, k3 / 2)]);
-            const h2 dv = as_h2(r[STG(p, 32 + o3 / 2)]);
-            const float in = (k3 & 1) ? (float)iv.y : (float)iv.x;
-            const float dd = (o3 & 1) ? (float)dv.y : (float)dv.x;
-            gw3 = fmaf(dd, in, gw3);
-            if (t >= 128 && t < 132) {  // db3[t - 128]
-                const h2 v = as_h2(r[STG(p, 32 + (t - 128) / 2)]);
-                gb += (t & 1) ? (float)v.y : (float)v.x;
-            }
-        }
+        // only 4 of the 32 A rows exist (the rest of the block is padding that is never written out)
+        if (wave >= 2) accx = contract(stage, kHid, 32 * (wave - 2), accx, lane, (lane & 31) < (int)kOut);
+        if (t >= 128 && t < 128 + kOut) gb += row_sum(stage, kHid + (t - 128));
     }
 
-    // per-workgroup partial sums, laid out like the torch parameters
+    // per-workgroup partial sums, laid out like the torch parameters. Accumulator element r of lane l is
+    // D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31] of the wave's 32x32 block.
     float* out = partials + (size_t)blockIdx.x * kGradWords;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) out[gW2 + (o4 + i) * kHid + k4 + j] = gw2[i][j];
-        out[gW1 + (o4 + i) * kIn + k2] = gw1[i][0];
-        out[gW1 + (o4 + i) * kIn + k2 + 1] = gw1[i][1];
+    for (int r = 0; r < 16; r++) {
+        const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+        out[gW2 + (32 * (wave >> 1) + row) * kHid + 32 * (wave & 1) + col] = acc2[r];
+        if (wave < 2) out[gW1 + (32 * wave + row) * kIn + col] = accx[r];
+        else if (row < kOut) out[gW3 + row * kHid + 32 * (wave - 2) + col] = accx[r];
     }
-    out[gW3 + o3 * kHid + k3] = gw3;
     if (t < 64) out[gB2 + t] = gb;
     else if (t < 128) out[gB1 + (t - 64)] = gb;
     else if (t < 132) out[gB3 + (t - 128)] = gb;
