@@ -217,6 +217,8 @@ int sdfx_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, 
  *   dw1..db3   float32 parameter gradients (overwritten)
  */
 uint32_t sdfx_field_packed_words(void);
+/* testing aid: 0 = matrix-core kernels (default), 1 = per-thread v_dot2 kernels, -1 = follow env SDFX_FIELD_IMPL */
+void sdfx_field_set_impl(int impl);
 uint64_t sdfx_field_backward_scratch_bytes(uint32_t B);
 int sdfx_field_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                     uint32_t* packed, sdfx_stream_t stream);

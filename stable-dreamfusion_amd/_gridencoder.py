@@ -54,7 +54,7 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C_, L, max_l
 
 # ---- binned scatter (D = 3, C = 2): persistent scratch per device -----------------------------------
 _BINNED = int(os.environ.get("SDFX_GRID_BWD_BINNED", "1"))
-_BINNED_CHUNK_POINTS = int(os.environ.get("SDFX_GRID_BWD_CHUNK", str(1 << 20)))
+_BINNED_CHUNK_POINTS = int(os.environ.get("SDFX_GRID_BWD_CHUNK", str(1 << 22)))
 _BINNED_SCRATCH = {}
 
 

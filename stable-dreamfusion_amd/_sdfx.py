@@ -50,6 +50,7 @@ _SIGNATURES = {
     "sdfx_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "sdfx_sh_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "sdfx_field_packed_words": [],
+    "sdfx_field_set_impl": [_int],
     "sdfx_field_backward_scratch_bytes": [_u32],
     "sdfx_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_field_forward": [_ptr, _int, _ptr, _ptr, _u32, _f32, _f32, _ptr, _ptr, _ptr],

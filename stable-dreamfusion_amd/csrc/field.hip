@@ -22,6 +22,8 @@
 //     layout (or [B, 32]), so the permute copies of gridencoder/grid.py:64,82 disappear on this path.
 #include "sdfx_common.h"
 
+#include <stdlib.h>
+
 using namespace sdfx;
 
 namespace {
@@ -39,7 +41,11 @@ constexpr uint32_t kW1T = kW2T + kHid * kHid / 2;    // [32][32]
 constexpr uint32_t kB1 = kW1T + kIn * kHid / 2;      // [64] float (rounded to half)
 constexpr uint32_t kB2 = kB1 + kHid;
 constexpr uint32_t kB3 = kB2 + kHid;
-constexpr uint32_t kPackedWords = kB3 + kOut;        // 6532
+constexpr uint32_t kDotWords = kB3 + kOut;           // 6532: the v_dot2 layouts + biases
+// MFMA A-operand fragments (v_mfma_f32_32x32x16_f16): fragment f, lane l = 8 halves A[32 mb + (l & 31)][16 s + 8 (l >> 5) + j]
+constexpr uint32_t fW1 = 0, fW2 = 4, fW3 = 12, fW3T = 16, fW2T = 18, fW1T = 26, kFrags = 30;
+constexpr uint32_t kFragBase = (kDotWords + 3) & ~3u;  // 16-byte aligned start of the fragment section
+constexpr uint32_t kPackedWords = kFragBase + kFrags * 64 * 4;  // 14212
 
 // gradient block (floats), same order as the torch parameters
 constexpr uint32_t gW1 = 0, gB1 = gW1 + kHid * kIn, gW2 = gB1 + kHid, gB2 = gW2 + kHid * kHid, gW3 = gB2 + kHid,
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256) void k_field_pack(const float* __restrict__ w1
                                                      const float* __restrict__ w2, const float* __restrict__ b2,
                                                      const float* __restrict__ w3, const float* __restrict__ b3,
                                                      uint32_t* __restrict__ packed) {
-    for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < kPackedWords; i += blockDim.x * gridDim.x) {
+    for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < kDotWords; i += blockDim.x * gridDim.x) {
         uint32_t v;
         if (i < kW2) {  // W1[o][2kp, 2kp+1]
             const uint32_t j = i - kW1, o = j / (kIn / 2), kp = j % (kIn / 2);
@@ -84,6 +90,35 @@ __global__ __launch_bounds__(256) void k_field_pack(const float* __restrict__ w1
             v = __builtin_bit_cast(uint32_t, (float)(_Float16)b);
         }
         packed[i] = v;
+    }
+    // MFMA fragments: one (fragment, lane) pair = 8 halves = 4 words
+    for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < kFrags * 64; i += blockDim.x * gridDim.x) {
+        const uint32_t f = i / 64, l = i % 64;
+        uint32_t layer, mb, st;
+        if (f < fW2) { layer = 0; mb = (f - fW1) / 2; st = (f - fW1) % 2; }
+        else if (f < fW3) { layer = 1; mb = (f - fW2) / 4; st = (f - fW2) % 4; }
+        else if (f < fW3T) { layer = 2; mb = 0; st = f - fW3; }
+        else if (f < fW2T) { layer = 3; mb = f - fW3T; st = 0; }
+        else if (f < fW1T) { layer = 4; mb = (f - fW2T) / 4; st = (f - fW2T) % 4; }
+        else { layer = 5; mb = 0; st = f - fW1T; }
+        const uint32_t m = 32 * mb + (l & 31);
+        float v8[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t k = 16 * st + 8 * (l >> 5) + j;
+            float v = 0.f;
+            switch (layer) {
+                case 0: v = w1[m * kIn + k]; break;                              // W1   [64 x 32]
+                case 1: v = w2[m * kHid + k]; break;                             // W2   [64 x 64]
+                case 2: v = m < kOut ? w3[m * kHid + k] : 0.f; break;            // W3   [4 (pad 32) x 64]
+                case 3: v = k < kOut ? w3[k * kHid + m] : 0.f; break;            // W3^T [64 x 4 (pad 16)]
+                case 4: v = w2[k * kHid + m]; break;                             // W2^T [64 x 64]
+                default: v = w1[k * kIn + m]; break;                             // W1^T [32 x 64]
+            }
+            v8[j] = v;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) packed[kFragBase + i * 4 + q] = as_u32(pack(v8[2 * q], v8[2 * q + 1]));
     }
 }
 
@@ -363,6 +398,266 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
     else if (t < 132) out[gB3 + (t - 128)] = gb;
 }
 
+// =========================================================================================
+// Matrix-core formulation of the same MLP (default). One wave = 64 samples, lane = sample, activations stay in
+// registers as packed halves exactly as in the v_dot2 kernels. A layer Y[M x 64] = W[M x K] . X[K x 64] is run as
+// v_mfma_f32_32x32x16_f16 with the weights as the A operand (pre-packed fragments, read through L1/L2) and the
+// samples as the N axis: v_permlane32_swap exchanges register halves between lanes l and l + 32, which turns
+// "lane owns a sample" into the B-operand layout (lane (n, hi) supplies features 16 s + 8 hi .. + 8 of sample n)
+// and the D layout back into "lane owns a sample" (validated on hardware by tools/ubench/mfma_probe.hip).
+// Same arithmetic as the v_dot2 path: fp16 operands, fp32 accumulation, layer outputs rounded to fp16.
+// =========================================================================================
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+// a = [a.lanes0-31 | b.lanes0-31], b = [a.lanes32-63 | b.lanes32-63]
+__device__ __forceinline__ void swap32(uint32_t& a, uint32_t& b) {
+    const u2v r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    const uint32_t x = r.x, y = r.y;  // (never __builtin_bit_cast a vector ELEMENT: clang reads element 0)
+    a = x;
+    b = y;
+}
+
+// e[mb][row] = sum_k W[32 mb + row][k] * x[k] for this lane's sample; x = KS * 8 packed words (16 KS features)
+template <int KS, int MB>
+__device__ __forceinline__ void mma_layer(const uint4* __restrict__ frags, int lane, const uint32_t (&x)[KS * 8],
+                                          float (&e)[MB][32]) {
+    uint4 B0[KS], B1[KS];  // B operands of the two 32-sample halves of the wave
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        uint32_t a0 = x[8 * s + 0], b0 = x[8 * s + 4]; swap32(a0, b0);
+        uint32_t a1 = x[8 * s + 1], b1 = x[8 * s + 5]; swap32(a1, b1);
+        uint32_t a2 = x[8 * s + 2], b2 = x[8 * s + 6]; swap32(a2, b2);
+        uint32_t a3 = x[8 * s + 3], b3 = x[8 * s + 7]; swap32(a3, b3);
+        B0[s] = make_uint4(a0, a1, a2, a3);
+        B1[s] = make_uint4(b0, b1, b2, b3);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const uint4 aw = frags[(size_t)(mb * KS + s) * 64 + lane];
+            const h8 A = __builtin_bit_cast(h8, aw);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, __builtin_bit_cast(h8, B0[s]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, __builtin_bit_cast(h8, B1[s]), acc1, 0, 0, 0);
+        }
+        // D element r of lane (n, hi) is row (r & 3) + 8 (r >> 2) + 4 hi of sample n (+32 for acc1)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float f0 = acc0[r], f1 = acc1[r];
+            uint32_t u0 = __float_as_uint(f0), u1 = __float_as_uint(f1);
+            swap32(u0, u1);
+            const int row = (r & 3) + 8 * (r >> 2);
+            e[mb][row] = __uint_as_float(u0);
+            e[mb][row + 4] = __uint_as_float(u1);
+        }
+    }
+}
+
+struct ActsW {  // activations of this lane's sample as packed words (2 features per word)
+    uint32_t enc[kIn / 2], h1[kHid / 2], h2[kHid / 2];
+    float h3[kOut];
+};
+
+__device__ __forceinline__ void mma_forward(const uint32_t* __restrict__ P, int lane, ActsW& a) {
+    const uint4* F = reinterpret_cast<const uint4*>(P + kFragBase);
+    const float* bias = reinterpret_cast<const float*>(P);
+    {
+        float e[2][32];
+        mma_layer<kIn / 16, 2>(F + fW1 * 64, lane, a.enc, e);
+#pragma unroll
+        for (int i = 0; i < kHid / 2; i++) {
+            const float v0 = e[(2 * i) / 32][(2 * i) % 32] + bias[kB1 + 2 * i], v1 = e[(2 * i + 1) / 32][(2 * i + 1) % 32] + bias[kB1 + 2 * i + 1];
+            a.h1[i] = as_u32(pack(fmaxf(v0, 0.f), fmaxf(v1, 0.f)));
+        }
+    }
+    {
+        float e[2][32];
+        mma_layer<kHid / 16, 2>(F + fW2 * 64, lane, a.h1, e);
+#pragma unroll
+        for (int i = 0; i < kHid / 2; i++) {
+            const float v0 = e[(2 * i) / 32][(2 * i) % 32] + bias[kB2 + 2 * i], v1 = e[(2 * i + 1) / 32][(2 * i + 1) % 32] + bias[kB2 + 2 * i + 1];
+            a.h2[i] = as_u32(pack(fmaxf(v0, 0.f), fmaxf(v1, 0.f)));
+        }
+    }
+    {
+        float e[1][32];
+        mma_layer<kHid / 16, 1>(F + fW3 * 64, lane, a.h2, e);
+#pragma unroll
+        for (int o = 0; o < (int)kOut; o++) a.h3[o] = (float)(_Float16)(e[0][o] + bias[kB3 + o]);
+    }
+}
+
+__device__ __forceinline__ void load_enc_words(const uint32_t* __restrict__ enc, int layout, uint32_t B, uint32_t b, bool valid,
+                                               uint32_t (&w)[kIn / 2]) {
+    if (!valid) {
+#pragma unroll
+        for (uint32_t l = 0; l < kIn / 2; l++) w[l] = 0u;
+        return;
+    }
+    if (layout == 0) {
+#pragma unroll
+        for (uint32_t l = 0; l < kIn / 2; l++) w[l] = enc[(size_t)l * B + b];
+    } else {
+        const uint4* row = reinterpret_cast<const uint4*>(enc + (size_t)b * (kIn / 2));
+#pragma unroll
+        for (uint32_t q = 0; q < kIn / 8; q++) {
+            const uint4 v = row[q];
+            w[q * 4 + 0] = v.x; w[q * 4 + 1] = v.y; w[q * 4 + 2] = v.z; w[q * 4 + 3] = v.w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_field_forward_mma(const uint32_t* __restrict__ enc, int enc_layout,
+                                                                 const float* __restrict__ x,
+                                                                 const uint32_t* __restrict__ P, uint32_t B,
+                                                                 float blob_density, float inv_2r2,
+                                                                 float* __restrict__ sigma, float* __restrict__ albedo) {
+    const uint32_t b = blockIdx.x * kThreads + threadIdx.x;
+    const bool valid = b < B;  // every lane takes part in the swaps and the MFMAs; out-of-range lanes compute on zeros
+    const int lane = (int)(threadIdx.x & 63);
+    ActsW a;
+    load_enc_words(enc, enc_layout, B, b, valid, a.enc);
+    mma_forward(P, lane, a);
+    if (!valid) return;
+    const float z = a.h3[0] + density_blob(x, b, blob_density, inv_2r2);
+    sigma[b] = expf(z);
+    albedo[(size_t)b * 3 + 0] = sigmoidf_(a.h3[1]);
+    albedo[(size_t)b * 3 + 1] = sigmoidf_(a.h3[2]);
+    albedo[(size_t)b * 3 + 2] = sigmoidf_(a.h3[3]);
+}
+
+__device__ __forceinline__ void stage_word(_Float16* stage, uint32_t row0, uint32_t i, uint32_t t, uint32_t w) {
+    stage_pair(stage, row0, i, t, as_h2(w));
+}
+
+// relu'(act) applied to a pair of gradients, packed
+__device__ __forceinline__ uint32_t masked_pack(uint32_t act, float g0, float g1) {
+    const h2 a = as_h2(act);
+    return as_u32(pack(a.x > (_Float16)0 ? g0 : 0.f, a.y > (_Float16)0 ? g1 : 0.f));
+}
+
+__global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t* __restrict__ enc, int enc_layout,
+                                                                  const float* __restrict__ x,
+                                                                  const uint32_t* __restrict__ P, uint32_t B,
+                                                                  float blob_density, float inv_2r2,
+                                                                  const float* __restrict__ dsigma,
+                                                                  const float* __restrict__ dalbedo,
+                                                                  uint32_t* __restrict__ denc,
+                                                                  float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * kRowHalves];
+    const uint4* F = reinterpret_cast<const uint4*>(P + kFragBase);
+    const uint32_t t = threadIdx.x;
+    const int lane = (int)(t & 63);
+    const uint32_t wave = t >> 6;
+    f32x16 acc2, accx;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc2[i] = 0.f; accx[i] = 0.f; }
+    float gb = 0.f;
+
+    const uint32_t ntiles = (B + kThreads - 1) / kThreads;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t b = tile * kThreads + t;
+        const bool valid = b < B;
+        ActsW a;
+        load_enc_words(enc, enc_layout, B, b, valid, a.enc);
+        mma_forward(P, lane, a);
+
+        // output activations: d sigma / d z = exp(min(z, 15)) (activation.py:13-16); d sigmoid = s (1 - s)
+        uint32_t dh3[8];
+        {
+            float g0 = 0.f, g[3] = {0.f, 0.f, 0.f};
+            if (valid) {
+                const float z = a.h3[0] + density_blob(x, b, blob_density, inv_2r2);
+                g0 = dsigma[b] * expf(fminf(z, 15.0f));
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float sg = sigmoidf_(a.h3[1 + c]);
+                    g[c] = dalbedo[(size_t)b * 3 + c] * sg * (1.0f - sg);
+                }
+            }
+            dh3[0] = as_u32(pack(g0, g[0]));
+            dh3[1] = as_u32(pack(g[1], g[2]));
+#pragma unroll
+            for (int i = 2; i < 8; i++) dh3[i] = 0u;  // K = 4 padded to one 16-wide step
+        }
+
+        // ---- dW3 += dh3 . h2^T ; db3 : rows [0,64) = h2, [64,68) = dh3 ---------------------------------------
+        __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < kHid / 2; i++) stage_word(stage, 0, i, t, a.h2[i]);
+        stage_word(stage, kHid, 0, t, dh3[0]);
+        stage_word(stage, kHid, 1, t, dh3[1]);
+        __syncthreads();
+        if (wave >= 2) accx = contract(stage, kHid, 32 * (wave - 2), accx, lane, (lane & 31) < (int)kOut);
+        if (t >= 128 && t < 128 + kOut) gb += row_sum(stage, kHid + (t - 128));
+
+        // d h2 = relu'(h2) * W3^T d h3
+        uint32_t dh2[kHid / 2];
+        {
+            float e[2][32];
+            mma_layer<1, 2>(F + fW3T * 64, lane, dh3, e);
+#pragma unroll
+            for (int i = 0; i < kHid / 2; i++) dh2[i] = masked_pack(a.h2[i], e[(2 * i) / 32][(2 * i) % 32], e[(2 * i + 1) / 32][(2 * i + 1) % 32]);
+        }
+
+        // ---- dW2 += dh2 . h1^T ; db2 : rows [0,64) = h1, [64,128) = dh2 ---------------------------------------
+        __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < kHid / 2; i++) { stage_word(stage, 0, i, t, a.h1[i]); stage_word(stage, kHid, i, t, dh2[i]); }
+        __syncthreads();
+        acc2 = contract(stage, kHid + 32 * (wave >> 1), 32 * (wave & 1), acc2, lane);
+        if (t < kHid) gb += row_sum(stage, kHid + t);
+
+        // d h1 = relu'(h1) * W2^T d h2
+        uint32_t dh1[kHid / 2];
+        {
+            float e[2][32];
+            mma_layer<kHid / 16, 2>(F + fW2T * 64, lane, dh2, e);
+#pragma unroll
+            for (int i = 0; i < kHid / 2; i++) dh1[i] = masked_pack(a.h1[i], e[(2 * i) / 32][(2 * i) % 32], e[(2 * i + 1) / 32][(2 * i + 1) % 32]);
+        }
+
+        // ---- dW1 += dh1 . enc^T ; db1 : rows [0,32) = enc, [32,96) = dh1 --------------------------------------
+        __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < kIn / 2; i++) stage_word(stage, 0, i, t, a.enc[i]);
+#pragma unroll
+        for (uint32_t i = 0; i < kHid / 2; i++) stage_word(stage, kIn, i, t, dh1[i]);
+        __syncthreads();
+        if (wave < 2) accx = contract(stage, kIn + 32 * wave, 0, accx, lane);
+        if (t >= 64 && t < 64 + kHid) gb += row_sum(stage, kIn + (t - 64));
+
+        // d features = W1^T d h1, written in the layout the features came in
+        {
+            float e[1][32];
+            mma_layer<kHid / 16, 1>(F + fW1T * 64, lane, dh1, e);
+            if (valid) {
+#pragma unroll
+                for (uint32_t i = 0; i < kIn / 2; i++) {
+                    const uint32_t w = as_u32(pack(e[0][2 * i], e[0][2 * i + 1]));
+                    if (enc_layout == 0) denc[(size_t)i * B + b] = w;
+                    else denc[(size_t)b * (kIn / 2) + i] = w;
+                }
+            }
+        }
+    }
+
+    float* out = partials + (size_t)blockIdx.x * kGradWords;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+        out[gW2 + (32 * (wave >> 1) + row) * kHid + 32 * (wave & 1) + col] = acc2[r];
+        if (wave < 2) out[gW1 + (32 * wave + row) * kIn + col] = accx[r];
+        else if (row < kOut) out[gW3 + row * kHid + 32 * (wave - 2) + col] = accx[r];
+    }
+    if (t < 64) out[gB2 + t] = gb;
+    else if (t < 128) out[gB1 + (t - 64)] = gb;
+    else if (t < 132) out[gB3 + (t - 128)] = gb;
+}
+
 // sum the per-workgroup partials into the six parameter gradients
 __global__ __launch_bounds__(64) void k_field_wgrad_reduce(const float* __restrict__ partials, uint32_t nblocks,
                                                              float* __restrict__ dw1, float* __restrict__ db1,
@@ -388,6 +683,13 @@ __global__ __launch_bounds__(64) void k_field_wgrad_reduce(const float* __restri
     else db3[i - gB3] = s;
 }
 
+int g_field_impl = -1;  // -1: from SDFX_FIELD_IMPL (default mma); 0: mma; 1: dot2
+bool use_dot2() {
+    if (g_field_impl >= 0) return g_field_impl == 1;
+    static const int v = [] { const char* e = getenv("SDFX_FIELD_IMPL"); return (e && e[0] == 'd') ? 1 : 0; }();
+    return v != 0;
+}
+
 uint32_t backward_blocks(uint32_t B) {
     const uint32_t tiles = div_up(B, kThreads);
     return tiles < kMaxBlocks ? tiles : kMaxBlocks;
@@ -398,6 +700,9 @@ uint32_t backward_blocks(uint32_t B) {
 extern "C" {
 
 uint32_t sdfx_field_packed_words(void) { return kPackedWords; }
+
+/* testing aid: 0 = matrix-core kernels (default), 1 = per-thread v_dot2 kernels, -1 = follow SDFX_FIELD_IMPL */
+void sdfx_field_set_impl(int impl) { g_field_impl = impl; }
 
 uint64_t sdfx_field_backward_scratch_bytes(uint32_t B) { return (uint64_t)backward_blocks(B ? B : 1) * kGradWords * sizeof(float); }
 
@@ -415,9 +720,15 @@ int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const ui
     SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_forward: features misaligned");
     SDFX_REQUIRE(blob_radius > 0, "field_forward: blob_radius must be positive");
     if (B == 0) return SDFX_OK;
-    hipLaunchKernelGGL(k_field_forward, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
-                       static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
-                       1.0f / (2 * blob_radius * blob_radius), sigma, albedo);
+    if (use_dot2()) {
+        hipLaunchKernelGGL(k_field_forward, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                           static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
+                           1.0f / (2 * blob_radius * blob_radius), sigma, albedo);
+    } else {
+        hipLaunchKernelGGL(k_field_forward_mma, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
+                           static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
+                           1.0f / (2 * blob_radius * blob_radius), sigma, albedo);
+    }
     return check_launch("field_forward");
 }
 
@@ -433,9 +744,15 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
     hipStream_t st = as_stream(stream);
     const uint32_t nblocks = B ? backward_blocks(B) : 0;
     if (B) {
-        hipLaunchKernelGGL(k_field_backward, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
-                           enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
-                           static_cast<uint32_t*>(denc), scratch);
+        if (use_dot2()) {
+            hipLaunchKernelGGL(k_field_backward, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
+                               enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
+                               static_cast<uint32_t*>(denc), scratch);
+        } else {
+            hipLaunchKernelGGL(k_field_backward_mma, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
+                               enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
+                               static_cast<uint32_t*>(denc), scratch);
+        }
     }
     hipLaunchKernelGGL(k_field_wgrad_reduce, dim3(div_up(kGradWords, 64)), dim3(64), 0, st, scratch, nblocks, dw1, db1,
                        dw2, db2, dw3, db3);

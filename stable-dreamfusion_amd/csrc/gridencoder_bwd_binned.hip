@@ -33,7 +33,7 @@ constexpr uint32_t kMaxBucketsPerLevel = 512;            // levels up to 2^20 ro
 constexpr uint32_t kBinThreads = 512;
 constexpr uint32_t kPointsPerThread = 1;
 constexpr uint32_t kReduceThreads = 256;
-constexpr uint32_t kItemsPerSplit = 32768;               // target items per K2 workgroup
+constexpr uint32_t kItemsPerSplit = 131072;              // a bucket holding more items than this is reduced by several workgroups
 constexpr uint32_t kMaxSplits = 64;
 
 struct BinPlan {
@@ -73,27 +73,43 @@ template <> struct Item<false> {  // {row in level, float2 contribution}
     __device__ __forceinline__ float2 value() const { return make_float2(a, b); }
 };
 
-// fold runs of equal `key` among neighbouring lanes: after the call the LAST lane of every run holds
-// the run's sums and returns true; the other lanes return false.
+// value of lane (l - n) of the same 16-lane row, `self` where there is none (DPP row_shr: a VALU move, no LDS traffic)
+template <int N>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t self) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)self, (int)v, 0x110 + N, 0xf, 0xf, false);
+}
+template <int N>
+__device__ __forceinline__ float row_shr(float v, float self) {
+    return __uint_as_float(row_shr<N>(__float_as_uint(v), __float_as_uint(self)));
+}
+// value of lane (l + 1) of the same row, `self` at the row's last lane (DPP row_shl:1)
+__device__ __forceinline__ uint32_t row_shl1(uint32_t v, uint32_t self) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)self, (int)v, 0x101, 0xf, 0xf, false);
+}
+
+// fold runs of equal `key` among neighbouring lanes of a 16-lane row: after the call the LAST lane of every run
+// holds the run's sums and returns true; the other lanes return false. (Runs are cut at row boundaries, which only
+// matters at the coarsest levels where a run could span more than 16 samples.) Segmented scan on DPP row shifts.
 __device__ __forceinline__ bool fold_lane_runs(uint32_t key, bool active, float& a, float& b, int lane) {
+    const int rl = lane & 15;
     // inactive lanes get a key no active lane can have, so they break runs and are never emitted
     const uint32_t k = active ? key : (0xFFFFFFFFu - (uint32_t)lane);
-    const uint32_t prev = __shfl_up(k, 1, kWave);
-    bool head = (lane == 0) || (prev != k);
-    bool f = head;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const float au = __shfl_up(a, o, kWave);
-        const float bu = __shfl_up(b, o, kWave);
-        const int fu = __shfl_up((int)f, o, kWave);
-        if (lane >= o && !f) {
-            a += au;
-            b += bu;
-            f = fu != 0;
-        }
+    const uint32_t prev = row_shr<1>(k, ~k);
+    const bool head = (rl == 0) || (prev != k);
+    uint32_t f = head ? 1u : 0u;
+#define SDFX_FOLD_STEP(N)                                              \
+    {                                                                  \
+        const float au = row_shr<N>(a, 0.f), bu = row_shr<N>(b, 0.f);  \
+        const uint32_t fu = row_shr<N>(f, 1u);                         \
+        if (rl >= N && !f) { a += au; b += bu; f = fu; }               \
     }
-    const int next_head = __shfl_down((int)head, 1, kWave);
-    const bool tail = (lane == kWave - 1) || (next_head != 0);
+    SDFX_FOLD_STEP(1)
+    SDFX_FOLD_STEP(2)
+    SDFX_FOLD_STEP(4)
+    SDFX_FOLD_STEP(8)
+#undef SDFX_FOLD_STEP
+    const uint32_t next_head = row_shl1(head ? 1u : 0u, 1u);
+    const bool tail = (rl == 15) || (next_head != 0u);
     return active && tail;
 }
 
@@ -224,8 +240,14 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce(typename Ele
     const uint32_t cap = bin.cap[level];
     uint32_t n = cursors[bin.bucket_first[level] + bucket];
     if (n > cap) n = cap;
-    // this split's slice of the item list
-    const uint32_t per = (n + splits - 1) / splits;
+    // How many of the `splits` workgroups launched for this bucket actually share it is decided from the
+    // item count found at run time: one workgroup (sole owner, plain read-modify-write flush) unless the
+    // bucket is heavy (unsorted input at a coarse level), in which case the flush has to be atomic.
+    uint32_t used = (n + kItemsPerSplit - 1) / kItemsPerSplit;
+    if (used < 1) used = 1;
+    if (used > splits) used = splits;
+    if (split >= used) return;
+    const uint32_t per = (n + used - 1) / used;
     const uint32_t begin = split * per;
     const uint32_t end = begin + per < n ? begin + per : n;
     if (begin >= end) return;
@@ -234,11 +256,27 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce(typename Ele
     __syncthreads();
 
     const Item<HALF>* src = items + (size_t)bin.item_first[level] * 1024u + (size_t)bucket * cap;
-    for (uint32_t i = begin + threadIdx.x; i < end; i += kReduceThreads) {
+    // kUnroll independent loads in flight per thread (the list is only read once: latency, not bandwidth, bounds a
+    // workgroup that owns a bucket alone)
+    constexpr uint32_t kUnroll = 8;
+    uint32_t i = begin + threadIdx.x;
+    for (; i + (kUnroll - 1) * kReduceThreads < end; i += kUnroll * kReduceThreads) {
+        Item<HALF> it[kUnroll];
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; u++) it[u] = src[i + u * kReduceThreads];
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; u++) {
+            const float2 v = it[u].value();
+            const uint32_t r = (it[u].row & (kBucketRows - 1)) * 2;
+            atomicAdd(&acc[r], v.x);      // ds_add_f32
+            atomicAdd(&acc[r + 1], v.y);
+        }
+    }
+    for (; i < end; i += kReduceThreads) {
         const Item<HALF> it = src[i];
         const float2 v = it.value();
         const uint32_t r = (it.row & (kBucketRows - 1)) * 2;
-        atomicAdd(&acc[r], v.x);      // ds_add_f32
+        atomicAdd(&acc[r], v.x);
         atomicAdd(&acc[r + 1], v.y);
     }
     __syncthreads();
@@ -252,7 +290,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce(typename Ele
         const uint32_t row = first_row + r;
         if (row >= level_rows) continue;
         T* dst = grad_table + ((size_t)row0 + row) * 2;
-        if (splits == 1) {  // sole owner of these rows: plain read-modify-write
+        if (used == 1) {  // sole owner of these rows: plain read-modify-write
             if constexpr (HALF) {
                 const __half2 o = *reinterpret_cast<const __half2*>(dst);
                 *reinterpret_cast<__half2*>(dst) =

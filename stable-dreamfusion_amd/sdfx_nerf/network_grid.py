@@ -19,6 +19,9 @@ from .renderer import NeRFRenderer, safe_normalize
 # fused encode -> MLP -> activation kernels for the fp16-autocast path (SDFX_FUSED_FIELD=0 keeps the
 # reference's module-by-module evaluation: GridEncoder -> nn.Linear stack -> torch activations)
 _FUSED = int(os.environ.get("SDFX_FUSED_FIELD", "1"))
+# evaluate the sample and its six finite-difference neighbours in ONE field call (the field is point-wise, so the
+# values are those of the reference's seven separate common_forward calls, network_grid.py:81-96, 108-115)
+_BATCH_STENCIL = int(os.environ.get("SDFX_BATCH_STENCIL", "1"))
 
 
 class _trunc_exp(Function):
@@ -114,13 +117,29 @@ class NeRFNetwork(NeRFRenderer):
         normal = safe_normalize(normal)
         return torch.nan_to_num(normal)
 
+    def _stencil_forward(self, x, epsilon=1e-2):
+        """sigma, albedo at x and -grad(sigma) by central differences, from one batched field evaluation of
+        [x, x+e_x, x-e_x, x+e_y, x-e_y, x+e_z, x-e_z] (offset points clamped to the box as the reference does)."""
+        N = x.shape[0]
+        e = epsilon
+        offs = torch.tensor([[e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]], device=x.device, dtype=x.dtype)
+        neigh = (x.unsqueeze(0) + offs.unsqueeze(1)).clamp(-self.bound, self.bound)      # [6, N, 3]
+        pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
+        sigma_all, albedo_all = self.common_forward(pts)
+        s = sigma_all.view(7, N)
+        normal = -torch.stack([0.5 * (s[1] - s[2]) / e, 0.5 * (s[3] - s[4]) / e, 0.5 * (s[5] - s[6]) / e], dim=-1)
+        return s[0], albedo_all.view(7, N, 3)[0], normal
+
     def forward(self, x, d, l=None, ratio=1, shading="albedo"):
-        sigma, albedo = self.common_forward(x)
+        if shading != "albedo" and _BATCH_STENCIL:
+            sigma, albedo, normal = self._stencil_forward(x)
+            normal = torch.nan_to_num(safe_normalize(normal))
+        else:
+            sigma, albedo = self.common_forward(x)
+            normal = None if shading == "albedo" else self.normal(x)
         if shading == "albedo":
-            normal = None
             color = albedo
         else:
-            normal = self.normal(x)
             lambertian = ratio + (1 - ratio) * (normal * l).sum(-1).clamp(min=0)
             if shading == "textureless":
                 color = lambertian.unsqueeze(-1).repeat(1, 3)

@@ -1,0 +1,25 @@
+#!/bin/bash
+TAG=${1:-pmcg}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$PWD
+cd /tmp
+python $REPO/tools/gridbwd_bench.py 3 2>&1 | tail -1 | tee $OUT/summary.txt
+i=0
+for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -o pmc -- python $REPO/tools/gridbwd_bench.py 1 > $OUT/p$i.log 2>&1
+  echo "set $i exit $?" | tee -a $OUT/summary.txt
+done
+find $OUT -type f -size +1M -delete 2>/dev/null
+python3 - <<PY | tee -a $OUT/summary.txt
+import csv, glob, collections
+for f in sorted(glob.glob("$OUT/p*/*counter_collection.csv")):
+    for kn in ("k_grid_bwd_bin", "k_grid_bwd_reduce"):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if kn in r.get("Kernel_Name", ""):
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        print(kn, {k: v[-1] for k, v in agg.items()})
+PY
