@@ -13,9 +13,10 @@
 //              hit the same table row: a wave-level segmented scan folds each run into one item.
 //              Items are binned by row range (2048 rows per bucket) with an LDS histogram and ONE
 //              global atomic per (workgroup, bucket) that reserves a slice of the bucket's item list.
-//   K2 reduce  one workgroup per bucket (several for over-full coarse buckets) sums its items into a
-//              2048 x 2 float accumulator in LDS and adds it to the table gradient with plain,
-//              coalesced read-modify-writes (the workgroup owns those rows).
+//   K2 reduce  one workgroup per bucket (several for over-full coarse buckets) sums its items into
+//              per-wave 2048 x float2 accumulators in LDS (plain read-modify-writes, same-row lanes
+//              serialised by a ticket byte; LDS float atomics are ~80x slower) and adds the result to
+//              the table gradient with plain, coalesced read-modify-writes (the workgroup owns those rows).
 //
 // Items that do not fit a bucket's reserved capacity fall back to a direct global atomic in K1, so
 // the result is complete for any input distribution. Sums are formed in float32 and rounded to the
@@ -34,13 +35,16 @@ constexpr uint32_t kBinThreads = 512;
 constexpr uint32_t kPointsPerThread = 1;
 constexpr uint32_t kReduceThreads = 256;
 constexpr uint32_t kItemsPerSplit = 131072;              // a bucket holding more items than this is reduced by several workgroups
-constexpr uint32_t kMaxSplits = 64;
+constexpr uint32_t kItemsPerSplitCoarse = 32768;         // ... for levels of few buckets, each of which gets a large share of the batch
+constexpr uint32_t kCoarseBuckets = 128;
+constexpr uint32_t kMaxSplits = 512;
 
 struct BinPlan {
     uint32_t bucket_first[kMaxLevels + 1];  // first bucket id of each level (prefix sum)
     uint32_t split_first[kMaxLevels + 1];   // first K2 workgroup id of each level
     uint32_t splits[kMaxLevels];            // K2 workgroups per bucket of this level
     uint32_t cap[kMaxLevels];               // item capacity of one bucket of this level
+    uint32_t per_split[kMaxLevels];         // items one K2 workgroup takes before a second one is brought in
     uint32_t item_first[kMaxLevels];        // first item slot (in units of 1024 items) of the level's bucket 0
     uint32_t merge_mask;                    // bit l: fold lane runs at level l before binning
     uint32_t levels;
@@ -87,30 +91,45 @@ __device__ __forceinline__ uint32_t row_shl1(uint32_t v, uint32_t self) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)self, (int)v, 0x101, 0xf, 0xf, false);
 }
 
-// fold runs of equal `key` among neighbouring lanes of a 16-lane row: after the call the LAST lane of every run
-// holds the run's sums and returns true; the other lanes return false. (Runs are cut at row boundaries, which only
-// matters at the coarsest levels where a run could span more than 16 samples.) Segmented scan on DPP row shifts.
-__device__ __forceinline__ bool fold_lane_runs(uint32_t key, bool active, float& a, float& b, int lane) {
+// Runs of neighbouring lanes (within a 16-lane DPP row) whose samples sit in the same grid cell: all 8 corners of
+// such samples address the same 8 table rows, so the run structure is found ONCE per sample from the cell id and
+// reused for every corner. Hillis-Steele segmented scan: step N adds the value N lanes down unless the lane's
+// segment flag is already set; `take[N]` is that condition as an all-ones / zero word, so that the per-corner
+// work is one masked DPP fetch per channel and step (v_and_b32_dpp) plus the add. After the scan the LAST lane
+// of every run holds the run's sum (`tail`). Runs are cut at row boundaries, which only matters at the coarsest
+// levels where a run could span more than 16 samples.
+struct RunScan {
+    uint32_t take1, take2, take4, take8;
+    bool tail;
+};
+
+__device__ __forceinline__ RunScan scan_cell_runs(uint32_t cell, bool active, int lane) {
     const int rl = lane & 15;
     // inactive lanes get a key no active lane can have, so they break runs and are never emitted
-    const uint32_t k = active ? key : (0xFFFFFFFFu - (uint32_t)lane);
+    const uint32_t k = active ? cell : (0xFFFFFFFFu - (uint32_t)lane);
     const uint32_t prev = row_shr<1>(k, ~k);
     const bool head = (rl == 0) || (prev != k);
-    uint32_t f = head ? 1u : 0u;
-#define SDFX_FOLD_STEP(N)                                              \
-    {                                                                  \
-        const float au = row_shr<N>(a, 0.f), bu = row_shr<N>(b, 0.f);  \
-        const uint32_t fu = row_shr<N>(f, 1u);                         \
-        if (rl >= N && !f) { a += au; b += bu; f = fu; }               \
-    }
-    SDFX_FOLD_STEP(1)
-    SDFX_FOLD_STEP(2)
-    SDFX_FOLD_STEP(4)
-    SDFX_FOLD_STEP(8)
-#undef SDFX_FOLD_STEP
+    RunScan r;
+    uint32_t f = head ? 1u : 0u;  // lanes below N read the fill value 1, so after step N every lane < 2N is closed
+    r.take1 = f ? 0u : 0xFFFFFFFFu; f |= row_shr<1>(f, 1u);
+    r.take2 = f ? 0u : 0xFFFFFFFFu; f |= row_shr<2>(f, 1u);
+    r.take4 = f ? 0u : 0xFFFFFFFFu; f |= row_shr<4>(f, 1u);
+    r.take8 = f ? 0u : 0xFFFFFFFFu;
     const uint32_t next_head = row_shl1(head ? 1u : 0u, 1u);
-    const bool tail = (rl == 15) || (next_head != 0u);
-    return active && tail;
+    r.tail = active && ((rl == 15) || (next_head != 0u));
+    return r;
+}
+
+template <int N>
+__device__ __forceinline__ float masked_shr(float v, uint32_t mask) {  // (value N lanes down, 0 outside the row) & mask
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x110 + N, 0xf, 0xf, true) & mask);
+}
+
+__device__ __forceinline__ void fold_runs(const RunScan& r, float& a, float& b) {
+    { const float au = masked_shr<1>(a, r.take1), bu = masked_shr<1>(b, r.take1); a += au; b += bu; }
+    { const float au = masked_shr<2>(a, r.take2), bu = masked_shr<2>(b, r.take2); a += au; b += bu; }
+    { const float au = masked_shr<4>(a, r.take4), bu = masked_shr<4>(b, r.take4); a += au; b += bu; }
+    { const float au = masked_shr<8>(a, r.take8), bu = masked_shr<8>(b, r.take8); a += au; b += bu; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -180,12 +199,20 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
             rows[i] = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
             va[i] = w * g0;
             vb[i] = w * g1;
-            bool emit = valid;
-            if (merge) emit = fold_lane_runs(rows[i], valid, va[i], vb[i], lane);  // all lanes participate
-            if (emit) {
-                alive |= 1u << i;
-                rank[i] = atomicAdd(&hist[rows[i] >> kBucketRowsLog2], 1u);  // LDS
-            }
+        }
+        bool emit = valid;
+        if (merge) {  // workgroup-uniform; all lanes participate in the DPP exchanges
+            // merged levels have res <= 640, so a cell id fits 10 bits per axis
+            const RunScan runs = scan_cell_runs(pos_grid[0] | (pos_grid[1] << 10) | (pos_grid[2] << 20), valid, lane);
+#pragma unroll
+            for (uint32_t idx = 0; idx < NCORN; idx++) fold_runs(runs, va[k * NCORN + idx], vb[k * NCORN + idx]);
+            emit = runs.tail;
+        }
+        if (emit) {
+            alive |= 0xFFu << (k * NCORN);
+#pragma unroll
+            for (uint32_t idx = 0; idx < NCORN; idx++)
+                rank[k * NCORN + idx] = atomicAdd(&hist[rows[k * NCORN + idx] >> kBucketRowsLog2], 1u);  // LDS
         }
     }
     __syncthreads();
@@ -221,93 +248,198 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
 // ---------------------------------------------------------------------------------------------
 // K2: per-bucket reduction in LDS, then one read-modify-write per touched table row
 // ---------------------------------------------------------------------------------------------
-template <bool HALF>
-__global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce(typename Elem<HALF>::type* __restrict__ grad_table,
-                                                                     GridPlan plan, BinPlan bin,
-                                                                     const uint32_t* __restrict__ cursors,
-                                                                     const Item<HALF>* __restrict__ items) {
-    using T = typename Elem<HALF>::type;
-    __shared__ float acc[kBucketRows * 2];
+// LDS float atomics are the wrong tool here: ds_add_f32 with 64 scattered addresses keeps the LDS pipe busy for
+// ~390 cycles per wave instruction on gfx950 (rocprofv3: SQ_LDS_IDX_ACTIVE 734 M cycles for 1.9 M ds_add_f32,
+// SQ_WAIT_INST_LDS = 92 % of the wave cycles; profiles/r01_pmc_gridbwd.txt), while plain ds_read/ds_write and
+// the INTEGER atomics of K1 cost 4-5 cycles.
+//
+//  * half items (the -O path): every finite half is an integer multiple of 2^-24 below 2^16, so value * 2^24 is
+//    an integer below 2^40 and a 64-bit integer accumulator (ds_add_u64) sums millions of items EXACTLY, in any
+//    order, however many lanes hit the same row. The bucket's sum is converted and rounded once at the flush.
+//    Non-finite items (an overflowed AMP step) bypass the accumulator and go to the table with a global atomic.
+//  * float items: every wave owns a PRIVATE 2048 x float2 accumulator and adds with ordinary read-modify-writes;
+//    lanes of one wave instruction that target the same row are serialised by a one-byte ticket: all pending
+//    lanes write their lane id to tag[row], read it back (LDS executes a wave's instructions in order), the lane
+//    whose id survived adds, the others go round again.
+constexpr uint32_t kReduceThreadsFixed = 512;
+constexpr uint32_t kReduceWaves = kReduceThreads / 64;
+constexpr uint32_t kReduceLdsBytes = kReduceWaves * kBucketRows * (sizeof(float2) + 1);
 
-    // workgroup -> (level, bucket, split)
+struct ReduceJob {
+    uint32_t level, bucket, used, begin, end, cap;
+};
+
+// workgroup -> (level, bucket, split) and its slice of the bucket's item list; false if there is nothing to do
+__device__ __forceinline__ bool reduce_job(const BinPlan& bin, const uint32_t* __restrict__ cursors, ReduceJob& j) {
     uint32_t level = 0;
     while (level + 1 < bin.levels && blockIdx.x >= bin.split_first[level + 1]) level++;
     const uint32_t splits = bin.splits[level];
     const uint32_t local = blockIdx.x - bin.split_first[level];
-    const uint32_t bucket = local / splits;
-    const uint32_t split = local - bucket * splits;
-
-    const uint32_t cap = bin.cap[level];
-    uint32_t n = cursors[bin.bucket_first[level] + bucket];
-    if (n > cap) n = cap;
+    j.level = level;
+    j.bucket = local / splits;
+    const uint32_t split = local - j.bucket * splits;
+    j.cap = bin.cap[level];
+    uint32_t n = cursors[bin.bucket_first[level] + j.bucket];
+    if (n > j.cap) n = j.cap;
     // How many of the `splits` workgroups launched for this bucket actually share it is decided from the
     // item count found at run time: one workgroup (sole owner, plain read-modify-write flush) unless the
-    // bucket is heavy (unsorted input at a coarse level), in which case the flush has to be atomic.
-    uint32_t used = (n + kItemsPerSplit - 1) / kItemsPerSplit;
+    // bucket is heavy (a coarse level, or unsorted input), in which case the flush has to be atomic.
+    const uint32_t per_split = bin.per_split[level];
+    uint32_t used = (n + per_split - 1) / per_split;
     if (used < 1) used = 1;
     if (used > splits) used = splits;
-    if (split >= used) return;
+    j.used = used;
+    if (split >= used) return false;
     const uint32_t per = (n + used - 1) / used;
-    const uint32_t begin = split * per;
-    const uint32_t end = begin + per < n ? begin + per : n;
-    if (begin >= end) return;
+    j.begin = split * per;
+    j.end = j.begin + per < n ? j.begin + per : n;
+    return j.begin < j.end;
+}
 
-    for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreads) acc[i] = 0.f;
-    __syncthreads();
-
-    const Item<HALF>* src = items + (size_t)bin.item_first[level] * 1024u + (size_t)bucket * cap;
-    // kUnroll independent loads in flight per thread (the list is only read once: latency, not bandwidth, bounds a
-    // workgroup that owns a bucket alone)
-    constexpr uint32_t kUnroll = 8;
-    uint32_t i = begin + threadIdx.x;
-    for (; i + (kUnroll - 1) * kReduceThreads < end; i += kUnroll * kReduceThreads) {
-        Item<HALF> it[kUnroll];
-#pragma unroll
-        for (uint32_t u = 0; u < kUnroll; u++) it[u] = src[i + u * kReduceThreads];
-#pragma unroll
-        for (uint32_t u = 0; u < kUnroll; u++) {
-            const float2 v = it[u].value();
-            const uint32_t r = (it[u].row & (kBucketRows - 1)) * 2;
-            atomicAdd(&acc[r], v.x);      // ds_add_f32
-            atomicAdd(&acc[r + 1], v.y);
+// add (a, b) to the table row this workgroup is flushing
+template <bool HALF>
+__device__ __forceinline__ void flush_row(typename Elem<HALF>::type* dst, float a, float b, bool sole_owner) {
+    if (sole_owner) {  // plain read-modify-write
+        if constexpr (HALF) {
+            const __half2 o = *reinterpret_cast<const __half2*>(dst);
+            *reinterpret_cast<__half2*>(dst) =
+                __halves2half2(__float2half_rn(__low2float(o) + a), __float2half_rn(__high2float(o) + b));
+        } else {
+            float2 o = *reinterpret_cast<const float2*>(dst);
+            o.x += a; o.y += b;
+            *reinterpret_cast<float2*>(dst) = o;
+        }
+    } else {
+        if constexpr (HALF) {
+            unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), __halves2half2(__float2half_rn(a), __float2half_rn(b)));
+        } else {
+            unsafeAtomicAdd(dst, a);
+            unsafeAtomicAdd(dst + 1, b);
         }
     }
-    for (; i < end; i += kReduceThreads) {
-        const Item<HALF> it = src[i];
-        const float2 v = it.value();
-        const uint32_t r = (it.row & (kBucketRows - 1)) * 2;
-        atomicAdd(&acc[r], v.x);
-        atomicAdd(&acc[r + 1], v.y);
+}
+
+// finite half (bit pattern) -> value * 2^24 as a signed 64-bit integer (exact)
+__device__ __forceinline__ long long half_to_fixed(uint32_t h) {
+    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    const unsigned long long mag = (unsigned long long)(e ? (m | 1024u) : m) << (e ? e - 1u : 0u);
+    return (h & 0x8000u) ? -(long long)mag : (long long)mag;
+}
+
+__global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(__half* __restrict__ grad_table, GridPlan plan,
+                                                                              BinPlan bin,
+                                                                              const uint32_t* __restrict__ cursors,
+                                                                              const Item<true>* __restrict__ items) {
+    __shared__ unsigned long long acc[kBucketRows * 2];  // 32 KiB
+    ReduceJob j;
+    if (!reduce_job(bin, cursors, j)) return;
+    for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) acc[i] = 0ull;
+    __syncthreads();
+
+    const uint32_t row0 = plan.off[j.level];
+    const Item<true>* src = items + (size_t)bin.item_first[j.level] * 1024u + (size_t)j.bucket * j.cap;
+    constexpr uint32_t kUnroll = 8;  // independent loads in flight per thread
+    for (uint32_t base = j.begin; base < j.end; base += kUnroll * kReduceThreadsFixed) {
+        Item<true> it[kUnroll];
+        bool have[kUnroll];
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; u++) {
+            const uint32_t i = base + u * kReduceThreadsFixed + threadIdx.x;
+            have[u] = i < j.end;
+            it[u] = src[have[u] ? i : j.begin];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; u++) {
+            if (!have[u]) continue;
+            const uint32_t v = it[u].val, lo = v & 0xFFFFu, hi = v >> 16;
+            if (((lo & 0x7C00u) == 0x7C00u) || ((hi & 0x7C00u) == 0x7C00u)) {  // inf / nan: straight to the table
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(grad_table + ((size_t)row0 + it[u].row) * 2),
+                                *reinterpret_cast<const __half2*>(&v));
+                continue;
+            }
+            const uint32_t r = (it[u].row & (kBucketRows - 1)) * 2;
+            if (lo & 0x7FFFu) atomicAdd(&acc[r], (unsigned long long)half_to_fixed(lo));      // ds_add_u64
+            if (hi & 0x7FFFu) atomicAdd(&acc[r + 1], (unsigned long long)half_to_fixed(hi));
+        }
     }
     __syncthreads();
 
-    const uint32_t row0 = plan.off[level];
-    const uint32_t level_rows = plan.off[level + 1] - row0;
-    const uint32_t first_row = bucket << kBucketRowsLog2;
+    const uint32_t level_rows = plan.off[j.level + 1] - row0;
+    const uint32_t first_row = j.bucket << kBucketRowsLog2;
+    for (uint32_t r = threadIdx.x; r < kBucketRows; r += kReduceThreadsFixed) {
+        const long long ia = (long long)acc[r * 2], ib = (long long)acc[r * 2 + 1];
+        if (ia == 0 && ib == 0) continue;
+        const uint32_t row = first_row + r;
+        if (row >= level_rows) continue;
+        // |sum| < 2^63 * 2^-24; the double is exact up to 2^53, the float conversion rounds once
+        const float a = (float)((double)ia * 0x1p-24), b = (float)((double)ib * 0x1p-24);
+        flush_row<true>(grad_table + ((size_t)row0 + row) * 2, a, b, j.used == 1);
+    }
+}
+
+typedef __attribute__((address_space(3))) volatile uint8_t lds_ticket_t;  // keeps ds_write_b8/ds_read_u8 (not flat_*)
+
+__device__ __forceinline__ void ticket_add(float2* __restrict__ acc, lds_ticket_t* tag, uint32_t r, float2 v,
+                                           bool pending, uint32_t lane) {
+    while (__ballot(pending)) {
+        if (pending) tag[r] = (uint8_t)lane;
+        if (pending && tag[r] == (uint8_t)lane) {
+            float2 a = acc[r];
+            a.x += v.x;
+            a.y += v.y;
+            acc[r] = a;
+            pending = false;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce_ticket(float* __restrict__ grad_table, GridPlan plan,
+                                                                            BinPlan bin,
+                                                                            const uint32_t* __restrict__ cursors,
+                                                                            const Item<false>* __restrict__ items) {
+    extern __shared__ __align__(16) unsigned char reduce_lds[];
+    float2* acc_all = reinterpret_cast<float2*>(reduce_lds);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    float2* acc = acc_all + wave * kBucketRows;
+    lds_ticket_t* tag = (lds_ticket_t*)(reduce_lds + kReduceWaves * kBucketRows * sizeof(float2) + wave * kBucketRows);
+
+    ReduceJob j;
+    if (!reduce_job(bin, cursors, j)) return;
+    for (uint32_t i = threadIdx.x; i < kReduceWaves * kBucketRows; i += kReduceThreads) acc_all[i] = make_float2(0.f, 0.f);
+    __syncthreads();
+
+    const Item<false>* src = items + (size_t)bin.item_first[j.level] * 1024u + (size_t)j.bucket * j.cap;
+    constexpr uint32_t kUnroll = 8;
+    for (uint32_t base = j.begin; base < j.end; base += kUnroll * kReduceThreads) {
+        Item<false> it[kUnroll];
+        bool have[kUnroll];
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; u++) {
+            const uint32_t i = base + u * kReduceThreads + threadIdx.x;
+            have[u] = i < j.end;
+            it[u] = src[have[u] ? i : j.begin];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; u++)
+            ticket_add(acc, tag, it[u].row & (kBucketRows - 1), it[u].value(), have[u], lane);
+    }
+    __syncthreads();
+
+    const uint32_t row0 = plan.off[j.level];
+    const uint32_t level_rows = plan.off[j.level + 1] - row0;
+    const uint32_t first_row = j.bucket << kBucketRowsLog2;
     for (uint32_t r = threadIdx.x; r < kBucketRows; r += kReduceThreads) {
-        const float a = acc[r * 2], b = acc[r * 2 + 1];
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (uint32_t w = 0; w < kReduceWaves; w++) {
+            const float2 p = acc_all[w * kBucketRows + r];
+            a += p.x;
+            b += p.y;
+        }
         if (a == 0.f && b == 0.f) continue;
         const uint32_t row = first_row + r;
         if (row >= level_rows) continue;
-        T* dst = grad_table + ((size_t)row0 + row) * 2;
-        if (used == 1) {  // sole owner of these rows: plain read-modify-write
-            if constexpr (HALF) {
-                const __half2 o = *reinterpret_cast<const __half2*>(dst);
-                *reinterpret_cast<__half2*>(dst) =
-                    __halves2half2(__float2half_rn(__low2float(o) + a), __float2half_rn(__high2float(o) + b));
-            } else {
-                float2 o = *reinterpret_cast<const float2*>(dst);
-                o.x += a; o.y += b;
-                *reinterpret_cast<float2*>(dst) = o;
-            }
-        } else {
-            if constexpr (HALF) {
-                unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), __halves2half2(__float2half_rn(a), __float2half_rn(b)));
-            } else {
-                unsafeAtomicAdd(dst, a);
-                unsafeAtomicAdd(dst + 1, b);
-            }
-        }
+        flush_row<false>(grad_table + ((size_t)row0 + row) * 2, a, b, j.used == 1);
     }
 }
 
@@ -329,7 +461,11 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
         uint64_t cap = (worst + nb - 1) / nb;
         cap = cap + cap / 4 + 256;
         b.cap[l] = (uint32_t)cap;
-        uint32_t splits = (uint32_t)((cap + kItemsPerSplit - 1) / kItemsPerSplit);
+        // A level of a few buckets (the 16^3 level has two) receives all 8*B contributions in those few lists: with
+        // 131072 items per workgroup only a few dozen workgroups would run (measured: 677 of 1756 us for that
+        // level alone). Such levels are cut finer and flushed atomically.
+        b.per_split[l] = nb <= kCoarseBuckets ? kItemsPerSplitCoarse : kItemsPerSplit;
+        uint32_t splits = (uint32_t)((cap + b.per_split[l] - 1) / b.per_split[l]);
         if (splits < 1) splits = 1;
         if (splits > kMaxSplits) splits = kMaxSplits;
         b.splits[l] = splits;
@@ -338,7 +474,7 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
         buckets += nb;
         wgs += nb * splits;
         // fold lane runs where neighbouring samples (~1/600 of the unit cube apart) usually share a cell
-        if (plan.res[l] <= 640) b.merge_mask |= 1u << l;
+        if (plan.res[l] <= 640) b.merge_mask |= 1u << l;  // (scan_cell_runs packs a cell id into 10 bits per axis: res <= 1024)
     }
     b.bucket_first[levels] = buckets;
     b.split_first[levels] = wgs;
@@ -398,6 +534,13 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
     if (B == 0) return SDFX_OK;
     hipStream_t st = as_stream(stream);
     const uint32_t eb = is_half ? 2 : 4;
+    {   // K2 needs more than the 64 KiB of LDS a kernel gets without asking
+        static bool lds_ok = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_bwd_reduce_ticket),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReduceLdsBytes) == hipSuccess;
+        }();
+        SDFX_REQUIRE(lds_ok, "grid_encode_backward_binned: cannot reserve LDS for the reduce kernel");
+    }
 
     // largest chunk (multiple of 512 samples) whose item lists fit the scratch
     uint32_t chunk = B;
@@ -430,13 +573,13 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
             hipLaunchKernelGGL(k_grid_bwd_bin<true>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const __half*>(grad),
                                inputs, static_cast<__half*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
                                interp, grad_layout, cursors, static_cast<Item<true>*>(items));
-            hipLaunchKernelGGL(k_grid_bwd_reduce<true>, dim3(nsplits), dim3(kReduceThreads), 0, st,
+            hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(nsplits), dim3(kReduceThreadsFixed), 0, st,
                                static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items));
         } else {
             hipLaunchKernelGGL(k_grid_bwd_bin<false>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const float*>(grad),
                                inputs, static_cast<float*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
                                interp, grad_layout, cursors, static_cast<Item<false>*>(items));
-            hipLaunchKernelGGL(k_grid_bwd_reduce<false>, dim3(nsplits), dim3(kReduceThreads), 0, st,
+            hipLaunchKernelGGL(k_grid_bwd_reduce_ticket, dim3(nsplits), dim3(kReduceThreads), kReduceLdsBytes, st,
                                static_cast<float*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<false>*>(items));
         }
     }

@@ -30,3 +30,14 @@ for i in range(n + 1):
     _gridencoder.grid_encode_backward(grad, x, table, offsets, gt, B, 3, 2, 16, 16, S, 16, None, None, 0, False, 1, 0)
 e_.record(); torch.cuda.synchronize()
 print(f"grid bwd binned B={B}: {s.elapsed_time(e_)/n*1e3:.1f} us/call")
+if os.environ.get("PER_LEVEL"):
+    prev = 0.0
+    for ml in range(1, 17):
+        for i in range(4):
+            if i == 1:
+                s.record()
+            _gridencoder.grid_encode_backward(grad, x, table, offsets, gt, B, 3, 2, 16, ml, S, 16, None, None, 0, False, 1, 0)
+        e_.record(); torch.cuda.synchronize()
+        t = s.elapsed_time(e_) / 3 * 1e3
+        print(f"  max_level={ml:2d}: {t:8.1f} us  (+{t - prev:7.1f})  rows={int(offsets_np[ml]-offsets_np[ml-1])}")
+        prev = t
