@@ -65,7 +65,7 @@ class KernelTimer:
         timer = self
 
         def timed(*a, **k):
-            if not timer.enabled:
+            if not timer.enabled or torch.cuda.is_current_stream_capturing():
                 return inner(*a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -317,24 +317,68 @@ def main():
         ro, rd, az = views[rank_view(rank, i, len(views))]
         return step.step(ro, rd, azimuth=az)
 
+    # GradScaler calibration, untimed and before the warmup: torch's GradScaler starts at 2^16 and SKIPS the optimiser
+    # step while the fp16 backward overflows (exactly what the reference's first iterations do, nerf/utils.py:1050).
+    # Timing those iterations would time a loop without its optimiser step, so iterate until the scale has settled.
+    def applied():
+        return step.applied_steps()
+
+    calib = 0
+    while calib < 64:
+        before = applied()
+        one_step(calib)
+        calib += 1
+        if applied() > before and calib >= 2:
+            break
+    if step.mode == "graph":
+        # one pass over the camera set, so that the sample-count buckets these views need have their graphs
+        # (a bucket met for the first time costs one eager iteration plus a capture)
+        for v in range(len(views)):
+            one_step(v)
+            calib += 1
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
+    applied_before = applied()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
     samples = 0
     t0 = time.perf_counter()
+    trace = os.environ.get("SDFX_BENCH_TRACE") == "1"   # diagnosis only: synchronises every iteration
     for i in range(args.steps):
+        if trace:
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
         one_step(args.warmup + i)
         samples += step.last["num_samples"]
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[trace] step {i}: {(time.perf_counter() - ts0) * 1e3:.2f} ms  M={step.last['num_samples']} {step.stats}",
+                  file=sys.stderr)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    applied_in_timed = applied() - applied_before
+    stats_timed = dict(step.stats)
+    roofline_pass = "timed region"
+    if step.mode == "graph":
+        # Launches inside a replayed HIP graph do not pass through Python, so the per-kernel HIP events are taken
+        # in a second, untimed pass over the next iterations of the same run with the graph switched off (same
+        # kernels, same launch sizes up to the capacity padding). rocprofv3 sees the replayed kernels directly:
+        # profiles/ holds that trace for comparison.
+        step.mode = "device"
+        timer.enabled = True
+        for i in range(min(args.steps, 8)):
+            one_step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        timer.enabled = False
+        step.mode = "graph"
+        roofline_pass = f"{min(args.steps, 8)} eager iterations after the timed region (graph replay hides launches from Python)"
     elapsed = job_elapsed(elapsed, dist, dev)
 
     if rank != 0:
@@ -359,9 +403,11 @@ def main():
                    "rays_per_iter": 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid},
         "rays_per_s": world * args.steps * 4096 / elapsed,
         "samples_per_iter": samples / max(args.steps, 1),
+        "optimizer_steps_applied": applied_in_timed, "scaler_calibration_iters": calib,
+        "grad_scale": step.get_scale(), "train_mode": step.mode, "graph_stats": stats_timed,
         "roofline": {"bound": "hbm", "kernel": "k_grid_forward<3,2,half>", "achieved": enc["GBps"], "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": enc["GBps"] / HBM_PEAK_GBPS, "traffic": None,
-                     "avg_launch_us": enc["avg_us"], "launches": enc["launches"],
+                     "avg_launch_us": enc["avg_us"], "launches": enc["launches"], "measured_in": roofline_pass,
                      "algorithmic_bytes_per_point": 588},
         "kernels_in_step": {k: {"GBps": round(v["GBps"], 1), "avg_us": round(v["avg_us"], 1), "launches": v["launches"]}
                             for k, v in ksum.items()},

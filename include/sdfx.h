@@ -229,6 +229,32 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
                         float* scratch, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
                         sdfx_stream_t stream);
 
+/* ------------------------------------------------------------ optimiser tail (extension) */
+
+/*
+ * Extension — loss scaling + Adan without a host round trip. The reference does this part in Python:
+ * torch.cuda.amp.GradScaler (nerf/utils.py:1047-1052: scale(loss).backward(); step(optimizer); update()) and
+ * Adan.step (optimizer.py:109-209, update rule :216-261), both of which read device values back to the host
+ * every iteration (found_inf; the clip factor at optimizer.py:125-127). These entry points keep that state in
+ * device memory so that an iteration has no host dependency after the sample count is known.
+ *
+ *   ctl    float32[sdfx_adan_ctl_words()]:  [0] loss scale (set before first use)  [1] growth tracker
+ *          [2] optimiser steps applied  [3] 1/scale  [4] clip factor  [5] 1 = this iteration overflowed
+ *          [6..8] bias corrections  [9] unscaled gradient norm  [10] iterations skipped
+ *   stats  float64[2], zero before the first use: sum of squares of all (scaled) gradients, non-finite count
+ *
+ * Per iteration: sdfx_amp_grad_stats for every gradient tensor, sdfx_adan_prepare once (also applies
+ * GradScaler.update()'s growth/back-off to ctl[0] and clears stats), sdfx_adan_update for every parameter
+ * tensor (a no-op when ctl[5] != 0, as GradScaler.step() skips optimizer.step()).
+ */
+uint32_t sdfx_adan_ctl_words(void);
+int sdfx_amp_grad_stats(const float* grad, uint64_t n, double* stats, sdfx_stream_t stream);
+int sdfx_adan_prepare(float* ctl, double* stats, float beta1, float beta2, float beta3, float max_grad_norm, float eps,
+                      float growth_factor, float backoff_factor, uint32_t growth_interval, sdfx_stream_t stream);
+int sdfx_adan_update(float* param, const float* grad, float* exp_avg, float* exp_avg_diff, float* exp_avg_sq, float* pre_grad,
+                     uint64_t n, const float* ctl, float lr, float weight_decay, float eps, float beta1, float beta2,
+                     float beta3, int no_prox, sdfx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,9 +35,10 @@ constexpr uint32_t kBinThreads = 512;
 constexpr uint32_t kPointsPerThread = 1;
 constexpr uint32_t kReduceThreads = 256;
 constexpr uint32_t kItemsPerSplit = 131072;              // a bucket holding more items than this is reduced by several workgroups
-constexpr uint32_t kItemsPerSplitCoarse = 32768;         // ... for levels of few buckets, each of which gets a large share of the batch
+constexpr uint32_t kItemsPerSplitCoarse = 65536;         // ... for levels of few buckets, each of which gets a large share of the batch
 constexpr uint32_t kCoarseBuckets = 128;
 constexpr uint32_t kMaxSplits = 512;
+constexpr uint32_t kNoSharedAcc = 0xFFFFFFFFu;
 
 struct BinPlan {
     uint32_t bucket_first[kMaxLevels + 1];  // first bucket id of each level (prefix sum)
@@ -45,6 +46,8 @@ struct BinPlan {
     uint32_t splits[kMaxLevels];            // K2 workgroups per bucket of this level
     uint32_t cap[kMaxLevels];               // item capacity of one bucket of this level
     uint32_t per_split[kMaxLevels];         // items one K2 workgroup takes before a second one is brought in
+    uint32_t acc_first[kMaxLevels];         // coarse levels: first row of the level in the shared fixed-point accumulator
+                                            // (kNoSharedAcc otherwise)
     uint32_t item_first[kMaxLevels];        // first item slot (in units of 1024 items) of the level's bucket 0
     uint32_t merge_mask;                    // bit l: fold lane runs at level l before binning
     uint32_t levels;
@@ -190,6 +193,9 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
             const T* g = grad_layout == 0 ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * L + level) * C;
             g0 = E::load(g);
             g1 = E::load(g + 1);
+            // nothing to scatter: samples behind a ray's early-termination cut, and the zero-gradient padding rows of
+            // fixed-capacity sample buffers (which all sit in ONE cell and would overflow its bucket)
+            if (g0 == 0.f && g1 == 0.f) valid = false;
         }
 #pragma unroll
         for (uint32_t idx = 0; idx < NCORN; idx++) {
@@ -329,8 +335,11 @@ __device__ __forceinline__ long long half_to_fixed(uint32_t h) {
 __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(__half* __restrict__ grad_table, GridPlan plan,
                                                                               BinPlan bin,
                                                                               const uint32_t* __restrict__ cursors,
-                                                                              const Item<true>* __restrict__ items) {
+                                                                              const Item<true>* __restrict__ items,
+                                                                              uint32_t* __restrict__ done,
+                                                                              unsigned long long* __restrict__ shared_acc) {
     __shared__ unsigned long long acc[kBucketRows * 2];  // 32 KiB
+    __shared__ uint32_t is_last;
     ReduceJob j;
     if (!reduce_job(bin, cursors, j)) return;
     for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) acc[i] = 0ull;
@@ -366,14 +375,44 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
 
     const uint32_t level_rows = plan.off[j.level + 1] - row0;
     const uint32_t first_row = j.bucket << kBucketRowsLog2;
+    const uint32_t shared_first = bin.acc_first[j.level];
+    if (j.used == 1 || shared_first == kNoSharedAcc) {
+        for (uint32_t r = threadIdx.x; r < kBucketRows; r += kReduceThreadsFixed) {
+            const long long ia = (long long)acc[r * 2], ib = (long long)acc[r * 2 + 1];
+            if (ia == 0 && ib == 0) continue;
+            const uint32_t row = first_row + r;
+            if (row >= level_rows) continue;
+            // |sum| < 2^63 * 2^-24; the double is exact up to 2^53, the float conversion rounds once
+            const float a = (float)((double)ia * 0x1p-24), b = (float)((double)ib * 0x1p-24);
+            flush_row<true>(grad_table + ((size_t)row0 + row) * 2, a, b, j.used == 1);
+        }
+        return;
+    }
+    // Several workgroups share this bucket (a coarse level): they add their exact partial sums into a 64-bit
+    // accumulator in global memory; the workgroup that finishes last rounds the total once and owns the table rows.
+    // The result is therefore independent of how the bucket was split and of the order of arrival.
+    unsigned long long* gacc = shared_acc + ((size_t)shared_first + first_row) * 2;
+    for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) {
+        const unsigned long long v = acc[i];
+        if (v) atomicAdd(&gacc[i], v);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ticket = atomicAdd(&done[bin.bucket_first[j.level] + j.bucket], 1u);
+        is_last = ticket == j.used - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
     for (uint32_t r = threadIdx.x; r < kBucketRows; r += kReduceThreadsFixed) {
-        const long long ia = (long long)acc[r * 2], ib = (long long)acc[r * 2 + 1];
-        if (ia == 0 && ib == 0) continue;
         const uint32_t row = first_row + r;
         if (row >= level_rows) continue;
-        // |sum| < 2^63 * 2^-24; the double is exact up to 2^53, the float conversion rounds once
+        const long long ia = (long long)__hip_atomic_load(&gacc[r * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long ib = (long long)__hip_atomic_load(&gacc[r * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ia == 0 && ib == 0) continue;
         const float a = (float)((double)ia * 0x1p-24), b = (float)((double)ib * 0x1p-24);
-        flush_row<true>(grad_table + ((size_t)row0 + row) * 2, a, b, j.used == 1);
+        flush_row<true>(grad_table + ((size_t)row0 + row) * 2, a, b, true);
     }
 }
 
@@ -445,12 +484,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce_ticket(float
 
 // host: bucket geometry for a chunk of `chunk` samples
 BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uint64_t* total_items_1024, uint32_t* total_buckets,
-                      uint32_t* total_splits) {
+                      uint32_t* total_splits, uint32_t* shared_acc_rows = nullptr) {
     BinPlan b;
     memset(&b, 0, sizeof(b));
     b.levels = levels;
     uint64_t items = 0;
-    uint32_t buckets = 0, wgs = 0;
+    uint32_t buckets = 0, wgs = 0, acc_rows = 0;
     for (uint32_t l = 0; l < levels; l++) {
         const uint32_t rows = plan.off[l + 1] - plan.off[l];
         const uint32_t nb = (rows + kBucketRows - 1) >> kBucketRowsLog2;
@@ -465,6 +504,11 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
         // 131072 items per workgroup only a few dozen workgroups would run (measured: 677 of 1756 us for that
         // level alone). Such levels are cut finer and flushed atomically.
         b.per_split[l] = nb <= kCoarseBuckets ? kItemsPerSplitCoarse : kItemsPerSplit;
+        b.acc_first[l] = kNoSharedAcc;
+        if (nb <= kCoarseBuckets) {
+            b.acc_first[l] = acc_rows;
+            acc_rows += nb * kBucketRows;
+        }
         uint32_t splits = (uint32_t)((cap + b.per_split[l] - 1) / b.per_split[l]);
         if (splits < 1) splits = 1;
         if (splits > kMaxSplits) splits = kMaxSplits;
@@ -481,6 +525,7 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
     *total_items_1024 = items;
     *total_buckets = buckets;
     *total_splits = wgs;
+    if (shared_acc_rows) *shared_acc_rows = acc_rows;
     return b;
 }
 
@@ -493,13 +538,18 @@ bool binned_supported(uint32_t D, uint32_t C, uint32_t L, const int32_t* offsets
     return true;
 }
 
+// scratch = [bucket cursors][per-bucket arrival counters][shared 64-bit accumulators of the coarse levels][item lists]
 constexpr uint64_t kCursorBytes = (uint64_t)kMaxLevels * kMaxBucketsPerLevel * sizeof(uint32_t);
+
+uint64_t header_bytes(uint32_t shared_acc_rows) {
+    return 2 * kCursorBytes + (uint64_t)shared_acc_rows * 2 * sizeof(unsigned long long);
+}
 
 uint64_t scratch_bytes_for(const GridPlan& plan, uint32_t levels, uint32_t chunk, bool half) {
     uint64_t items;
-    uint32_t nb, wg;
-    make_bin_plan(plan, levels, chunk, &items, &nb, &wg);
-    return kCursorBytes + items * 1024u * (half ? sizeof(Item<true>) : sizeof(Item<false>));
+    uint32_t nb, wg, acc_rows;
+    make_bin_plan(plan, levels, chunk, &items, &nb, &wg, &acc_rows);
+    return header_bytes(acc_rows) + items * 1024u * (half ? sizeof(Item<true>) : sizeof(Item<false>));
 }
 
 }  // namespace
@@ -556,7 +606,8 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         }
     }
     uint32_t* cursors = static_cast<uint32_t*>(scratch);
-    void* items = static_cast<char*>(scratch) + kCursorBytes;
+    uint32_t* done = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + kCursorBytes);
+    unsigned long long* shared_acc = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + 2 * kCursorBytes);
 
     for (uint32_t b0 = 0; b0 < B; b0 += chunk) {
         const uint32_t b1 = b0 + chunk < B ? b0 + chunk : B;
@@ -565,16 +616,18 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         const GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, eb,
                                         (uint64_t)div_up(n, kBinThreads * kPointsPerThread) * kTile);
         uint64_t items_1024;
-        uint32_t nbuckets, nsplits;
-        const BinPlan bin = make_bin_plan(plan, max_level, chunk, &items_1024, &nbuckets, &nsplits);
-        (void)hipMemsetAsync(cursors, 0, (size_t)nbuckets * sizeof(uint32_t), st);
+        uint32_t nbuckets, nsplits, acc_rows;
+        const BinPlan bin = make_bin_plan(plan, max_level, chunk, &items_1024, &nbuckets, &nsplits, &acc_rows);
+        void* items = static_cast<char*>(scratch) + header_bytes(acc_rows);
+        (void)hipMemsetAsync(scratch, 0, (size_t)header_bytes(is_half ? acc_rows : 0), st);  // cursors, counters, accumulators
         const uint32_t grid1 = plan_grid_size(plan);
         if (is_half) {
             hipLaunchKernelGGL(k_grid_bwd_bin<true>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const __half*>(grad),
                                inputs, static_cast<__half*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
                                interp, grad_layout, cursors, static_cast<Item<true>*>(items));
             hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(nsplits), dim3(kReduceThreadsFixed), 0, st,
-                               static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items));
+                               static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items),
+                               done, shared_acc);
         } else {
             hipLaunchKernelGGL(k_grid_bwd_bin<false>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const float*>(grad),
                                inputs, static_cast<float*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,

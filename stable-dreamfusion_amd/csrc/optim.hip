@@ -1,0 +1,202 @@
+// optim.hip — the tail of a training iteration without a host round trip: dynamic loss scaling
+// (torch.cuda.amp.GradScaler as Trainer.train_one_epoch drives it, nerf/utils.py:1047-1052) and the Adan update
+// the `-O` path constructs (main.py:365-368 -> optimizer.py:75-170), as three kinds of launches that read and
+// write their control state in device memory:
+//
+//   k_grad_stats     per gradient tensor: sum of squares (double) and a non-finite flag
+//   k_adan_prepare   one thread: unscale factor, overflow verdict, global-norm clip factor, step count and bias
+//                    corrections, and the GradScaler growth / back-off bookkeeping for the next iteration
+//   k_adan_update    per parameter tensor: one pass over (p, g, m, v, n, g_prev) instead of the ~16 foreach passes
+//                    of the Python formulation; a no-op when the iteration overflowed
+//
+// The reference reads `found_inf` and the clip factor back to the host every iteration (GradScaler.step,
+// optimizer.py:125-127); here nothing leaves the device, which is what lets the whole iteration be replayed
+// as a HIP graph. Streaming kernels, HBM-bound: 44 bytes per parameter and iteration for the update.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sdfx.h"
+#include "sdfx_common.h"
+
+using namespace sdfx;
+
+namespace {
+
+constexpr uint32_t kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void k_grad_stats(const float* __restrict__ g, uint64_t n, double* __restrict__ stats) {
+    __shared__ double part[kThreads / 64];
+    __shared__ int bad_any;
+    if (threadIdx.x == 0) bad_any = 0;
+    __syncthreads();
+    double acc = 0.0;
+    bool bad = false;
+    const uint64_t stride = (uint64_t)gridDim.x * kThreads * 4;
+    for (uint64_t i = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) * 4; i < n; i += stride) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (i + 4 <= n && (reinterpret_cast<uintptr_t>(g + i) & 15) == 0) {
+            const float4 q = *reinterpret_cast<const float4*>(g + i);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            for (uint32_t k = 0; k < 4 && i + k < n; k++) v[k] = g[i + k];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            bad |= !(fabsf(v[k]) <= 3.402823466e38f);  // inf or nan
+            acc += (double)v[k] * (double)v[k];
+        }
+    }
+    // wave reduction, then one atomic per workgroup
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) bad_any = 1;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (uint32_t w = 0; w < kThreads / 64; w++) s += part[w];
+        atomicAdd(&stats[0], s);
+        if (bad_any) atomicAdd(&stats[1], 1.0);
+    }
+}
+
+// ctl layout (float words; integers are stored as their float value, exact far beyond any step count reached)
+//  [0] loss scale S            (in/out)   [1] growth tracker     (in/out)   [2] applied steps k  (in/out)
+//  [3] 1/S of this iteration   (out)      [4] clip factor        (out)      [5] skip (1 = overflow) (out)
+//  [6] 1-b1^k  [7] 1-b2^k  [8] sqrt(1-b3^k)  (out)      [9] ||g|| unscaled (out)   [10] skipped iterations (in/out)
+__global__ void k_adan_prepare(float* __restrict__ ctl, double* __restrict__ stats, float b1, float b2, float b3,
+                               float max_grad_norm, float eps, float growth, float backoff, float growth_interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float S = ctl[0];
+    const float inv = 1.0f / S;
+    const double sumsq = stats[0];
+    const bool overflow = stats[1] != 0.0 || !(sumsq <= 1.7976931348623157e308);
+    stats[0] = 0.0;  // ready for the next iteration
+    stats[1] = 0.0;
+    ctl[3] = inv;
+    ctl[5] = overflow ? 1.0f : 0.0f;
+    if (overflow) {  // GradScaler.update(): back off, restart the growth count (amp_update_scale)
+        ctl[0] = S * backoff;
+        ctl[1] = 0.0f;
+        ctl[4] = 0.0f;
+        ctl[9] = __builtin_inff();
+        ctl[10] += 1.0f;
+        return;
+    }
+    float tracker = ctl[1] + 1.0f;
+    if (tracker >= growth_interval) {
+        const float grown = S * growth;
+        if (grown <= 3.402823466e38f) ctl[0] = grown;
+        tracker = 0.0f;
+    }
+    ctl[1] = tracker;
+    const float norm = (float)(sqrt(sumsq) * (double)inv);
+    ctl[9] = norm;
+    // optimizer.py:121-127: clip_global_grad_norm = clamp(max_grad_norm / (||g|| + eps), max = 1)
+    ctl[4] = max_grad_norm > 0.f ? fminf(max_grad_norm / (norm + eps), 1.0f) : 1.0f;
+    const float k = ctl[2] + 1.0f;
+    ctl[2] = k;
+    ctl[6] = 1.0f - powf(b1, k);          // optimizer.py:137-141
+    ctl[7] = 1.0f - powf(b2, k);
+    ctl[8] = sqrtf(1.0f - powf(b3, k));
+}
+
+struct AdanHyper {
+    float lr, wd, eps, b1, b2, b3;
+    int no_prox;
+};
+
+__device__ __forceinline__ void adan_one(float& p, float gs, float& m, float& v, float& nn, float& prev, float unscale,
+                                         bool first, float bc1, float bc2, float bc3, const AdanHyper& h) {
+    const float g = gs * unscale;                       // unscale and clip (optimizer.py:154 grad.mul_(clip))
+    const float diff = first ? 0.f : g - prev;          // optimizer.py:145-148: pre_grad := grad on the first step
+    m = m * h.b1 + (1.f - h.b1) * g;                    // exp_avg
+    v = v * h.b2 + (1.f - h.b2) * diff;                 // exp_avg_diff
+    const float u = g + h.b2 * diff;
+    nn = nn * h.b3 + (1.f - h.b3) * u * u;              // exp_avg_sq
+    const float denom = sqrtf(nn) / bc3 + h.eps;
+    const float step1 = h.lr / bc1, step2 = h.lr * h.b2 / bc2;
+    if (h.no_prox) {
+        p = p * (1.f - h.lr * h.wd);
+        p = p - step1 * (m / denom);
+        p = p - step2 * (v / denom);
+    } else {                                             // optimizer.py:246-249 (default)
+        p = p - step1 * (m / denom);
+        p = p - step2 * (v / denom);
+        p = p / (1.f + h.lr * h.wd);
+    }
+    prev = g;
+}
+
+__global__ __launch_bounds__(kThreads) void k_adan_update(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          float* __restrict__ nn, float* __restrict__ prev, uint64_t n,
+                                                          const float* __restrict__ ctl, AdanHyper h) {
+    if (ctl[5] != 0.f) return;  // overflowed iteration: GradScaler.step() skips optimizer.step()
+    const float unscale = ctl[3] * ctl[4];
+    const bool first = ctl[2] == 1.0f;
+    const float bc1 = ctl[6], bc2 = ctl[7], bc3 = ctl[8];
+    const uint64_t stride = (uint64_t)gridDim.x * kThreads * 4;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                           reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(nn) |
+                           reinterpret_cast<uintptr_t>(prev)) & 15) == 0;
+    for (uint64_t i = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) * 4; i < n; i += stride) {
+        if (aligned && i + 4 <= n) {
+            float4 P = *reinterpret_cast<float4*>(p + i);
+            const float4 G = *reinterpret_cast<const float4*>(g + i);
+            float4 M = *reinterpret_cast<float4*>(m + i), V = *reinterpret_cast<float4*>(v + i);
+            float4 N = *reinterpret_cast<float4*>(nn + i), R = *reinterpret_cast<float4*>(prev + i);
+            adan_one(P.x, G.x, M.x, V.x, N.x, R.x, unscale, first, bc1, bc2, bc3, h);
+            adan_one(P.y, G.y, M.y, V.y, N.y, R.y, unscale, first, bc1, bc2, bc3, h);
+            adan_one(P.z, G.z, M.z, V.z, N.z, R.z, unscale, first, bc1, bc2, bc3, h);
+            adan_one(P.w, G.w, M.w, V.w, N.w, R.w, unscale, first, bc1, bc2, bc3, h);
+            *reinterpret_cast<float4*>(p + i) = P;
+            *reinterpret_cast<float4*>(m + i) = M;
+            *reinterpret_cast<float4*>(v + i) = V;
+            *reinterpret_cast<float4*>(nn + i) = N;
+            *reinterpret_cast<float4*>(prev + i) = R;
+        } else {
+            for (uint32_t k = 0; k < 4 && i + k < n; k++)
+                adan_one(p[i + k], g[i + k], m[i + k], v[i + k], nn[i + k], prev[i + k], unscale, first, bc1, bc2, bc3, h);
+        }
+    }
+}
+
+uint32_t blocks_for(uint64_t n) {
+    const uint64_t b = div_up(n, (uint64_t)kThreads * 4);
+    return (uint32_t)(b < 1 ? 1 : (b > 8192 ? 8192 : b));  // 32 workgroups per CU at most; grid-stride beyond
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t sdfx_adan_ctl_words(void) { return 16; }
+
+int sdfx_amp_grad_stats(const float* grad, uint64_t n, double* stats, sdfx_stream_t stream) {
+    SDFX_REQUIRE(stats && (grad || n == 0), "amp_grad_stats: null pointer");
+    if (n == 0) return SDFX_OK;
+    hipLaunchKernelGGL(k_grad_stats, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), grad, n, stats);
+    return check_launch("amp_grad_stats");
+}
+
+int sdfx_adan_prepare(float* ctl, double* stats, float beta1, float beta2, float beta3, float max_grad_norm, float eps,
+                      float growth_factor, float backoff_factor, uint32_t growth_interval, sdfx_stream_t stream) {
+    SDFX_REQUIRE(ctl && stats, "adan_prepare: null pointer");
+    hipLaunchKernelGGL(k_adan_prepare, dim3(1), dim3(64), 0, as_stream(stream), ctl, stats, beta1, beta2, beta3, max_grad_norm,
+                       eps, growth_factor, backoff_factor, (float)growth_interval);
+    return check_launch("adan_prepare");
+}
+
+int sdfx_adan_update(float* param, const float* grad, float* exp_avg, float* exp_avg_diff, float* exp_avg_sq, float* pre_grad,
+                     uint64_t n, const float* ctl, float lr, float weight_decay, float eps, float beta1, float beta2,
+                     float beta3, int no_prox, sdfx_stream_t stream) {
+    SDFX_REQUIRE(ctl && (n == 0 || (param && grad && exp_avg && exp_avg_diff && exp_avg_sq && pre_grad)),
+                 "adan_update: null pointer");
+    if (n == 0) return SDFX_OK;
+    const AdanHyper h{lr, weight_decay, eps, beta1, beta2, beta3, no_prox};
+    hipLaunchKernelGGL(k_adan_update, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), param, grad, exp_avg,
+                       exp_avg_diff, exp_avg_sq, pre_grad, n, ctl, h);
+    return check_launch("adan_update");
+}
+
+}  // extern "C"

@@ -14,7 +14,8 @@ from torch.amp import custom_bwd, custom_fwd
 import _raymarching as _backend
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "flatten_rays",
-           "march_rays_train", "composite_rays_train", "march_rays", "composite_rays", "compact_rays"]
+           "march_rays_train", "composite_rays_train", "march_rays", "composite_rays", "compact_rays",
+           "march_rays_train_count", "march_rays_train_write"]
 
 
 def _cuda(t):
@@ -169,6 +170,56 @@ class _march_rays_train(Function):
 
 
 march_rays_train = _march_rays_train.apply
+
+
+# Extension — the two passes of march_rays_train as separate calls, so that a caller can put the one host
+# synchronisation of an iteration (reading the sample total) wherever it wants and give the writing pass a
+# CAPACITY instead of the exact total: output shapes then no longer depend on the scene, which is what a HIP-graph
+# replay of the rest of the iteration needs. Same kernels, same values as march_rays_train.
+@torch.no_grad()
+def march_rays_train_count(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, perturb=False, dt_gamma=0,
+                           max_steps=1024, contract=False, noises=None, state=None):
+    """Counting pass. Returns a state dict {rays [N,2] i32 (offset, count), counter [1] i32 (device), noises,
+    scratch, ...}; pass `state` back in to reuse its buffers (their addresses then stay fixed)."""
+    rays_o = _cuda(rays_o).float().contiguous().view(-1, 3)
+    rays_d = _cuda(rays_d).float().contiguous().view(-1, 3)
+    N = rays_o.shape[0]
+    device = rays_o.device
+    if state is None or state["rays"].shape[0] != N or state["max_steps"] != max_steps:
+        state = {"rays": torch.empty(N, 2, dtype=torch.int32, device=device),
+                 "counter": torch.zeros(1, dtype=torch.int32, device=device),
+                 "scratch": torch.empty(N * max_steps, dtype=torch.float32, device=device),
+                 "noises": torch.zeros(N, dtype=torch.float32, device=device), "max_steps": max_steps}
+    state["counter"].zero_()  # offsets are handed out starting from counter[0] (raymarching.cu:470-474)
+    if noises is not None:
+        state["noises"].copy_(_cuda(noises).float().view(-1))
+    elif perturb:
+        state["noises"].uniform_(0, 1)
+    else:
+        state["noises"].zero_()
+    state.update(rays_o=rays_o, rays_d=rays_d, grid=_cuda(density_bitfield).contiguous(), nears=nears.contiguous(),
+                 fars=fars.contiguous(), args=(bound, contract, dt_gamma, max_steps, N, C, H))
+    bound, contract, dt_gamma, max_steps, N, C, H = state["args"]
+    _backend.march_rays_train(rays_o, rays_d, state["grid"], bound, contract, dt_gamma, max_steps, N, C, H, state["nears"],
+                              state["fars"], None, None, None, state["rays"], state["counter"], state["noises"],
+                              state["scratch"])
+    return state
+
+
+@torch.no_grad()
+def march_rays_train_write(state, capacity):
+    """Writing pass into xyzs/dirs [capacity,3], ts [capacity,2]; rows past the sample total stay zero.
+    `capacity` must be at least the total the counting pass found (the caller read it, or bounds it)."""
+    device = state["rays"].device
+    xyzs = torch.zeros(capacity, 3, dtype=torch.float32, device=device)
+    dirs = torch.zeros(capacity, 3, dtype=torch.float32, device=device)
+    ts = torch.zeros(capacity, 2, dtype=torch.float32, device=device)
+    bound, contract, dt_gamma, max_steps, N, C, H = state["args"]
+    if capacity > 0:
+        _backend.march_rays_train(state["rays_o"], state["rays_d"], state["grid"], bound, contract, dt_gamma, max_steps, N,
+                                  C, H, state["nears"], state["fars"], xyzs, dirs, ts, state["rays"], state["counter"],
+                                  state["noises"], state["scratch"])
+    return xyzs, dirs, ts, state["rays"]
 
 
 class _composite_rays_train(Function):

@@ -38,6 +38,10 @@ class SyntheticUNet(nn.Module):
         with torch.no_grad():
             for p in self.parameters():
                 p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+            # text-conditioned minus unconditioned prediction of ~0.1 per element, as a trained UNet gives; times
+            # guidance_scale = 100 that is the O(10) SDS gradient the loss scaler has to cope with
+            self.ctx.weight.mul_(0.1)
+            self.ctx.bias.mul_(0.1)
 
     def forward(self, x, t, encoder_hidden_states):
         c = self.ctx(encoder_hidden_states.mean(dim=1).to(x.dtype))[:, :, None, None]

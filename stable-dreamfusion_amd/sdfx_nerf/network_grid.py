@@ -87,6 +87,9 @@ class NeRFNetwork(NeRFRenderer):
             self.bg_net = MLP(self.in_dim_bg, 3, hidden_dim_bg, num_layers_bg, bias=True)
         else:
             self.bg_net = None
+        e = 1e-2  # finite-difference step of network_grid.py:81 (kept on the device: no per-call host tensor)
+        self.register_buffer("_fd_offsets", torch.tensor([[e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]],
+                                                         dtype=torch.float32), persistent=False)
 
     def common_forward(self, x):
         if _FUSED and _ff.supported(self.encoder, self.sigma_net, x, self.opt.density_activation, self.max_level):
@@ -122,7 +125,7 @@ class NeRFNetwork(NeRFRenderer):
         [x, x+e_x, x-e_x, x+e_y, x-e_y, x+e_z, x-e_z] (offset points clamped to the box as the reference does)."""
         N = x.shape[0]
         e = epsilon
-        offs = torch.tensor([[e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]], device=x.device, dtype=x.dtype)
+        offs = self._fd_offsets if e == 1e-2 else self._fd_offsets * (e / 1e-2)
         neigh = (x.unsqueeze(0) + offs.unsqueeze(1)).clamp(-self.bound, self.bound)      # [6, N, 3]
         pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
         sigma_all, albedo_all = self.common_forward(pts)

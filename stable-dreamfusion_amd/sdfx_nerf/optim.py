@@ -1,9 +1,13 @@
 """Adan (Xie et al., arXiv:2208.06677) — the optimiser `-O` training constructs
 (main.py:365-368: Adan(get_params(5*lr), eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0)).
 
-Written from the paper's update rule with the bias corrections and decoupled ("prox") weight
-decay of the published algorithm; torch._foreach ops, and the global-norm clip factor stays on
-the device (the reference reads it back with .item() every step, optimizer.py:125-127).
+Two forms of the same update rule (optimizer.py:216-261, default `no_prox=False`: the proximal weight
+decay `p /= 1 + lr*wd` AFTER the two moment steps):
+
+  Adan        torch._foreach ops behind the torch.optim.Optimizer interface, for torch.amp.GradScaler to
+              drive as the reference does; the global-norm clip factor stays on the device.
+  DeviceAdan  loss scaling + overflow check + clip + update in HIP kernels (csrc/optim.hip) whose control
+              state lives in device memory: no .item() anywhere, so the iteration can be captured as a HIP graph.
 """
 from __future__ import annotations
 
@@ -14,8 +18,10 @@ from torch.optim.optimizer import Optimizer
 
 
 class Adan(Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=0.0):
-        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+    def __init__(self, params, lr=1e-3, betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=0.0,
+                 no_prox=False):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
+                        no_prox=no_prox)
         super().__init__(params, defaults)
 
     @torch.no_grad()
@@ -64,9 +70,85 @@ class Adan(Optimizer):
             denom = torch._foreach_sqrt(n)
             torch._foreach_div_(denom, bc3)
             torch._foreach_add_(denom, eps)
-            torch._foreach_mul_(params, 1 - lr * wd)                   # decoupled weight decay before the step
+            if group["no_prox"]:
+                torch._foreach_mul_(params, 1 - lr * wd)
             torch._foreach_addcdiv_(params, m, denom, value=-lr / bc1)
             torch._foreach_addcdiv_(params, v, denom, value=-lr * b2 / bc2)
+            if not group["no_prox"]:
+                torch._foreach_div_(params, 1 + lr * wd)               # optimizer.py:246-249
             for pg, g in zip(prev, grads):
                 pg.copy_(g)
         return loss
+
+
+class DeviceAdan:
+    """GradScaler + Adan with all control state on the device (csrc/optim.hip).
+
+        loss_scaled = loss * opt.scale          # a 0-dim view of the control block, read at execution time
+        loss_scaled.backward()
+        opt.step()                              # stats -> prepare (overflow verdict, clip, scale update) -> update
+
+    Semantics are torch.amp.GradScaler(init_scale=2**16, growth_factor=2, backoff_factor=0.5,
+    growth_interval=2000) around the reference's Adan: an iteration whose gradients hold inf/nan leaves the
+    parameters and moments untouched, halves the scale and does not count as an optimiser step."""
+
+    def __init__(self, param_groups, betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=0.0, no_prox=False,
+                 amp=True, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        import _sdfx as S
+        self._S = S
+        self.betas, self.eps, self.max_grad_norm, self.no_prox = betas, eps, max_grad_norm, no_prox
+        self.growth = (growth_factor, backoff_factor, growth_interval) if amp else (1.0, 1.0, 1 << 30)
+        self.param_groups = []
+        for g in param_groups:
+            params = [p for p in g["params"] if p.requires_grad]
+            self.param_groups.append({"params": params, "lr": g.get("lr", 1e-3),
+                                      "weight_decay": g.get("weight_decay", weight_decay)})
+        dev = self.param_groups[0]["params"][0].device
+        self.ctl = torch.zeros(int(S.lib().sdfx_adan_ctl_words()), dtype=torch.float32, device=dev)
+        self.ctl[0] = init_scale if amp else 1.0
+        self.stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.scale = self.ctl[0]
+        self.state = {}
+        for g in self.param_groups:
+            for p in g["params"]:
+                assert p.dtype == torch.float32 and p.is_contiguous(), "DeviceAdan: float32 contiguous parameters"
+                self.state[p] = tuple(torch.zeros_like(p) for _ in range(4))  # exp_avg, exp_avg_diff, exp_avg_sq, pre_grad
+
+    def parameters(self):
+        return [p for g in self.param_groups for p in g["params"]]
+
+    def zero_grad(self):
+        for p in self.parameters():
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        S = self._S
+        st = S.stream()
+        todo = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                grad = p.grad
+                if grad.dtype != torch.float32 or not grad.is_contiguous():
+                    raise RuntimeError("DeviceAdan: gradients must be contiguous float32")
+                S.call("sdfx_amp_grad_stats", S.ptr(grad), grad.numel(), S.ptr(self.stats), st)
+                todo.append((g, p, grad))
+        b1, b2, b3 = self.betas
+        S.call("sdfx_adan_prepare", S.ptr(self.ctl), S.ptr(self.stats), b1, b2, b3, self.max_grad_norm, self.eps,
+               self.growth[0], self.growth[1], self.growth[2], st)
+        for g, p, grad in todo:
+            m, v, n, prev = self.state[p]
+            S.call("sdfx_adan_update", S.ptr(p), S.ptr(grad), S.ptr(m), S.ptr(v), S.ptr(n), S.ptr(prev), p.numel(),
+                   S.ptr(self.ctl), g["lr"], g["weight_decay"], self.eps, b1, b2, b3, int(self.no_prox), st)
+
+    # reporting only (each of these synchronises)
+    def applied_steps(self):
+        return int(self.ctl[2].item())
+
+    def skipped_steps(self):
+        return int(self.ctl[10].item())
+
+    def get_scale(self):
+        return float(self.ctl[0].item())

@@ -64,7 +64,10 @@ class NeRFRenderer(nn.Module):
 
     # --------------------------------------------------------------------------- run_cuda
     def run_cuda(self, rays_o, rays_d, light_d=None, ambient_ratio=1.0, shading="albedo", bg_color=None, perturb=False,
-                 T_thresh=1e-4, binarize=False, **kwargs):
+                 T_thresh=1e-4, binarize=False, marched=None, **kwargs):
+        """`marched` (extension): (xyzs, dirs, ts, rays, n_valid) from raymarching.march_rays_train_count/_write when
+        the caller has already marched into fixed-capacity buffers; n_valid is the device-side sample total and
+        replaces the buffer length wherever the reference averages over samples."""
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -72,16 +75,21 @@ class NeRFRenderer(nn.Module):
         device = rays_o.device
 
         # NOTE: min_near is not forwarded (the reference does not either), so the op's 0.2 default applies
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer)
+        if marched is None:
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer)
 
         if light_d is None:
             light_d = safe_normalize(rays_o + torch.randn(3, device=device))
 
         results = {}
         if self.training:
-            xyzs, dirs, ts, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield,
-                                                                self.cascade, self.grid_size, nears, fars, perturb,
-                                                                self.opt.dt_gamma, self.opt.max_steps)
+            n_valid = None
+            if marched is not None:
+                xyzs, dirs, ts, rays, n_valid = marched
+            else:
+                xyzs, dirs, ts, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield,
+                                                                    self.cascade, self.grid_size, nears, fars, perturb,
+                                                                    self.opt.dt_gamma, self.opt.max_steps)
             dirs = safe_normalize(dirs)
             if light_d.shape[0] > 1:
                 flatten_rays = raymarching.flatten_rays(rays, xyzs.shape[0]).long()
@@ -92,7 +100,8 @@ class NeRFRenderer(nn.Module):
 
             if self.opt.lambda_orient > 0 and normals is not None:
                 loss_orient = weights.detach() * (normals * dirs).sum(-1).clamp(min=0) ** 2
-                results["loss_orient"] = loss_orient.mean()
+                # padded rows have weight 0, so only the divisor differs from .mean()
+                results["loss_orient"] = loss_orient.mean() if n_valid is None else loss_orient.sum() / n_valid
             if self.opt.lambda_3d_normal_smooth > 0 and normals is not None:
                 normals_perturb = self.normal(xyzs + torch.randn_like(xyzs) * 1e-2)
                 results["loss_normal_perturb"] = (normals - normals_perturb).abs().mean()
@@ -102,6 +111,7 @@ class NeRFRenderer(nn.Module):
                 results["normal_image"] = normal_image
             results["weights"] = weights
             results["num_samples"] = xyzs.shape[0]
+            results["num_valid"] = n_valid
         else:
             dtype = torch.float32
             weights_sum = torch.zeros(N, dtype=dtype, device=device)

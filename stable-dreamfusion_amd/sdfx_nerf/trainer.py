@@ -1,48 +1,87 @@
 """One training iteration of the `-O` path: Trainer.train_one_epoch's loop body
 (nerf/utils.py:1032-1070) around Trainer.train_step (:439-717) — density-grid refresh every
 `update_extra_interval` steps, shading schedule, render, SDS loss, entropy / orientation
-regularisers, AMP backward, optimiser step."""
+regularisers, AMP backward, optimiser step.
+
+Three ways of driving the same arithmetic (`mode`, default from SDFX_TRAIN_MODE, else "graph"):
+
+  "reference"  the reference's host flow: torch.amp.GradScaler + Adan behind the Optimizer interface; the
+               host reads back the sample total, found_inf and nothing else. ~270 launches per iteration, each
+               paid for in Python/dispatch time: on MI355X the iteration is launch-bound (GPU busy 40 %).
+  "device"     loss scale, overflow check, clip and Adan update in HIP kernels with device-resident control
+               state (optim.DeviceAdan): the only host read left is the sample total.
+  "graph"      "device", with everything after the sample total replayed as a HIP graph. Shapes are made static
+               by marching into fixed-capacity buffers (raymarching.march_rays_train_write) — the capacity is the
+               total rounded up to the next step of a capacity ladder, padded rows carry zero weight — and the
+               per-iteration scalars of the schedule (ambient ratio, background colour, text-embedding weights,
+               regulariser weights) are read from a small device block refreshed by one H2D copy. Graphs are
+               captured per (capacity, shading, as_latent, background kind); capacities come from a geometric ladder
+               (ratio 1.1) and a miss captures the neighbouring ladder steps too, since the sample total drifts.
+"""
 from __future__ import annotations
 
+import os
 import random
 
-import numpy as np
 import torch
 
-from .optim import Adan
+import raymarching
+
+from .optim import Adan, DeviceAdan
+
+# layout of the per-iteration scalar block
+_SC_AMBIENT, _SC_BG, _SC_WF, _SC_WS, _SC_WB, _SC_ENTROPY, _SC_WORDS = 0, 1, 4, 5, 6, 7, 8
 
 
 class TrainStep:
-    def __init__(self, opt, model, guidance, device, seed=0):
+    def __init__(self, opt, model, guidance, device, seed=0, mode=None):
         self.opt, self.model, self.guidance, self.device = opt, model, guidance, device
+        self.mode = mode or os.environ.get("SDFX_TRAIN_MODE", "graph")
+        assert self.mode in ("reference", "device", "graph")
         self.global_step = 0
         self.rng = random.Random(seed)
-        if opt.optim == "adan":
-            self.optimizer = Adan(model.get_params(5 * opt.lr), eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0)
+        if opt.optim != "adan" and self.mode != "reference":
+            self.mode = "reference"  # the device-side tail implements Adan only
+        if self.mode == "reference":
+            if opt.optim == "adan":
+                self.optimizer = Adan(model.get_params(5 * opt.lr), eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0)
+            else:
+                self.optimizer = torch.optim.Adam(model.get_params(opt.lr), betas=(0.9, 0.99), eps=1e-15)
+            self.scaler = torch.amp.GradScaler("cuda", enabled=opt.fp16)
         else:
-            self.optimizer = torch.optim.Adam(model.get_params(opt.lr), betas=(0.9, 0.99), eps=1e-15)
-        self.scaler = torch.amp.GradScaler("cuda", enabled=opt.fp16)
+            self.optimizer = DeviceAdan(model.get_params(5 * opt.lr), eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0,
+                                        amp=opt.fp16)
+            self.scaler = None
         # text embeddings for [uncond, front/side/back]; the view-dependent interpolation is the reference's
         self.embeddings = {k: guidance.get_text_embeds([k]) for k in ("uncond", "front", "side", "back")}
         self.last = {}
+        # static inputs of the captured region
+        self.sc_host = torch.zeros(_SC_WORDS, dtype=torch.float32).pin_memory() if device.type == "cuda" else \
+            torch.zeros(_SC_WORDS, dtype=torch.float32)
+        self.sc = torch.zeros(_SC_WORDS, dtype=torch.float32, device=device)
+        self.rays_o = self.rays_d = None
+        self.march_state = None
+        self.n_valid = torch.ones((), dtype=torch.float32, device=device)
+        self._num_samples = 0
+        self.hw = (opt.h, opt.w)
+        self.graph_bucket = int(os.environ.get("SDFX_GRAPH_BUCKET", "32768"))
+        self.graph_ratio = float(os.environ.get("SDFX_GRAPH_RATIO", "1.1"))   # capacity ladder: <= 10 % padding
+        self.graph_prime_span = 1.5      # on a miss, capture every ladder step within this factor of the need
+        self.max_graphs = int(os.environ.get("SDFX_MAX_GRAPHS", "64"))
+        self._warm = set()               # kinds that have run eagerly once
+        self.graphs = {}                 # (capacity, shading, as_latent, bg_kind) -> (CUDAGraph, loss tensor)
+        self.graph_uses = {}
+        self.stats = {"replays": 0, "captures": 0, "eager": 0}
 
-    def text_z(self, azimuth: float):
-        """nerf/utils.py:601-621"""
-        e = self.embeddings
-        if -90 <= azimuth < 90:
-            r = 1 - azimuth / 90 if azimuth >= 0 else 1 + azimuth / 90
-            start_z, end_z = e["front"], e["side"]
-        else:
-            r = 1 - (azimuth - 90) / 90 if azimuth >= 0 else 1 + (azimuth + 90) / 90
-            start_z, end_z = e["side"], e["back"]
-        return torch.cat([e["uncond"], r * start_z + (1 - r) * end_z], dim=0)
-
-    def train_step(self, rays_o, rays_d, azimuth=0.0, H=64, W=64):
+    # ------------------------------------------------------------------------------ schedule (host)
+    def _schedule(self, azimuth):
+        """Trainer.train_step's per-iteration choices (nerf/utils.py:497-530, 601-621) -> (kinds, scalar block)."""
         opt = self.opt
         exp_iter_ratio = (self.global_step - opt.exp_start_iter) / (opt.exp_end_iter - opt.exp_start_iter)
-        B = rays_o.shape[0]
+        sc = self.sc_host
+        sc.zero_()
         if exp_iter_ratio <= opt.latent_iter_ratio:
-            ambient_ratio, shading, as_latent, bg_color = 1.0, "normal", True, None
+            ambient_ratio, shading, as_latent, bg_kind = 1.0, "normal", True, "net"
         else:
             if exp_iter_ratio <= opt.albedo_iter_ratio:
                 ambient_ratio, shading = 1.0, "albedo"
@@ -51,42 +90,166 @@ class TrainStep:
                 shading = "textureless" if self.rng.random() >= (1.0 - opt.textureless_ratio) else "lambertian"
             as_latent = False
             if opt.bg_radius > 0 and self.rng.random() > 0.5:
-                bg_color = None
+                bg_kind = "net"
             else:
-                bg_color = torch.rand(3).to(self.device)
+                bg_kind = "rand"
+                for k in range(3):
+                    sc[_SC_BG + k] = self.rng.random()
+        sc[_SC_AMBIENT] = ambient_ratio
+        # text_z: r * start + (1 - r) * end between (front, side) or (side, back)
+        if -90 <= azimuth < 90:
+            r = 1 - azimuth / 90 if azimuth >= 0 else 1 + azimuth / 90
+            sc[_SC_WF], sc[_SC_WS] = r, 1 - r
+        else:
+            r = 1 - (azimuth - 90) / 90 if azimuth >= 0 else 1 + (azimuth + 90) / 90
+            sc[_SC_WS], sc[_SC_WB] = r, 1 - r
+        sc[_SC_ENTROPY] = opt.lambda_entropy * min(1, 2 * self.global_step / opt.iters)
+        return shading, as_latent, bg_kind
 
-        outputs = self.model.render(rays_o, rays_d, None, H, W, staged=False, perturb=True, bg_color=bg_color,
-                                    ambient_ratio=ambient_ratio, shading=shading, binarize=False)
+    def text_z(self):
+        e, sc = self.embeddings, self.sc
+        dt = e["front"].dtype
+        z = sc[_SC_WF].to(dt) * e["front"] + sc[_SC_WS].to(dt) * e["side"] + sc[_SC_WB].to(dt) * e["back"]
+        return torch.cat([e["uncond"], z], dim=0)
+
+    # ------------------------------------------------------------------------------ loss (device)
+    def train_step(self, marched, shading, as_latent, bg_kind):
+        opt, sc = self.opt, self.sc
+        B = 1
+        H, W = self.hw
+        bg_color = None if bg_kind == "net" else sc[_SC_BG:_SC_BG + 3]
+        outputs = self.model.render(self.rays_o, self.rays_d, None, H, W, staged=False, perturb=True, bg_color=bg_color,
+                                    ambient_ratio=sc[_SC_AMBIENT], shading=shading, binarize=False, marched=marched)
+        self._num_samples = outputs.get("num_samples", 0)
         if as_latent:
             pred_rgb = torch.cat([outputs["image"], outputs["weights_sum"].unsqueeze(-1)], dim=-1).reshape(B, H, W, 4)
         else:
             pred_rgb = outputs["image"].reshape(B, H, W, 3)
         pred_rgb = pred_rgb.permute(0, 3, 1, 2).contiguous()
 
-        loss = self.guidance.train_step(self.text_z(azimuth), pred_rgb, as_latent=as_latent,
+        loss = self.guidance.train_step(self.text_z(), pred_rgb, as_latent=as_latent,
                                         guidance_scale=opt.guidance_scale, grad_scale=opt.lambda_guidance)
         if opt.lambda_opacity > 0:
             loss = loss + opt.lambda_opacity * (outputs["weights_sum"] ** 2).mean()
         if opt.lambda_entropy > 0:
             alphas = outputs["weights"].clamp(1e-5, 1 - 1e-5)
-            loss_entropy = (-alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas)).mean()
-            loss = loss + opt.lambda_entropy * min(1, 2 * self.global_step / opt.iters) * loss_entropy
+            ent = -alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas)
+            n_valid = outputs["num_valid"]
+            if n_valid is None:
+                loss_entropy = ent.mean()
+            else:  # fixed-capacity buffers: rows past the sample total are padding
+                live = torch.arange(ent.shape[0], device=ent.device) < n_valid
+                loss_entropy = (ent * live).sum() / n_valid
+            loss = loss + sc[_SC_ENTROPY] * loss_entropy
         if opt.lambda_orient > 0 and "loss_orient" in outputs:
             loss = loss + opt.lambda_orient * outputs["loss_orient"]
-        self.last = {"num_samples": outputs.get("num_samples", 0), "shading": shading}
         return loss
+
+    # ------------------------------------------------------------------------------ iteration body
+    def _body(self, capacity, shading, as_latent, bg_kind, *_hw):
+        """Everything after the sample total is known; no host reads (modes "device" and "graph")."""
+        opt = self.opt
+        xyzs, dirs, ts, rays = raymarching.march_rays_train_write(self.march_state, capacity)
+        self.optimizer.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
+            loss = self.train_step((xyzs, dirs, ts, rays, self.n_valid), shading, as_latent, bg_kind)
+        (loss * self.optimizer.scale).backward()
+        if opt.grad_clip >= 0 or opt.lambda_tv > 0 or opt.lambda_wd > 0:
+            raise NotImplementedError("grad_clip / lambda_tv / lambda_wd act on unscaled gradients: use mode='reference'")
+        self.optimizer.step()
+        return loss.detach()
+
+    def _count(self, rays_o, rays_d):
+        """Static-shape prologue + the one host read: rays -> near/far -> jitter -> counting pass -> M."""
+        m = self.model
+        if self.rays_o is None:
+            self.rays_o = torch.empty(rays_o.numel() // 3, 3, dtype=torch.float32, device=self.device)
+            self.rays_d = torch.empty_like(self.rays_o)
+        self.rays_o.copy_(rays_o.reshape(-1, 3))
+        self.rays_d.copy_(rays_d.reshape(-1, 3))
+        nears, fars = raymarching.near_far_from_aabb(self.rays_o, self.rays_d, m.aabb_train)
+        self.march_state = raymarching.march_rays_train_count(self.rays_o, self.rays_d, m.bound, m.density_bitfield, m.cascade,
+                                                              m.grid_size, nears, fars, True, self.opt.dt_gamma,
+                                                              self.opt.max_steps, state=self.march_state)
+        self.n_valid.copy_(self.march_state["counter"][0])       # int32 -> float32, on the device
+        return int(self.march_state["counter"].item())           # the host read of the iteration
+
+    def _ladder(self, M):
+        """Smallest capacity of the geometric ladder (ratio `graph_ratio`, multiples of `graph_bucket`) holding M."""
+        b = self.graph_bucket
+        cap = b
+        while cap < M:
+            cap = max(cap + b, -(-int(cap * self.graph_ratio) // b) * b)
+        return cap
+
+    def _capture(self, key):
+        """Record the iteration body for `key` = (capacity, shading, as_latent, bg_kind, H, W). Capturing executes
+        nothing, so it needs no valid sample data — only that the lazy initialisations behind the body (MIOpen
+        find, hipBLASLt heuristics, scratch allocations) have happened in an earlier eager iteration."""
+        if len(self.graphs) >= self.max_graphs:
+            victim = min(self.graphs, key=lambda k: self.graph_uses.get(k, 0))
+            del self.graphs[victim]
+            self.graph_uses.pop(victim, None)
+        g = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad()
+        with torch.cuda.graph(g):
+            loss = self._body(*key)
+        self.graphs[key] = (g, loss)
+        self.graph_uses[key] = 0
+        self.stats["captures"] += 1
+
+    def _prime(self, key):
+        """Capture `key` and the ladder steps around it (the sample total drifts as the scene trains)."""
+        cap, kinds = key[0], key[1:]
+        lo, hi = cap / self.graph_prime_span, cap * self.graph_prime_span
+        c = self._ladder(max(int(lo), 1))
+        while c <= hi:
+            if (c,) + kinds not in self.graphs:
+                self._capture((c,) + kinds)
+            c = self._ladder(c + 1)
 
     def step(self, rays_o, rays_d, azimuth=0.0, H=64, W=64):
         """update_extra_state (every N steps) -> train_step under autocast -> backward -> optimiser."""
         opt = self.opt
+        self.hw = (H, W)
         self.model.train()
         if self.global_step % opt.update_extra_interval == 0:
             with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
                 self.model.update_extra_state()
+        kinds = self._schedule(azimuth)
         self.global_step += 1
+        self.sc.copy_(self.sc_host, non_blocking=True)
+        if self.mode == "reference":
+            return self._step_reference(rays_o, rays_d, kinds)
+
+        M = self._count(rays_o, rays_d)
+        if self.mode == "device":
+            loss = self._body(M, *kinds)
+            self.stats["eager"] += 1
+        else:
+            kinds = kinds + (H, W)
+            key = (self._ladder(M),) + kinds
+            if kinds not in self._warm:
+                loss = self._body(*key)      # first iteration of this kind runs eagerly: every lazy initialisation happens
+                self._warm.add(kinds)
+                self.stats["eager"] += 1
+                self._prime(key)
+            else:
+                if key not in self.graphs:
+                    self._prime(key)
+                g, loss = self.graphs[key]
+                g.replay()
+                self.graph_uses[key] += 1
+                self.stats["replays"] += 1
+        self.last = {"num_samples": M, "shading": kinds[0]}
+        return loss
+
+    def _step_reference(self, rays_o, rays_d, kinds):
+        opt = self.opt
+        self.rays_o, self.rays_d = rays_o, rays_d
         self.optimizer.zero_grad()
         with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
-            loss = self.train_step(rays_o, rays_d, azimuth, H, W)
+            loss = self.train_step(None, *kinds)
         self.scaler.scale(loss).backward()
         self.scaler.unscale_(self.optimizer)
         if opt.grad_clip >= 0:
@@ -98,4 +261,14 @@ class TrainStep:
             self.model.encoder.grad_weight_decay(opt.lambda_wd)
         self.scaler.step(self.optimizer)
         self.scaler.update()
+        self.last = {"num_samples": int(self._num_samples), "shading": kinds[0]}
         return loss
+
+    # ------------------------------------------------------------------------------ reporting (these synchronise)
+    def applied_steps(self):
+        if self.mode == "reference":
+            return int(self.optimizer.param_groups[0].get("step", 0))
+        return self.optimizer.applied_steps()
+
+    def get_scale(self):
+        return float(self.scaler.get_scale()) if self.mode == "reference" else self.optimizer.get_scale()

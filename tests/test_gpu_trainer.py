@@ -1,0 +1,136 @@
+"""-m gpu: the device-resident tail of the iteration (loss scaling + Adan in HIP, fixed-capacity marching, HIP-graph
+replay) against the host-driven formulation of the same arithmetic (torch GradScaler semantics + the foreach Adan,
+which restates optimizer.py:216-261)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf import optim
+    return optim
+
+
+def test_device_adan_matches_foreach_adan(dev):
+    optim = _mods()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1000003,), (64, 32), (4,), (257, 2)]     # odd sizes: unaligned tails of the float4 path
+    pa = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.1).to(dev)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    groups = lambda ps: [{"params": ps[:1], "lr": 5e-2}, {"params": ps[1:], "lr": 5e-3}]
+    ref = optim.Adan(groups(pa), eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0)
+    devopt = optim.DeviceAdan(groups(pb), eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0, amp=True, init_scale=1024.0,
+                              growth_interval=3)
+    scale = 1024.0
+    applied = 0
+    tracker = 0
+    for it in range(8):
+        mag = 10.0 if it in (1, 5) else 1e-3               # it 1, 5: the global-norm clip is active
+        grads = [(torch.randn(s, generator=g) * mag).to(dev) for s in shapes]
+        if it == 2:
+            grads[0][12345] = float("inf")                   # overflowed iteration
+        if it == 6:
+            grads[3][5, 1] = float("nan")
+        assert devopt.get_scale() == scale
+        for p, gr in zip(pb, grads):
+            p.grad = gr * scale                              # what backward of (loss * scale) leaves
+        devopt.step()
+        finite = all(bool(torch.isfinite(gr).all()) for gr in grads)
+        if finite:                                           # GradScaler.step + update
+            for p, gr in zip(pa, grads):
+                p.grad = gr.clone()
+            ref.step()
+            applied += 1
+            tracker += 1
+            if tracker == 3:
+                scale *= 2.0
+                tracker = 0
+        else:
+            scale *= 0.5
+            tracker = 0
+        assert devopt.applied_steps() == applied
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), f"iteration {it}: max diff {(a - b).abs().max().item():.3e}"
+    assert devopt.skipped_steps() == 2 and devopt.get_scale() == scale
+
+
+def _make(dev, mode, seed=0, hw=32):
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf.guidance import synthetic_prior
+    from sdfx_nerf.network_grid import NeRFNetwork
+    from sdfx_nerf.options import default_opt
+    from sdfx_nerf.trainer import TrainStep
+    torch.manual_seed(seed)
+    opt = default_opt(w=hw, h=hw)
+    model = NeRFNetwork(opt).to(dev)
+    return TrainStep(opt, model, synthetic_prior(dev, opt.fp16), dev, seed=seed, mode=mode), model
+
+
+def _rays(dev, view, hw=32):
+    o, d = synth.s_rays(view, hw, hw)
+    return torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev)
+
+
+def test_padded_capacity_equals_exact_capacity(dev):
+    """Marching into a larger fixed-capacity buffer must not change the loss or the gradients."""
+    step, model = _make(dev, "device")
+    ro, rd = _rays(dev, 0)
+    step.model.train()
+    with torch.autocast("cuda", dtype=torch.float16):
+        model.update_extra_state()
+    kinds = step._schedule(30.0)
+    step.sc.copy_(step.sc_host)
+    M = step._count(ro, rd)
+    assert M > 1000
+    outs = []
+    for cap in (M, M + 4097):
+        torch.manual_seed(11)                      # same light direction / timestep / noise draws
+        marched = __import__("raymarching").march_rays_train_write(step.march_state, cap)
+        for p in model.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = step.train_step(marched[:3] + (marched[3], step.n_valid), *kinds)
+        (loss * 64.0).backward()                    # keeps the fp16 table gradient out of the subnormal range
+        outs.append((loss.detach().float().item(), model.encoder.embeddings.grad.detach().clone(),
+                     model.sigma_net.net[0].weight.grad.detach().clone()))
+    (l0, g0, w0), (l1, g1, w1) = outs
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    assert (g0 - g1).abs().max().item() <= 2e-3 * g0.abs().max().item() + 1e-12    # fp16 table gradient
+    assert (w0 - w1).abs().max().item() <= 1e-3 * w0.abs().max().item() + 1e-12
+
+
+@pytest.mark.parametrize("mode", ["reference", "device", "graph"])
+def test_train_modes_run_and_update(dev, mode):
+    step, model = _make(dev, mode)
+    before = model.encoder.embeddings.detach().clone()
+    losses = []
+    for it in range(30):
+        ro, rd = _rays(dev, it % 2)
+        losses.append(step.step(ro, rd, azimuth=30.0 if it % 2 == 0 else -120.0, H=32, W=32))
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(l.float()).all()) for l in losses[-5:])
+    assert step.applied_steps() >= 5, "the optimiser never stepped (loss scale never settled)"
+    assert (model.encoder.embeddings.detach() - before).abs().max().item() > 0
+    assert step.last["num_samples"] > 0
+    if mode == "graph":
+        assert step.stats["replays"] >= 20 and step.stats["captures"] >= 1, step.stats
+
+
+def test_graph_and_device_modes_agree_on_first_iterations(dev):
+    """Same seeds, same views: the scale back-off sequence (a function of the gradient magnitudes) must coincide and
+    the tables must stay close (the random draws inside a replayed graph come from different Philox offsets)."""
+    a, ma = _make(dev, "device", seed=3)
+    b, mb = _make(dev, "graph", seed=3)
+    for it in range(28):     # the loss scale needs ~15 halvings from 2^16 before the first step is applied
+        ro, rd = _rays(dev, 0)
+        a.step(ro, rd, azimuth=10.0, H=32, W=32)
+        b.step(ro, rd, azimuth=10.0, H=32, W=32)
+    assert a.applied_steps() > 0 and abs(a.applied_steps() - b.applied_steps()) <= 2
+    assert abs(np.log2(a.get_scale()) - np.log2(b.get_scale())) <= 1
