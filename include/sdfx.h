@@ -243,16 +243,20 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
  *          [6..8] bias corrections  [9] unscaled gradient norm  [10] iterations skipped
  *   stats  float64[2], zero before the first use: sum of squares of all (scaled) gradients, non-finite count
  *
- * Per iteration: sdfx_amp_grad_stats for every gradient tensor, sdfx_adan_prepare once (also applies
- * GradScaler.update()'s growth/back-off to ctl[0] and clears stats), sdfx_adan_update for every parameter
- * tensor (a no-op when ctl[5] != 0, as GradScaler.step() skips optimizer.step()).
+ * Per iteration: sdfx_amp_grad_stats over all gradient tensors, sdfx_adan_prepare (also applies
+ * GradScaler.update()'s growth/back-off to ctl[0] and clears stats), sdfx_adan_update over all parameter
+ * tensors (a no-op when ctl[5] != 0, as GradScaler.step() skips optimizer.step()). The tensor lists are HOST
+ * arrays of device pointers / element counts / per-tensor lr and weight decay; they travel in the kernel
+ * arguments, so one launch covers up to 16 tensors.
  */
 uint32_t sdfx_adan_ctl_words(void);
-int sdfx_amp_grad_stats(const float* grad, uint64_t n, double* stats, sdfx_stream_t stream);
+int sdfx_amp_grad_stats(const float* const* grads, const uint64_t* counts, uint32_t tensors, double* stats,
+                        sdfx_stream_t stream);
 int sdfx_adan_prepare(float* ctl, double* stats, float beta1, float beta2, float beta3, float max_grad_norm, float eps,
                       float growth_factor, float backoff_factor, uint32_t growth_interval, sdfx_stream_t stream);
-int sdfx_adan_update(float* param, const float* grad, float* exp_avg, float* exp_avg_diff, float* exp_avg_sq, float* pre_grad,
-                     uint64_t n, const float* ctl, float lr, float weight_decay, float eps, float beta1, float beta2,
+int sdfx_adan_update(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_diff,
+                     float* const* exp_avg_sq, float* const* pre_grad, const uint64_t* counts, const float* lrs,
+                     const float* weight_decays, uint32_t tensors, const float* ctl, float eps, float beta1, float beta2,
                      float beta3, int no_prox, sdfx_stream_t stream);
 
 #ifdef __cplusplus

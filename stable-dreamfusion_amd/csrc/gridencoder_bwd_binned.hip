@@ -336,10 +336,8 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
                                                                               BinPlan bin,
                                                                               const uint32_t* __restrict__ cursors,
                                                                               const Item<true>* __restrict__ items,
-                                                                              uint32_t* __restrict__ done,
                                                                               unsigned long long* __restrict__ shared_acc) {
     __shared__ unsigned long long acc[kBucketRows * 2];  // 32 KiB
-    __shared__ uint32_t is_last;
     ReduceJob j;
     if (!reduce_job(bin, cursors, j)) return;
     for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) acc[i] = 0ull;
@@ -389,30 +387,44 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
         return;
     }
     // Several workgroups share this bucket (a coarse level): they add their exact partial sums into a 64-bit
-    // accumulator in global memory; the workgroup that finishes last rounds the total once and owns the table rows.
-    // The result is therefore independent of how the bucket was split and of the order of arrival.
+    // accumulator in global memory, which k_grid_bwd_finish rounds ONCE into the table. The result is therefore
+    // independent of how the bucket was split and of the order of arrival. (A last-arriver flush inside this kernel
+    // needs a device-scope release per workgroup, i.e. an L2 write-back on this multi-XCD part: +170 us measured.)
     unsigned long long* gacc = shared_acc + ((size_t)shared_first + first_row) * 2;
     for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) {
         const unsigned long long v = acc[i];
         if (v) atomicAdd(&gacc[i], v);
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t ticket = atomicAdd(&done[bin.bucket_first[j.level] + j.bucket], 1u);
-        is_last = ticket == j.used - 1;
+}
+
+// K3: one workgroup per bucket of the coarse levels; buckets that were reduced by a single workgroup are done already
+__global__ __launch_bounds__(256) void k_grid_bwd_finish(__half* __restrict__ grad_table, GridPlan plan, BinPlan bin,
+                                                         const uint32_t* __restrict__ cursors,
+                                                         const unsigned long long* __restrict__ shared_acc) {
+    uint32_t level = 0, b = blockIdx.x;
+    for (;; level++) {  // coarse levels are the first ones of the plan
+        const uint32_t nb = bin.bucket_first[level + 1] - bin.bucket_first[level];
+        if (b < nb) break;
+        b -= nb;
     }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    for (uint32_t r = threadIdx.x; r < kBucketRows; r += kReduceThreadsFixed) {
+    const uint32_t shared_first = bin.acc_first[level];
+    uint32_t n = cursors[bin.bucket_first[level] + b];
+    if (n > bin.cap[level]) n = bin.cap[level];
+    const uint32_t per_split = bin.per_split[level];
+    uint32_t used = (n + per_split - 1) / per_split;
+    if (used > bin.splits[level]) used = bin.splits[level];
+    if (used <= 1 || shared_first == kNoSharedAcc) return;
+    const uint32_t row0 = plan.off[level];
+    const uint32_t level_rows = plan.off[level + 1] - row0;
+    const uint32_t first_row = b << kBucketRowsLog2;
+    const unsigned long long* gacc = shared_acc + ((size_t)shared_first + first_row) * 2;
+    for (uint32_t r = threadIdx.x; r < kBucketRows; r += 256) {
         const uint32_t row = first_row + r;
         if (row >= level_rows) continue;
-        const long long ia = (long long)__hip_atomic_load(&gacc[r * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long ib = (long long)__hip_atomic_load(&gacc[r * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long ia = (long long)gacc[r * 2], ib = (long long)gacc[r * 2 + 1];
         if (ia == 0 && ib == 0) continue;
-        const float a = (float)((double)ia * 0x1p-24), b = (float)((double)ib * 0x1p-24);
-        flush_row<true>(grad_table + ((size_t)row0 + row) * 2, a, b, true);
+        const float a = (float)((double)ia * 0x1p-24), bb = (float)((double)ib * 0x1p-24);
+        flush_row<true>(grad_table + ((size_t)row0 + row) * 2, a, bb, true);
     }
 }
 
@@ -484,12 +496,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce_ticket(float
 
 // host: bucket geometry for a chunk of `chunk` samples
 BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uint64_t* total_items_1024, uint32_t* total_buckets,
-                      uint32_t* total_splits, uint32_t* shared_acc_rows = nullptr) {
+                      uint32_t* total_splits, uint32_t* shared_acc_rows = nullptr, uint32_t* coarse_buckets = nullptr) {
     BinPlan b;
     memset(&b, 0, sizeof(b));
     b.levels = levels;
     uint64_t items = 0;
-    uint32_t buckets = 0, wgs = 0, acc_rows = 0;
+    uint32_t buckets = 0, wgs = 0, acc_rows = 0, coarse = 0;
     for (uint32_t l = 0; l < levels; l++) {
         const uint32_t rows = plan.off[l + 1] - plan.off[l];
         const uint32_t nb = (rows + kBucketRows - 1) >> kBucketRowsLog2;
@@ -508,6 +520,7 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
         if (nb <= kCoarseBuckets) {
             b.acc_first[l] = acc_rows;
             acc_rows += nb * kBucketRows;
+            if (coarse == buckets) coarse += nb;  // K3 covers the leading run of coarse levels
         }
         uint32_t splits = (uint32_t)((cap + b.per_split[l] - 1) / b.per_split[l]);
         if (splits < 1) splits = 1;
@@ -526,6 +539,7 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
     *total_buckets = buckets;
     *total_splits = wgs;
     if (shared_acc_rows) *shared_acc_rows = acc_rows;
+    if (coarse_buckets) *coarse_buckets = coarse;
     return b;
 }
 
@@ -538,11 +552,11 @@ bool binned_supported(uint32_t D, uint32_t C, uint32_t L, const int32_t* offsets
     return true;
 }
 
-// scratch = [bucket cursors][per-bucket arrival counters][shared 64-bit accumulators of the coarse levels][item lists]
+// scratch = [bucket cursors][shared 64-bit accumulators of the coarse levels][item lists]
 constexpr uint64_t kCursorBytes = (uint64_t)kMaxLevels * kMaxBucketsPerLevel * sizeof(uint32_t);
 
 uint64_t header_bytes(uint32_t shared_acc_rows) {
-    return 2 * kCursorBytes + (uint64_t)shared_acc_rows * 2 * sizeof(unsigned long long);
+    return kCursorBytes + (uint64_t)shared_acc_rows * 2 * sizeof(unsigned long long);
 }
 
 uint64_t scratch_bytes_for(const GridPlan& plan, uint32_t levels, uint32_t chunk, bool half) {
@@ -606,8 +620,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         }
     }
     uint32_t* cursors = static_cast<uint32_t*>(scratch);
-    uint32_t* done = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + kCursorBytes);
-    unsigned long long* shared_acc = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + 2 * kCursorBytes);
+    unsigned long long* shared_acc = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + kCursorBytes);
 
     for (uint32_t b0 = 0; b0 < B; b0 += chunk) {
         const uint32_t b1 = b0 + chunk < B ? b0 + chunk : B;
@@ -616,10 +629,10 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         const GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, eb,
                                         (uint64_t)div_up(n, kBinThreads * kPointsPerThread) * kTile);
         uint64_t items_1024;
-        uint32_t nbuckets, nsplits, acc_rows;
-        const BinPlan bin = make_bin_plan(plan, max_level, chunk, &items_1024, &nbuckets, &nsplits, &acc_rows);
+        uint32_t nbuckets, nsplits, acc_rows, coarse_buckets;
+        const BinPlan bin = make_bin_plan(plan, max_level, chunk, &items_1024, &nbuckets, &nsplits, &acc_rows, &coarse_buckets);
         void* items = static_cast<char*>(scratch) + header_bytes(acc_rows);
-        (void)hipMemsetAsync(scratch, 0, (size_t)header_bytes(is_half ? acc_rows : 0), st);  // cursors, counters, accumulators
+        (void)hipMemsetAsync(scratch, 0, (size_t)header_bytes(is_half ? acc_rows : 0), st);  // cursors, accumulators
         const uint32_t grid1 = plan_grid_size(plan);
         if (is_half) {
             hipLaunchKernelGGL(k_grid_bwd_bin<true>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const __half*>(grad),
@@ -627,7 +640,10 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
                                interp, grad_layout, cursors, static_cast<Item<true>*>(items));
             hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(nsplits), dim3(kReduceThreadsFixed), 0, st,
                                static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items),
-                               done, shared_acc);
+                               shared_acc);
+            if (coarse_buckets)
+                hipLaunchKernelGGL(k_grid_bwd_finish, dim3(coarse_buckets), dim3(256), 0, st, static_cast<__half*>(grad_embeddings),
+                                   plan, bin, cursors, shared_acc);
         } else {
             hipLaunchKernelGGL(k_grid_bwd_bin<false>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const float*>(grad),
                                inputs, static_cast<float*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,

@@ -3,17 +3,18 @@
 // the `-O` path constructs (main.py:365-368 -> optimizer.py:75-170), as three kinds of launches that read and
 // write their control state in device memory:
 //
-//   k_grad_stats     per gradient tensor: sum of squares (double) and a non-finite flag
+//   k_grad_stats     all gradient tensors in one launch: sum of squares (double) and a non-finite flag
 //   k_adan_prepare   one thread: unscale factor, overflow verdict, global-norm clip factor, step count and bias
 //                    corrections, and the GradScaler growth / back-off bookkeeping for the next iteration
-//   k_adan_update    per parameter tensor: one pass over (p, g, m, v, n, g_prev) instead of the ~16 foreach passes
-//                    of the Python formulation; a no-op when the iteration overflowed
+//   k_adan_update    all parameter tensors in one launch: one pass over (p, g, m, v, n, g_prev) instead of the ~16
+//                    foreach passes of the Python formulation; a no-op when the iteration overflowed
 //
 // The reference reads `found_inf` and the clip factor back to the host every iteration (GradScaler.step,
 // optimizer.py:125-127); here nothing leaves the device, which is what lets the whole iteration be replayed
 // as a HIP graph. Streaming kernels, HBM-bound: 44 bytes per parameter and iteration for the update.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "sdfx.h"
 #include "sdfx_common.h"
@@ -24,15 +25,17 @@ namespace {
 
 constexpr uint32_t kThreads = 256;
 
-__global__ __launch_bounds__(kThreads) void k_grad_stats(const float* __restrict__ g, uint64_t n, double* __restrict__ stats) {
+// one workgroup's share of one gradient tensor: `nblocks` workgroups stride over it
+__device__ __forceinline__ void grad_stats_body(const float* __restrict__ g, uint64_t n, uint32_t block, uint32_t nblocks,
+                                                double* __restrict__ stats) {
     __shared__ double part[kThreads / 64];
     __shared__ int bad_any;
     if (threadIdx.x == 0) bad_any = 0;
     __syncthreads();
     double acc = 0.0;
     bool bad = false;
-    const uint64_t stride = (uint64_t)gridDim.x * kThreads * 4;
-    for (uint64_t i = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) * 4; i < n; i += stride) {
+    const uint64_t stride = (uint64_t)nblocks * kThreads * 4;
+    for (uint64_t i = ((uint64_t)block * kThreads + threadIdx.x) * 4; i < n; i += stride) {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (i + 4 <= n && (reinterpret_cast<uintptr_t>(g + i) & 15) == 0) {
             const float4 q = *reinterpret_cast<const float4*>(g + i);
@@ -57,6 +60,33 @@ __global__ __launch_bounds__(kThreads) void k_grad_stats(const float* __restrict
         atomicAdd(&stats[0], s);
         if (bad_any) atomicAdd(&stats[1], 1.0);
     }
+}
+
+// All tensors of a model in ONE launch: the descriptor travels in the kernel arguments (so a captured HIP graph
+// needs no side buffer), workgroup b belongs to the tensor t with first[t] <= b < first[t + 1].
+constexpr uint32_t kMaxTensors = 16;
+struct TensorList {
+    const float* g[kMaxTensors];
+    float* p[kMaxTensors];
+    float* m[kMaxTensors];
+    float* v[kMaxTensors];
+    float* n[kMaxTensors];
+    float* prev[kMaxTensors];
+    uint64_t count[kMaxTensors];
+    float lr[kMaxTensors], wd[kMaxTensors];
+    uint32_t first[kMaxTensors + 1];
+    uint32_t tensors;
+};
+
+__device__ __forceinline__ uint32_t tensor_of_block(const TensorList& tl, uint32_t b) {
+    uint32_t t = 0;
+    while (t + 1 < tl.tensors && b >= tl.first[t + 1]) t++;
+    return t;
+}
+
+__global__ __launch_bounds__(kThreads) void k_grad_stats(TensorList tl, double* __restrict__ stats) {
+    const uint32_t t = tensor_of_block(tl, blockIdx.x);
+    grad_stats_body(tl.g[t], tl.count[t], blockIdx.x - tl.first[t], tl.first[t + 1] - tl.first[t], stats);
 }
 
 // ctl layout (float words; integers are stored as their float value, exact far beyond any step count reached)
@@ -127,19 +157,27 @@ __device__ __forceinline__ void adan_one(float& p, float gs, float& m, float& v,
     prev = g;
 }
 
-__global__ __launch_bounds__(kThreads) void k_adan_update(float* __restrict__ p, const float* __restrict__ g,
-                                                          float* __restrict__ m, float* __restrict__ v,
-                                                          float* __restrict__ nn, float* __restrict__ prev, uint64_t n,
-                                                          const float* __restrict__ ctl, AdanHyper h) {
+__global__ __launch_bounds__(kThreads) void k_adan_update(TensorList tl, const float* __restrict__ ctl, AdanHyper h) {
     if (ctl[5] != 0.f) return;  // overflowed iteration: GradScaler.step() skips optimizer.step()
+    const uint32_t t = tensor_of_block(tl, blockIdx.x);
+    float* __restrict__ p = tl.p[t];
+    const float* __restrict__ g = tl.g[t];
+    float* __restrict__ m = tl.m[t];
+    float* __restrict__ v = tl.v[t];
+    float* __restrict__ nn = tl.n[t];
+    float* __restrict__ prev = tl.prev[t];
+    const uint64_t n = tl.count[t];
+    h.lr = tl.lr[t];
+    h.wd = tl.wd[t];
+    const uint32_t block = blockIdx.x - tl.first[t], nblocks = tl.first[t + 1] - tl.first[t];
     const float unscale = ctl[3] * ctl[4];
     const bool first = ctl[2] == 1.0f;
     const float bc1 = ctl[6], bc2 = ctl[7], bc3 = ctl[8];
-    const uint64_t stride = (uint64_t)gridDim.x * kThreads * 4;
+    const uint64_t stride = (uint64_t)nblocks * kThreads * 4;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                            reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(nn) |
                            reinterpret_cast<uintptr_t>(prev)) & 15) == 0;
-    for (uint64_t i = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) * 4; i < n; i += stride) {
+    for (uint64_t i = ((uint64_t)block * kThreads + threadIdx.x) * 4; i < n; i += stride) {
         if (aligned && i + 4 <= n) {
             float4 P = *reinterpret_cast<float4*>(p + i);
             const float4 G = *reinterpret_cast<const float4*>(g + i);
@@ -172,10 +210,28 @@ extern "C" {
 
 uint32_t sdfx_adan_ctl_words(void) { return 16; }
 
-int sdfx_amp_grad_stats(const float* grad, uint64_t n, double* stats, sdfx_stream_t stream) {
-    SDFX_REQUIRE(stats && (grad || n == 0), "amp_grad_stats: null pointer");
-    if (n == 0) return SDFX_OK;
-    hipLaunchKernelGGL(k_grad_stats, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), grad, n, stats);
+int sdfx_amp_grad_stats(const float* const* grads, const uint64_t* counts, uint32_t tensors, double* stats,
+                        sdfx_stream_t stream) {
+    SDFX_REQUIRE(stats && (tensors == 0 || (grads && counts)), "amp_grad_stats: null pointer");
+    for (uint32_t t0 = 0; t0 < tensors; t0 += kMaxTensors) {
+        TensorList tl;
+        memset(&tl, 0, sizeof(tl));
+        uint32_t blocks = 0;
+        for (uint32_t t = t0; t < tensors && t < t0 + kMaxTensors; t++) {
+            if (counts[t] == 0) continue;
+            SDFX_REQUIRE(grads[t], "amp_grad_stats: null gradient pointer");
+            const uint32_t k = tl.tensors++;
+            tl.g[k] = grads[t];
+            tl.count[k] = counts[t];
+            tl.first[k] = blocks;
+            // every workgroup ends in one double atomic on the same two words: keep their number small
+            const uint32_t nb = blocks_for(counts[t]);
+            blocks += nb > 512 ? 512 : nb;
+        }
+        tl.first[tl.tensors] = blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(k_grad_stats, dim3(blocks), dim3(kThreads), 0, as_stream(stream), tl, stats);
+    }
     return check_launch("amp_grad_stats");
 }
 
@@ -187,15 +243,33 @@ int sdfx_adan_prepare(float* ctl, double* stats, float beta1, float beta2, float
     return check_launch("adan_prepare");
 }
 
-int sdfx_adan_update(float* param, const float* grad, float* exp_avg, float* exp_avg_diff, float* exp_avg_sq, float* pre_grad,
-                     uint64_t n, const float* ctl, float lr, float weight_decay, float eps, float beta1, float beta2,
+int sdfx_adan_update(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_diff,
+                     float* const* exp_avg_sq, float* const* pre_grad, const uint64_t* counts, const float* lrs,
+                     const float* weight_decays, uint32_t tensors, const float* ctl, float eps, float beta1, float beta2,
                      float beta3, int no_prox, sdfx_stream_t stream) {
-    SDFX_REQUIRE(ctl && (n == 0 || (param && grad && exp_avg && exp_avg_diff && exp_avg_sq && pre_grad)),
+    SDFX_REQUIRE(ctl && (tensors == 0 || (params && grads && exp_avg && exp_avg_diff && exp_avg_sq && pre_grad && counts && lrs &&
+                                          weight_decays)),
                  "adan_update: null pointer");
-    if (n == 0) return SDFX_OK;
-    const AdanHyper h{lr, weight_decay, eps, beta1, beta2, beta3, no_prox};
-    hipLaunchKernelGGL(k_adan_update, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), param, grad, exp_avg,
-                       exp_avg_diff, exp_avg_sq, pre_grad, n, ctl, h);
+    const AdanHyper h{0.f, 0.f, eps, beta1, beta2, beta3, no_prox};
+    for (uint32_t t0 = 0; t0 < tensors; t0 += kMaxTensors) {
+        TensorList tl;
+        memset(&tl, 0, sizeof(tl));
+        uint32_t blocks = 0;
+        for (uint32_t t = t0; t < tensors && t < t0 + kMaxTensors; t++) {
+            if (counts[t] == 0) continue;
+            SDFX_REQUIRE(params[t] && grads[t] && exp_avg[t] && exp_avg_diff[t] && exp_avg_sq[t] && pre_grad[t],
+                         "adan_update: null tensor pointer");
+            const uint32_t k = tl.tensors++;
+            tl.p[k] = params[t]; tl.g[k] = grads[t]; tl.m[k] = exp_avg[t]; tl.v[k] = exp_avg_diff[t];
+            tl.n[k] = exp_avg_sq[t]; tl.prev[k] = pre_grad[t];
+            tl.count[k] = counts[t]; tl.lr[k] = lrs[t]; tl.wd[k] = weight_decays[t];
+            tl.first[k] = blocks;
+            blocks += blocks_for(counts[t]);
+        }
+        tl.first[tl.tensors] = blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(k_adan_update, dim3(blocks), dim3(kThreads), 0, as_stream(stream), tl, ctl, h);
+    }
     return check_launch("adan_update");
 }
 

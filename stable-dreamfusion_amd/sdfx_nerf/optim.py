@@ -123,6 +123,7 @@ class DeviceAdan:
 
     @torch.no_grad()
     def step(self):
+        import ctypes as C
         S = self._S
         st = S.stream()
         todo = []
@@ -130,18 +131,22 @@ class DeviceAdan:
             for p in g["params"]:
                 if p.grad is None:
                     continue
-                grad = p.grad
-                if grad.dtype != torch.float32 or not grad.is_contiguous():
+                if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
                     raise RuntimeError("DeviceAdan: gradients must be contiguous float32")
-                S.call("sdfx_amp_grad_stats", S.ptr(grad), grad.numel(), S.ptr(self.stats), st)
-                todo.append((g, p, grad))
+                todo.append((g, p))
+        n = len(todo)
+        ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        grads = ptrs([p.grad for _, p in todo])
+        counts = (C.c_uint64 * n)(*[p.numel() for _, p in todo])
+        S.call("sdfx_amp_grad_stats", grads, counts, n, S.ptr(self.stats), st)
         b1, b2, b3 = self.betas
         S.call("sdfx_adan_prepare", S.ptr(self.ctl), S.ptr(self.stats), b1, b2, b3, self.max_grad_norm, self.eps,
                self.growth[0], self.growth[1], self.growth[2], st)
-        for g, p, grad in todo:
-            m, v, n, prev = self.state[p]
-            S.call("sdfx_adan_update", S.ptr(p), S.ptr(grad), S.ptr(m), S.ptr(v), S.ptr(n), S.ptr(prev), p.numel(),
-                   S.ptr(self.ctl), g["lr"], g["weight_decay"], self.eps, b1, b2, b3, int(self.no_prox), st)
+        state = [self.state[p] for _, p in todo]
+        S.call("sdfx_adan_update", ptrs([p for _, p in todo]), grads, ptrs([s_[0] for s_ in state]), ptrs([s_[1] for s_ in state]),
+               ptrs([s_[2] for s_ in state]), ptrs([s_[3] for s_ in state]), counts,
+               (C.c_float * n)(*[g["lr"] for g, _ in todo]), (C.c_float * n)(*[g["weight_decay"] for g, _ in todo]), n,
+               S.ptr(self.ctl), self.eps, b1, b2, b3, int(self.no_prox), st)
 
     # reporting only (each of these synchronises)
     def applied_steps(self):

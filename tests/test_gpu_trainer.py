@@ -123,14 +123,20 @@ def test_train_modes_run_and_update(dev, mode):
         assert step.stats["replays"] >= 20 and step.stats["captures"] >= 1, step.stats
 
 
-def test_graph_and_device_modes_agree_on_first_iterations(dev):
-    """Same seeds, same views: the scale back-off sequence (a function of the gradient magnitudes) must coincide and
-    the tables must stay close (the random draws inside a replayed graph come from different Philox offsets)."""
-    a, ma = _make(dev, "device", seed=3)
-    b, mb = _make(dev, "graph", seed=3)
-    for it in range(28):     # the loss scale needs ~15 halvings from 2^16 before the first step is applied
-        ro, rd = _rays(dev, 0)
-        a.step(ro, rd, azimuth=10.0, H=32, W=32)
-        b.step(ro, rd, azimuth=10.0, H=32, W=32)
-    assert a.applied_steps() > 0 and abs(a.applied_steps() - b.applied_steps()) <= 2
-    assert abs(np.log2(a.get_scale()) - np.log2(b.get_scale())) <= 1
+def test_graph_replay_reproduces_eager_iterations(dev):
+    """Same seed, same views, one mode after the other: the replayed graph must go through the same loss-scale
+    back-off sequence as the eager device-resident path and end with the same table (padding rows, capture and
+    replay change nothing but float summation order)."""
+    out = {}
+    for mode in ("device", "graph"):
+        step, model = _make(dev, mode, seed=3)
+        losses = []
+        for it in range(28):     # the loss scale needs ~14 halvings from 2^16 before the first step is applied
+            ro, rd = _rays(dev, it % 2)
+            losses.append(float(step.step(ro, rd, azimuth=10.0, H=32, W=32)))
+        out[mode] = (step.applied_steps(), step.get_scale(), losses, model.encoder.embeddings.detach().clone(), step.stats)
+    (na, sa, la, ta, _), (nb, sb, lb, tb, stats) = out["device"], out["graph"]
+    assert stats["replays"] >= 20
+    assert na == nb and na > 0 and sa == sb
+    assert np.allclose(la[:na], lb[:na], rtol=1e-3)
+    assert (ta - tb).abs().max().item() <= 0.05 * (ta.abs().max().item())

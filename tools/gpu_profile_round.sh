@@ -1,0 +1,40 @@
+#!/bin/bash
+# Evidence for profiles/: (1) rocprofv3 kernel stats of the default bench, (2) separate PMC passes (FETCH_SIZE, WRITE_SIZE)
+# over the same command for the dominant kernel, reduced to a small JSON that bench.py reports as roofline.traffic.
+# Usage on the GPU box:  bash tools/gpu_profile_round.sh <tag>
+TAG=${1:-round}
+OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$PWD
+CMD="python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-bench"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
+echo "stats exit $?" | tee $OUT/summary.txt
+tail -1 $OUT/stats.log | cut -c1-300 | tee -a $OUT/summary.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- $CMD > $OUT/pmc_$C.log 2>&1
+  echo "pmc $C exit $?" | tee -a $OUT/summary.txt
+done
+python3 - <<PY | tee -a $OUT/summary.txt
+import csv, glob, json, collections
+out = {}
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob("$OUT/pmc_%s/*counter_collection.csv" % C):
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != C:
+                continue
+            n = r["Kernel_Name"]
+            for key in ("k_grid_forward", "k_grid_bwd_bin", "k_grid_bwd_reduce", "k_field_backward_mma", "k_field_forward_mma",
+                        "k_composite_train_fwd", "k_composite_train_bwd", "k_march_count", "k_adan_update"):
+                if key in n:
+                    per[key].append(float(r["Counter_Value"]))
+        for k, v in per.items():
+            out.setdefault(k, {})[C + "_KB_avg"] = sum(v) / len(v)
+            out[k]["launches"] = len(v)
+json.dump(out, open("$OUT/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out))
+PY
+cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+find $OUT -type f -size +1M -delete 2>/dev/null
+du -sh $OUT
