@@ -388,6 +388,16 @@ def main():
         return
 
     ksum = timer.summary()
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the number comes
+    # from the committed summary of `tools/gpu_profile_round.sh` over this same command (FETCH_SIZE doubled: on
+    # gfx950 it tallies 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM"); null when the file is absent.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")) as f:
+            pm = json.load(f)["k_grid_forward"]
+        traffic = (2.0 * pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        pass
     enc = ksum.get("grid_encode_forward", {"GBps": 0.0, "avg_us": 0.0, "launches": 0, "bytes": 0})
     iters_per_s = job_throughput(world, args.steps, elapsed)
     result = {
@@ -406,7 +416,9 @@ def main():
         "optimizer_steps_applied": applied_in_timed, "scaler_calibration_iters": calib,
         "grad_scale": step.get_scale(), "train_mode": step.mode, "graph_stats": stats_timed,
         "roofline": {"bound": "hbm", "kernel": "k_grid_forward<3,2,half>", "achieved": enc["GBps"], "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": enc["GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                     "unit": "GB/s", "frac": enc["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_unit": "bytes per launch (profiles/r01_v3_pmc_traffic.json)",
+                     "algorithmic_bytes_per_launch": (enc["bytes"] / enc["launches"]) if enc.get("launches") else None,
                      "avg_launch_us": enc["avg_us"], "launches": enc["launches"], "measured_in": roofline_pass,
                      "algorithmic_bytes_per_point": 588},
         "kernels_in_step": {k: {"GBps": round(v["GBps"], 1), "avg_us": round(v["avg_us"], 1), "launches": v["launches"]}
