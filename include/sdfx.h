@@ -229,6 +229,32 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
                         float* scratch, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
                         sdfx_stream_t stream);
 
+/* ------------------------------------------------------ normal / shading glue (extension) */
+
+/*
+ * Extension — the part of NeRFNetwork.forward between the field and the compositor (nerf/network_grid.py:81-130:
+ * finite-difference normal from the six neighbour densities, safe_normalize + nan_to_num, Lambertian / textureless /
+ * normal shading), the view-direction normalisation (nerf/renderer.py:734) and the per-sample factor
+ * clamp(normal . dir, 0)^2 of loss_orient (renderer.py:744-746). ~100 elementwise PyTorch launches per iteration
+ * in the reference; one kernel each way here (one wavefront per ray: the light direction
+ * safe_normalize(rays_o[n] + light_offset) is per ray, renderer.py:727).
+ *
+ *   sigma7 [7, capacity] f32 (x, x+e_x, x-e_x, x+e_y, x-e_y, x+e_z, x-e_z); albedo [capacity, 3] (mode 1 only);
+ *   dirs [capacity, 3] un-normalised; rays [n_rays, 2] (offset, count); rays_o [n_rays, 3]; light_offset [3];
+ *   ratio: device scalar (ambient ratio); total: device int32, rows >= total are padding (outputs zeroed);
+ *   mode 1 = lambertian (albedo * lambert), 2 = textureless (lambert), 3 = normal ((n + 1) / 2).
+ *   backward: dnormal may be NULL; dsigma7 [7, capacity] (row 0 is zero: the centre density only feeds the
+ *   compositor); dalbedo [capacity, 3] for mode 1, else NULL.
+ */
+int sdfx_shade_forward(const float* sigma7, const float* albedo, const float* dirs, const int32_t* rays, const float* rays_o,
+                       const float* light_offset, const float* ratio, int mode, float epsilon, uint32_t capacity,
+                       uint32_t n_rays, const int32_t* total, float* color, float* normal, float* orient,
+                       sdfx_stream_t stream);
+int sdfx_shade_backward(const float* sigma7, const float* albedo, const float* dirs, const int32_t* rays, const float* rays_o,
+                        const float* light_offset, const float* ratio, int mode, float epsilon, uint32_t capacity,
+                        uint32_t n_rays, const int32_t* total, const float* dcolor, const float* dnormal, const float* dorient,
+                        float* dsigma7, float* dalbedo, sdfx_stream_t stream);
+
 /* ------------------------------------------------------------ optimiser tail (extension) */
 
 /*

@@ -1,0 +1,74 @@
+"""Fused normal / shading / orientation term (csrc/shade.hip) behind an autograd Function.
+
+    color, normal, orient = fused_shade(sigma7, albedo0, dirs, rays, rays_o, light_offset, ratio, total, shading)
+
+== the tail of NeRFNetwork.forward (nerf/network_grid.py:98-130) for shading in {'lambertian', 'textureless',
+'normal'} after the seven densities of the finite-difference stencil are known, plus `dirs = safe_normalize(dirs)`
+(renderer.py:734) and the per-sample factor `clamp(normal . dirs, 0)^2` of loss_orient (renderer.py:744-746).
+
+  sigma7        [7 * cap] float32: densities at x, x+e_x, x-e_x, x+e_y, x-e_y, x+e_z, x-e_z (stencil-major)
+  albedo0       [cap, 3] float32 albedo at x (only read for 'lambertian')
+  dirs          [cap, 3] un-normalised view directions as the march wrote them
+  rays          [N, 2] int32 (offset, count); rays_o [N, 3]; light_offset [3] (the reference's torch.randn(3))
+  ratio         0-dim float32 tensor (ambient ratio); total int32 [1] = number of valid rows (rest is padding)
+"""
+from __future__ import annotations
+
+import torch
+from torch.amp import custom_bwd, custom_fwd
+from torch.autograd import Function
+
+import _sdfx as S
+
+MODES = {"lambertian": 1, "textureless": 2, "normal": 3}
+_F32 = torch.float32
+
+
+class _fused_shade(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, sigma7, albedo0, dirs, rays, rays_o, light_offset, ratio, total, mode, epsilon):
+        sigma7 = sigma7.contiguous()
+        dirs = dirs.contiguous()
+        cap = dirs.shape[0]
+        assert sigma7.numel() == 7 * cap
+        if mode == 1:
+            albedo0 = albedo0.contiguous()
+        rays_o = rays_o.contiguous().view(-1, 3)
+        n_rays = rays.shape[0]
+        dev = sigma7.device
+        color = torch.empty(cap, 3, dtype=_F32, device=dev)
+        normal = torch.empty(cap, 3, dtype=_F32, device=dev)
+        orient = torch.empty(cap, dtype=_F32, device=dev)
+        S.call("sdfx_shade_forward", S.ptr(S.check_tensor(sigma7, "sigma7", _F32)), S.ptr(albedo0 if mode == 1 else None),
+               S.ptr(S.check_tensor(dirs, "dirs", _F32)), S.ptr(S.check_tensor(rays, "rays", torch.int32)),
+               S.ptr(S.check_tensor(rays_o, "rays_o", _F32)), S.ptr(S.check_tensor(light_offset, "light_offset", _F32)),
+               S.ptr(S.check_tensor(ratio, "ratio", _F32)), mode, float(epsilon), cap, n_rays,
+               S.ptr(S.check_tensor(total, "total", torch.int32)), S.ptr(color), S.ptr(normal), S.ptr(orient), S.stream())
+        ctx.save_for_backward(sigma7, albedo0 if mode == 1 else None, dirs, rays, rays_o, light_offset, ratio, total)
+        ctx.meta = (mode, float(epsilon), cap, n_rays)
+        ctx.set_materialize_grads(False)
+        return color, normal, orient
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, dcolor, dnormal, dorient):
+        sigma7, albedo0, dirs, rays, rays_o, light_offset, ratio, total = ctx.saved_tensors
+        mode, epsilon, cap, n_rays = ctx.meta
+        dev = sigma7.device
+        dcolor = torch.zeros(cap, 3, dtype=_F32, device=dev) if dcolor is None else dcolor.float().contiguous()
+        dorient = torch.zeros(cap, dtype=_F32, device=dev) if dorient is None else dorient.float().contiguous()
+        dnormal = None if dnormal is None else dnormal.float().contiguous()
+        dsigma7 = torch.empty(7 * cap, dtype=_F32, device=dev)
+        dalbedo = torch.empty(cap, 3, dtype=_F32, device=dev) if mode == 1 else None
+        S.call("sdfx_shade_backward", S.ptr(sigma7), S.ptr(albedo0), S.ptr(dirs), S.ptr(rays), S.ptr(rays_o), S.ptr(light_offset),
+               S.ptr(ratio), mode, epsilon, cap, n_rays, S.ptr(total), S.ptr(dcolor), S.ptr(dnormal), S.ptr(dorient),
+               S.ptr(dsigma7), S.ptr(dalbedo), S.stream())
+        return dsigma7, dalbedo, None, None, None, None, None, None, None, None
+
+
+def fused_shade(sigma7, albedo0, dirs, rays, rays_o, light_offset, ratio, total, shading, epsilon=1e-2):
+    if not torch.is_tensor(ratio):
+        ratio = torch.tensor(float(ratio), dtype=_F32, device=sigma7.device)
+    return _fused_shade.apply(sigma7.reshape(-1), albedo0, dirs, rays, rays_o, light_offset, ratio.to(_F32), total,
+                              MODES[shading], epsilon)

@@ -14,6 +14,7 @@ from freqencoder import FreqEncoder
 from gridencoder import GridEncoder
 
 from . import fused_field as _ff
+from . import fused_shade as _fs
 from .renderer import NeRFRenderer, safe_normalize
 
 # fused encode -> MLP -> activation kernels for the fp16-autocast path (SDFX_FUSED_FIELD=0 keeps the
@@ -22,6 +23,8 @@ _FUSED = int(os.environ.get("SDFX_FUSED_FIELD", "1"))
 # evaluate the sample and its six finite-difference neighbours in ONE field call (the field is point-wise, so the
 # values are those of the reference's seven separate common_forward calls, network_grid.py:81-96, 108-115)
 _BATCH_STENCIL = int(os.environ.get("SDFX_BATCH_STENCIL", "1"))
+# normal / shading / orientation glue between the field and the compositor in one HIP kernel each way
+_FUSED_SHADE = int(os.environ.get("SDFX_FUSED_SHADE", "1"))
 
 
 class _trunc_exp(Function):
@@ -132,6 +135,21 @@ class NeRFNetwork(NeRFRenderer):
         s = sigma_all.view(7, N)
         normal = -torch.stack([0.5 * (s[1] - s[2]) / e, 0.5 * (s[3] - s[4]) / e, 0.5 * (s[5] - s[6]) / e], dim=-1)
         return s[0], albedo_all.view(7, N, 3)[0], normal
+
+    def forward_fused(self, x, dirs, rays, rays_o, light_offset, total, ratio=1, shading="lambertian"):
+        """forward() for shading != 'albedo' with the light direction given per RAY (rays_o + light_offset, normalised)
+        instead of per sample, `dirs` un-normalised; also returns clamp(normal . dir, 0)^2 for loss_orient.
+        Arithmetic of network_grid.py:98-130 on the batched 7-point field evaluation (csrc/shade.hip)."""
+        N = x.shape[0]
+        neigh = (x.unsqueeze(0) + self._fd_offsets.unsqueeze(1)).clamp(-self.bound, self.bound)
+        pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
+        sigma_all, albedo_all = self.common_forward(pts)
+        color, normal, orient = _fs.fused_shade(sigma_all, albedo_all[:N] if shading == "lambertian" else None, dirs, rays,
+                                                rays_o, light_offset, ratio, total, shading)
+        return sigma_all[:N], color, normal, orient
+
+    def fused_shade_available(self, shading):
+        return bool(_FUSED_SHADE and _BATCH_STENCIL and shading in _fs.MODES)
 
     def forward(self, x, d, l=None, ratio=1, shading="albedo"):
         if shading != "albedo" and _BATCH_STENCIL:

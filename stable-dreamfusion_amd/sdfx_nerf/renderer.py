@@ -78,28 +78,42 @@ class NeRFRenderer(nn.Module):
         if marched is None:
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer)
 
+        # one kernel for normal + shading + orientation term when nothing else needs the intermediate tensors
+        fused = (self.training and light_d is None and hasattr(self, "fused_shade_available")
+                 and self.fused_shade_available(shading) and self.opt.lambda_3d_normal_smooth <= 0
+                 and self.opt.lambda_2d_normal_smooth <= 0 and self.opt.lambda_normal <= 0)
         if light_d is None:
-            light_d = safe_normalize(rays_o + torch.randn(3, device=device))
+            light_offset = torch.randn(3, device=device)
+            if not fused:
+                light_d = safe_normalize(rays_o + light_offset)
 
         results = {}
         if self.training:
-            n_valid = None
+            n_valid = total = None
             if marched is not None:
-                xyzs, dirs, ts, rays, n_valid = marched
+                xyzs, dirs, ts, rays, n_valid, total = marched
             else:
                 xyzs, dirs, ts, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield,
                                                                     self.cascade, self.grid_size, nears, fars, perturb,
                                                                     self.opt.dt_gamma, self.opt.max_steps)
-            dirs = safe_normalize(dirs)
-            if light_d.shape[0] > 1:
-                flatten_rays = raymarching.flatten_rays(rays, xyzs.shape[0]).long()
-                light_d = light_d[flatten_rays]
-
-            sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
+            orient = None
+            if fused:
+                if total is None:  # offsets are the exclusive prefix sum of the counts in ray order
+                    total = (rays[-1, 0] + rays[-1, 1]).reshape(1).to(torch.int32)
+                sigmas, rgbs, normals, orient = self.forward_fused(xyzs, dirs, rays, rays_o, light_offset, total,
+                                                                   ratio=ambient_ratio, shading=shading)
+            else:
+                dirs = safe_normalize(dirs)
+                if light_d.shape[0] > 1:
+                    flatten_rays = raymarching.flatten_rays(rays, xyzs.shape[0]).long()
+                    light_d = light_d[flatten_rays]
+                sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
             weights, weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ts, rays, T_thresh, binarize)
 
             if self.opt.lambda_orient > 0 and normals is not None:
-                loss_orient = weights.detach() * (normals * dirs).sum(-1).clamp(min=0) ** 2
+                if orient is None:
+                    orient = (normals * dirs).sum(-1).clamp(min=0) ** 2
+                loss_orient = weights.detach() * orient
                 # padded rows have weight 0, so only the divisor differs from .mean()
                 results["loss_orient"] = loss_orient.mean() if n_valid is None else loss_orient.sum() / n_valid
             if self.opt.lambda_3d_normal_smooth > 0 and normals is not None:

@@ -152,7 +152,7 @@ class TrainStep:
         xyzs, dirs, ts, rays = raymarching.march_rays_train_write(self.march_state, capacity)
         self.optimizer.zero_grad()
         with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
-            loss = self.train_step((xyzs, dirs, ts, rays, self.n_valid), shading, as_latent, bg_kind)
+            loss = self.train_step((xyzs, dirs, ts, rays, self.n_valid, self.march_state["counter"]), shading, as_latent, bg_kind)
         (loss * self.optimizer.scale).backward()
         if opt.grad_clip >= 0 or opt.lambda_tv > 0 or opt.lambda_wd > 0:
             raise NotImplementedError("grad_clip / lambda_tv / lambda_wd act on unscaled gradients: use mode='reference'")
