@@ -313,9 +313,31 @@ def main():
         az = float(np.degrees(np.arctan2(poses[v][0, 3], poses[v][2, 3])))
         views.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), az))
 
+    verbose = os.environ.get("SDFX_BENCH_TRACE") == "2"   # diagnosis only: loss scale / overflow flag of every iteration
+
     def one_step(i):
         ro, rd, az = views[rank_view(rank, i, len(views))]
-        return step.step(ro, rd, azimuth=az)
+        nxt = views[rank_view(rank, i + 1, len(views))]      # what a data loader knows: the next camera's rays
+        out = step.step(ro, rd, azimuth=az, next_rays=(nxt[0], nxt[1]))
+        if verbose and step.mode != "reference":
+            c = step.optimizer.ctl.tolist()
+            print(f"[it {step.global_step}] view={rank_view(rank, i, len(views))} S={c[0]:g} skip={int(c[5])} norm={c[9]:.3g} "
+                  f"loss={float(out):.3g} M={step.last['num_samples']} {step.stats}", file=sys.stderr)
+            if int(c[5]) and step.mode == "graph" and getattr(step, "last_key", None) in step.graphs and step.global_step > 20:
+                grads = step.graphs[step.last_key][4]
+                names = [n for n, _ in model.named_parameters()]
+                bad = [(names[k] if k < len(names) else k, int(torch.isnan(g).sum()), int(torch.isinf(g).sum()), g.numel())
+                       for k, g in enumerate(grads) if g is not None and not bool(torch.isfinite(g).all())]
+                print(f"      key={step.last_key[:2]} non-finite grads (name, nan, inf, numel): {bad}", file=sys.stderr)
+                g = grads[0]
+                if g is not None and g.dim() == 2 and not bool(torch.isfinite(g).all()):
+                    offs = model.encoder.offsets.tolist()
+                    rows = (~torch.isfinite(g)).any(1).nonzero().flatten()
+                    per = [int(((rows >= offs[l]) & (rows < offs[l + 1])).sum()) for l in range(16)]
+                    fin = g[torch.isfinite(g).all(1)]
+                    print(f"      bad rows per level: {per}; finite |g| max {float(fin.abs().max()):.3g}; first bad rows {rows[:6].tolist()} "
+                          f"values {g[rows[:3]].tolist()}", file=sys.stderr)
+        return out
 
     # GradScaler calibration, untimed and before the warmup: torch's GradScaler starts at 2^16 and SKIPS the optimiser
     # step while the fp16 backward overflows (exactly what the reference's first iterations do, nerf/utils.py:1050).

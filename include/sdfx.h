@@ -255,6 +255,16 @@ int sdfx_shade_backward(const float* sigma7, const float* albedo, const float* d
                         uint32_t n_rays, const int32_t* total, const float* dcolor, const float* dnormal, const float* dorient,
                         float* dsigma7, float* dalbedo, sdfx_stream_t stream);
 
+/*
+ * Extension — the entropy regulariser of Trainer.train_step (nerf/utils.py:571-575) on the compositing weights:
+ * sum_out[0] = sum over rows < total of H(clamp(w, 1e-5, 1 - 1e-5)), H the binary entropy in bits (double; the
+ * caller divides by the sample total for the reference's .mean()); backward: grad_weights = grad_sum[0] * dH/dw
+ * inside the clamp range, 0 outside and on padding rows.
+ */
+int sdfx_entropy_forward(const float* weights, uint32_t capacity, const int32_t* total, double* sum_out, sdfx_stream_t stream);
+int sdfx_entropy_backward(const float* weights, uint32_t capacity, const int32_t* total, const float* grad_sum,
+                          float* grad_weights, sdfx_stream_t stream);
+
 /* ------------------------------------------------------------ optimiser tail (extension) */
 
 /*

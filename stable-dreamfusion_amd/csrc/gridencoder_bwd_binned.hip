@@ -632,7 +632,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         uint32_t nbuckets, nsplits, acc_rows, coarse_buckets;
         const BinPlan bin = make_bin_plan(plan, max_level, chunk, &items_1024, &nbuckets, &nsplits, &acc_rows, &coarse_buckets);
         void* items = static_cast<char*>(scratch) + header_bytes(acc_rows);
-        (void)hipMemsetAsync(scratch, 0, (size_t)header_bytes(is_half ? acc_rows : 0), st);  // cursors, accumulators
+        zero_device(scratch, header_bytes(is_half ? acc_rows : 0), st);  // cursors, accumulators
         const uint32_t grid1 = plan_grid_size(plan);
         if (is_half) {
             hipLaunchKernelGGL(k_grid_bwd_bin<true>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const __half*>(grad),

@@ -679,7 +679,7 @@ int sdfx_compact_rays(const int32_t* rays_alive_in, uint32_t n, int32_t* rays_al
     SDFX_REQUIRE(count_out && scratch, "compact_rays: null pointer");
     hipStream_t st = as_stream(stream);
     if (n == 0) {
-        (void)hipMemsetAsync(count_out, 0, sizeof(int32_t), st);
+        zero_device(count_out, sizeof(int32_t), st);
         return check_launch("compact_rays(empty)");
     }
     SDFX_REQUIRE(rays_alive_in && rays_alive_out, "compact_rays: null pointer");

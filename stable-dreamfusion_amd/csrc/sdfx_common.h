@@ -29,6 +29,22 @@ int check_launch(const char* what);
 static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 static inline hipStream_t as_stream(sdfx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Zero `bytes` (a multiple of 4) of device memory with a KERNEL. hipMemsetAsync is avoided on purpose: captured into
+// a HIP graph it becomes a memset node, and the 5 MB one of the binned scatter did not clear its whole range on
+// replay (ROCm 7.2): accumulators kept sums from earlier iterations until the table gradient overflowed.
+#if defined(__HIPCC__)
+__global__ __launch_bounds__(256) static void k_zero_words(uint32_t* __restrict__ p, uint64_t words) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (uint64_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline void zero_device(void* p, uint64_t bytes, hipStream_t st) {
+    const uint64_t words = bytes / 4;
+    if (words == 0) return;
+    const uint64_t blocks = (words + 1023) / 1024;
+    hipLaunchKernelGGL(k_zero_words, dim3((uint32_t)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st,
+                       static_cast<uint32_t*>(p), words);
+}
+#endif
+
 // ---- wave-level primitives (wave64) ----------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 

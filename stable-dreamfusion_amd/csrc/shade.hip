@@ -24,6 +24,8 @@ namespace {
 
 constexpr uint32_t kThreads = 256;
 constexpr uint32_t kPadBlocks = 64;
+
+inline uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 constexpr float kNormEps = 1e-20f;  // safe_normalize's clamp (nerf/utils.py:109-110)
 constexpr float kFltMax = 3.402823466e38f;
 
@@ -191,6 +193,42 @@ __global__ __launch_bounds__(kThreads) void k_shade_backward(const float* __rest
     }
 }
 
+// ---- binary entropy of the sample weights (Trainer.train_step's lambda_entropy term, nerf/utils.py:571-575):
+//      alphas = weights.clamp(1e-5, 1 - 1e-5);  H = -alphas log2 alphas - (1 - alphas) log2(1 - alphas);  sum over rows < total
+constexpr float kAlphaLo = 1e-5f, kAlphaHi = 1.f - 1e-5f;
+
+__global__ __launch_bounds__(kThreads) void k_entropy_forward(const float* __restrict__ w, uint32_t cap,
+                                                              const int32_t* __restrict__ total_p, double* __restrict__ out) {
+    __shared__ double part[kThreads / 64];
+    const uint32_t total = min((uint32_t)total_p[0], cap);
+    double acc = 0.0;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < total; i += gridDim.x * kThreads) {
+        const float a = fminf(fmaxf(w[i], kAlphaLo), kAlphaHi);
+        acc += (double)(-a * log2f(a) - (1.f - a) * log2f(1.f - a));
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (uint32_t k = 0; k < kThreads / 64; k++) s += part[k];
+        if (s != 0.0) atomicAdd(out, s);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_entropy_backward(const float* __restrict__ w, uint32_t cap,
+                                                               const int32_t* __restrict__ total_p,
+                                                               const float* __restrict__ gout, float* __restrict__ dw) {
+    const uint32_t total = min((uint32_t)total_p[0], cap);
+    const float g = gout[0];
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < cap; i += gridDim.x * kThreads) {
+        const float x = w[i];
+        float d = 0.f;
+        if (i < total && x >= kAlphaLo && x <= kAlphaHi) d = g * (log2f(1.f - x) - log2f(x));  // clamp passes the gradient inside
+        dw[i] = d;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -225,6 +263,26 @@ int sdfx_shade_backward(const float* sigma7, const float* albedo, const float* d
                        dirs, rays, rays_o, light_offset, ratio, mode, epsilon, capacity, n_rays, ray_blocks, total, dcolor,
                        dnormal, dorient, dsigma7, dalbedo);
     return check_launch("shade_backward");
+}
+
+int sdfx_entropy_forward(const float* weights, uint32_t capacity, const int32_t* total, double* sum_out, sdfx_stream_t stream) {
+    SDFX_REQUIRE(total && sum_out && (weights || capacity == 0), "entropy_forward: null pointer");
+    hipStream_t st = as_stream(stream);
+    zero_device(sum_out, sizeof(double), st);
+    if (capacity == 0) return SDFX_OK;
+    const uint32_t blocks = (uint32_t)min_u64(div_up(capacity, kThreads * 4), 256);
+    hipLaunchKernelGGL(k_entropy_forward, dim3(blocks), dim3(kThreads), 0, st, weights, capacity, total, sum_out);
+    return check_launch("entropy_forward");
+}
+
+int sdfx_entropy_backward(const float* weights, uint32_t capacity, const int32_t* total, const float* grad_sum,
+                          float* grad_weights, sdfx_stream_t stream) {
+    SDFX_REQUIRE(total && grad_sum && (capacity == 0 || (weights && grad_weights)), "entropy_backward: null pointer");
+    if (capacity == 0) return SDFX_OK;
+    const uint32_t blocks = (uint32_t)min_u64(div_up(capacity, kThreads * 4), 2048);
+    hipLaunchKernelGGL(k_entropy_backward, dim3(blocks), dim3(kThreads), 0, as_stream(stream), weights, capacity, total,
+                       grad_sum, grad_weights);
+    return check_launch("entropy_backward");
 }
 
 }  // extern "C"

@@ -72,3 +72,29 @@ def fused_shade(sigma7, albedo0, dirs, rays, rays_o, light_offset, ratio, total,
         ratio = torch.tensor(float(ratio), dtype=_F32, device=sigma7.device)
     return _fused_shade.apply(sigma7.reshape(-1), albedo0, dirs, rays, rays_o, light_offset, ratio.to(_F32), total,
                               MODES[shading], epsilon)
+
+
+class _weights_entropy(Function):
+    """sum_{i < total} H(clamp(w_i, 1e-5, 1 - 1e-5)) in bits — the un-normalised lambda_entropy term (nerf/utils.py:571-575)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, weights, total):
+        weights = weights.contiguous()
+        out = torch.empty(1, dtype=torch.float64, device=weights.device)
+        S.call("sdfx_entropy_forward", S.ptr(S.check_tensor(weights, "weights", _F32)), weights.numel(),
+               S.ptr(S.check_tensor(total, "total", torch.int32)), S.ptr(out), S.stream())
+        ctx.save_for_backward(weights, total)
+        return out.to(_F32).reshape(())
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        weights, total = ctx.saved_tensors
+        dw = torch.empty_like(weights)
+        S.call("sdfx_entropy_backward", S.ptr(weights), weights.numel(), S.ptr(total), S.ptr(g.float().contiguous()), S.ptr(dw),
+               S.stream())
+        return dw, None
+
+
+weights_entropy_sum = _weights_entropy.apply

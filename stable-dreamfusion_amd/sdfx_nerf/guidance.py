@@ -8,8 +8,9 @@ the latents is exactly `grad`.
 
 The frozen 2D prior itself (UNet / VAE / text encoder) is third-party code the reference pulls from
 `diffusers` with hub weights (guidance/sd_utils.py:37-65); neither exists in this image. Two stand-ins:
-  * `synthetic_prior()`  — a deterministic conv "UNet" and a strided-conv "VAE": exercises every line of
-    the SDS arithmetic and the backward path into the renderer at negligible cost;
+  * `synthetic_prior()`  — a deterministic consistent "denoiser" (pulls towards a fixed target image, see
+    SyntheticUNet) and a strided-conv "VAE": exercises every line of the SDS arithmetic and the backward path into
+    the renderer at negligible cost, and gives a gradient the field can actually follow;
   * `sd15_random_prior()` (sd15_arch.py) — the SD-1.5 UNet / VAE-encoder ARCHITECTURE in plain PyTorch with
     random weights: same shapes and FLOPs as the real prior, for timing full SDS iterations.
 """
@@ -27,8 +28,12 @@ def ddim_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0
 
 
 class SyntheticUNet(nn.Module):
-    """Deterministic stand-in noise predictor: depends on the noisy latents, the timestep and the text
-    embedding so that classifier-free guidance has two different branches to combine."""
+    """Deterministic stand-in noise predictor with the one property of a trained denoiser that matters for SDS: its
+    prediction is CONSISTENT — eps_hat(x_t, t, c) = (x_t - sqrt(abar_t) * T(c)) / sqrt(1 - abar_t) is the exact noise
+    if the clean latents were the (text-dependent) target T(c). The SDS gradient w(t) (eps_hat - eps) then pulls the
+    rendered latents towards a fixed smooth image (a centred blob with a colour ramp), so optimisation converges
+    instead of random-walking the field into overflow the way a random conv does. A small conv term keeps a
+    convolution-shaped kernel in the loop; timestep and text embedding enter as in the real UNet's signature."""
 
     def __init__(self, ctx_dim=768):
         super().__init__()
@@ -38,14 +43,20 @@ class SyntheticUNet(nn.Module):
         with torch.no_grad():
             for p in self.parameters():
                 p.copy_(torch.randn(p.shape, generator=g) * 0.2)
-            # text-conditioned minus unconditioned prediction of ~0.1 per element, as a trained UNet gives; times
-            # guidance_scale = 100 that is the O(10) SDS gradient the loss scaler has to cope with
-            self.ctx.weight.mul_(0.1)
-            self.ctx.bias.mul_(0.1)
+        yy, xx = torch.meshgrid(torch.linspace(-1, 1, 64), torch.linspace(-1, 1, 64), indexing="ij")
+        blob = torch.exp(-(xx ** 2 + yy ** 2) / (2 * 0.35 ** 2))
+        target = torch.stack([blob * (0.5 + 0.5 * xx), blob * (0.5 - 0.5 * yy), blob * 0.6, blob], dim=0) * 2 - 1
+        self.register_buffer("target", target[None])
+        self.register_buffer("alphas", ddim_alphas_cumprod())
 
     def forward(self, x, t, encoder_hidden_states):
-        c = self.ctx(encoder_hidden_states.mean(dim=1).to(x.dtype))[:, :, None, None]
-        return self.conv(x) * torch.cos(t.to(x.dtype) * 1e-3)[:, None, None, None] + c
+        abar = self.alphas[t].to(x.dtype)[:, None, None, None]
+        a, b = abar.sqrt(), (1 - abar).sqrt()
+        # text-conditioned and unconditional targets differ by ~1e-3 per channel: times guidance_scale = 100 that is the
+        # O(0.1) shift classifier-free guidance applies
+        shift = 1e-3 * torch.tanh(self.ctx(encoder_hidden_states.mean(dim=1).to(x.dtype)))[:, :, None, None]
+        tgt = self.target.to(x.dtype) + shift
+        return (x - a * tgt) / b + 0.02 * self.conv(x) * torch.cos(t.to(x.dtype) * 1e-3)[:, None, None, None]
 
 
 class SyntheticVAE(nn.Module):

@@ -25,6 +25,11 @@ _FUSED = int(os.environ.get("SDFX_FUSED_FIELD", "1"))
 _BATCH_STENCIL = int(os.environ.get("SDFX_BATCH_STENCIL", "1"))
 # normal / shading / orientation glue between the field and the compositor in one HIP kernel each way
 _FUSED_SHADE = int(os.environ.get("SDFX_FUSED_SHADE", "1"))
+# The background MLP (4096 rays x 1.4 k MACs) is evaluated in float32 even under autocast: its gradient is the image
+# gradient times the loss scale, un-attenuated by compositing weights, and is what overflows fp16 first — in half it
+# caps the loss scale ~64x lower (field gradients underflow) and costs a GradScaler skip every ~12 iterations.
+# SDFX_BG_FP32=0 restores the reference's autocast behaviour (nn.Linear in half, nerf/network_grid.py:132-139).
+_BG_FP32 = int(os.environ.get("SDFX_BG_FP32", "1"))
 
 
 class _trunc_exp(Function):
@@ -176,6 +181,9 @@ class NeRFNetwork(NeRFRenderer):
 
     def background(self, d):
         h = self.encoder_bg(d)
+        if _BG_FP32:
+            with torch.autocast("cuda", enabled=False):
+                return torch.sigmoid(self.bg_net(h.float()))
         h = self.bg_net(h)
         return torch.sigmoid(h)
 

@@ -126,6 +126,7 @@ class NeRFRenderer(nn.Module):
             results["weights"] = weights
             results["num_samples"] = xyzs.shape[0]
             results["num_valid"] = n_valid
+            results["num_total"] = total
         else:
             dtype = torch.float32
             weights_sum = torch.zeros(N, dtype=dtype, device=device)

@@ -27,7 +27,12 @@ import torch
 
 import raymarching
 
+from .fused_shade import weights_entropy_sum
 from .optim import Adan, DeviceAdan
+
+_FUSED_ENTROPY = int(os.environ.get("SDFX_FUSED_ENTROPY", "1"))
+_PREFETCH = int(os.environ.get("SDFX_PREFETCH", "1"))      # counting pass of the next iteration on a second stream
+_STEP_SYNC = int(os.environ.get("SDFX_STEP_SYNC", "0"))    # debugging aid: device-wide synchronisation after every step
 
 # layout of the per-iteration scalar block
 _SC_AMBIENT, _SC_BG, _SC_WF, _SC_WS, _SC_WB, _SC_ENTROPY, _SC_WORDS = 0, 1, 4, 5, 6, 7, 8
@@ -56,11 +61,20 @@ class TrainStep:
         self.embeddings = {k: guidance.get_text_embeds([k]) for k in ("uncond", "front", "side", "back")}
         self.last = {}
         # static inputs of the captured region
-        self.sc_host = torch.zeros(_SC_WORDS, dtype=torch.float32).pin_memory() if device.type == "cuda" else \
-            torch.zeros(_SC_WORDS, dtype=torch.float32)
+        # pinned staging for the scalar block: a ring, because with the counting pass prefetched the host can run a full
+        # iteration ahead of the GPU and must not overwrite a block whose asynchronous H2D copy has not executed yet
+        self.sc_ring = [torch.zeros(_SC_WORDS, dtype=torch.float32).pin_memory() if device.type == "cuda"
+                        else torch.zeros(_SC_WORDS, dtype=torch.float32) for _ in range(8)]
+        self.sc_host = self.sc_ring[0]
         self.sc = torch.zeros(_SC_WORDS, dtype=torch.float32, device=device)
-        self.rays_o = self.rays_d = None
+        self.rays_o = self.rays_d = self.in_rays_o = self.in_rays_d = self.cur_rays = None
+        self.cur_total = torch.zeros(1, dtype=torch.int32, device=device)
         self.march_state = None
+        self._pending = None
+        if device.type == "cuda":
+            self.side_stream = torch.cuda.Stream(device=device)
+            self.staging_free, self.count_done = torch.cuda.Event(), torch.cuda.Event()
+            self.count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.n_valid = torch.ones((), dtype=torch.float32, device=device)
         self._num_samples = 0
         self.hw = (opt.h, opt.w)
@@ -71,14 +85,14 @@ class TrainStep:
         self._warm = set()               # kinds that have run eagerly once
         self.graphs = {}                 # (capacity, shading, as_latent, bg_kind) -> (CUDAGraph, loss tensor)
         self.graph_uses = {}
-        self.stats = {"replays": 0, "captures": 0, "eager": 0}
+        self.stats = {"replays": 0, "captures": 0, "eager": 0, "prefetched": 0}
 
     # ------------------------------------------------------------------------------ schedule (host)
     def _schedule(self, azimuth):
         """Trainer.train_step's per-iteration choices (nerf/utils.py:497-530, 601-621) -> (kinds, scalar block)."""
         opt = self.opt
         exp_iter_ratio = (self.global_step - opt.exp_start_iter) / (opt.exp_end_iter - opt.exp_start_iter)
-        sc = self.sc_host
+        sc = self.sc_host = self.sc_ring[self.global_step % len(self.sc_ring)]
         sc.zero_()
         if exp_iter_ratio <= opt.latent_iter_ratio:
             ambient_ratio, shading, as_latent, bg_kind = 1.0, "normal", True, "net"
@@ -132,47 +146,95 @@ class TrainStep:
         if opt.lambda_opacity > 0:
             loss = loss + opt.lambda_opacity * (outputs["weights_sum"] ** 2).mean()
         if opt.lambda_entropy > 0:
-            alphas = outputs["weights"].clamp(1e-5, 1 - 1e-5)
-            ent = -alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas)
             n_valid = outputs["num_valid"]
-            if n_valid is None:
-                loss_entropy = ent.mean()
-            else:  # fixed-capacity buffers: rows past the sample total are padding
-                live = torch.arange(ent.shape[0], device=ent.device) < n_valid
-                loss_entropy = (ent * live).sum() / n_valid
+            if n_valid is not None and _FUSED_ENTROPY:   # fixed-capacity buffers: one kernel each way, padding excluded
+                loss_entropy = weights_entropy_sum(outputs["weights"], outputs["num_total"]) / n_valid
+            else:
+                alphas = outputs["weights"].clamp(1e-5, 1 - 1e-5)
+                ent = -alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas)
+                if n_valid is None:
+                    loss_entropy = ent.mean()
+                else:
+                    live = torch.arange(ent.shape[0], device=ent.device) < n_valid
+                    loss_entropy = (ent * live).sum() / n_valid
             loss = loss + sc[_SC_ENTROPY] * loss_entropy
         if opt.lambda_orient > 0 and "loss_orient" in outputs:
             loss = loss + opt.lambda_orient * outputs["loss_orient"]
         return loss
 
     # ------------------------------------------------------------------------------ iteration body
-    def _body(self, capacity, shading, as_latent, bg_kind, *_hw):
-        """Everything after the sample total is known; no host reads (modes "device" and "graph")."""
+    # Two stages so that the counting pass of the NEXT iteration can run on a second stream while this one trains:
+    #   _stage_march   copies what the counting pass left in the staging buffers (rays, total, ray origins/directions) into
+    #                  the iteration's own buffers and runs the writing pass; after it the staging buffers are free again
+    #   _stage_train   everything else (field, compositing, loss, backward, optimiser); reads only the iteration's buffers
+    def _stage_march(self, capacity):
+        st = self.march_state
+        self.cur_rays.copy_(st["rays"])
+        self.cur_total.copy_(st["counter"])
+        self.n_valid.copy_(st["counter"][0])                     # int32 -> float32, on the device
+        self.rays_o.copy_(self.in_rays_o)
+        self.rays_d.copy_(self.in_rays_d)
+        xyzs, dirs, ts, _ = raymarching.march_rays_train_write(st, capacity)
+        return xyzs, dirs, ts
+
+    def _stage_train(self, marched, shading, as_latent, bg_kind, *_hw):
         opt = self.opt
-        xyzs, dirs, ts, rays = raymarching.march_rays_train_write(self.march_state, capacity)
+        xyzs, dirs, ts = marched
         self.optimizer.zero_grad()
         with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
-            loss = self.train_step((xyzs, dirs, ts, rays, self.n_valid, self.march_state["counter"]), shading, as_latent, bg_kind)
+            loss = self.train_step((xyzs, dirs, ts, self.cur_rays, self.n_valid, self.cur_total), shading, as_latent, bg_kind)
         (loss * self.optimizer.scale).backward()
         if opt.grad_clip >= 0 or opt.lambda_tv > 0 or opt.lambda_wd > 0:
             raise NotImplementedError("grad_clip / lambda_tv / lambda_wd act on unscaled gradients: use mode='reference'")
         self.optimizer.step()
         return loss.detach()
 
-    def _count(self, rays_o, rays_d):
-        """Static-shape prologue + the one host read: rays -> near/far -> jitter -> counting pass -> M."""
+    def _body(self, capacity, *kinds):
+        """Everything after the sample total is known, eagerly; no host reads."""
+        marched = self._stage_march(capacity)
+        self.staging_free.record()
+        return self._stage_train(marched, *kinds)
+
+    def _launch_count(self, rays_o, rays_d):
+        """Static-shape prologue on the current stream: rays -> near/far -> jitter -> counting pass -> total to pinned memory."""
         m = self.model
-        if self.rays_o is None:
-            self.rays_o = torch.empty(rays_o.numel() // 3, 3, dtype=torch.float32, device=self.device)
-            self.rays_d = torch.empty_like(self.rays_o)
-        self.rays_o.copy_(rays_o.reshape(-1, 3))
-        self.rays_d.copy_(rays_d.reshape(-1, 3))
-        nears, fars = raymarching.near_far_from_aabb(self.rays_o, self.rays_d, m.aabb_train)
-        self.march_state = raymarching.march_rays_train_count(self.rays_o, self.rays_d, m.bound, m.density_bitfield, m.cascade,
-                                                              m.grid_size, nears, fars, True, self.opt.dt_gamma,
+        if self.in_rays_o is None:
+            n = rays_o.numel() // 3
+            f = dict(dtype=torch.float32, device=self.device)
+            self.in_rays_o, self.in_rays_d = torch.empty(n, 3, **f), torch.empty(n, 3, **f)
+            self.rays_o, self.rays_d = torch.empty(n, 3, **f), torch.empty(n, 3, **f)
+            self.cur_rays = torch.empty(n, 2, dtype=torch.int32, device=self.device)
+        self.in_rays_o.copy_(rays_o.reshape(-1, 3), non_blocking=True)
+        self.in_rays_d.copy_(rays_d.reshape(-1, 3), non_blocking=True)
+        nears, fars = raymarching.near_far_from_aabb(self.in_rays_o, self.in_rays_d, m.aabb_train)
+        self.march_state = raymarching.march_rays_train_count(self.in_rays_o, self.in_rays_d, m.bound, m.density_bitfield,
+                                                              m.cascade, m.grid_size, nears, fars, True, self.opt.dt_gamma,
                                                               self.opt.max_steps, state=self.march_state)
-        self.n_valid.copy_(self.march_state["counter"][0])       # int32 -> float32, on the device
-        return int(self.march_state["counter"].item())           # the host read of the iteration
+        self.count_host.copy_(self.march_state["counter"], non_blocking=True)
+        self.count_done.record()
+
+    def _count(self, rays_o, rays_d):
+        """The sample total of this iteration: already on its way if the previous step() prefetched it, else counted now.
+        This is the one host read of an iteration."""
+        pending, self._pending = self._pending, None
+        if pending is not None and pending["step"] == self.global_step and pending["rays"] is rays_o:
+            torch.cuda.current_stream().wait_event(self.count_done)   # the training stream consumes the staging buffers
+            self.stats["prefetched"] += 1
+        else:
+            if pending is not None:
+                self.count_done.synchronize()                            # a stale prefetch still owns the staging buffers
+            self._launch_count(rays_o, rays_d)
+        self.count_done.synchronize()
+        return int(self.count_host[0])
+
+    def _prefetch(self, rays_o, rays_d):
+        """Counting pass of the next iteration on the side stream, overlapping this iteration's training stage. It only
+        depends on the rays and the occupancy bitfield — not on the parameters being updated."""
+        side = self.side_stream
+        side.wait_event(self.staging_free)                                # this iteration has copied the staging buffers
+        with torch.cuda.stream(side):
+            self._launch_count(rays_o, rays_d)
+        self._pending = {"step": self.global_step + 1, "rays": rays_o}   # global_step as _count will see it in the next step()
 
     def _ladder(self, M):
         """Smallest capacity of the geometric ladder (ratio `graph_ratio`, multiples of `graph_bucket`) holding M."""
@@ -190,11 +252,15 @@ class TrainStep:
             victim = min(self.graphs, key=lambda k: self.graph_uses.get(k, 0))
             del self.graphs[victim]
             self.graph_uses.pop(victim, None)
-        g = torch.cuda.CUDAGraph()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            marched = self._stage_march(key[0])
         self.optimizer.zero_grad()
-        with torch.cuda.graph(g):
-            loss = self._body(*key)
-        self.graphs[key] = (g, loss)
+        with torch.cuda.graph(g2):
+            loss = self._stage_train(marched, *key[1:])
+        # (the gradient buffers of this graph are kept reachable for diagnostics: Python's p.grad only names the
+        # buffers of the most recent capture)
+        self.graphs[key] = (g1, g2, loss, marched, [p.grad for p in self.optimizer.parameters()])
         self.graph_uses[key] = 0
         self.stats["captures"] += 1
 
@@ -208,8 +274,10 @@ class TrainStep:
                 self._capture((c,) + kinds)
             c = self._ladder(c + 1)
 
-    def step(self, rays_o, rays_d, azimuth=0.0, H=64, W=64):
-        """update_extra_state (every N steps) -> train_step under autocast -> backward -> optimiser."""
+    def step(self, rays_o, rays_d, azimuth=0.0, H=64, W=64, next_rays=None):
+        """update_extra_state (every N steps) -> train_step under autocast -> backward -> optimiser.
+        `next_rays` = (rays_o, rays_d) of the following call, if the caller knows them (a data loader does): their
+        counting pass then overlaps this iteration instead of leaving the GPU idle around the host read."""
         opt = self.opt
         self.hw = (H, W)
         self.model.train()
@@ -237,10 +305,18 @@ class TrainStep:
             else:
                 if key not in self.graphs:
                     self._prime(key)
-                g, loss = self.graphs[key]
-                g.replay()
+                g1, g2, loss = self.graphs[key][:3]
+                self.last_key = key
+                g1.replay()
+                self.staging_free.record()
+                g2.replay()
                 self.graph_uses[key] += 1
                 self.stats["replays"] += 1
+        # the next iteration refreshes the occupancy grid first if its index is a multiple of the interval: no prefetch then
+        if next_rays is not None and self.global_step % opt.update_extra_interval != 0 and _PREFETCH:
+            self._prefetch(*next_rays)
+        if _STEP_SYNC:
+            torch.cuda.synchronize()
         self.last = {"num_samples": M, "shading": kinds[0]}
         return loss
 
