@@ -415,7 +415,7 @@ def main():
     # gfx950 it tallies 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM"); null when the file is absent.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")) as f:
             pm = json.load(f)["k_grid_forward"]
         traffic = (2.0 * pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]) * 1024.0
     except (OSError, KeyError, ValueError):
@@ -439,7 +439,7 @@ def main():
         "grad_scale": step.get_scale(), "train_mode": step.mode, "graph_stats": stats_timed,
         "roofline": {"bound": "hbm", "kernel": "k_grid_forward<3,2,half>", "achieved": enc["GBps"], "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": enc["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_unit": "bytes per launch (profiles/r01_v3_pmc_traffic.json)",
+                     "traffic_unit": "bytes per launch (profiles/r01_v4_pmc_traffic.json)",
                      "algorithmic_bytes_per_launch": (enc["bytes"] / enc["launches"]) if enc.get("launches") else None,
                      "avg_launch_us": enc["avg_us"], "launches": enc["launches"], "measured_in": roofline_pass,
                      "algorithmic_bytes_per_point": 588},
