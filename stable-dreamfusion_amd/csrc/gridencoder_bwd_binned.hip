@@ -33,6 +33,7 @@ constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;  // rows per bucket (16 
 constexpr uint32_t kMaxBucketsPerLevel = 512;            // levels up to 2^20 rows
 constexpr uint32_t kBinThreads = 512;
 constexpr uint32_t kPointsPerThread = 1;
+static_assert(kMaxBucketsPerLevel <= kBinThreads, "K1 scans the bucket histogram with one thread per bucket");
 constexpr uint32_t kReduceThreads = 256;
 constexpr uint32_t kItemsPerSplit = 131072;              // a bucket holding more items than this is reduced by several workgroups
 constexpr uint32_t kItemsPerSplitCoarse = 65536;         // ... for levels of few buckets, each of which gets a large share of the batch
@@ -152,6 +153,10 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
     constexpr uint32_t D = 3, C = 2, NCORN = 8, NITEM = NCORN * kPointsPerThread;
     __shared__ uint32_t hist[kMaxBucketsPerLevel];
     __shared__ uint32_t gbase[kMaxBucketsPerLevel];
+    __shared__ uint32_t boff[kMaxBucketsPerLevel];
+    __shared__ uint32_t wave_tot[kBinThreads / 64];
+    __shared__ uint32_t block_total;
+    __shared__ Item<HALF> stage[kBinThreads * NITEM];   // 32 KiB (half items) / 48 KiB (float items)
 
     uint32_t level, tile;
     const bool has_item = plan_item(plan, level, tile);  // wave-uniform (depends on blockIdx only)
@@ -222,30 +227,52 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
         }
     }
     __syncthreads();
-    // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's item list
-    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) {
-        const uint32_t cnt = hist[i];
-        gbase[i] = cnt ? atomicAdd(&cursors[bin.bucket_first[level] + i], cnt) : 0u;
+    // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's item list; and an exclusive
+    // prefix sum of the histogram = where each bucket's items go in the workgroup's LDS staging area
+    uint32_t my_cnt = 0;
+    if (threadIdx.x < nb) {
+        my_cnt = hist[threadIdx.x];
+        gbase[threadIdx.x] = my_cnt ? atomicAdd(&cursors[bin.bucket_first[level] + threadIdx.x], my_cnt) : 0u;
+    }
+    {   // nb <= kMaxBucketsPerLevel = kBinThreads: thread b scans bucket b (wave scan + per-wave totals)
+        const uint32_t incl = wave_incl_sum_u32(my_cnt, lane);
+        if (lane == (int)kWave - 1) wave_tot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) woff += wave_tot[w];
+        if (threadIdx.x < nb) boff[threadIdx.x] = woff + incl - my_cnt;
+        if (threadIdx.x == kBinThreads - 1) block_total = woff + incl;
+    }
+    __syncthreads();
+
+    // Stage the items in LDS grouped by bucket, then stream them out: consecutive staging slots of one bucket go to
+    // consecutive slots of its list, so a wave store covers a few contiguous runs instead of 64 unrelated 8-byte
+    // writes (the scattered version was bound by L2 write transactions: one per item).
+#pragma unroll
+    for (uint32_t i = 0; i < NITEM; i++) {
+        if (!((alive >> i) & 1u)) continue;
+        stage[boff[rows[i] >> kBucketRowsLog2] + rank[i]] = Item<HALF>::make(rows[i], va[i], vb[i]);
     }
     __syncthreads();
 
     const uint32_t cap = bin.cap[level];
     Item<HALF>* level_items = items + (size_t)bin.item_first[level] * 1024u;
     T* gtab = grad_table + (size_t)row0 * C;
-#pragma unroll
-    for (uint32_t i = 0; i < NITEM; i++) {
-        if (!((alive >> i) & 1u)) continue;
-        const uint32_t bucket = rows[i] >> kBucketRowsLog2;
-        const uint32_t slot = gbase[bucket] + rank[i];
+    const uint32_t total = block_total;
+    for (uint32_t k = threadIdx.x; k < total; k += kBinThreads) {
+        const Item<HALF> it = stage[k];
+        const uint32_t bucket = it.row >> kBucketRowsLog2;
+        const uint32_t slot = gbase[bucket] + (k - boff[bucket]);
         if (slot < cap) {
-            level_items[(size_t)bucket * cap + slot] = Item<HALF>::make(rows[i], va[i], vb[i]);
+            level_items[(size_t)bucket * cap + slot] = it;
         } else {  // bucket over capacity: add directly (complete for any input distribution)
-            T* dst = gtab + (size_t)rows[i] * C;
+            T* dst = gtab + (size_t)it.row * C;
+            const float2 v = it.value();
             if constexpr (HALF) {
-                unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), __halves2half2(__float2half_rn(va[i]), __float2half_rn(vb[i])));
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), __halves2half2(__float2half_rn(v.x), __float2half_rn(v.y)));
             } else {
-                unsafeAtomicAdd(dst, va[i]);
-                unsafeAtomicAdd(dst + 1, vb[i]);
+                unsafeAtomicAdd(dst, v.x);
+                unsafeAtomicAdd(dst + 1, v.y);
             }
         }
     }
