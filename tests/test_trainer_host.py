@@ -1,0 +1,120 @@
+"""Host-side logic of the training iteration that needs no GPU: the capacity ladder, the per-iteration schedule block
+(against the reference's expressions, nerf/utils.py:497-530 and 601-621) and the foreach Adan against a literal
+numpy transcription of the update rule (optimizer.py:216-261), which the GPU test then uses as DeviceAdan's yardstick."""
+import importlib
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def mods():
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf import optim, options, trainer
+    return types.SimpleNamespace(optim=optim, options=options, trainer=trainer)
+
+
+class _Guidance:
+    def get_text_embeds(self, prompt):
+        return torch.zeros(1, 2, 4)
+
+
+def _step(mods, **over):
+    opt = mods.options.default_opt(**over)
+    dummy = types.SimpleNamespace(get_params=lambda lr: [{"params": [torch.nn.Parameter(torch.zeros(3))], "lr": lr}])
+    return mods.trainer.TrainStep(opt, dummy, _Guidance(), torch.device("cpu"), seed=0, mode="reference"), opt
+
+
+def test_capacity_ladder(mods):
+    st, _ = _step(mods)
+    caps = sorted({st._ladder(m) for m in range(1, 4096 * 1024, 9973)})
+    assert all(c % st.graph_bucket == 0 for c in caps)
+    for m in (1, 32768, 32769, 262144, 419816, 999999, 4096 * 1024):
+        c = st._ladder(m)
+        assert c >= m and (c - m) <= max(st.graph_bucket, 0.1 * m + st.graph_bucket)     # at most ~10 % padding
+    ratios = [b / a for a, b in zip(caps, caps[1:]) if a >= 16 * st.graph_bucket]
+    assert max(ratios) <= 1.1 + 1e-9 + 1 / 16 and len(caps) < 60                          # a few dozen graphs cover every total
+
+
+@pytest.mark.parametrize("azimuth", [-170.0, -90.0, -35.0, 0.0, 49.0, 89.9, 90.0, 147.0])
+def test_text_embedding_weights_follow_reference_interpolation(mods, azimuth):
+    st, opt = _step(mods)
+    T = mods.trainer
+    st._schedule(azimuth)
+    sc = st.sc_host
+    if -90 <= azimuth < 90:                                   # nerf/utils.py:603-611
+        r = 1 - azimuth / 90 if azimuth >= 0 else 1 + azimuth / 90
+        want = (r, 1 - r, 0.0)
+    else:                                                     # :612-620
+        r = 1 - (azimuth - 90) / 90 if azimuth >= 0 else 1 + (azimuth + 90) / 90
+        want = (0.0, r, 1 - r)
+    got = (float(sc[T._SC_WF]), float(sc[T._SC_WS]), float(sc[T._SC_WB]))
+    assert np.allclose(got, want, atol=1e-6) and abs(sum(got) - 1) < 1e-6
+
+
+def test_schedule_phases(mods):
+    st, opt = _step(mods)
+    T = mods.trainer
+    st.global_step = 0
+    assert st._schedule(0.0) == ("normal", True, "net") and float(st.sc_host[T._SC_AMBIENT]) == 1.0   # latent warm-up phase
+    st.global_step = int(opt.iters * opt.latent_iter_ratio) + 1
+    seen = set()
+    for _ in range(200):
+        shading, as_latent, bg = st._schedule(10.0)
+        seen.add((shading, bg))
+        assert not as_latent and shading in ("textureless", "lambertian")
+        amb = float(st.sc_host[T._SC_AMBIENT])
+        assert opt.min_ambient_ratio <= amb <= 1.0
+        if bg == "rand":
+            assert all(0.0 <= float(st.sc_host[T._SC_BG + k]) <= 1.0 for k in range(3))
+    assert len(seen) == 4
+    st.global_step = 2500
+    st._schedule(0.0)
+    assert abs(float(st.sc_host[T._SC_ENTROPY]) - opt.lambda_entropy * min(1, 2 * 2500 / opt.iters)) < 1e-9
+
+
+def _adan_numpy(p, g, state, k, lr, wd, betas, eps, clip, no_prox):
+    """optimizer.py:216-261 for one tensor, float64."""
+    b1, b2, b3 = betas
+    g = g * clip
+    if k == 1:
+        state["prev"] = g.copy()
+    diff = g - state["prev"]
+    state["m"] = state["m"] * b1 + (1 - b1) * g
+    state["v"] = state["v"] * b2 + (1 - b2) * diff
+    u = g + b2 * diff
+    state["n"] = state["n"] * b3 + (1 - b3) * u * u
+    denom = np.sqrt(state["n"]) / math.sqrt(1 - b3 ** k) + eps
+    s1, s2 = lr / (1 - b1 ** k), lr * b2 / (1 - b2 ** k)
+    if no_prox:
+        p = p * (1 - lr * wd) - s1 * state["m"] / denom - s2 * state["v"] / denom
+    else:
+        p = (p - s1 * state["m"] / denom - s2 * state["v"] / denom) / (1 + lr * wd)
+    state["prev"] = g.copy()
+    return p
+
+
+@pytest.mark.parametrize("no_prox", [False, True])
+def test_foreach_adan_is_the_reference_rule(mods, no_prox):
+    rng = np.random.default_rng(0)
+    shapes = [(1001,), (8, 5)]
+    params = [torch.nn.Parameter(torch.from_numpy(rng.normal(size=s).astype(np.float32))) for s in shapes]
+    ref = [p.detach().double().numpy().copy() for p in params]
+    states = [{"m": np.zeros(s), "v": np.zeros(s), "n": np.zeros(s), "prev": np.zeros(s)} for s in shapes]
+    betas, eps, wd, lr, max_norm = (0.98, 0.92, 0.99), 1e-8, 2e-5, 5e-2, 5.0
+    opt = mods.optim.Adan([{"params": params, "lr": lr}], betas=betas, eps=eps, weight_decay=wd, max_grad_norm=max_norm,
+                          no_prox=no_prox)
+    for k in range(1, 7):
+        grads = [rng.normal(size=s).astype(np.float32) * (30.0 if k % 2 else 1e-2) for s in shapes]
+        norm = math.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads))
+        clip = min(1.0, max_norm / (norm + eps))
+        for p, g in zip(params, grads):
+            p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        for i, g in enumerate(grads):
+            ref[i] = _adan_numpy(ref[i], g.astype(np.float64), states[i], k, lr, wd, betas, eps, clip, no_prox)
+        for p, r in zip(params, ref):
+            assert np.allclose(p.detach().numpy(), r, rtol=2e-5, atol=1e-7), f"step {k}"
