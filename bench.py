@@ -415,7 +415,7 @@ def main():
     # gfx950 it tallies 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM"); null when the file is absent.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")) as f:
             pm = json.load(f)["k_grid_forward"]
         traffic = (2.0 * pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]) * 1024.0
     except (OSError, KeyError, ValueError):
@@ -431,7 +431,7 @@ def main():
                                "backward, Adan step, grid refresh every 16 iters",
                    "guidance": guidance_kind + (" (SD-1.5 UNet+VAE architecture, random weights; diffusers/hub weights absent)"
                                                 if guidance_kind == "sd15_random" else
-                                                " (conv stand-in for the frozen prior; diffusers/hub weights absent)"),
+                                                " (consistent-denoiser stand-in for the frozen prior; diffusers/hub weights absent)"),
                    "rays_per_iter": 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid},
         "rays_per_s": world * args.steps * 4096 / elapsed,
         "samples_per_iter": samples / max(args.steps, 1),
@@ -439,7 +439,7 @@ def main():
         "grad_scale": step.get_scale(), "train_mode": step.mode, "graph_stats": stats_timed,
         "roofline": {"bound": "hbm", "kernel": "k_grid_forward<3,2,half>", "achieved": enc["GBps"], "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": enc["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_unit": "bytes per launch (profiles/r01_v4_pmc_traffic.json)",
+                     "traffic_unit": "bytes per launch (profiles/r01_v5_pmc_traffic.json)",
                      "algorithmic_bytes_per_launch": (enc["bytes"] / enc["launches"]) if enc.get("launches") else None,
                      "avg_launch_us": enc["avg_us"], "launches": enc["launches"], "measured_in": roofline_pass,
                      "algorithmic_bytes_per_point": 588},

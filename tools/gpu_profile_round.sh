@@ -36,5 +36,17 @@ json.dump(out, open("$OUT/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
 cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+python3 - <<PY | tee -a $OUT/summary.txt
+import csv, collections
+rows = list(csv.DictReader(open("$OUT/stats/bench_kernel_trace.csv")))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "copyBuffer" in r["Kernel_Name"]]
+d.sort()
+print("copyBuffer: n=%d median=%.1f us p90=%.1f us max=%.1f us sum=%.1f ms; >100us: %d" % (len(d), d[len(d)//2], d[int(len(d)*0.9)], d[-1], sum(d)/1e3, sum(1 for x in d if x > 100)))
+# what runs right before / after the long ones
+long = [i for i, r in enumerate(rows) if "copyBuffer" in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 100000]
+for i in long[-4:]:
+    print("  long copy %.0f us, stream %s; prev: %s | next: %s" % ((int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3, rows[i].get("Stream_Id", rows[i].get("Queue_Id", "?")), rows[i-1]["Kernel_Name"][:40], rows[i+1]["Kernel_Name"][:40]))
+PY
 find $OUT -type f -size +1M -delete 2>/dev/null
 du -sh $OUT
