@@ -185,6 +185,39 @@ def kernel_microbench(dev):
                                                                               ws, dep, img, M, 4096, 1e-4, False, gs, gc), iters=20)
         out[f"composite_bwd_{gname}"] = {"ms": ms, "M": M, "Mrays_per_s": 4096 / ms / 1e3,
                                          "GBps": (M * 44 + 4096 * 48) / ms / 1e6}
+    # inference operators (march_rays / composite_rays / compact_rays, renderer.py:759-794) with synthetic densities:
+    # the loop the reference runs at test time, n_step samples per alive ray and round, until every ray is done
+    for gname, bf in (("init", synth.s_grid_init()[2]),):
+        bfd = to(bf)
+        N = od.shape[0]
+
+        def infer():
+            ws, dep, img = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
+            alive = torch.arange(N, dtype=torch.int32, device=dev)
+            rays_t = nears.clone()
+            step_i, rounds = 0, 0
+            while step_i < 1024 and alive.shape[0] > 0:
+                n_alive = alive.shape[0]
+                n_step = max(min(N // n_alive, 8), 1)
+                xyzs, dirs, ts = raymarching.march_rays(n_alive, n_step, alive, rays_t, od, dd, 1.0, bfd, 1, 128, nears, fars,
+                                                        False, 0, 1024)
+                sig = torch.full((xyzs.shape[0],), 8.0, device=dev)
+                rgb = xyzs * 0.5 + 0.5
+                raymarching.composite_rays(n_alive, n_step, alive, rays_t, sig, rgb, ts, ws, dep, img, 1e-4)
+                alive = raymarching.compact_rays(alive)
+                step_i += n_step
+                rounds += 1
+            return rounds
+
+        rounds = infer()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            infer()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        out[f"infer_loop_{gname}"] = {"ms": ms, "rounds": rounds, "Mrays_per_s": N / ms / 1e3,
+                                      "note": "4096 rays to termination, sigma = 8 everywhere occupied; host-paced (one sync per round)"}
     return out
 
 
