@@ -49,6 +49,7 @@ def parse():
                     help="occupancy the model starts from (the iteration refreshes it every 16 steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
+    ap.add_argument("--no-nerf-only", action="store_true", help="skip the second timed pass without the SD-1.5 UNet")
     ap.add_argument("--cpu-rays", type=int, default=256, help="rays in the CPU-oracle baseline sample")
     return ap.parse_args()
 
@@ -436,6 +437,25 @@ def main():
         roofline_pass = f"{min(args.steps, 8)} eager iterations after the timed region (graph replay hides launches from Python)"
     elapsed = job_elapsed(elapsed, dist, dev)
 
+    # second figure, same run: the iteration without the frozen prior's UNet (the part of it this repository implements)
+    nerf_only = None
+    if guidance_kind == "sd15_random" and not args.no_nerf_only:
+        prior.unet.skip_unet = True
+        step.graphs.clear(); step.graph_uses.clear(); step._warm.clear()
+        for v in range(len(views) + 2):
+            one_step(v)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        nerf_only = job_throughput(world, args.steps, job_elapsed(time.perf_counter() - t1, dist, dev))
+        prior.unet.skip_unet = False
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -462,12 +482,13 @@ def main():
         "config": {"workload": "BASELINE configs[1]: Instant-NGP -O iteration, 4096 rays (64x64), 128^3 occupancy grid, "
                                "<=1024 steps/ray, 16-level hash grid (2^19 x 2 fp16), 7 field evals/sample, SDS loss, AMP "
                                "backward, Adan step, grid refresh every 16 iters",
-                   "guidance": guidance_kind + (" (SD-1.5 UNet+VAE architecture, random weights; diffusers/hub weights absent)"
+                   "guidance": guidance_kind + (" (SD-1.5 UNet + VAE-encoder architecture, 860 M + 34 M parameters, random weights, evaluated in full; its damped output is added to the consistent stand-in; diffusers/hub weights absent)"
                                                 if guidance_kind == "sd15_random" else
                                                 " (consistent-denoiser stand-in for the frozen prior; diffusers/hub weights absent)"),
                    "rays_per_iter": 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid},
         "rays_per_s": world * args.steps * 4096 / elapsed,
         "samples_per_iter": samples / max(args.steps, 1),
+        "iters_per_sec_without_unet": nerf_only,
         "optimizer_steps_applied": applied_in_timed, "scaler_calibration_iters": calib,
         "grad_scale": step.get_scale(), "train_mode": step.mode, "graph_stats": stats_timed,
         "roofline": {"bound": "hbm", "kernel": "k_grid_forward<3,2,half>", "achieved": enc["GBps"], "peak": HBM_PEAK_GBPS,

@@ -118,3 +118,19 @@ def test_foreach_adan_is_the_reference_rule(mods, no_prox):
             ref[i] = _adan_numpy(ref[i], g.astype(np.float64), states[i], k, lr, wd, betas, eps, clip, no_prox)
         for p, r in zip(params, ref):
             assert np.allclose(p.detach().numpy(), r, rtol=2e-5, atol=1e-7), f"step {k}"
+
+
+def test_sd15_architecture_size_and_wiring(mods):
+    """The SD-1.5-architecture prior used for timing: parameter counts of the published model (859.5 M UNet, 34.2 M VAE
+    encoder) and a forward pass of a width-reduced instance (same topology) through every skip connection."""
+    from sdfx_nerf import sd15_arch as A
+    with torch.device("meta"):
+        unet, vae = A.UNetSD15(), A.VAEEncoderSD15()
+    assert sum(p.numel() for p in unet.parameters()) == 859_520_964
+    assert sum(p.numel() for p in vae.parameters()) == 34_162_128
+    torch.manual_seed(0)
+    small = A.UNetSD15(base=32, ctx_dim=48)
+    y = small(torch.randn(2, 4, 32, 32), torch.tensor([10, 500]), torch.randn(2, 77, 48))
+    assert y.shape == (2, 4, 32, 32) and bool(torch.isfinite(y).all())
+    z = A.VAEEncoderSD15(ch=32).encode_sample(torch.randn(1, 3, 64, 64))
+    assert z.shape == (1, 4, 8, 8) and bool(torch.isfinite(z).all())
