@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import os
 import random
+import warnings
 
 import torch
 
@@ -248,8 +249,9 @@ class TrainStep:
         """Record the iteration body for `key` = (capacity, shading, as_latent, bg_kind, H, W). Capturing executes
         nothing, so it needs no valid sample data — only that the lazy initialisations behind the body (MIOpen
         find, hipBLASLt heuristics, scratch allocations) have happened in an earlier eager iteration."""
-        if len(self.graphs) >= self.max_graphs:
-            victim = min(self.graphs, key=lambda k: self.graph_uses.get(k, 0))
+        if len(self.graphs) >= self.max_graphs:   # evict the least used graph (never one captured for the current kinds just now)
+            old = [k for k in self.graphs if self.graph_uses.get(k, 0) > 0 or k[1:] != key[1:]] or list(self.graphs)
+            victim = min(old, key=lambda k: self.graph_uses.get(k, 0))
             del self.graphs[victim]
             self.graph_uses.pop(victim, None)
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -297,21 +299,31 @@ class TrainStep:
         else:
             kinds = kinds + (H, W)
             key = (self._ladder(M),) + kinds
-            if kinds not in self._warm:
+            first = kinds not in self._warm
+            if first:
                 loss = self._body(*key)      # first iteration of this kind runs eagerly: every lazy initialisation happens
                 self._warm.add(kinds)
                 self.stats["eager"] += 1
-                self._prime(key)
-            else:
-                if key not in self.graphs:
+            if key not in self.graphs:
+                try:
                     self._prime(key)
-                g1, g2, loss = self.graphs[key][:3]
-                self.last_key = key
-                g1.replay()
-                self.staging_free.record()
-                g2.replay()
-                self.graph_uses[key] += 1
-                self.stats["replays"] += 1
+                except Exception as exc:     # noqa: BLE001 — capture is an optimisation: without it the iteration runs eagerly
+                    warnings.warn(f"HIP-graph capture failed ({type(exc).__name__}: {exc}); continuing in mode='device'")
+                    self.mode = "device"
+                    self.graphs.clear()
+                    self.graph_uses.clear()
+            if not first:
+                if self.mode == "graph":
+                    g1, g2, loss = self.graphs[key][:3]
+                    self.last_key = key
+                    g1.replay()
+                    self.staging_free.record()
+                    g2.replay()
+                    self.graph_uses[key] += 1
+                    self.stats["replays"] += 1
+                else:
+                    loss = self._body(M, *kinds)
+                    self.stats["eager"] += 1
         # the next iteration refreshes the occupancy grid first if its index is a multiple of the interval: no prefetch then
         if next_rays is not None and self.global_step % opt.update_extra_interval != 0 and _PREFETCH:
             self._prefetch(*next_rays)

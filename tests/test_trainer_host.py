@@ -134,3 +134,70 @@ def test_sd15_architecture_size_and_wiring(mods):
     assert y.shape == (2, 4, 32, 32) and bool(torch.isfinite(y).all())
     z = A.VAEEncoderSD15(ch=32).encode_sample(torch.randn(1, 3, 64, 64))
     assert z.shape == (1, 4, 8, 8) and bool(torch.isfinite(z).all())
+
+
+class _FakeGraph:
+    def __init__(self, log, name):
+        self.log, self.name = log, name
+
+    def replay(self):
+        self.log.append(("replay", self.name))
+
+
+class _FakeEvent:
+    def record(self):
+        pass
+
+
+def _graph_step(mods, fail_capture=False):
+    """TrainStep(mode='graph') with the GPU-touching pieces replaced: exercises step()'s control flow on the CPU."""
+    opt = mods.options.default_opt()
+    p = torch.nn.Parameter(torch.zeros(4))
+    dummy = types.SimpleNamespace(get_params=lambda lr: [{"params": [p], "lr": lr}], train=lambda: None,
+                                  update_extra_state=lambda: None)
+    st = mods.trainer.TrainStep(opt, dummy, _Guidance(), torch.device("cpu"), seed=0, mode="graph")
+    log = []
+    st.staging_free = _FakeEvent()
+    totals = iter([300_000, 301_000, 650_000, 299_000, 302_000, 100_000])
+    st._count = lambda ro, rd: next(totals)
+    st._body = lambda cap, *k: log.append(("eager", cap)) or torch.tensor(1.0)
+
+    def capture(key):
+        if fail_capture:
+            raise RuntimeError("capture not supported here")
+        st.graphs[key] = (_FakeGraph(log, ("g1", key[0])), _FakeGraph(log, ("g2", key[0])), torch.tensor(2.0), None, [])
+        st.graph_uses[key] = 0
+        st.stats["captures"] += 1
+    st._capture = capture
+    import contextlib
+    st._autocast = contextlib.nullcontext
+    return st, log
+
+
+def test_graph_mode_control_flow(mods, monkeypatch):
+    monkeypatch.setattr(torch, "autocast", lambda *a, **k: __import__("contextlib").nullcontext())
+    st, log = _graph_step(mods)
+    ro = rd = torch.zeros(1, 8, 3)
+    for _ in range(6):
+        st.step(ro, rd, azimuth=10.0)
+    caps = sorted({k[0] for k in st.graphs})
+    assert log[0][0] == "eager" and log[0][1] == st._ladder(300_000)           # the first iteration of a kind runs eagerly...
+    assert st.stats["eager"] == 1 and st.stats["replays"] == 5                  # ...every later one is two graph replays
+    assert [e for e in log if e[0] == "replay"][0] == ("replay", ("g1", st._ladder(301_000)))
+    assert st._ladder(650_000) in caps and st._ladder(100_000) in caps          # misses captured on demand
+    lo, hi = st._ladder(300_000) / st.graph_prime_span, st._ladder(300_000) * st.graph_prime_span
+    assert all(c in caps for c in (st._ladder(int(lo) + 1), st._ladder(int(hi * 0.99))))   # neighbours primed with it
+    assert len(log) == 1 + 2 * 5
+
+
+def test_graph_capture_failure_falls_back_to_eager(mods, monkeypatch):
+    monkeypatch.setattr(torch, "autocast", lambda *a, **k: __import__("contextlib").nullcontext())
+    st, log = _graph_step(mods, fail_capture=True)
+    ro = rd = torch.zeros(1, 8, 3)
+    with pytest.warns(UserWarning, match="capture failed"):
+        st.step(ro, rd, azimuth=10.0)
+    assert st.mode == "device"
+    for _ in range(3):
+        st.step(ro, rd, azimuth=10.0)
+    assert [e[0] for e in log] == ["eager"] * 4 and st.stats["replays"] == 0
+    assert log[1][1] == 301_000                                                  # exact size once eager
