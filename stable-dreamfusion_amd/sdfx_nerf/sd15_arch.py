@@ -181,9 +181,9 @@ class Sd15PriorUNet(nn.Module):
     the cost configs[1] times — but with random weights its output is not a score; damped to 1e-3 it leaves the
     optimisation the stand-in defines (and every optimiser step applied) while all of its kernels run."""
 
-    def __init__(self, damp=1e-3):
+    def __init__(self, damp=1e-3, **unet_kwargs):
         super().__init__()
-        self.unet = UNetSD15()
+        self.unet = UNetSD15(**unet_kwargs)
         self.standin = G.SyntheticUNet()
         self.damp = damp
         self.skip_unet = False   # bench.py's second pass: the same iteration without the 860 M-parameter network
@@ -192,7 +192,10 @@ class Sd15PriorUNet(nn.Module):
         out = self.standin(x, t, encoder_hidden_states)
         if self.skip_unet:
             return out
-        return out + self.damp * torch.nan_to_num(self.unet(x, t, encoder_hidden_states))
+        # channels-last activations: MIOpen's NHWC implicit-GEMM kernels then run without the NCHW<->NHWC transposes
+        # that were 147 launches / 1.25 ms of a forward pass (profiles/README.md)
+        y = self.unet(x.contiguous(memory_format=torch.channels_last), t, encoder_hidden_states)
+        return out + self.damp * torch.nan_to_num(y)
 
 
 def sd15_random_prior(device, fp16=True, seed=1234):
@@ -202,4 +205,5 @@ def sd15_random_prior(device, fp16=True, seed=1234):
         unet, vae = Sd15PriorUNet(), VAEEncoderSD15()
     finally:
         torch.random.set_rng_state(gen_state)
+    unet.unet.to(memory_format=torch.channels_last)
     return G.SDSGuidance(unet, vae, device, fp16)

@@ -201,3 +201,21 @@ def test_graph_capture_failure_falls_back_to_eager(mods, monkeypatch):
         st.step(ro, rd, azimuth=10.0)
     assert [e[0] for e in log] == ["eager"] * 4 and st.stats["replays"] == 0
     assert log[1][1] == 301_000                                                  # exact size once eager
+
+
+@pytest.mark.parametrize("as_latent", [True, False])
+def test_sds_guidance_half_precision_path_is_dtype_consistent(mods, as_latent):
+    """The frozen prior runs in half OUTSIDE autocast (guidance.py): every op must then get matching dtypes by itself.
+    Width-reduced SD-1.5 topology + consistent stand-in, half weights, both the latent and the RGB (VAE-encoder) phase."""
+    from sdfx_nerf import guidance as G, sd15_arch as A
+    torch.manual_seed(0)
+    unet = A.Sd15PriorUNet(base=32)
+    unet.unet.to(memory_format=torch.channels_last)
+    g = G.SDSGuidance(unet, A.VAEEncoderSD15(ch=32), torch.device("cpu"), fp16=True)
+    z = torch.cat([g.get_text_embeds(["uncond"]), g.get_text_embeds(["front"])])
+    x = torch.rand(1, 4 if as_latent else 3, 64, 64, requires_grad=True)
+    loss = g.train_step(z, x, guidance_scale=100, as_latent=as_latent, grad_scale=1)
+    loss.backward()
+    assert torch.isfinite(loss) and bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0
+    unet.skip_unet = True                                 # bench.py's second pass
+    assert torch.isfinite(g.train_step(z, x.detach(), guidance_scale=100, as_latent=as_latent, grad_scale=1))
