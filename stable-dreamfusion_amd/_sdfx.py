@@ -61,6 +61,7 @@ _SIGNATURES = {
                             _ptr],
     "sdfx_entropy_forward": [_ptr, _u32, _ptr, _ptr, _ptr],
     "sdfx_entropy_backward": [_ptr, _u32, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_march_set_impl": [_int],
     "sdfx_adan_ctl_words": [],
     "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],
     "sdfx_adan_prepare": [_ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _u32, _ptr],

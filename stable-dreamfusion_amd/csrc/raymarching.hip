@@ -154,6 +154,71 @@ __global__ __launch_bounds__(64) void k_march_count(const float* __restrict__ ra
     rays[n * 2 + 1] = (int32_t)step;
 }
 
+// Pass 1, one WAVE per ray (experimental, off by default: sdfx_march_set_impl(1) / SDFX_MARCH_WAVE=1; validated lane by
+// lane on the CPU in tests/hostmath — hm_march_count_wave reproduces the serial march bit for bit — but not yet on the
+// GPU). Every ray time the march visits lies on one occupancy-independent lattice (march_advance), so 64 consecutive
+// lattice points are probed at once — each lane: is my cell occupied, and if not, how many lattice points does the
+// serial march skip from here (the literal do-while of raymarching.cu:459-462)? — and the serial decision chain is
+// then replayed over the 64 results with scalar ballots / readlanes. The dependent global loads of the bitfield, which
+// bound the thread-per-ray kernel (one ~1 us load per probe, ~100-300 probes per ray), become 64 loads in flight.
+__global__ __launch_bounds__(256) void k_march_count_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                          const uint8_t* __restrict__ grid, MarchParams p,
+                                                          uint32_t max_steps, uint32_t N, const float* __restrict__ nears,
+                                                          const float* __restrict__ fars, const float* __restrict__ noises,
+                                                          int32_t* __restrict__ rays, float* __restrict__ tbuf) {
+    const uint32_t n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= N) return;  // wave-uniform
+    const uint32_t lane = (uint32_t)lane_id();
+    const MarchRay r = make_march_ray(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3);
+    const float far = fars[n];
+    float base = nears[n];
+    base += clampf_(base * p.dt_gamma, p.dt_min, p.dt_max) * noises[n];  // raymarching.cu:389-391
+    float* trow = tbuf ? tbuf + (size_t)n * max_steps : nullptr;
+    uint32_t step = 0;
+    bool done = false;
+    while (!done) {
+        // lane j takes lattice point j of this chunk (sequential float adds: the lattice is not a closed form)
+        float t = base, tl = base;
+        for (uint32_t j = 0; j < kWave; j++) {
+            if (j == lane) tl = t;
+            t = march_advance(p, t);
+        }
+        const float t_next_chunk = t;
+        const bool live = tl < far;
+        bool occ = false;
+        uint32_t hop = 1;
+        float tafter = tl;
+        if (live) {
+            float tt = tl, dt, cx, cy, cz;
+            uint32_t h = 1;
+            occ = march_probe(r, p, grid, tt, dt, cx, cy, cz, &h);
+            if (occ) {
+                tafter = tl + dt;
+            } else {
+                hop = h;
+                tafter = tt;
+            }
+        }
+        const uint64_t live_mask = __ballot(live), occ_mask = __ballot(occ);
+        // the serial decision chain over the chunk (everything below is wave-uniform)
+        uint32_t q = 0, emitted = 0;
+        uint64_t emit_mask = 0;
+        float carry = t_next_chunk;
+        for (;;) {
+            if (q >= kWave) { base = carry; break; }
+            if (!((live_mask >> q) & 1ull) || step + emitted >= max_steps) { done = true; break; }
+            if ((occ_mask >> q) & 1ull) { emit_mask |= 1ull << q; emitted++; }
+            const uint32_t h = (uint32_t)__shfl((int)hop, (int)q);
+            carry = __shfl(tafter, (int)q);
+            q += h;
+            if (q == kWave) carry = t_next_chunk;
+        }
+        if (trow && ((emit_mask >> lane) & 1ull)) trow[step + (uint32_t)__popcll(emit_mask & ((1ull << lane) - 1ull))] = tl;
+        step += emitted;
+    }
+    if (lane == 0) rays[n * 2 + 1] = (int32_t)step;
+}
+
 // Offsets = exclusive prefix sum of the counts in ray order, starting from counter[0]; the
 // total is added to counter[0] (the reference's atomicAdd bookkeeping, raymarching.cu:470-474,
 // made deterministic). Single workgroup; N is a few thousand rays on the training path.
@@ -537,7 +602,18 @@ __global__ __launch_bounds__(kCompactBlock) void k_compact_scatter(const int32_t
 // =========================================================================================
 // C ABI
 // =========================================================================================
+namespace {
+int g_march_impl = -1;  // -1: follow SDFX_MARCH_WAVE (default 0 = thread per ray), 0 / 1 forced by sdfx_march_set_impl
+bool march_wave_impl() {
+    if (g_march_impl >= 0) return g_march_impl == 1;
+    static const bool env = [] { const char* e = getenv("SDFX_MARCH_WAVE"); return e && atoi(e) == 1; }();
+    return env;
+}
+}  // namespace
+
 extern "C" {
+
+void sdfx_march_set_impl(int impl) { g_march_impl = impl; }
 
 int sdfx_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
                             float* nears, float* fars, sdfx_stream_t stream) {
@@ -603,8 +679,12 @@ int sdfx_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
     const MarchParams p = make_march_params(bound, contract, dt_gamma, max_steps, C, H);
     hipStream_t st = as_stream(stream);
     if (xyzs == nullptr) {  // pass 1
-        hipLaunchKernelGGL(k_march_count, dim3(div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N,
-                           nears, fars, noises, rays, scratch);
+        if (march_wave_impl())
+            hipLaunchKernelGGL(k_march_count_wave, dim3(div_up((uint64_t)N * kWave, 256)), dim3(256), 0, st, rays_o, rays_d, grid,
+                               p, max_steps, N, nears, fars, noises, rays, scratch);
+        else
+            hipLaunchKernelGGL(k_march_count, dim3(div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N,
+                               nears, fars, noises, rays, scratch);
         hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, rays, N, counter);
         return check_launch("march_rays_train(count)");
     }

@@ -125,7 +125,7 @@ SDFX_HD float march_dt(const MarchParams& p, float t) { return clampf_(t * p.dt_
 // `grid` is the packed occupancy bitfield (bit i of byte b = cell 8b+i, raymarching.cu:427).
 template <typename GridPtr>
 SDFX_HD bool march_probe(const MarchRay& r, const MarchParams& p, GridPtr grid, float& t, float& dt, float& cx,
-                         float& cy, float& cz) {
+                         float& cy, float& cz, uint32_t* advanced = nullptr) {
     // position is clamped BEFORE the level is chosen (raymarching.cu:398-405)
     const float x = clampf_(r.ox + t * r.dx, -p.bound, p.bound);
     const float y = clampf_(r.oy + t * r.dy, -p.bound, p.bound);
@@ -161,8 +161,10 @@ SDFX_HD bool march_probe(const MarchRay& r, const MarchParams& p, GridPtr grid, 
     const bool occ = (grid[index / 8] & (1 << (index % 8))) != 0;
     if (occ) return true;
 
+    uint32_t hops = 0;  // how many times t was advanced (the wave-per-ray march needs the lattice index it lands on)
     if (p.contract && mag > 1) {
         t += dt;  // contraction: no voxel skipping (raymarching.cu:449-450)
+        hops = 1;
     } else {
         // distance to the exit face of the current voxel (raymarching.cu:454-463)
         const float tx = (((nx + 0.5f + 0.5f * signf_(r.dx)) * p.rH * 2 - 1) * mip_bound - cx) * r.rdx;
@@ -172,10 +174,17 @@ SDFX_HD bool march_probe(const MarchRay& r, const MarchParams& p, GridPtr grid, 
         do {
             dt = clampf_(t * p.dt_gamma, p.dt_min, p.dt_max);
             t += dt;
+            hops++;
         } while (t < tt);
     }
+    if (advanced) *advanced = hops;
     return false;
 }
+
+// Every ray time the march ever visits lies on ONE sequence that does not depend on the occupancy grid:
+// L[0] = start, L[k+1] = L[k] + clamp(L[k] * dt_gamma, dt_min, dt_max) — the emit path (raymarching.cu:446), the
+// skip loop (:459-462) and the contraction path (:450) all advance t by exactly this expression of the current t.
+SDFX_HD float march_advance(const MarchParams& p, float t) { return t + clampf_(t * p.dt_gamma, p.dt_min, p.dt_max); }
 
 // ---------------------------------------------------------------------------------------
 // Multi-resolution grid (gridencoder.cu:45-79, 133-160).

@@ -35,6 +35,57 @@ void hm_march_count(const float* rays_o, const float* rays_d, const uint8_t* gri
     }
 }
 
+// The wave-per-ray counting pass (k_march_count_wave) emulated lane by lane: 64 consecutive points of the ray's time
+// lattice are probed "in parallel" (each lane: occupied? if not, how many lattice steps does the serial march skip?),
+// then the serial decision chain is replayed over the 64 results. Must reproduce hm_march_count bit for bit.
+void hm_march_count_wave(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, int contract,
+                         float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
+                         const float* fars, const float* noises, int32_t* counts, float* tbuf) {
+    const MarchParams p = make_march_params(bound, contract, dt_gamma, max_steps, C, H);
+    constexpr uint32_t W = 64;
+    for (uint32_t n = 0; n < N; n++) {
+        const MarchRay r = make_march_ray(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3);
+        const float far = fars[n];
+        float base = nears[n];
+        base += clampf_(base * p.dt_gamma, p.dt_min, p.dt_max) * noises[n];
+        uint32_t step = 0;
+        bool done = false;
+        while (!done) {
+            float tl[W], tafter[W];
+            uint32_t hop[W];
+            bool occ[W], live[W];
+            float t = base;
+            for (uint32_t j = 0; j < W; j++) {          // lane j: lattice point j of this chunk
+                tl[j] = t;
+                t = march_advance(p, t);
+            }
+            const float t_next_chunk = t;                // lattice point 64
+            for (uint32_t j = 0; j < W; j++) {          // "parallel" probes
+                live[j] = tl[j] < far;
+                occ[j] = false; hop[j] = 1; tafter[j] = tl[j];
+                if (!live[j]) continue;
+                float tt = tl[j], dt, cx, cy, cz;
+                occ[j] = march_probe(r, p, grid, tt, dt, cx, cy, cz, &hop[j]);
+                if (occ[j]) { hop[j] = 1; tafter[j] = tl[j] + dt; } else tafter[j] = tt;
+            }
+            uint32_t q = 0;                              // the serial decision chain over the chunk
+            float carry = t_next_chunk;
+            for (;;) {
+                if (q >= W) { base = carry; break; }
+                if (!live[q] || step >= max_steps) { done = true; break; }
+                if (occ[q]) {
+                    if (tbuf) tbuf[(size_t)n * max_steps + step] = tl[q];
+                    step++;
+                }
+                carry = tafter[q];                       // lattice value at index q + hop[q]
+                q += hop[q];
+                if (q == W) carry = t_next_chunk;
+            }
+        }
+        counts[n] = (int32_t)step;
+    }
+}
+
 // body of k_march_write_tbuf for one ray
 void hm_march_write(const float* rays_o, const float* rays_d, float bound, int contract, float dt_gamma,
                     uint32_t max_steps, uint32_t C, uint32_t H, uint32_t n, uint32_t count, const float* tbuf,

@@ -543,3 +543,26 @@ def test_fused_field_network_matches_unfused(oracle, dev):
     assert torch.abs(c1 - c0).max().item() < 2e-2
     assert torch.abs(gw1 - gw0).max().item() < 3e-2 * gw0.abs().max().item()
     assert torch.abs(ge1 - ge0).max().item() < 3e-2 * ge0.abs().max().item()
+
+
+@pytest.mark.skipif(os.environ.get("SDFX_TEST_EXPERIMENTAL") != "1",
+                    reason="wave-per-ray counting pass: verified on the CPU (tests/test_hostmath.py), GPU run pending")
+@pytest.mark.parametrize("gridname", ["init", "blobs", "full"])
+def test_wave_per_ray_march_matches_thread_per_ray(oracle, dev, gridname):
+    import raymarching
+    import _sdfx as S
+    bf = {"init": lambda: synth.s_grid_init()[2], "blobs": synth.s_grid_blobs, "full": synth.s_grid_full}[gridname]()
+    o, d = synth.s_rays(1)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
+    noises = synth.s_noises(4096, seed=5)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    outs = []
+    try:
+        for impl in (0, 1):
+            S.lib().sdfx_march_set_impl(impl)
+            outs.append(raymarching.march_rays_train(T(o), T(d), 1.0, T(bf), 1, 128, T(nears), T(fars), True, 0, 1024, False,
+                                                     T(noises)))
+    finally:
+        S.lib().sdfx_march_set_impl(-1)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

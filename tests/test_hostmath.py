@@ -63,6 +63,45 @@ def test_march_cascades_contract_and_dt_gamma(oracle, hostmath):
         assert counts.sum() > 0
 
 
+def _march_wave(hostmath, o, d, bf, nears, fars, noises, bound=1.0, contract=0, dt_gamma=0.0, max_steps=1024, Cc=1, H=128):
+    N = o.shape[0]
+    counts = np.zeros(N, np.int32)
+    tbuf = np.zeros((N, max_steps), np.float32)
+    hostmath.hm_march_count_wave(_p(o), _p(d), _p(bf), f32(bound), i32(contract), f32(dt_gamma), u32(max_steps), u32(N),
+                                 u32(Cc), u32(H), _p(nears), _p(fars), _p(noises), _p(counts), _p(tbuf))
+    return counts, tbuf
+
+
+@pytest.mark.parametrize("case", ["init", "blobs", "full", "cascade2", "cascade2_cone", "cascade2_contract", "few_steps"])
+def test_wave_per_ray_march_reproduces_the_serial_march(oracle, hostmath, case):
+    """The lane-emulated wave-per-ray counting pass (64 lattice points probed at once, serial decision chain replayed
+    over the results; kernel k_march_count_wave) against the thread-per-ray loop: every count and every recorded ray
+    time bit for bit, across cascades, cone stepping, contraction and the max_steps cap."""
+    kw = dict(bound=1.0, contract=0, dt_gamma=0.0, max_steps=1024, Cc=1)
+    if case in ("init", "blobs", "full", "few_steps"):
+        bf = {"init": lambda: synth.s_grid_init()[2], "blobs": synth.s_grid_blobs, "full": synth.s_grid_full,
+              "few_steps": synth.s_grid_full}[case]()
+        aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+        if case == "few_steps":
+            kw["max_steps"] = 96            # rays hit the cap in the middle of a 64-point chunk
+    else:
+        bf = synth.s_grid_blobs(cascade=2, seed=5)
+        aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+        kw.update(bound=2.0, Cc=2, max_steps=512)
+        if case == "cascade2_cone":
+            kw["dt_gamma"] = 1.0 / 128
+        if case == "cascade2_contract":
+            kw["contract"] = 1
+    for view in (0, 3):
+        o, d = synth.s_rays(view)
+        nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+        noises = synth.s_noises(4096, seed=11 + view)
+        c0, t0 = _march_host(hostmath, o, d, bf, nears, fars, noises, **kw)
+        c1, t1 = _march_wave(hostmath, o, d, bf, nears, fars, noises, **kw)
+        assert np.array_equal(c0, c1) and c0.sum() > 0
+        assert np.array_equal(t0, t1)
+
+
 @pytest.mark.parametrize("gridtype,interp,align", [(0, 1, 0), (0, 0, 0), (1, 0, 1)])
 def test_grid_forward_bit_exact_vs_oracle(oracle, hostmath, gridtype, interp, align):
     offsets, pls = oracle.grid_offsets(desired_resolution=2048)
