@@ -321,10 +321,19 @@ def main():
         try:
             from sdfx_nerf.sd15_arch import sd15_random_prior
             prior = sd15_random_prior(dev, opt.fp16)
+            # one call of the SDS glue through the big network before anything depends on it (MIOpen's solver search for
+            # its 36 convolution shapes happens here, a few seconds); any failure falls back to the synthetic prior
+            with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
+                z = torch.cat([prior.get_text_embeds(["uncond"]), prior.get_text_embeds(["front"])])
+                probe = prior.train_step(z, torch.rand(1, 4, 64, 64, device=dev), as_latent=True)
+            if not bool(torch.isfinite(probe)):
+                raise RuntimeError("non-finite SDS loss from the SD-1.5-architecture prior")
+            del z, probe
             guidance_kind = "sd15_random"
         except Exception as exc:  # noqa: BLE001
             if args.guidance == "sd15_random":
                 raise
+            prior = None
             if rank == 0:
                 print(f"[bench] SD-1.5-architecture prior unavailable ({type(exc).__name__}: {exc}); synthetic prior",
                       file=sys.stderr)
