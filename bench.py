@@ -337,6 +337,11 @@ def main():
             if rank == 0:
                 print(f"[bench] SD-1.5-architecture prior unavailable ({type(exc).__name__}: {exc}); synthetic prior",
                       file=sys.stderr)
+    if dist is not None:   # every rank must time the same configuration (and take the same barriers)
+        ok = torch.tensor([0 if prior is None else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            prior = None
     if prior is None:
         prior = G.synthetic_prior(dev, opt.fp16)
         guidance_kind = "synthetic"
