@@ -352,12 +352,7 @@ __device__ __forceinline__ void flush_row(typename Elem<HALF>::type* dst, float 
     }
 }
 
-// finite half (bit pattern) -> value * 2^24 as a signed 64-bit integer (exact)
-__device__ __forceinline__ long long half_to_fixed(uint32_t h) {
-    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
-    const unsigned long long mag = (unsigned long long)(e ? (m | 1024u) : m) << (e ? e - 1u : 0u);
-    return (h & 0x8000u) ? -(long long)mag : (long long)mag;
-}
+// half_to_fixed / fixed_to_float: sdfx_math.h (checked exhaustively on the host, tests/test_hostmath.py)
 
 __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(__half* __restrict__ grad_table, GridPlan plan,
                                                                               BinPlan bin,
@@ -408,7 +403,7 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
             const uint32_t row = first_row + r;
             if (row >= level_rows) continue;
             // |sum| < 2^63 * 2^-24; the double is exact up to 2^53, the float conversion rounds once
-            const float a = (float)((double)ia * 0x1p-24), b = (float)((double)ib * 0x1p-24);
+            const float a = fixed_to_float(ia), b = fixed_to_float(ib);
             flush_row<true>(grad_table + ((size_t)row0 + row) * 2, a, b, j.used == 1);
         }
         return;
@@ -450,7 +445,7 @@ __global__ __launch_bounds__(256) void k_grid_bwd_finish(__half* __restrict__ gr
         if (row >= level_rows) continue;
         const long long ia = (long long)gacc[r * 2], ib = (long long)gacc[r * 2 + 1];
         if (ia == 0 && ib == 0) continue;
-        const float a = (float)((double)ia * 0x1p-24), bb = (float)((double)ib * 0x1p-24);
+        const float a = fixed_to_float(ia), bb = fixed_to_float(ib);
         flush_row<true>(grad_table + ((size_t)row0 + row) * 2, a, bb, true);
     }
 }

@@ -242,4 +242,17 @@ SDFX_HD void grid_locate_axis(float in, uint32_t resolution, bool align_corners,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Exact accumulation of half-precision values (gridencoder_bwd_binned.hip, K2 / K3).
+// Every finite half is an integer multiple of 2^-24 (the smallest subnormal) below 2^16, so value * 2^24 is an
+// integer below 2^40: a 64-bit integer accumulator sums millions of them exactly, in any order.
+// ---------------------------------------------------------------------------------------
+SDFX_HD long long half_to_fixed(uint32_t h) {  // h: IEEE binary16 bit pattern of a FINITE value
+    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    const unsigned long long mag = (unsigned long long)(e ? (m | 1024u) : m) << (e ? e - 1u : 0u);
+    return (h & 0x8000u) ? -(long long)mag : (long long)mag;
+}
+// |sum| < 2^63 * 2^-24; the double is exact up to 2^53 units, the float conversion rounds once
+SDFX_HD float fixed_to_float(long long units) { return (float)((double)units * 0x1p-24); }
+
 }  // namespace sdfx

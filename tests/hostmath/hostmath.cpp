@@ -86,6 +86,10 @@ void hm_march_count_wave(const float* rays_o, const float* rays_d, const uint8_t
     }
 }
 
+// fixed-point helpers of the binned table-gradient scatter
+long long hm_half_to_fixed(uint32_t h) { return half_to_fixed(h); }
+float hm_fixed_to_float(long long units) { return fixed_to_float(units); }
+
 // body of k_march_write_tbuf for one ray
 void hm_march_write(const float* rays_o, const float* rays_d, float bound, int contract, float dt_gamma,
                     uint32_t max_steps, uint32_t C, uint32_t H, uint32_t n, uint32_t count, const float* tbuf,

@@ -118,3 +118,26 @@ def test_grid_forward_bit_exact_vs_oracle(oracle, hostmath, gridtype, interp, al
                                       u32(int(offsets[level + 1] - offsets[level])), u32(res), u32(gridtype), i32(align),
                                       u32(interp), _p(out))
         assert np.array_equal(out, lbc[level]), level
+
+
+def test_half_fixed_point_is_exact_for_every_finite_half(hostmath):
+    """The binned table-gradient scatter sums half values as 64-bit integers in units of 2^-24: the conversion must be
+    exact for all 63 488 finite bit patterns, sums must be exact and order-independent, and the way back rounds once."""
+    import ctypes
+    hostmath.hm_half_to_fixed.restype = ctypes.c_longlong
+    hostmath.hm_half_to_fixed.argtypes = [ctypes.c_uint32]
+    hostmath.hm_fixed_to_float.restype = ctypes.c_float
+    hostmath.hm_fixed_to_float.argtypes = [ctypes.c_longlong]
+    bits = np.arange(65536, dtype=np.uint32)
+    finite = bits[((bits >> 10) & 31) != 31]
+    vals = finite.astype(np.uint16).view(np.float16).astype(np.float64)
+    fixed = np.array([hostmath.hm_half_to_fixed(int(b)) for b in finite], dtype=np.int64)
+    assert np.array_equal(fixed.astype(np.float64) * 2.0 ** -24, vals)             # exact, including subnormals and -0
+    assert int(np.abs(fixed).max()) < 2 ** 40
+    rng = np.random.default_rng(0)
+    pick = rng.integers(0, finite.size, 200000)
+    total = int(fixed[pick].sum())
+    assert total == int(fixed[pick[::-1]].sum()) == int(fixed[rng.permutation(pick)].sum())   # any order
+    exact = float(np.sum(vals[pick]))                                                # float64 sums of these are exact too
+    assert total * 2.0 ** -24 == exact
+    assert hostmath.hm_fixed_to_float(total) == np.float32(exact)                    # one rounding on the way back
