@@ -346,3 +346,100 @@ def field_forward(enc, x, weights, biases, blob_density=5.0, blob_radius=0.2):
     sigma = np.exp(h[..., 0] + density_blob(x, blob_density, blob_radius))
     albedo = 1.0 / (1.0 + np.exp(-h[..., 1:]))
     return sigma.astype(np.float32), albedo.astype(np.float32)
+
+
+# ---- glue between the field and the compositor (numpy float32 restatement; csrc/shade.hip) -----------------------------
+_SHADE_MODES = ("lambertian", "textureless", "normal")
+_F = np.float32
+
+
+def _safe_normalize(x, eps=1e-20):
+    """nerf/utils.py:109-110: x / sqrt(clamp(sum(x * x, -1), min=eps)); returns (y, q, s)."""
+    q = (x * x).sum(-1, dtype=_F)
+    s = np.sqrt(np.maximum(q, _F(eps)), dtype=_F)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (x / s[..., None]).astype(_F), q, s
+
+
+def _ray_ids(rays):
+    return np.repeat(np.arange(rays.shape[0]), rays[:, 1].astype(np.int64))
+
+
+def shade_forward(sigma7, albedo, dirs, rays, rays_o, light_offset, ratio, shading, epsilon=1e-2):
+    """NeRFNetwork.forward for shading != 'albedo' once the seven stencil densities are known
+    (nerf/network_grid.py:81-96 finite_difference_normal, :98-104 normal, :117-130 shading), with the light
+    direction of nerf/renderer.py:727 (safe_normalize(rays_o + offset), gathered per sample :736-737), the
+    view-direction normalisation of :734 and the per-sample factor of loss_orient (:744-746).
+    sigma7 [7, M] = densities at x, x+e_x, x-e_x, x+e_y, x-e_y, x+e_z, x-e_z. Returns color [M,3], normal [M,3], orient [M]."""
+    assert shading in _SHADE_MODES
+    s7 = np.asarray(sigma7, _F)
+    e = _F(epsilon)
+    with np.errstate(invalid="ignore", over="ignore"):
+        raw = -np.stack([_F(0.5) * (s7[1] - s7[2]) / e, _F(0.5) * (s7[3] - s7[4]) / e, _F(0.5) * (s7[5] - s7[6]) / e], -1)
+        y, _, _ = _safe_normalize(raw)
+    n = np.nan_to_num(y, nan=0.0, posinf=np.finfo(_F).max, neginf=np.finfo(_F).min).astype(_F)
+    light = _safe_normalize(np.asarray(rays_o, _F) + np.asarray(light_offset, _F))[0][_ray_ids(rays)]
+    d = _safe_normalize(np.asarray(dirs, _F))[0]
+    ratio = _F(ratio)
+    lambert = ratio + (_F(1) - ratio) * np.maximum((n * light).sum(-1, dtype=_F), _F(0))
+    if shading == "textureless":
+        color = np.repeat(lambert[:, None], 3, 1)
+    elif shading == "normal":
+        color = (n + _F(1)) / _F(2)
+    else:
+        color = np.asarray(albedo, _F) * lambert[:, None]
+    orient = np.maximum((n * d).sum(-1, dtype=_F), _F(0)) ** 2
+    return color.astype(_F), n, orient.astype(_F)
+
+
+def shade_backward(sigma7, albedo, dirs, rays, rays_o, light_offset, ratio, shading, dcolor, dorient, epsilon=1e-2):
+    """Gradient of shade_forward's (color, orient) w.r.t. sigma7 [7, M] (row 0 is zero) and albedo [M, 3], with
+    torch.autograd's conventions for the pieces involved: clamp(min=0) passes the gradient where its input is >= 0,
+    nan_to_num blocks it where it replaced a value, the normaliser's clamp(min=1e-20) passes it where |x|^2 >= 1e-20."""
+    s7 = np.asarray(sigma7, _F)
+    e = _F(epsilon)
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        raw = -np.stack([_F(0.5) * (s7[1] - s7[2]) / e, _F(0.5) * (s7[3] - s7[4]) / e, _F(0.5) * (s7[5] - s7[6]) / e], -1)
+        y, q, s = _safe_normalize(raw)
+        n = np.nan_to_num(y, nan=0.0, posinf=np.finfo(_F).max, neginf=np.finfo(_F).min).astype(_F)
+        light = _safe_normalize(np.asarray(rays_o, _F) + np.asarray(light_offset, _F))[0][_ray_ids(rays)]
+        d = _safe_normalize(np.asarray(dirs, _F))[0]
+        ratio = _F(ratio)
+        ndl, ndd = (n * light).sum(-1, dtype=_F), (n * d).sum(-1, dtype=_F)
+        lambert = ratio + (_F(1) - ratio) * np.maximum(ndl, _F(0))
+        gc = np.asarray(dcolor, _F)
+        dn = np.zeros_like(n)
+        dalbedo = np.zeros_like(n)
+        if shading == "normal":
+            dn += gc / _F(2)
+            dlambert = np.zeros_like(ndl)
+        elif shading == "textureless":
+            dlambert = gc.sum(-1, dtype=_F)
+        else:
+            alb = np.asarray(albedo, _F)
+            dlambert = (gc * alb).sum(-1, dtype=_F)
+            dalbedo = gc * lambert[:, None]
+        dn += np.where(ndl >= 0, dlambert * (_F(1) - ratio), _F(0))[:, None] * light
+        dn += np.where(ndd > 0, np.asarray(dorient, _F) * _F(2) * ndd, _F(0))[:, None] * d
+        dy = np.where(y == n, dn, _F(0))
+        dr = dy / s[:, None]
+        dot = (dy * raw).sum(-1, dtype=_F)
+        dr = dr - np.where(q >= _F(1e-20), dot / (s * s * s), _F(0))[:, None] * raw
+        h = _F(0.5) / e
+        ds7 = np.zeros_like(s7)
+        ds7[1], ds7[2] = -h * dr[:, 0], h * dr[:, 0]
+        ds7[3], ds7[4] = -h * dr[:, 1], h * dr[:, 1]
+        ds7[5], ds7[6] = -h * dr[:, 2], h * dr[:, 2]
+    return ds7.astype(_F), dalbedo.astype(_F)
+
+
+def weights_entropy(weights, total):
+    """Sum over the first `total` weights of the binary entropy (bits) of clamp(w, 1e-5, 1 - 1e-5) and its gradient
+    (Trainer.train_step's lambda_entropy term before the mean, nerf/utils.py:571-575)."""
+    w = np.asarray(weights, _F)
+    a = np.clip(w[:total], _F(1e-5), _F(1) - _F(1e-5))
+    ent = (-a * np.log2(a) - (_F(1) - a) * np.log2(_F(1) - a)).astype(np.float64).sum()
+    g = np.zeros_like(w)
+    inside = (w[:total] >= _F(1e-5)) & (w[:total] <= _F(1) - _F(1e-5))
+    g[:total] = np.where(inside, np.log2(_F(1) - a) - np.log2(a), _F(0))
+    return float(ent), g

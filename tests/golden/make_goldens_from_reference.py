@@ -11,6 +11,10 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
                  + sigmoid on random features -> pins oracle.field_forward and the fused field kernel.
   run_composite_ref.npz  the cumprod compositing of NeRFRenderer.run (nerf/renderer.py:648-672)
                  -> pins composite_rays_train (same maths without the early stop).
+  shade_ref.npz  nerf/network_grid.py NeRFNetwork.forward / normal / finite_difference_normal called UNBOUND on a stub
+                 whose common_forward hands out prescribed densities (so the reference's own shading code runs, forward
+                 and through autograd backward), for 'lambertian', 'textureless' and 'normal' shading, plus the
+                 orientation term of nerf/renderer.py:744-746 -> pins oracle.shade_* and csrc/shade.hip.
   sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
                  text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
 """
@@ -148,6 +152,50 @@ def make_run_composite():
     print("run_composite_ref.npz", N, T)
 
 
+def make_shade():
+    from nerf.network_grid import NeRFNetwork
+    from nerf.utils import safe_normalize
+    g = torch.Generator().manual_seed(21)
+    n_rays, eps = 37, 1e-2
+    counts = torch.randint(0, 40, (n_rays,), generator=g)
+    counts[3] = 0
+    offsets = torch.cumsum(counts, 0) - counts
+    N = int(counts.sum())
+    rays = torch.stack([offsets, counts], dim=1).to(torch.int32)
+    rays_o = torch.randn(n_rays, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 3.2])
+    light_offset = torch.randn(3, generator=g)
+    ray_id = torch.repeat_interleave(torch.arange(n_rays), counts)
+    light = safe_normalize(rays_o + light_offset)[ray_id]                    # renderer.py:727 + :736-737
+    dirs_raw = torch.randn(N, 3, generator=g) * 1.3
+    dirs = safe_normalize(dirs_raw)                                          # renderer.py:734
+    sigma7 = torch.rand(7, N, generator=g) * 3
+    sigma7[1:, 5] = sigma7[1, 5]                                             # flat neighbourhood: zero normal
+    sigma7[1, 9] = float("inf")                                              # nan_to_num branch
+    albedo = torch.rand(N, 3, generator=g)
+    gc, go = torch.randn(N, 3, generator=g), torch.randn(N, generator=g)
+    ratio = 0.3
+    out = dict(rays=rays.numpy(), rays_o=rays_o.numpy(), light_offset=light_offset.numpy(), dirs_raw=dirs_raw.numpy(),
+               sigma7=sigma7.numpy(), albedo=albedo.numpy(), gc=gc.numpy(), go=go.numpy(), ratio=np.float32(ratio),
+               epsilon=np.float32(eps))
+    x = torch.zeros(N, 3)
+    for shading in ("lambertian", "textureless", "normal"):
+        s7 = sigma7.clone().requires_grad_()
+        alb = albedo.clone().requires_grad_()
+        calls = iter(range(7))                                               # centre, then +x -x +y -y +z -z (network_grid.py:82-88)
+        fake = types.SimpleNamespace(bound=1.0, common_forward=lambda p: (s7[next(calls)], alb))
+        fake.finite_difference_normal = lambda p, epsilon=eps: NeRFNetwork.finite_difference_normal(fake, p, epsilon)
+        fake.normal = lambda p: NeRFNetwork.normal(fake, p)
+        sigma, color, normal = NeRFNetwork.forward(fake, x, dirs, light, ratio=ratio, shading=shading)
+        orient = (normal * dirs).sum(-1).clamp(min=0) ** 2                   # renderer.py:745
+        ((color * gc).sum() + (orient * go).sum()).backward()
+        out.update({f"{shading}_color": color.detach().numpy(), f"{shading}_normal": normal.detach().numpy(),
+                    f"{shading}_orient": orient.detach().numpy(), f"{shading}_dsigma7": s7.grad.numpy(),
+                    f"{shading}_dalbedo": (alb.grad if alb.grad is not None else torch.zeros_like(alb)).numpy()})
+        assert torch.equal(sigma, s7[0])
+    np.savez_compressed(os.path.join(OUT, "shade_ref.npz"), **out)
+    print("shade_ref.npz", N)
+
+
 def make_sh():
     src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
     body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
@@ -182,7 +230,11 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "reference checkout not mounted"
     sys.path.insert(0, REF)
     install_stubs()
+    if "--only-shade" in sys.argv:
+        make_shade()
+        sys.exit(0)
     make_sh()
+    make_shade()
     make_freq()
     make_run_composite()
     make_field()

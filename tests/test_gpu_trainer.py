@@ -2,6 +2,7 @@
 replay) against the host-driven formulation of the same arithmetic (torch GradScaler semantics + the foreach Adan,
 which restates optimizer.py:216-261)."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -159,7 +160,6 @@ def test_fused_shade_matches_torch_composition(dev, oracle, shading):
     forward and backward, including a zero-gradient normal (nan_to_num / clamp branches) and padding rows."""
     importlib.import_module("stable-dreamfusion_amd")
     from sdfx_nerf.fused_shade import fused_shade
-    from sdfx_nerf.renderer import safe_normalize
     o, d = synth.s_rays(1, 32, 32)
     nears, fars = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
     xyzs, dirs, ts, rays = oracle.march_rays_train(o, d, 1.0, synth.s_grid_init()[2], 1, 128, nears, fars,
@@ -185,21 +185,10 @@ def test_fused_shade_matches_torch_composition(dev, oracle, shading):
     ds_f, da_f = sigma7.grad.clone(), (albedo.grad.clone() if albedo.grad is not None else torch.zeros_like(albedo))
     sigma7.grad = None; albedo.grad = None
 
-    # the reference's expressions on the valid rows
-    e = 1e-2
-    s = sigma7[:, :M]
-    n = -torch.stack([0.5 * (s[1] - s[2]) / e, 0.5 * (s[3] - s[4]) / e, 0.5 * (s[5] - s[6]) / e], dim=-1)
-    n = torch.nan_to_num(safe_normalize(n))
-    ray_id = torch.repeat_interleave(torch.arange(rays_t.shape[0], device=dev), rays_t[:, 1].long())
-    l = safe_normalize(rays_o + light_off)[ray_id]
-    lambertian = ratio + (1 - ratio) * (n * l).sum(-1).clamp(min=0)
-    if shading == "textureless":
-        c_ref = lambertian.unsqueeze(-1).repeat(1, 3)
-    elif shading == "normal":
-        c_ref = (n + 1) / 2
-    else:
-        c_ref = albedo[:M] * lambertian.unsqueeze(-1)
-    o_ref = (n * safe_normalize(dirs_t[:M])).sum(-1).clamp(min=0) ** 2
+    # the reference's expressions on the valid rows (tests/shade_ref.py: pinned bit for bit, on the CPU, to the output of
+    # the reference's own NeRFNetwork.forward, tests/test_shade_golden.py)
+    import shade_ref
+    c_ref, n, o_ref = shade_ref.torch_shade(sigma7[:, :M], albedo[:M], dirs_t[:M], rays_t, rays_o, light_off, ratio, shading)
     (c_ref * gc[:M]).sum().add((o_ref * go[:M]).sum()).backward()
 
     assert torch.allclose(color[:M], c_ref, rtol=1e-5, atol=1e-6) and torch.allclose(normal[:M], n, rtol=1e-5, atol=1e-6)
@@ -232,3 +221,28 @@ def test_fused_entropy_matches_torch(dev):
     (ref * 0.37).backward()
     assert abs(float(s) - float(ref)) <= 1e-5 * abs(float(ref))
     assert torch.allclose(gf, w.grad, rtol=1e-5, atol=1e-6) and float(gf[M:].abs().sum()) == 0
+
+
+@pytest.mark.skipif(os.environ.get("SDFX_TEST_EXPERIMENTAL") != "1",
+                    reason="direct HIP-vs-reference-golden comparison: enabled after its first GPU run (the same chain is "
+                           "already covered by HIP == torch_shade on the GPU and torch_shade == golden on the CPU)")
+@pytest.mark.parametrize("shading", ["lambertian", "textureless", "normal"])
+def test_fused_shade_matches_reference_golden(dev, shading):
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf.fused_shade import fused_shade
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "shade_ref.npz"))
+    T = lambda k: torch.from_numpy(np.asarray(g[k])).to(dev)
+    s7, alb = T("sigma7").requires_grad_(), T("albedo").requires_grad_()
+    M = s7.shape[1]
+    total = torch.tensor([M], dtype=torch.int32, device=dev)
+    color, normal, orient = fused_shade(s7, alb, T("dirs_raw"), T("rays"), T("rays_o"), T("light_offset"),
+                                        torch.tensor(float(g["ratio"]), device=dev), total, shading, float(g["epsilon"]))
+    ((color * T("gc")).sum() + (orient * T("go")).sum()).backward()
+    N_ = lambda t: t.detach().cpu().numpy()
+    assert np.allclose(N_(color), g[f"{shading}_color"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(N_(normal), g[f"{shading}_normal"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(N_(orient), g[f"{shading}_orient"], rtol=1e-5, atol=1e-6)
+    ref, got = g[f"{shading}_dsigma7"], N_(s7.grad)
+    ok = np.isfinite(ref).all(0) & np.isfinite(got).all(0)
+    assert (~ok).sum() <= 2 and np.abs(got[:, ok] - ref[:, ok]).max() <= 2e-5 * np.abs(ref[:, ok]).max()
