@@ -15,6 +15,9 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
                  whose common_forward hands out prescribed densities (so the reference's own shading code runs, forward
                  and through autograd backward), for 'lambertian', 'textureless' and 'normal' shading, plus the
                  orientation term of nerf/renderer.py:744-746 -> pins oracle.shade_* and csrc/shade.hip.
+  adan_ref.npz   optimizer.py Adan (the optimiser `-O` constructs, main.py:365-368) stepped six times on prescribed
+                 gradients, two parameter groups, global-norm clipping active on some steps -> pins sdfx_nerf.optim.Adan
+                 (and through it csrc/optim.hip's DeviceAdan).
   sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
                  text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
 """
@@ -196,6 +199,27 @@ def make_shade():
     print("shade_ref.npz", N)
 
 
+def make_adan():
+    from optimizer import Adan
+    g = torch.Generator().manual_seed(33)
+    shapes = [(1001,), (8, 5), (3,)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g) * 0.1) for s in shapes]
+    out = {f"p0_{i}": p.detach().numpy().copy() for i, p in enumerate(params)}
+    opt = Adan([{"params": params[:1], "lr": 5e-2}, {"params": params[1:], "lr": 5e-3}], eps=1e-8, weight_decay=2e-5,
+               max_grad_norm=5.0, foreach=False)
+    for k in range(6):
+        mag = 30.0 if k % 2 == 0 else 1e-2                      # even steps: the global-norm clip is active
+        for i, p in enumerate(params):
+            gr = torch.randn(p.shape, generator=g) * mag
+            out[f"g{k}_{i}"] = gr.numpy().copy()
+            p.grad = gr.clone()
+        opt.step()
+        for i, p in enumerate(params):
+            out[f"p{k + 1}_{i}"] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "adan_ref.npz"), **out)
+    print("adan_ref.npz", len(out))
+
+
 def make_sh():
     src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
     body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
@@ -233,8 +257,12 @@ if __name__ == "__main__":
     if "--only-shade" in sys.argv:
         make_shade()
         sys.exit(0)
+    if "--only-adan" in sys.argv:
+        make_adan()
+        sys.exit(0)
     make_sh()
     make_shade()
+    make_adan()
     make_freq()
     make_run_composite()
     make_field()

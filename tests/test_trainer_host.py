@@ -219,3 +219,20 @@ def test_sds_guidance_half_precision_path_is_dtype_consistent(mods, as_latent):
     assert torch.isfinite(loss) and bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0
     unet.skip_unet = True                                 # bench.py's second pass
     assert torch.isfinite(g.train_step(z, x.detach(), guidance_scale=100, as_latent=as_latent, grad_scale=1))
+
+
+def test_foreach_adan_reproduces_the_reference_optimizer(mods):
+    """tests/golden/adan_ref.npz: parameters after each of six steps of the reference's own optimizer.Adan (two groups,
+    weight decay, global-norm clipping on the even steps), generated in the build container."""
+    import os
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "adan_ref.npz"))
+    params = [torch.nn.Parameter(torch.from_numpy(g[f"p0_{i}"].copy())) for i in range(3)]
+    opt = mods.optim.Adan([{"params": params[:1], "lr": 5e-2}, {"params": params[1:], "lr": 5e-3}], eps=1e-8, weight_decay=2e-5,
+                          max_grad_norm=5.0)
+    for k in range(6):
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(g[f"g{k}_{i}"].copy())
+        opt.step()
+        for i, p in enumerate(params):
+            assert np.allclose(p.detach().numpy(), g[f"p{k + 1}_{i}"], rtol=1e-5, atol=1e-7), (k, i)
