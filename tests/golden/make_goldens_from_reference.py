@@ -18,6 +18,10 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
   adan_ref.npz   optimizer.py Adan (the optimiser `-O` constructs, main.py:365-368) stepped six times on prescribed
                  gradients, two parameter groups, global-norm clipping active on some steps -> pins sdfx_nerf.optim.Adan
                  (and through it csrc/optim.hip's DeviceAdan).
+  sds_ref.npz    guidance/sd_utils.py StableDiffusion.train_step called UNBOUND on a stub (diffusers / transformers are
+                 not installed: the frozen networks are this repository's synthetic stand-ins, scheduler.add_noise and
+                 encode_imgs are restated) -> pins the SDS arithmetic of sdfx_nerf/guidance.py: timestep and noise draws,
+                 classifier-free guidance, w(t), nan_to_num, the mse surrogate and its gradient into the rendering.
   sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
                  text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
 """
@@ -220,6 +224,47 @@ def make_adan():
     print("adan_ref.npz", len(out))
 
 
+def make_sds():
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return self
+        def __getattr__(self, k): return _Any()
+    stub("transformers", CLIPTextModel=_Any, CLIPTokenizer=_Any, logging=_Any())
+    stub("diffusers", AutoencoderKL=_Any, UNet2DConditionModel=_Any, PNDMScheduler=_Any, DDIMScheduler=_Any,
+         StableDiffusionPipeline=_Any)
+    stub("diffusers.utils")
+    stub("diffusers.utils.import_utils", is_xformers_available=lambda: False)
+    from guidance.sd_utils import StableDiffusion
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))            # repo root
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf import guidance as G
+    unet, vae = G.SyntheticUNet(), G.SyntheticVAE()
+    alphas = G.ddim_alphas_cumprod()
+
+    def add_noise(latents, noise, t):                                     # DDIMScheduler.add_noise (diffusers, absent)
+        a = alphas[t].to(latents.dtype)
+        return a.sqrt()[:, None, None, None] * latents + (1 - a).sqrt()[:, None, None, None] * noise
+
+    fake = types.SimpleNamespace(
+        device="cpu", min_step=20, max_step=980, alphas=alphas, precision_t=torch.float32,
+        scheduler=types.SimpleNamespace(add_noise=add_noise),
+        unet=lambda x, t, encoder_hidden_states: types.SimpleNamespace(sample=unet(x, t, encoder_hidden_states)),
+        encode_imgs=lambda imgs: vae.encode_sample(2 * imgs - 1) * vae.scaling_factor)  # sd_utils.py:249-256 restated
+    g = torch.Generator().manual_seed(8)
+    emb = torch.randn(2, 77, 768, generator=g)
+    out = dict(text_embeddings=emb.numpy())
+    for name, as_latent, ch in (("latent", True, 4), ("rgb", False, 3)):
+        pred = torch.rand(1, ch, 64, 64, generator=g).requires_grad_()
+        torch.manual_seed(77)
+        loss = StableDiffusion.train_step(fake, emb, pred, guidance_scale=100, as_latent=as_latent, grad_scale=1)
+        loss.backward()
+        out.update({f"{name}_pred": pred.detach().numpy(), f"{name}_loss": np.float64(loss.item()),
+                    f"{name}_grad": pred.grad.numpy()})
+    np.savez_compressed(os.path.join(OUT, "sds_ref.npz"), **out)
+    print("sds_ref.npz", {k: float(v) for k, v in out.items() if k.endswith("loss")})
+
+
 def make_sh():
     src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
     body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
@@ -260,9 +305,13 @@ if __name__ == "__main__":
     if "--only-adan" in sys.argv:
         make_adan()
         sys.exit(0)
+    if "--only-sds" in sys.argv:
+        make_sds()
+        sys.exit(0)
     make_sh()
     make_shade()
     make_adan()
+    make_sds()
     make_freq()
     make_run_composite()
     make_field()

@@ -236,3 +236,21 @@ def test_foreach_adan_reproduces_the_reference_optimizer(mods):
         opt.step()
         for i, p in enumerate(params):
             assert np.allclose(p.detach().numpy(), g[f"p{k + 1}_{i}"], rtol=1e-5, atol=1e-7), (k, i)
+
+
+@pytest.mark.parametrize("phase", ["latent", "rgb"])
+def test_sds_arithmetic_reproduces_the_reference_train_step(mods, phase):
+    """tests/golden/sds_ref.npz: loss and d loss / d pred_rgb of the reference's own StableDiffusion.train_step
+    (guidance/sd_utils.py:86-163) around this repository's synthetic frozen networks, same seed."""
+    import os
+    from conftest import ROOT
+    from sdfx_nerf import guidance as G
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sds_ref.npz"))
+    sds = G.SDSGuidance(G.SyntheticUNet(), G.SyntheticVAE(), torch.device("cpu"), fp16=False)
+    pred = torch.from_numpy(g[f"{phase}_pred"].copy()).requires_grad_()
+    torch.manual_seed(77)
+    loss = sds.train_step(torch.from_numpy(g["text_embeddings"]), pred, guidance_scale=100, as_latent=(phase == "latent"),
+                          grad_scale=1)
+    loss.backward()
+    assert abs(float(loss) - float(g[f"{phase}_loss"])) <= 1e-6 * abs(float(g[f"{phase}_loss"]))
+    assert np.allclose(pred.grad.numpy(), g[f"{phase}_grad"], rtol=1e-5, atol=1e-7)
