@@ -286,8 +286,8 @@ class TrainStep:
         if self.global_step % opt.update_extra_interval == 0:
             with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
                 self.model.update_extra_state()
+        self.global_step += 1                 # before the schedule, as in train_one_epoch (nerf/utils.py:1039-1049)
         kinds = self._schedule(azimuth)
-        self.global_step += 1
         self.sc.copy_(self.sc_host, non_blocking=True)
         if self.mode == "reference":
             return self._step_reference(rays_o, rays_d, kinds)

@@ -22,6 +22,10 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
                  not installed: the frozen networks are this repository's synthetic stand-ins, scheduler.add_noise and
                  encode_imgs are restated) -> pins the SDS arithmetic of sdfx_nerf/guidance.py: timestep and noise draws,
                  classifier-free guidance, w(t), nan_to_num, the mse surrogate and its gradient into the rendering.
+  trainstep_ref.npz  nerf/utils.py Trainer.train_step called UNBOUND on a stub trainer (stub model.render returning prescribed
+                 outputs, stub SD guidance whose loss is a fixed linear functional of pred_rgb and text_z) at several
+                 global steps / azimuths / seeds -> pins TrainStep's schedule (shading, ambient ratio, background kind,
+                 text-embedding interpolation, the order of the random.random() draws) and loss composition.
   sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
                  text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
 """
@@ -265,6 +269,60 @@ def make_sds():
     print("sds_ref.npz", {k: float(v) for k, v in out.items() if k.endswith("loss")})
 
 
+def make_trainstep():
+    import argparse
+    from nerf.utils import Trainer
+    g = torch.Generator().manual_seed(41)
+    H = W = 8
+    N = H * W
+    M = 500
+    outputs = {"image": torch.rand(1, N, 3, generator=g), "depth": torch.rand(1, N, generator=g),
+               "weights_sum": torch.rand(1, N, generator=g), "weights": torch.rand(M, generator=g) * 1.2 - 0.1,
+               "loss_orient": torch.rand((), generator=g)}
+    emb = {k: torch.randn(1, 5, 7, generator=g) for k in ("uncond", "front", "side", "back")}
+    probe_rgb3, probe_rgb4 = torch.randn(1, 3, H, W, generator=g), torch.randn(1, 4, H, W, generator=g)
+    probe_z = torch.randn(2, 5, 7, generator=g)
+    opt = argparse.Namespace(images=None, known_view_interval=4, exp_start_iter=0, exp_end_iter=10000, progressive_view=False,
+                             progressive_level=False, batch_size=1, latent_iter_ratio=0.2, albedo_iter_ratio=0.0,
+                             min_ambient_ratio=0.1, textureless_ratio=0.2, bg_radius=1.4, perpneg=False, guidance_scale=100.0,
+                             lambda_guidance=1.0, dmtet=False, lambda_opacity=0.0, lambda_entropy=1e-3, iters=10000,
+                             lambda_2d_normal_smooth=0.0, lambda_orient=1e-2, lambda_3d_normal_smooth=0.0,
+                             known_view_noise_scale=0.0)
+    cases, rec = [], {}
+    for ci, (gstep, azimuth, seed) in enumerate([(1, 30.0, 0), (1500, -120.0, 1), (2500, 10.0, 2), (2600, -35.0, 3),
+                                                 (4000, 147.0, 4), (5200, 95.0, 5), (9000, -170.0, 6), (9999, 0.0, 7)]):
+        seen = {}
+
+        def render(rays_o, rays_d, mvp, h, w, staged=False, perturb=True, bg_color=None, ambient_ratio=1.0, shading="albedo",
+                   binarize=False, **kw):
+            seen.update(shading=shading, ambient=float(ambient_ratio), bg_none=bg_color is None, perturb=perturb, staged=staged)
+            return outputs
+
+        def sd_train_step(text_z, pred_rgb, as_latent=False, guidance_scale=100, grad_scale=1, save_guidance_path=None):
+            seen.update(as_latent=as_latent, text_z=text_z.clone(), guidance_scale=guidance_scale, grad_scale=grad_scale)
+            probe = probe_rgb4 if as_latent else probe_rgb3
+            return (pred_rgb * probe).sum() + (text_z * probe_z).sum()
+
+        fake = types.SimpleNamespace(opt=opt, global_step=gstep, device="cpu",
+                                     model=types.SimpleNamespace(render=render),
+                                     guidance={"SD": types.SimpleNamespace(train_step=sd_train_step)},
+                                     embeddings={"SD": emb})
+        data = {"rays_o": torch.zeros(1, N, 3), "rays_d": torch.zeros(1, N, 3), "mvp": torch.eye(4)[None], "H": H, "W": W,
+                "azimuth": torch.tensor([azimuth])}
+        random.seed(seed)
+        torch.manual_seed(seed)
+        pred_rgb, pred_depth, loss = Trainer.train_step(fake, data)
+        cases.append((gstep, azimuth, seed))
+        rec.update({f"c{ci}_loss": np.float64(loss.item()), f"c{ci}_shading": np.array(seen["shading"]),
+                    f"c{ci}_ambient": np.float64(seen["ambient"]), f"c{ci}_bg_none": np.array(seen["bg_none"]),
+                    f"c{ci}_as_latent": np.array(seen["as_latent"]), f"c{ci}_text_z": seen["text_z"].numpy()})
+    np.savez_compressed(os.path.join(OUT, "trainstep_ref.npz"), cases=np.array(cases, np.float64),
+                        probe_rgb3=probe_rgb3.numpy(), probe_rgb4=probe_rgb4.numpy(), probe_z=probe_z.numpy(),
+                        **{f"out_{k}": v.numpy() for k, v in outputs.items()}, **{f"emb_{k}": v.numpy() for k, v in emb.items()},
+                        **rec)
+    print("trainstep_ref.npz", [str(rec[f"c{i}_shading"]) for i in range(len(cases))])
+
+
 def make_sh():
     src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
     body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
@@ -308,10 +366,14 @@ if __name__ == "__main__":
     if "--only-sds" in sys.argv:
         make_sds()
         sys.exit(0)
+    if "--only-trainstep" in sys.argv:
+        make_trainstep()
+        sys.exit(0)
     make_sh()
     make_shade()
     make_adan()
     make_sds()
+    make_trainstep()
     make_freq()
     make_run_composite()
     make_field()

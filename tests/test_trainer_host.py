@@ -254,3 +254,52 @@ def test_sds_arithmetic_reproduces_the_reference_train_step(mods, phase):
     loss.backward()
     assert abs(float(loss) - float(g[f"{phase}_loss"])) <= 1e-6 * abs(float(g[f"{phase}_loss"]))
     assert np.allclose(pred.grad.numpy(), g[f"{phase}_grad"], rtol=1e-5, atol=1e-7)
+
+
+def test_train_step_schedule_and_loss_reproduce_the_reference_trainer(mods):
+    """tests/golden/trainstep_ref.npz: the reference's own Trainer.train_step (nerf/utils.py:439-722) run on a stub
+    trainer at eight (global_step, azimuth, seed) points. Same stubs behind TrainStep.train_step: the shading mode,
+    ambient ratio, background kind, latent switch, interpolated text embedding and the total loss must coincide."""
+    import os
+    import random
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "trainstep_ref.npz"))
+    T = lambda k: torch.from_numpy(np.asarray(g[k]))
+    outputs = {k[4:]: T(k) for k in g.files if k.startswith("out_")}
+    outputs.update(num_valid=None, num_samples=int(outputs["weights"].shape[0]), num_total=None)
+    H = W = 8
+    seen = {}
+
+    def render(rays_o, rays_d, mvp, h, w, **kw):
+        seen.update(shading=kw["shading"], ambient=float(kw["ambient_ratio"]), bg_none=kw["bg_color"] is None,
+                    perturb=kw["perturb"], staged=kw["staged"])
+        return outputs
+
+    class Guid:
+        def get_text_embeds(self, prompt):
+            return T("emb_" + prompt[0])
+
+        def train_step(self, text_z, pred_rgb, as_latent=False, guidance_scale=100, grad_scale=1):
+            seen.update(as_latent=as_latent, text_z=text_z.clone(), guidance_scale=guidance_scale, grad_scale=grad_scale)
+            return (pred_rgb * (T("probe_rgb4") if as_latent else T("probe_rgb3"))).sum() + (text_z * T("probe_z")).sum()
+
+    opt = mods.options.default_opt(w=W, h=H)
+    p = torch.nn.Parameter(torch.zeros(3))
+    model = types.SimpleNamespace(render=render, get_params=lambda lr: [{"params": [p], "lr": lr}])
+    for ci, (gstep, azimuth, seed) in enumerate(g["cases"]):
+        st = mods.trainer.TrainStep(opt, model, Guid(), torch.device("cpu"), seed=int(seed), mode="reference")
+        st.rng = random.Random(int(seed))                     # the reference draws from the global `random`, seeded alike
+        st.global_step = int(gstep)
+        st.rays_o = st.rays_d = torch.zeros(1, H * W, 3)
+        kinds = st._schedule(float(azimuth))
+        st.sc.copy_(st.sc_host)
+        loss = st.train_step(None, *kinds)
+        assert kinds[0] == str(g[f"c{ci}_shading"]) == seen["shading"]
+        assert kinds[1] == bool(g[f"c{ci}_as_latent"]) == seen["as_latent"]
+        assert (kinds[2] == "net") == bool(g[f"c{ci}_bg_none"]) == seen["bg_none"]
+        assert abs(seen["ambient"] - float(g[f"c{ci}_ambient"])) < 1e-6
+        assert seen["perturb"] is True and seen["staged"] is False
+        assert np.allclose(seen["text_z"].numpy(), g[f"c{ci}_text_z"], rtol=1e-6, atol=1e-6)
+        assert seen["guidance_scale"] == opt.guidance_scale and seen["grad_scale"] == opt.lambda_guidance
+        ref = float(g[f"c{ci}_loss"])
+        assert abs(float(loss) - ref) <= 1e-5 * abs(ref), (ci, float(loss), ref)
