@@ -26,6 +26,11 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
                  outputs, stub SD guidance whose loss is a fixed linear functional of pred_rgb and text_z) at several
                  global steps / azimuths / seeds -> pins TrainStep's schedule (shading, ambient ratio, background kind,
                  text-embedding interpolation, the order of the random.random() draws) and loss composition.
+  renderer_ref.npz  nerf/renderer.py NeRFRenderer.update_extra_state and run_cuda (training branch) called UNBOUND on a stub
+                 renderer with an analytic field, running the reference's own raymarching/raymarching.py wrappers on top of
+                 the CPU oracle (tests/oracle_backend.py installed as `_raymarching`): occupancy refresh over two cascades,
+                 march, per-sample light, compositing, orientation loss, background mixing, and the gradient of a scalar
+                 functional of the outputs w.r.t. the field parameters -> pins sdfx_nerf/renderer.py.
   sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
                  text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
 """
@@ -323,6 +328,86 @@ def make_trainstep():
     print("trainstep_ref.npz", [str(rec[f"c{i}_shading"]) for i in range(len(cases))])
 
 
+class _StubField:
+    """Analytic field shared by make_renderer() and tests/test_renderer_golden.py (kept in the golden as `theta`)."""
+
+    @staticmethod
+    def sigma(x, theta):
+        return theta[0] * 30.0 * torch.exp(-(x * x).sum(-1) / (2 * 0.5 ** 2))
+
+    @staticmethod
+    def forward(x, d, l, ratio, shading, theta):
+        from nerf.utils import safe_normalize
+        sigma = _StubField.sigma(x, theta)
+        normal = safe_normalize(x)
+        albedo = torch.sigmoid(theta[1:4] + x)
+        if shading == "albedo":
+            return sigma, albedo, None
+        lambertian = ratio + (1 - ratio) * (normal * l).sum(-1).clamp(min=0)
+        return sigma, albedo * lambertian.unsqueeze(-1), normal
+
+
+def make_renderer():
+    import argparse
+    repo = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    import oracle_backend
+    import synth
+    sys.modules["_raymarching"] = oracle_backend.OracleBackend()
+    torch.Tensor.cuda = lambda self, *a, **k: self              # the reference's wrappers move CPU inputs with .cuda()
+    from nerf.renderer import NeRFRenderer
+    G_ = 32
+    theta = torch.tensor([1.0, 0.3, -0.2, 0.5], requires_grad=True)
+    opt = argparse.Namespace(dt_gamma=0.0, max_steps=256, lambda_orient=1e-2, lambda_3d_normal_smooth=0.0,
+                             lambda_2d_normal_smooth=0.0, lambda_normal=0.0, bg_radius=1.4)
+
+    class Stub:
+        pass
+    r = Stub()
+    r.opt, r.bound, r.cascade, r.grid_size, r.cuda_ray, r.taichi_ray = opt, 2.0, 2, G_, True, False
+    r.training, r.density_thresh, r.mean_density, r.iter_density = True, 10.0, 0, 0
+    r.aabb_train = torch.tensor([-2.0, -2, -2, 2, 2, 2]); r.aabb_infer = r.aabb_train.clone()
+    r.density_grid = torch.zeros(2, G_ ** 3)
+    r.density_bitfield = torch.zeros(2 * G_ ** 3 // 8, dtype=torch.uint8)
+    r.density = lambda x: {"sigma": _StubField.sigma(x, theta)}
+    r.background = lambda d: torch.sigmoid(d * theta[1:4])
+    Stub.__call__ = lambda self, x, d, l, ratio=1, shading="albedo": _StubField.forward(x, d, l, ratio, shading, theta)
+
+    torch.manual_seed(9)
+    NeRFRenderer.update_extra_state(r)
+    grid_after = r.density_grid.clone()
+    out = dict(theta=theta.detach().numpy(), grid_size=np.int32(G_), mean_density=np.float64(r.mean_density),
+               density_grid_sub=grid_after[:, ::37].numpy(), density_bitfield=r.density_bitfield.numpy().copy(),
+               density_grid_sum=np.float64(grid_after.double().sum().item()))
+    torch.manual_seed(10)
+    NeRFRenderer.update_extra_state(r)                                       # second refresh: the EMA / max branch
+    out.update(mean_density2=np.float64(r.mean_density), density_bitfield2=r.density_bitfield.numpy().copy(),
+               density_grid_sum2=np.float64(r.density_grid.double().sum().item()))
+
+    o, d = synth.s_rays(0, 16, 16)
+    rays_o, rays_d = torch.from_numpy(o * 1.0)[None], torch.from_numpy(d)[None]
+    gi = torch.randn(256, 3, generator=torch.Generator().manual_seed(3))
+    for shading, ratio, bg in (("lambertian", 0.4, None), ("albedo", 1.0, torch.tensor([0.2, 0.5, 0.9]))):
+        torch.manual_seed(11)
+        res = NeRFRenderer.run_cuda(r, rays_o, rays_d, light_d=None, ambient_ratio=ratio, shading=shading, bg_color=bg,
+                                    perturb=True)
+        loss = (res["image"].reshape(-1, 3) * gi).sum() + res["weights_sum"].sum() + 0.1 * res["depth"].sum()
+        if "loss_orient" in res:
+            loss = loss + 100 * res["loss_orient"]
+        theta.grad = None
+        loss.backward()
+        out.update({f"{shading}_image": res["image"].detach().numpy(), f"{shading}_depth": res["depth"].detach().numpy(),
+                    f"{shading}_weights_sum": res["weights_sum"].detach().numpy(),
+                    f"{shading}_weights": res["weights"].detach().numpy(), f"{shading}_dtheta": theta.grad.numpy().copy(),
+                    f"{shading}_loss": np.float64(loss.item())})
+        if "loss_orient" in res:
+            out[f"{shading}_loss_orient"] = np.float64(res["loss_orient"].item())
+    out.update(rays_o=rays_o.numpy(), rays_d=rays_d.numpy(), gi=gi.numpy())
+    np.savez_compressed(os.path.join(OUT, "renderer_ref.npz"), **out)
+    print("renderer_ref.npz", out["mean_density"], out["lambertian_weights"].shape, float(out["lambertian_loss"]))
+
+
 def make_sh():
     src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
     body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
@@ -369,11 +454,15 @@ if __name__ == "__main__":
     if "--only-trainstep" in sys.argv:
         make_trainstep()
         sys.exit(0)
+    if "--only-renderer" in sys.argv:
+        make_renderer()
+        sys.exit(0)
     make_sh()
     make_shade()
     make_adan()
     make_sds()
     make_trainstep()
+    make_renderer()      # last: it monkey-patches torch.Tensor.cuda
     make_freq()
     make_run_composite()
     make_field()

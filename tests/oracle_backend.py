@@ -1,0 +1,128 @@
+"""TEST INFRASTRUCTURE: the CPU oracle dressed up as the reference's compiled `_raymarching` backend (pybind-level
+signatures, results written in place into CPU tensors), plus the Python-level operator set on top of it.
+
+Two uses, both on the CPU:
+  * tests/golden/make_goldens_from_reference.py installs `OracleBackend()` as `sys.modules['_raymarching']`, so that the
+    REFERENCE's own Python (raymarching/raymarching.py wrappers, NeRFRenderer.run_cuda / update_extra_state) runs end
+    to end in the build container and its outputs become golden files;
+  * tests/test_renderer_golden.py swaps `OracleOps()` in for the HIP operator package inside sdfx_nerf/renderer.py and
+    checks this repository's restatement of that Python against those goldens.
+Nothing here is imported by the shipped package."""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+import oracle as O
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+class OracleBackend:
+    """Signatures of raymarching/src/bindings.cpp (the subset the training path and update_extra_state use)."""
+
+    def __init__(self):
+        self._march = None
+
+    def near_far_from_aabb(self, rays_o, rays_d, aabb, N, min_near, nears, fars):
+        n, f = O.near_far_from_aabb(_np(rays_o), _np(rays_d), _np(aabb), float(min_near))
+        nears.copy_(torch.from_numpy(n)); fars.copy_(torch.from_numpy(f))
+
+    def morton3D(self, coords, N, indices):
+        indices.copy_(torch.from_numpy(O.morton3D(_np(coords))))
+
+    def packbits(self, grid, N, thresh, bitfield):
+        bitfield.copy_(torch.from_numpy(O.packbits(_np(grid).reshape(-1, _np(grid).shape[-1]), float(thresh))))
+
+    def flatten_rays(self, rays, N, M, res):
+        res.copy_(torch.from_numpy(O.flatten_rays(_np(rays), int(M))))
+
+    def march_rays_train(self, rays_o, rays_d, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars, xyzs, dirs, ts,
+                         rays, counter, noises):
+        if xyzs is None:   # counting call of the two-call protocol: run the whole march once and keep the samples
+            self._march = O.march_rays_train(_np(rays_o), _np(rays_d), float(bound), _np(grid), int(C), int(H), _np(nears),
+                                             _np(fars), _np(noises), float(dt_gamma), int(max_steps), bool(contract))
+            rays.copy_(torch.from_numpy(self._march[3]))
+            counter += int(self._march[0].shape[0])
+        else:
+            x, d, t, _ = self._march
+            xyzs.copy_(torch.from_numpy(x)); dirs.copy_(torch.from_numpy(d)); ts.copy_(torch.from_numpy(t))
+
+    def composite_rays_train_forward(self, sigmas, rgbs, ts, rays, M, N, T_thresh, binarize, weights, weights_sum, depth, image):
+        w, ws, dp, im = O.composite_rays_train_forward(_np(sigmas), _np(rgbs), _np(ts), _np(rays), float(T_thresh), bool(binarize))
+        for dst, src in ((weights, w), (weights_sum, ws), (depth, dp), (image, im)):
+            dst.copy_(torch.from_numpy(src))
+
+    def composite_rays_train_backward(self, grad_weights, grad_weights_sum, grad_depth, grad_image, sigmas, rgbs, ts, rays,
+                                      weights_sum, depth, image, M, N, T_thresh, binarize, grad_sigmas, grad_rgbs):
+        gs, gc = O.composite_rays_train_backward(_np(grad_weights), _np(grad_weights_sum), _np(grad_depth), _np(grad_image),
+                                                 _np(sigmas), _np(rgbs), _np(ts), _np(rays), _np(weights_sum), _np(depth),
+                                                 _np(image), float(T_thresh), bool(binarize))
+        grad_sigmas.copy_(torch.from_numpy(gs)); grad_rgbs.copy_(torch.from_numpy(gc))
+
+
+class OracleOps:
+    """The Python-level operators sdfx_nerf/renderer.py calls (`import raymarching`), on CPU tensors."""
+
+    def __init__(self):
+        self.backend = B = OracleBackend()
+
+        class _composite(Function):
+            @staticmethod
+            def forward(ctx, sigmas, rgbs, ts, rays, T_thresh=1e-4, binarize=False):
+                M, N = sigmas.shape[0], rays.shape[0]
+                weights, weights_sum, depth = torch.zeros(M), torch.empty(N), torch.empty(N)
+                image = torch.empty(N, 3)
+                B.composite_rays_train_forward(sigmas, rgbs, ts, rays, M, N, T_thresh, binarize, weights, weights_sum, depth, image)
+                ctx.save_for_backward(sigmas, rgbs, ts, rays, weights_sum, depth, image)
+                ctx.dims = (M, N, T_thresh, binarize)
+                return weights, weights_sum, depth, image
+
+            @staticmethod
+            def backward(ctx, gw, gws, gd, gi):
+                sigmas, rgbs, ts, rays, weights_sum, depth, image = ctx.saved_tensors
+                M, N, T_thresh, binarize = ctx.dims
+                gs, gc = torch.zeros_like(sigmas), torch.zeros_like(rgbs)
+                B.composite_rays_train_backward(gw.contiguous(), gws.contiguous(), gd.contiguous(), gi.contiguous(), sigmas, rgbs,
+                                                ts, rays, weights_sum, depth, image, M, N, T_thresh, binarize, gs, gc)
+                return gs, gc, None, None, None, None
+
+        self.composite_rays_train = _composite.apply
+
+    def near_far_from_aabb(self, rays_o, rays_d, aabb, min_near=0.2):
+        N = rays_o.reshape(-1, 3).shape[0]
+        nears, fars = torch.empty(N), torch.empty(N)
+        self.backend.near_far_from_aabb(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), aabb, N, min_near, nears, fars)
+        return nears, fars
+
+    def march_rays_train(self, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, perturb=False, dt_gamma=0,
+                         max_steps=1024, contract=False):
+        N = rays_o.shape[0]
+        counter = torch.zeros(1, dtype=torch.int32)
+        noises = torch.rand(N) if perturb else torch.zeros(N)          # raymarching/raymarching.py:233-236
+        rays = torch.empty(N, 2, dtype=torch.int32)
+        args = (rays_o, rays_d, density_bitfield, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars)
+        self.backend.march_rays_train(*args, None, None, None, rays, counter, noises)
+        M = int(counter.item())
+        xyzs, dirs, ts = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+        self.backend.march_rays_train(*args, xyzs, dirs, ts, rays, counter, noises)
+        return xyzs, dirs, ts, rays
+
+    def flatten_rays(self, rays, M):
+        res = torch.zeros(M, dtype=torch.int32)
+        self.backend.flatten_rays(rays, rays.shape[0], M, res)
+        return res
+
+    def morton3D(self, coords):
+        out = torch.empty(coords.shape[0], dtype=torch.int32)
+        self.backend.morton3D(coords.int(), coords.shape[0], out)
+        return out
+
+    def packbits(self, grid, thresh, bitfield=None):
+        grid = grid.contiguous()
+        C, H3 = grid.shape
+        if bitfield is None:
+            bitfield = torch.empty(C * H3 // 8, dtype=torch.uint8)
+        self.backend.packbits(grid, C * H3 // 8, thresh, bitfield)
+        return bitfield
