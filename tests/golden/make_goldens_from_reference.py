@@ -31,6 +31,10 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
                  the CPU oracle (tests/oracle_backend.py installed as `_raymarching`): occupancy refresh over two cascades,
                  march, per-sample light, compositing, orientation loss, background mixing, and the gradient of a scalar
                  functional of the outputs w.r.t. the field parameters -> pins sdfx_nerf/renderer.py.
+  gridmodule_ref.npz  gridencoder/grid.py GridEncoder (the -O configuration) with the CPU oracle installed as its `_gridencoder`
+                 backend: level offsets and scale from its constructor, forward (bound mapping, level-major -> [B, 32]
+                 permute, max_level truncation), backward (table gradient, input gradient through dy_dx) and the two
+                 regulariser-gradient methods -> pins this repository's gridencoder/grid.py wrapper.
   sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
                  text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
 """
@@ -408,6 +412,51 @@ def make_renderer():
     print("renderer_ref.npz", out["mean_density"], out["lambertian_weights"].shape, float(out["lambertian_loss"]))
 
 
+def _sparse(t):
+    rows = (t != 0).any(1).nonzero().flatten()
+    return rows.numpy().astype(np.int32), t[rows].numpy()
+
+
+def make_gridmodule():
+    repo = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    import oracle_backend
+    sys.modules["_gridencoder"] = oracle_backend.OracleGridBackend()
+    from gridencoder.grid import GridEncoder
+    torch.manual_seed(17)
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048,
+                      interpolation="smoothstep")
+    enc.embeddings.data.uniform_(-0.1, 0.1)
+    g = torch.Generator().manual_seed(18)
+    x = (torch.rand(300, 3, generator=g) * 2.4 - 1.2)           # some points outside [-bound, bound]
+    gout = torch.randn(300, 32, generator=g)
+    out = dict(offsets=enc.offsets.numpy(), per_level_scale=np.float64(enc.per_level_scale), x=x.numpy(), gout=gout.numpy(),
+               n_rows=np.int64(enc.embeddings.shape[0]), output_dim=np.int32(enc.output_dim))
+    for name, max_level, bound in (("full", None, 1.0), ("half", 0.5, 1.5)):
+        xr = x.clone().requires_grad_()
+        enc.embeddings.grad = None
+        y = enc(xr, bound=bound, max_level=max_level)
+        (y * gout).sum().backward()
+        rows, vals = _sparse(enc.embeddings.grad)
+        out.update({f"{name}_y": y.detach().numpy(), f"{name}_dx": xr.grad.numpy(), f"{name}_grows": rows, f"{name}_gvals": vals})
+    enc.embeddings.grad = torch.zeros_like(enc.embeddings)
+    torch.manual_seed(19)
+    enc.grad_total_variation(weight=1e-3, inputs=None, bound=1, B=500)
+    rows, vals = _sparse(enc.embeddings.grad)
+    out.update(tv_grows=rows, tv_gvals=vals)
+    enc.embeddings.grad = torch.zeros_like(enc.embeddings)
+    enc.grad_total_variation(weight=1e-3, inputs=x[:50], bound=1.5)
+    rows, vals = _sparse(enc.embeddings.grad)
+    out.update(tv2_grows=rows, tv2_gvals=vals)
+    enc.embeddings.grad = torch.zeros_like(enc.embeddings)
+    enc.grad_weight_decay(weight=0.1)
+    wd = enc.embeddings.grad
+    out.update(wd_sub=wd[::4099].numpy(), wd_sum=np.float64(wd.double().sum().item()), wd_abs=np.float64(wd.double().abs().sum().item()))
+    np.savez_compressed(os.path.join(OUT, "gridmodule_ref.npz"), **out)
+    print("gridmodule_ref.npz", out["full_y"].shape, len(out["full_grows"]), len(out["tv_grows"]))
+
+
 def make_sh():
     src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
     body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
@@ -457,11 +506,15 @@ if __name__ == "__main__":
     if "--only-renderer" in sys.argv:
         make_renderer()
         sys.exit(0)
+    if "--only-gridmodule" in sys.argv:
+        make_gridmodule()
+        sys.exit(0)
     make_sh()
     make_shade()
     make_adan()
     make_sds()
     make_trainstep()
+    make_gridmodule()
     make_renderer()      # last: it monkey-patches torch.Tensor.cuda
     make_freq()
     make_run_composite()

@@ -126,3 +126,53 @@ class OracleOps:
             bitfield = torch.empty(C * H3 // 8, dtype=torch.uint8)
         self.backend.packbits(grid, C * H3 // 8, thresh, bitfield)
         return bitfield
+
+
+class OracleGridBackend:
+    """Signatures of gridencoder/src/bindings.cpp (+ this repository's optional trailing layout flag, 0 only)."""
+
+    @staticmethod
+    def _tab(t):
+        a = np.ascontiguousarray(_np(t))
+        return a, int(a.dtype == np.float16)
+
+    def grid_encode_forward(self, inputs, embeddings, offsets, outputs, B, D, C, L, max_level, S, H, dy_dx, gridtype,
+                            align_corners, interp, layout=0):
+        assert layout == 0
+        emb, is_half = self._tab(embeddings)
+        out = np.ascontiguousarray(_np(outputs))          # keeps the zero rows of levels that are not computed
+        dy = None if dy_dx is None else np.ascontiguousarray(_np(dy_dx))
+        x, offs = np.ascontiguousarray(_np(inputs), np.float32), np.ascontiguousarray(_np(offsets), np.int32)
+        O.lib().orc_grid_encode_forward(O._p(x), O._p(emb), O._p(offs), O._p(out), O.u32(B), O.u32(D), O.u32(C), O.u32(L),
+                                        O.u32(max_level), O.f32(S), O.u32(H), O._p(dy), O.u32(gridtype),
+                                        O.i32(int(align_corners)), O.u32(interp), O.i32(is_half))
+        outputs.copy_(torch.from_numpy(out))
+        if dy_dx is not None:
+            dy_dx.copy_(torch.from_numpy(dy))
+
+    def grid_encode_backward(self, grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, max_level, S, H, dy_dx,
+                             grad_inputs, gridtype, align_corners, interp, layout=0):
+        assert layout == 0
+        emb, is_half = self._tab(embeddings)
+        g = np.ascontiguousarray(_np(grad))
+        ge = np.ascontiguousarray(_np(grad_embeddings))
+        gi = None if grad_inputs is None else np.ascontiguousarray(_np(grad_inputs))
+        dy = None if dy_dx is None else np.ascontiguousarray(_np(dy_dx))
+        x, offs = np.ascontiguousarray(_np(inputs), np.float32), np.ascontiguousarray(_np(offsets), np.int32)
+        O.lib().orc_grid_encode_backward(O._p(g), O._p(x), O._p(emb), O._p(offs), O._p(ge), O.u32(B), O.u32(D), O.u32(C),
+                                         O.u32(L), O.u32(max_level), O.f32(S), O.u32(H), O._p(dy), O._p(gi), O.u32(gridtype),
+                                         O.i32(int(align_corners)), O.u32(interp), O.i32(is_half))
+        grad_embeddings.copy_(torch.from_numpy(ge))
+        if grad_inputs is not None:
+            grad_inputs.copy_(torch.from_numpy(gi))
+
+    def grad_total_variation(self, inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
+        g = np.ascontiguousarray(_np(grad), np.float32)
+        O.grad_total_variation(_np(inputs), _np(embeddings), g, _np(offsets), float(weight), float(2.0 ** S), int(H),
+                               int(gridtype), bool(align_corners))
+        grad.copy_(torch.from_numpy(g))
+
+    def grad_weight_decay(self, embeddings, grad, offsets, weight, B, C, L):
+        g = np.ascontiguousarray(_np(grad), np.float32)
+        O.grad_weight_decay(_np(embeddings), g, _np(offsets), float(weight))
+        grad.copy_(torch.from_numpy(g))
