@@ -35,6 +35,11 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
                  backend: level offsets and scale from its constructor, forward (bound mapping, level-major -> [B, 32]
                  permute, max_level truncation), backward (table gradient, input gradient through dy_dx) and the two
                  regulariser-gradient methods -> pins this repository's gridencoder/grid.py wrapper.
+  network_ref.npz  nerf/network_grid.py NeRFNetwork (the whole module: hash-grid encoder, sigma MLP, trunc_exp, density blob,
+                 finite-difference normals, shading, frequency-encoded background MLP) built and evaluated by the reference
+                 code on the CPU over the oracle backends: state_dict keys / shapes / dtypes, parameter-group learning
+                 rates, outputs for the four shading modes, density(), background(), gradients of a scalar functional
+                 w.r.t. every MLP parameter and (sub-sampled) the table -> pins sdfx_nerf/network_grid.py.
   sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
                  text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
 """
@@ -457,6 +462,58 @@ def make_gridmodule():
     print("gridmodule_ref.npz", out["full_y"].shape, len(out["full_grows"]), len(out["tv_grows"]))
 
 
+def make_network():
+    import argparse
+    repo = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    import oracle_backend
+    sys.modules["_gridencoder"] = oracle_backend.OracleGridBackend()
+    sys.modules["_freqencoder"] = oracle_backend.OracleFreqBackend()
+    sys.modules.setdefault("_raymarching", oracle_backend.OracleBackend())
+    torch.Tensor.cuda = lambda self, *a, **k: self              # the reference's wrappers move CPU inputs with .cuda()
+    from nerf.network_grid import NeRFNetwork
+    opt = argparse.Namespace(bound=1.0, dmtet=False, cuda_ray=True, taichi_ray=False, min_near=0.01, density_thresh=10.0,
+                             density_activation="exp", blob_density=5.0, blob_radius=0.2, bg_radius=1.4)
+    torch.manual_seed(23)
+    net = NeRFNetwork(opt)
+    net.encoder.embeddings.data.uniform_(-0.5, 0.5, generator=torch.Generator().manual_seed(24))
+    sd = net.state_dict()
+    out = {"sd_keys": np.array(list(sd.keys())), "sd_shapes": np.array([str(tuple(v.shape)) for v in sd.values()]),
+           "sd_dtypes": np.array([str(v.dtype) for v in sd.values()])}
+    small = {k: v for k, v in sd.items() if v.numel() < 100000 and v.dtype == torch.float32}
+    out.update({"w_" + k: v.numpy().copy() for k, v in small.items()})
+    out["table_checksum"] = np.float64(sd["encoder.embeddings"].double().abs().sum().item())
+    groups = net.get_params(1e-3)
+    out["group_lrs"] = np.array([g["lr"] for g in groups], np.float64)
+    out["group_sizes"] = np.array([sum(p.numel() for p in g["params"]) for g in groups], np.int64)
+    g = torch.Generator().manual_seed(25)
+    x = torch.rand(200, 3, generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(200, 3, generator=g), dim=-1)
+    l = torch.nn.functional.normalize(torch.randn(200, 3, generator=g), dim=-1)
+    gs, gc = torch.randn(200, generator=g), torch.randn(200, 3, generator=g)
+    out.update(x=x.numpy(), d=d.numpy(), l=l.numpy(), gs=gs.numpy(), gc=gc.numpy())
+    names = [n for n, p in net.named_parameters() if p.numel() < 100000]
+    for shading in ("albedo", "lambertian", "textureless", "normal"):
+        net.zero_grad()
+        sigma, color, normal = net(x, d, l, ratio=0.3, shading=shading)
+        ((sigma * gs).sum() + (color * gc).sum()).backward()
+        out.update({f"{shading}_sigma": sigma.detach().numpy(), f"{shading}_color": color.detach().numpy()})
+        if normal is not None:
+            out[f"{shading}_normal"] = normal.detach().numpy()
+        for n, p in net.named_parameters():
+            if n in names and p.grad is not None:
+                out[f"{shading}_g_{n}"] = p.grad.numpy().copy()
+        tg = net.encoder.embeddings.grad
+        out[f"{shading}_tg_sub"] = tg[::1531].numpy().copy()
+        out[f"{shading}_tg_abs"] = np.float64(tg.double().abs().sum().item())
+    with torch.no_grad():
+        out["density_sigma"] = net.density(x)["sigma"].numpy()
+        out["background"] = net.background(d).numpy()
+    np.savez_compressed(os.path.join(OUT, "network_ref.npz"), **out)
+    print("network_ref.npz", list(sd.keys()), out["group_lrs"])
+
+
 def make_sh():
     src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
     body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
@@ -509,12 +566,16 @@ if __name__ == "__main__":
     if "--only-gridmodule" in sys.argv:
         make_gridmodule()
         sys.exit(0)
+    if "--only-network" in sys.argv:
+        make_network()
+        sys.exit(0)
     make_sh()
     make_shade()
     make_adan()
     make_sds()
     make_trainstep()
     make_gridmodule()
+    make_network()
     make_renderer()      # last: it monkey-patches torch.Tensor.cuda
     make_freq()
     make_run_composite()

@@ -176,3 +176,13 @@ class OracleGridBackend:
         g = np.ascontiguousarray(_np(grad), np.float32)
         O.grad_weight_decay(_np(embeddings), g, _np(offsets), float(weight))
         grad.copy_(torch.from_numpy(g))
+
+
+class OracleFreqBackend:
+    """Signatures of freqencoder/src/bindings.cpp."""
+
+    def freq_encode_forward(self, inputs, B, D, degree, output_dim, outputs):
+        outputs.copy_(torch.from_numpy(O.freq_encode_forward(_np(inputs), int(degree))))
+
+    def freq_encode_backward(self, grad, outputs, B, D, degree, output_dim, grad_inputs):
+        grad_inputs.copy_(torch.from_numpy(O.freq_encode_backward(_np(grad), _np(outputs), int(D), int(degree))))
