@@ -412,6 +412,17 @@ def make_renderer():
                     f"{shading}_loss": np.float64(loss.item())})
         if "loss_orient" in res:
             out[f"{shading}_loss_orient"] = np.float64(res["loss_orient"].item())
+    # inference branch (renderer.py:759-794): n_step-at-a-time march / composite over the alive rays, mask compaction
+    r.training = False
+    with torch.no_grad():
+        fixed_light = torch.nn.functional.normalize(torch.tensor([0.3, 0.5, 0.8]), dim=0)   # [3]: what eval_step passes
+        for shading, ratio, bg, light in (("albedo", 1.0, None, None), ("lambertian", 0.25, torch.tensor([1.0, 1.0, 1.0]), fixed_light)):
+            torch.manual_seed(12)
+            res = NeRFRenderer.run_cuda(r, rays_o, rays_d, light_d=light, ambient_ratio=ratio, shading=shading, bg_color=bg,
+                                        perturb=False, T_thresh=1e-4)
+            out.update({f"eval_{shading}_image": res["image"].numpy(), f"eval_{shading}_depth": res["depth"].numpy(),
+                        f"eval_{shading}_weights_sum": res["weights_sum"].numpy()})
+    r.training = True
     out.update(rays_o=rays_o.numpy(), rays_d=rays_d.numpy(), gi=gi.numpy())
     np.savez_compressed(os.path.join(OUT, "renderer_ref.npz"), **out)
     print("renderer_ref.npz", out["mean_density"], out["lambertian_weights"].shape, float(out["lambertian_loss"]))

@@ -49,6 +49,26 @@ class OracleBackend:
             x, d, t, _ = self._march
             xyzs.copy_(torch.from_numpy(x)); dirs.copy_(torch.from_numpy(d)); ts.copy_(torch.from_numpy(t))
 
+    def sph_from_ray(self, rays_o, rays_d, radius, N, coords):
+        coords.copy_(torch.from_numpy(O.sph_from_ray(_np(rays_o), _np(rays_d), float(radius))))
+
+    def morton3D_invert(self, indices, N, coords):
+        coords.copy_(torch.from_numpy(O.morton3D_invert(_np(indices))))
+
+    def march_rays(self, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, contract, dt_gamma, max_steps, C, H, grid,
+                   nears, fars, xyzs, dirs, ts, noises):
+        x, d, t = O.march_rays(int(n_alive), int(n_step), _np(rays_alive), _np(rays_t), _np(rays_o), _np(rays_d), float(bound),
+                               _np(grid), int(C), int(H), _np(nears), _np(fars), _np(noises), float(dt_gamma), int(max_steps),
+                               bool(contract))
+        xyzs.copy_(torch.from_numpy(x)); dirs.copy_(torch.from_numpy(d)); ts.copy_(torch.from_numpy(t))
+
+    def composite_rays(self, n_alive, n_step, T_thresh, binarize, rays_alive, rays_t, sigmas, rgbs, ts, weights_sum, depth, image):
+        bufs = [np.ascontiguousarray(_np(a)) for a in (rays_alive, rays_t, weights_sum, depth, image)]
+        O.composite_rays(int(n_alive), int(n_step), bufs[0], bufs[1], _np(sigmas), _np(rgbs), _np(ts), bufs[2], bufs[3], bufs[4],
+                         float(T_thresh), bool(binarize))
+        for dst, src in zip((rays_alive, rays_t, weights_sum, depth, image), bufs):
+            dst.copy_(torch.from_numpy(src))
+
     def composite_rays_train_forward(self, sigmas, rgbs, ts, rays, M, N, T_thresh, binarize, weights, weights_sum, depth, image):
         w, ws, dp, im = O.composite_rays_train_forward(_np(sigmas), _np(rgbs), _np(ts), _np(rays), float(T_thresh), bool(binarize))
         for dst, src in ((weights, w), (weights_sum, ws), (depth, dp), (image, im)):
@@ -108,6 +128,24 @@ class OracleOps:
         xyzs, dirs, ts = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
         self.backend.march_rays_train(*args, xyzs, dirs, ts, rays, counter, noises)
         return xyzs, dirs, ts, rays
+
+    def march_rays(self, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,
+                   perturb=False, dt_gamma=0, max_steps=1024, contract=False):
+        M = n_alive * n_step
+        xyzs, dirs, ts = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+        noises = torch.rand(n_alive) if perturb else torch.zeros(n_alive)     # raymarching/raymarching.py:358-362
+        self.backend.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, contract, dt_gamma, max_steps, C, H,
+                                density_bitfield, near, far, xyzs, dirs, ts, noises)
+        return xyzs, dirs, ts
+
+    def composite_rays(self, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, ts, weights_sum, depth, image, T_thresh=1e-2,
+                       binarize=False):
+        self.backend.composite_rays(n_alive, n_step, T_thresh, binarize, rays_alive, rays_t, sigmas.float().contiguous(),
+                                    rgbs.float().contiguous(), ts, weights_sum, depth, image)
+        return tuple()
+
+    def compact_rays(self, rays_alive):
+        return rays_alive[rays_alive >= 0]                                    # nerf/renderer.py:791
 
     def flatten_rays(self, rays, M):
         res = torch.zeros(M, dtype=torch.int32)

@@ -89,3 +89,20 @@ def test_run_cuda_reproduces_the_reference(renderer, shading, ratio, bg):
     loss.backward()
     assert abs(float(loss) - float(GOLD[f"{shading}_loss"])) <= 1e-5 * abs(float(GOLD[f"{shading}_loss"]))
     assert np.allclose(theta.grad.numpy(), GOLD[f"{shading}_dtheta"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shading,ratio,bg,fixed_light", [("albedo", 1.0, None, False), ("lambertian", 0.25, (1.0, 1.0, 1.0), True)])
+def test_inference_branch_reproduces_the_reference(renderer, shading, ratio, bg, fixed_light):
+    """renderer.py:759-794: n_step-at-a-time march / composite over the alive rays with compaction in between."""
+    r, _ = renderer
+    torch.manual_seed(9); r.update_extra_state()
+    torch.manual_seed(10); r.update_extra_state()
+    r.eval()
+    rays_o, rays_d = torch.from_numpy(GOLD["rays_o"]), torch.from_numpy(GOLD["rays_d"])
+    light = torch.nn.functional.normalize(torch.tensor([0.3, 0.5, 0.8]), dim=0) if fixed_light else None
+    with torch.no_grad():
+        torch.manual_seed(12)
+        res = r.run_cuda(rays_o, rays_d, light_d=light, ambient_ratio=ratio, shading=shading,
+                         bg_color=None if bg is None else torch.tensor(bg), perturb=False, T_thresh=1e-4)
+    for k in ("image", "depth", "weights_sum"):
+        assert np.allclose(res[k].numpy(), GOLD[f"eval_{shading}_{k}"], rtol=1e-5, atol=1e-6), k
