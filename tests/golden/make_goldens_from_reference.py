@@ -40,6 +40,10 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
                  code on the CPU over the oracle backends: state_dict keys / shapes / dtypes, parameter-group learning
                  rates, outputs for the four shading modes, density(), background(), gradients of a scalar functional
                  w.r.t. every MLP parameter and (sub-sampled) the table -> pins sdfx_nerf/network_grid.py.
+  rmwrap_ref.npz  the ten operators of raymarching/raymarching.py called through the reference's own Python wrappers over
+                 the oracle backend (defaults such as min_near = 0.2, the two-call march protocol and its internal
+                 torch.rand jitter, zero-initialised outputs, in-place inference accumulators, autograd of the
+                 compositor) -> pins this repository's raymarching/raymarching.py wrappers call for call.
   sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
                  text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
 """
@@ -525,6 +529,65 @@ def make_network():
     print("network_ref.npz", list(sd.keys()), out["group_lrs"])
 
 
+def make_rmwrap():
+    repo = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    import oracle_backend
+    import synth
+    sys.modules["_raymarching"] = oracle_backend.OracleBackend()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import raymarching as rm
+    assert rm.__file__.startswith(REF)
+    o, d = synth.s_rays(2, 16, 16)
+    rays_o, rays_d = torch.from_numpy(o), torch.from_numpy(d)
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1])
+    bf = torch.from_numpy(synth.s_grid_blobs())
+    out = dict(rays_o=o, rays_d=d)
+    n0, f0 = rm.near_far_from_aabb(rays_o, rays_d, aabb)
+    n1, f1 = rm.near_far_from_aabb(rays_o, rays_d, aabb, 0.05)
+    out.update(nears=n0.numpy(), fars=f0.numpy(), nears_005=n1.numpy(), fars_005=f1.numpy())
+    out["sph"] = rm.sph_from_ray(rays_o, rays_d, 1.4).numpy()
+    coords = torch.randint(0, 128, (500, 3), generator=torch.Generator().manual_seed(1))
+    m = rm.morton3D(coords)
+    out.update(coords=coords.numpy(), morton=m.numpy(), morton_dtype=np.array(str(m.dtype)),
+               morton_inv=rm.morton3D_invert(m).numpy())
+    grid = torch.rand(1, 128 ** 3, generator=torch.Generator().manual_seed(2)) * 20
+    b1 = rm.packbits(grid, 10.0)
+    reuse = torch.zeros(128 ** 3 // 8, dtype=torch.uint8)
+    b2 = rm.packbits(grid, 5.0, reuse)
+    out.update(pack_seed=np.int64(2), bits_10=b1.numpy(), bits_5=b2.numpy(), pack_reused=np.array(b2.data_ptr() == reuse.data_ptr()))
+    for tag, extra in (("plain", (False,)), ("jitter", (True,)), ("cone", (True, 1 / 128, 512))):   # perturb, dt_gamma, max_steps
+        torch.manual_seed(31)
+        xyzs, dirs, ts, rays = rm.march_rays_train(rays_o, rays_d, 1.0, bf, 1, 128, n0, f0, *extra)
+        out.update({f"march_{tag}_xyzs": xyzs.numpy(), f"march_{tag}_dirs": dirs.numpy(), f"march_{tag}_ts": ts.numpy(),
+                    f"march_{tag}_rays": rays.numpy()})
+    M = xyzs.shape[0]
+    out["flatten"] = rm.flatten_rays(rays, M).numpy()
+    g = torch.Generator().manual_seed(32)
+    sig = (torch.rand(M, generator=g) * 30).requires_grad_()
+    rgb = torch.rand(M, 3, generator=g).requires_grad_()
+    w, ws, dp, im = rm.composite_rays_train(sig, rgb, ts, rays)
+    gw, gws, gd, gi = torch.randn(M, generator=g) * 0.1, torch.randn(256, generator=g), torch.randn(256, generator=g), torch.randn(256, 3, generator=g)
+    ((w * gw).sum() + (ws * gws).sum() + (dp * gd).sum() + (im * gi).sum()).backward()
+    out.update(c_sig=sig.detach().numpy(), c_rgb=rgb.detach().numpy(), c_w=w.detach().numpy(), c_ws=ws.detach().numpy(),
+               c_depth=dp.detach().numpy(), c_image=im.detach().numpy(), c_gw=gw.numpy(), c_gws=gws.numpy(), c_gd=gd.numpy(),
+               c_gi=gi.numpy(), c_dsig=sig.grad.numpy(), c_drgb=rgb.grad.numpy())
+    # one round of the inference pair
+    N = 256
+    alive = torch.arange(N, dtype=torch.int32)
+    rays_t = n0.clone()
+    torch.manual_seed(33)
+    x2, d2, t2 = rm.march_rays(N, 4, alive, rays_t, rays_o, rays_d, 1.0, bf, 1, 128, n0, f0, True, 0, 1024)
+    ws2, dp2, im2 = torch.zeros(N), torch.zeros(N), torch.zeros(N, 3)
+    s2 = torch.full((N * 4,), 12.0)
+    rm.composite_rays(N, 4, alive, rays_t, s2, x2 * 0.5 + 0.5, t2, ws2, dp2, im2, 1e-4)
+    out.update(i_xyzs=x2.numpy(), i_dirs=d2.numpy(), i_ts=t2.numpy(), i_alive=alive.numpy(), i_rays_t=rays_t.numpy(),
+               i_ws=ws2.numpy(), i_depth=dp2.numpy(), i_image=im2.numpy())
+    np.savez_compressed(os.path.join(OUT, "rmwrap_ref.npz"), **out)
+    print("rmwrap_ref.npz", M, int((alive < 0).sum()))
+
+
 def make_sh():
     src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
     body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
@@ -580,6 +643,9 @@ if __name__ == "__main__":
     if "--only-network" in sys.argv:
         make_network()
         sys.exit(0)
+    if "--only-rmwrap" in sys.argv:
+        make_rmwrap()
+        sys.exit(0)
     make_sh()
     make_shade()
     make_adan()
@@ -587,6 +653,7 @@ if __name__ == "__main__":
     make_trainstep()
     make_gridmodule()
     make_network()
+    make_rmwrap()
     make_renderer()      # last: it monkey-patches torch.Tensor.cuda
     make_freq()
     make_run_composite()

@@ -39,7 +39,7 @@ class OracleBackend:
         res.copy_(torch.from_numpy(O.flatten_rays(_np(rays), int(M))))
 
     def march_rays_train(self, rays_o, rays_d, grid, bound, contract, dt_gamma, max_steps, N, C, H, nears, fars, xyzs, dirs, ts,
-                         rays, counter, noises):
+                         rays, counter, noises, scratch=None):   # `scratch`: this repository's optional extension, unused here
         if xyzs is None:   # counting call of the two-call protocol: run the whole march once and keep the samples
             self._march = O.march_rays_train(_np(rays_o), _np(rays_d), float(bound), _np(grid), int(C), int(H), _np(nears),
                                              _np(fars), _np(noises), float(dt_gamma), int(max_steps), bool(contract))
