@@ -44,6 +44,9 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
                  the oracle backend (defaults such as min_near = 0.2, the two-call march protocol and its internal
                  torch.rand jitter, zero-initialised outputs, in-place inference accumulators, autograd of the
                  compositor) -> pins this repository's raymarching/raymarching.py wrappers call for call.
+  encmodule_ref.npz  freqencoder/freq.py FreqEncoder and shencoder/sphere_harmonics.py SHEncoder modules (prefix-shape
+                 handling, output_dim, the `size` scaling of SHEncoder, backward through dy_dx) run by the reference code
+                 over the oracle backends -> pins this repository's two encoder wrappers.
   sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
                  text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
 """
@@ -588,6 +591,37 @@ def make_rmwrap():
     print("rmwrap_ref.npz", M, int((alive < 0).sum()))
 
 
+def make_encmodule():
+    repo = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    import oracle_backend
+    sys.modules["_freqencoder"] = oracle_backend.OracleFreqBackend()
+    sys.modules["_shencoder"] = oracle_backend.OracleSHBackend()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from freqencoder import FreqEncoder
+    from shencoder import SHEncoder
+    g = torch.Generator().manual_seed(51)
+    x = (torch.rand(5, 41, 3, generator=g) * 2 - 1)
+    out = dict(x=x.numpy())
+    fe = FreqEncoder(input_dim=3, degree=6)
+    xr = x.clone().requires_grad_()
+    y = fe(xr)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    out.update(freq_y=y.detach().numpy(), freq_gy=gy.numpy(), freq_dx=xr.grad.numpy(), freq_output_dim=np.int32(fe.output_dim))
+    for degree, size in ((4, 1), (8, 2.0)):
+        se = SHEncoder(input_dim=3, degree=degree)
+        xr = x.clone().requires_grad_()
+        y = se(xr, size=size)
+        gy = torch.randn(y.shape, generator=g)
+        (y * gy).sum().backward()
+        out.update({f"sh{degree}_y": y.detach().numpy(), f"sh{degree}_gy": gy.numpy(), f"sh{degree}_dx": xr.grad.numpy(),
+                    f"sh{degree}_output_dim": np.int32(se.output_dim)})
+    np.savez_compressed(os.path.join(OUT, "encmodule_ref.npz"), **out)
+    print("encmodule_ref.npz", out["freq_y"].shape, out["sh8_y"].shape)
+
+
 def make_sh():
     src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
     body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
@@ -646,6 +680,9 @@ if __name__ == "__main__":
     if "--only-rmwrap" in sys.argv:
         make_rmwrap()
         sys.exit(0)
+    if "--only-encmodule" in sys.argv:
+        make_encmodule()
+        sys.exit(0)
     make_sh()
     make_shade()
     make_adan()
@@ -654,6 +691,7 @@ if __name__ == "__main__":
     make_gridmodule()
     make_network()
     make_rmwrap()
+    make_encmodule()
     make_renderer()      # last: it monkey-patches torch.Tensor.cuda
     make_freq()
     make_run_composite()

@@ -224,3 +224,16 @@ class OracleFreqBackend:
 
     def freq_encode_backward(self, grad, outputs, B, D, degree, output_dim, grad_inputs):
         grad_inputs.copy_(torch.from_numpy(O.freq_encode_backward(_np(grad), _np(outputs), int(D), int(degree))))
+
+
+class OracleSHBackend:
+    """Signatures of shencoder/src/bindings.cpp."""
+
+    def sh_encode_forward(self, inputs, outputs, B, D, degree, dy_dx):
+        out, dy = O.sh_encode_forward(_np(inputs), int(degree), dy_dx is not None)
+        outputs.copy_(torch.from_numpy(out))
+        if dy_dx is not None:
+            dy_dx.copy_(torch.from_numpy(dy))
+
+    def sh_encode_backward(self, grad, inputs, B, D, degree, dy_dx, grad_inputs):
+        grad_inputs.copy_(torch.from_numpy(O.sh_encode_backward(_np(grad), _np(inputs), int(degree), _np(dy_dx))))
