@@ -1,57 +1,57 @@
-"""`freqencoder` — sin/cos positional encoding (surface of the reference's freqencoder/freq.py)."""
+"""`freqencoder` — sin/cos positional encoding.
+
+    y = [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), cos(2^1 x), ..., sin(2^(n-1) x), cos(2^(n-1) x)]      (n = degree)
+
+Same public surface as the reference's freqencoder/freq.py (`FreqEncoder(input_dim, degree)`, `.output_dim`,
+`forward(inputs, **kwargs)`, `freq_encode(inputs, degree, output_dim)`), computed by libsdfx_hip.so; checked against
+the reference module in tests/test_encmodule_golden.py.
+"""
 from __future__ import annotations
 
 import torch
-import torch.nn as nn
-from torch.autograd import Function
+from torch import nn
 from torch.amp import custom_bwd, custom_fwd
 
 import _freqencoder as _backend
+from _encoder_common import as_rows, on_gpu, restore
 
 
-class _freq_encoder(Function):
+class _FreqOp(torch.autograd.Function):
+    """rows x input_dim -> rows x width; the backward needs the outputs (d sin = cos, d cos = -sin) rather than the inputs."""
+
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # always float32, as the reference (freq.py:16)
-    def forward(ctx, inputs, degree, output_dim):
-        """inputs [B, D] -> [B, D + 2*D*degree] = [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]."""
-        if not inputs.is_cuda:
-            inputs = inputs.cuda()
-        inputs = inputs.contiguous()
-        B, input_dim = inputs.shape
-        outputs = torch.empty(B, output_dim, dtype=inputs.dtype, device=inputs.device)
-        _backend.freq_encode_forward(inputs, B, input_dim, degree, output_dim, outputs)
-        ctx.save_for_backward(inputs, outputs)
-        ctx.dims = [B, input_dim, degree, output_dim]
-        return outputs
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # float32 whatever autocast says (freq.py:16)
+    def forward(ctx, x, octaves, width):
+        x = on_gpu(x).contiguous()
+        rows, dim = x.shape
+        y = x.new_empty(rows, width)
+        _backend.freq_encode_forward(x, rows, dim, octaves, width, y)
+        ctx.shape_info = (rows, dim, octaves, width)
+        ctx.save_for_backward(x, y)
+        return y
 
     @staticmethod
     @custom_bwd(device_type="cuda")
-    def backward(ctx, grad):
-        grad = grad.contiguous()
-        inputs, outputs = ctx.saved_tensors
-        B, input_dim, degree, output_dim = ctx.dims
-        grad_inputs = torch.zeros_like(inputs)
-        _backend.freq_encode_backward(grad, outputs, B, input_dim, degree, output_dim, grad_inputs)
-        return grad_inputs, None, None
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        rows, dim, octaves, width = ctx.shape_info
+        dx = torch.zeros_like(x)
+        _backend.freq_encode_backward(dy.contiguous(), y, rows, dim, octaves, width, dx)
+        return dx, None, None
 
 
-freq_encode = _freq_encoder.apply
+freq_encode = _FreqOp.apply
 
 
 class FreqEncoder(nn.Module):
-    """freqencoder/freq.py:55-76"""
-
     def __init__(self, input_dim=3, degree=4):
         super().__init__()
-        self.input_dim = input_dim
-        self.degree = degree
-        self.output_dim = input_dim + input_dim * 2 * degree
+        self.input_dim, self.degree = input_dim, degree
+        self.output_dim = input_dim * (1 + 2 * degree)
+
+    def forward(self, inputs, **kwargs):
+        flat, lead = as_rows(inputs, self.input_dim)
+        return restore(freq_encode(flat, self.degree, self.output_dim), lead, self.output_dim)
 
     def __repr__(self):
         return f"FreqEncoder: input_dim={self.input_dim} degree={self.degree} output_dim={self.output_dim}"
-
-    def forward(self, inputs, **kwargs):
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.reshape(-1, self.input_dim)
-        outputs = freq_encode(inputs, self.degree, self.output_dim)
-        return outputs.reshape(prefix_shape + [self.output_dim])

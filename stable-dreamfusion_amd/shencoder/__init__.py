@@ -1,1 +1,4 @@
-from .sphere_harmonics import SHEncoder  # noqa: F401
+"""Real spherical-harmonics direction encoding on MI355X (libsdfx_hip.so): `from shencoder import SHEncoder`."""
+from .sphere_harmonics import SHEncoder, sh_encode
+
+__all__ = ["SHEncoder", "sh_encode"]

@@ -1,63 +1,66 @@
-"""`shencoder` — real spherical-harmonics basis, degree <= 8 (surface of the reference's
-shencoder/sphere_harmonics.py)."""
+"""`shencoder` — real spherical harmonics Y_l^m(d) for l < degree <= 8 (degree^2 outputs per direction).
+
+Same public surface as the reference's shencoder/sphere_harmonics.py (`SHEncoder(input_dim=3, degree)`,
+`forward(inputs, size=1)`, `sh_encode(inputs, degree, calc_grad_inputs)`), computed by libsdfx_hip.so; checked against the
+reference module in tests/test_encmodule_golden.py.
+"""
 from __future__ import annotations
 
 import torch
-import torch.nn as nn
-from torch.autograd import Function
+from torch import nn
 from torch.amp import custom_bwd, custom_fwd
 
 import _shencoder as _backend
+from _encoder_common import as_rows, restore
+
+MAX_DEGREE = 8
 
 
-class _sh_encoder(Function):
+class _SHOp(torch.autograd.Function):
+    """The Jacobian d Y / d d is produced by the forward kernel when the input needs a gradient and contracted with the
+    incoming gradient in the backward kernel."""
+
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, inputs, degree, calc_grad_inputs=False):
-        """inputs [B, 3] in [-1, 1] -> [B, degree^2] (sphere_harmonics.py:14-38)."""
-        inputs = inputs.contiguous()
-        B, input_dim = inputs.shape
-        output_dim = degree ** 2
-        outputs = torch.empty(B, output_dim, dtype=inputs.dtype, device=inputs.device)
-        dy_dx = torch.empty(B, input_dim * output_dim, dtype=inputs.dtype, device=inputs.device) if calc_grad_inputs else None
-        _backend.sh_encode_forward(inputs, outputs, B, input_dim, degree, dy_dx)
-        ctx.save_for_backward(inputs, dy_dx)
-        ctx.dims = [B, input_dim, degree]
-        return outputs
+    def forward(ctx, dirs, degree, want_jacobian=False):
+        dirs = dirs.contiguous()
+        rows, dim = dirs.shape
+        n_basis = degree * degree
+        basis = dirs.new_empty(rows, n_basis)
+        jac = dirs.new_empty(rows, dim * n_basis) if want_jacobian else None
+        _backend.sh_encode_forward(dirs, basis, rows, dim, degree, jac)
+        ctx.shape_info = (rows, dim, degree)
+        ctx.save_for_backward(dirs, jac)
+        return basis
 
     @staticmethod
     @custom_bwd(device_type="cuda")
-    def backward(ctx, grad):
-        inputs, dy_dx = ctx.saved_tensors
-        if dy_dx is None:
+    def backward(ctx, dbasis):
+        dirs, jac = ctx.saved_tensors
+        if jac is None:                       # forward was told the input needs no gradient
             return None, None, None
-        grad = grad.contiguous()
-        B, input_dim, degree = ctx.dims
-        grad_inputs = torch.zeros_like(inputs)
-        _backend.sh_encode_backward(grad, inputs, B, input_dim, degree, dy_dx, grad_inputs)
-        return grad_inputs, None, None
+        rows, dim, degree = ctx.shape_info
+        ddirs = torch.zeros_like(dirs)
+        _backend.sh_encode_backward(dbasis.contiguous(), dirs, rows, dim, degree, jac, ddirs)
+        return ddirs, None, None
 
 
-sh_encode = _sh_encoder.apply
+sh_encode = _SHOp.apply
 
 
 class SHEncoder(nn.Module):
-    """shencoder/sphere_harmonics.py:61-86"""
-
     def __init__(self, input_dim=3, degree=4):
         super().__init__()
-        self.input_dim = input_dim
-        self.degree = degree
-        self.output_dim = degree ** 2
-        assert self.input_dim == 3, "SH encoder only support input dim == 3"
-        assert self.degree > 0 and self.degree <= 8, "SH encoder only supports degree in [1, 8]"
+        if input_dim != 3:
+            raise AssertionError("SH encoder only support input dim == 3")
+        if not 0 < degree <= MAX_DEGREE:
+            raise AssertionError(f"SH encoder only supports degree in [1, {MAX_DEGREE}]")
+        self.input_dim, self.degree, self.output_dim = input_dim, degree, degree * degree
+
+    def forward(self, inputs, size=1):
+        """`inputs` are directions scaled by `size` (they are divided by it to land in [-1, 1])."""
+        flat, lead = as_rows(inputs / size, self.input_dim)
+        return restore(sh_encode(flat, self.degree, flat.requires_grad), lead, self.output_dim)
 
     def __repr__(self):
         return f"SHEncoder: input_dim={self.input_dim} degree={self.degree}"
-
-    def forward(self, inputs, size=1):
-        inputs = inputs / size  # [-1, 1]
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.reshape(-1, self.input_dim)
-        outputs = sh_encode(inputs, self.degree, inputs.requires_grad)
-        return outputs.reshape(prefix_shape + [self.output_dim])
