@@ -100,6 +100,16 @@ class _grid_encode(Function):
 grid_encode = _grid_encode.apply
 
 
+def level_row_offsets(input_dim, num_levels, per_level_scale, base_resolution, max_rows):
+    """First row of every level in the concatenated table (+ the total as last entry), int32.
+    Level i has ceil(base * scale^i)^D vertices, capped at `max_rows` (beyond that it is hashed), and is padded to a
+    multiple of 8 rows (gridencoder/grid.py:126-134; float64 host arithmetic as there)."""
+    res = np.ceil(base_resolution * np.power(float(per_level_scale), np.arange(num_levels))).astype(np.int64)
+    rows = np.array([min(int(max_rows), int(r) ** input_dim) for r in res], dtype=np.int64)
+    rows = (np.ceil(rows / 8) * 8).astype(np.int64)
+    return np.concatenate([[0], np.cumsum(rows)]).astype(np.int32)
+
+
 class GridEncoder(nn.Module):
     """gridencoder/grid.py:103-206. Parameter `embeddings` [rows, level_dim] and buffer `offsets`
     [num_levels+1] int32 keep the reference's names, shapes and dtypes so its checkpoints load."""
@@ -108,63 +118,43 @@ class GridEncoder(nn.Module):
                  log2_hashmap_size=19, desired_resolution=None, gridtype="hash", align_corners=False,
                  interpolation="linear"):
         super().__init__()
-
-        # the finest resolution desired at the last level overrides per_level_scale
-        if desired_resolution is not None:
+        if desired_resolution is not None:   # the finest resolution wanted at the last level fixes the growth factor
             per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
-
-        self.input_dim = input_dim
-        self.num_levels = num_levels
-        self.level_dim = level_dim
-        self.per_level_scale = per_level_scale
-        self.log2_hashmap_size = log2_hashmap_size
-        self.base_resolution = base_resolution
-        self.output_dim = num_levels * level_dim
-        self.gridtype = gridtype
-        self.gridtype_id = _gridtype_to_id[gridtype]
-        self.interpolation = interpolation
-        self.interp_id = _interp_to_id[interpolation]
-        self.align_corners = align_corners
-
-        # table layout: each level holds min(2^log2_hashmap_size, resolution^D) rows, padded to a multiple of 8
-        offsets = []
-        offset = 0
         self.max_params = 2 ** log2_hashmap_size
-        for i in range(num_levels):
-            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
-            params_in_level = min(self.max_params, resolution ** input_dim)
-            params_in_level = int(np.ceil(params_in_level / 8) * 8)
-            offsets.append(offset)
-            offset += params_in_level
-        offsets.append(offset)
-        offsets = torch.from_numpy(np.array(offsets, dtype=np.int32))
-        self.register_buffer("offsets", offsets)
+        starts = level_row_offsets(input_dim, num_levels, per_level_scale, base_resolution, self.max_params)
+        self.register_buffer("offsets", torch.from_numpy(starts))
+        total_rows = int(starts[-1])
 
-        self.n_params = offsets[-1] * level_dim
-
-        self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
+        # attribute names are the reference's (other code reads them: encoding.py, network_grid.py, checkpoints)
+        for name, value in dict(input_dim=input_dim, num_levels=num_levels, level_dim=level_dim, per_level_scale=per_level_scale,
+                                log2_hashmap_size=log2_hashmap_size, base_resolution=base_resolution,
+                                output_dim=num_levels * level_dim, gridtype=gridtype, gridtype_id=_gridtype_to_id[gridtype],
+                                interpolation=interpolation, interp_id=_interp_to_id[interpolation],
+                                align_corners=align_corners).items():
+            setattr(self, name, value)
+        self.n_params = self.offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(total_rows, level_dim))
         self.reset_parameters()
 
     def reset_parameters(self):
-        std = 1e-4
-        self.embeddings.data.uniform_(-std, std)
-
-    def __repr__(self):
-        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
-                f"resolution={self.base_resolution} -> "
-                f"{int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
-                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} "
-                f"gridtype={self.gridtype} align_corners={self.align_corners} interpolation={self.interpolation}")
+        self.embeddings.data.uniform_(-1e-4, 1e-4)     # grid.py:145-147
 
     def forward(self, inputs, bound=1, max_level=None):
         """inputs [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim];
         max_level in (0, 1]: fraction of the levels to evaluate (the rest stay zero)."""
-        inputs = (inputs + bound) / (2 * bound)  # map to [0, 1]
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.view(-1, self.input_dim)
-        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
-                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level)
-        return outputs.view(prefix_shape + [self.output_dim])
+        unit = (inputs + bound) / (2 * bound)           # the kernels work on the unit cube
+        lead = list(unit.shape[:-1])
+        flat = unit.view(-1, self.input_dim)
+        feats = grid_encode(flat, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                            flat.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, max_level)
+        return feats.view(lead + [self.output_dim])
+
+    def __repr__(self):
+        finest = int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> {finest} per_level_scale={self.per_level_scale:.4f} "
+                f"params={tuple(self.embeddings.shape)} gridtype={self.gridtype} align_corners={self.align_corners} "
+                f"interpolation={self.interpolation}")
 
     @torch.amp.autocast("cuda", enabled=False)
     def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
