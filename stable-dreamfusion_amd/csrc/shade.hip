@@ -17,8 +17,10 @@
 
 #include "sdfx.h"
 #include "sdfx_common.h"
+#include "shade_math.h"
 
 using namespace sdfx;
+using namespace sdfx::shade;
 
 namespace {
 
@@ -26,56 +28,7 @@ constexpr uint32_t kThreads = 256;
 constexpr uint32_t kPadBlocks = 64;
 
 inline uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
-constexpr float kNormEps = 1e-20f;  // safe_normalize's clamp (nerf/utils.py:109-110)
-constexpr float kFltMax = 3.402823466e38f;
-
-enum { kLambertian = 1, kTextureless = 2, kNormal = 3 };
-
-struct Vec3 {
-    float x, y, z;
-};
-
-__device__ __forceinline__ float nan_to_num_(float v) {  // torch.nan_to_num defaults
-    if (v != v) return 0.f;
-    if (v > kFltMax) return kFltMax;
-    if (v < -kFltMax) return -kFltMax;
-    return v;
-}
-
-// light direction of ray n: safe_normalize(rays_o[n] + offset)
-__device__ __forceinline__ Vec3 ray_light(const float* __restrict__ rays_o, const float* __restrict__ off, uint32_t n) {
-    const float x = rays_o[n * 3 + 0] + off[0], y = rays_o[n * 3 + 1] + off[1], z = rays_o[n * 3 + 2] + off[2];
-    const float s = sqrtf(fmaxf(x * x + y * y + z * z, kNormEps));
-    return {x / s, y / s, z / s};
-}
-
-struct Sample {
-    Vec3 raw;      // un-normalised normal
-    float q, s;    // |raw|^2 and sqrt(max(q, eps))
-    Vec3 y;        // raw / s before nan_to_num
-    Vec3 n;        // the normal
-    Vec3 d;        // normalised view direction
-    float ndl, ndd;
-};
-
-__device__ __forceinline__ Sample load_sample(const float* __restrict__ sigma7, const float* __restrict__ dirs, uint32_t cap,
-                                              uint32_t i, float e, const Vec3& l) {
-    Sample p;
-    const float* s = sigma7 + i;
-    p.raw.x = -(0.5f * (s[1 * (size_t)cap] - s[2 * (size_t)cap]) / e);
-    p.raw.y = -(0.5f * (s[3 * (size_t)cap] - s[4 * (size_t)cap]) / e);
-    p.raw.z = -(0.5f * (s[5 * (size_t)cap] - s[6 * (size_t)cap]) / e);
-    p.q = p.raw.x * p.raw.x + p.raw.y * p.raw.y + p.raw.z * p.raw.z;
-    p.s = sqrtf(fmaxf(p.q, kNormEps));
-    p.y = {p.raw.x / p.s, p.raw.y / p.s, p.raw.z / p.s};
-    p.n = {nan_to_num_(p.y.x), nan_to_num_(p.y.y), nan_to_num_(p.y.z)};
-    const float dx = dirs[(size_t)i * 3 + 0], dy = dirs[(size_t)i * 3 + 1], dz = dirs[(size_t)i * 3 + 2];
-    const float ds = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, kNormEps));
-    p.d = {dx / ds, dy / ds, dz / ds};
-    p.ndl = p.n.x * l.x + p.n.y * l.y + p.n.z * l.z;
-    p.ndd = p.n.x * p.d.x + p.n.y * p.d.y + p.n.z * p.d.z;
-    return p;
-}
+// (per-sample arithmetic: shade_math.h, shared with the host test harness)
 
 __global__ __launch_bounds__(kThreads) void k_shade_forward(const float* __restrict__ sigma7, const float* __restrict__ albedo,
                                                             const float* __restrict__ dirs, const int32_t* __restrict__ rays,
@@ -103,20 +56,11 @@ __global__ __launch_bounds__(kThreads) void k_shade_forward(const float* __restr
         const uint32_t i = offset + k;
         if (i >= cap) break;
         const Sample p = load_sample(sigma7, dirs, cap, i, e, l);
-        const float lambert = ratio + (1.f - ratio) * fmaxf(p.ndl, 0.f);
-        float cx, cy, cz;
-        if (mode == kNormal) {
-            cx = (p.n.x + 1.f) / 2.f; cy = (p.n.y + 1.f) / 2.f; cz = (p.n.z + 1.f) / 2.f;
-        } else if (mode == kTextureless) {
-            cx = cy = cz = lambert;
-        } else {
-            cx = albedo[(size_t)i * 3 + 0] * lambert; cy = albedo[(size_t)i * 3 + 1] * lambert;
-            cz = albedo[(size_t)i * 3 + 2] * lambert;
-        }
-        color[(size_t)i * 3 + 0] = cx; color[(size_t)i * 3 + 1] = cy; color[(size_t)i * 3 + 2] = cz;
+        float c[3], o;
+        sample_forward(p, ratio, mode, mode == kLambertian ? albedo + (size_t)i * 3 : nullptr, c, o);
+        color[(size_t)i * 3 + 0] = c[0]; color[(size_t)i * 3 + 1] = c[1]; color[(size_t)i * 3 + 2] = c[2];
         normal[(size_t)i * 3 + 0] = p.n.x; normal[(size_t)i * 3 + 1] = p.n.y; normal[(size_t)i * 3 + 2] = p.n.z;
-        const float o = fmaxf(p.ndd, 0.f);
-        orient[i] = o * o;
+        orient[i] = o;
     }
 }
 
@@ -148,48 +92,14 @@ __global__ __launch_bounds__(kThreads) void k_shade_backward(const float* __rest
         const uint32_t i = offset + k;
         if (i >= cap) break;
         const Sample p = load_sample(sigma7, dirs, cap, i, e, l);
-        const float gx = dcolor[(size_t)i * 3 + 0], gy = dcolor[(size_t)i * 3 + 1], gz = dcolor[(size_t)i * 3 + 2];
-        // gradient with respect to the (normalised, nan_to_num'ed) normal
-        Vec3 dn = {0.f, 0.f, 0.f};
-        if (dnormal) dn = {dnormal[(size_t)i * 3 + 0], dnormal[(size_t)i * 3 + 1], dnormal[(size_t)i * 3 + 2]};
-        const float lambert = ratio + (1.f - ratio) * fmaxf(p.ndl, 0.f);
-        float dlambert = 0.f;
-        if (mode == kNormal) {
-            dn.x += gx / 2.f; dn.y += gy / 2.f; dn.z += gz / 2.f;
-        } else if (mode == kTextureless) {
-            dlambert = gx + gy + gz;
-        } else {
-            const float ax = albedo[(size_t)i * 3 + 0], ay = albedo[(size_t)i * 3 + 1], az = albedo[(size_t)i * 3 + 2];
-            dlambert = gx * ax + gy * ay + gz * az;
-            dalbedo[(size_t)i * 3 + 0] = gx * lambert; dalbedo[(size_t)i * 3 + 1] = gy * lambert;
-            dalbedo[(size_t)i * 3 + 2] = gz * lambert;
-        }
-        if (mode != kLambertian && dalbedo) {
-            dalbedo[(size_t)i * 3 + 0] = 0.f; dalbedo[(size_t)i * 3 + 1] = 0.f; dalbedo[(size_t)i * 3 + 2] = 0.f;
-        }
-        if (p.ndl >= 0.f) {  // torch's clamp(min=0) backward passes the gradient where input >= bound (equality included)
-            const float c = dlambert * (1.f - ratio);
-            dn.x += c * l.x; dn.y += c * l.y; dn.z += c * l.z;
-        }
-        if (p.ndd > 0.f) {  // orient = clamp(n.d, 0)^2
-            const float c = dorient[i] * 2.f * p.ndd;
-            dn.x += c * p.d.x; dn.y += c * p.d.y; dn.z += c * p.d.z;
-        }
-        // nan_to_num: no gradient through replaced entries
-        Vec3 dy = {(p.y.x == p.n.x) ? dn.x : 0.f, (p.y.y == p.n.y) ? dn.y : 0.f, (p.y.z == p.n.z) ? dn.z : 0.f};
-        // y = raw / s, s = sqrt(clamp(q, eps)): draw = dy / s - raw (dy . raw) / s^3 [q >= eps]
-        Vec3 dr = {dy.x / p.s, dy.y / p.s, dy.z / p.s};
-        if (p.q >= kNormEps) {
-            const float dot = dy.x * p.raw.x + dy.y * p.raw.y + dy.z * p.raw.z;
-            const float c = dot / (p.s * p.s * p.s);
-            dr.x -= p.raw.x * c; dr.y -= p.raw.y * c; dr.z -= p.raw.z * c;
-        }
-        // raw_k = -(0.5 (s_pos - s_neg) / e)
-        const float h = 0.5f / e;
-        dsigma7[i] = 0.f;
-        dsigma7[(size_t)1 * cap + i] = -h * dr.x; dsigma7[(size_t)2 * cap + i] = h * dr.x;
-        dsigma7[(size_t)3 * cap + i] = -h * dr.y; dsigma7[(size_t)4 * cap + i] = h * dr.y;
-        dsigma7[(size_t)5 * cap + i] = -h * dr.z; dsigma7[(size_t)6 * cap + i] = h * dr.z;
+        const float g[3] = {dcolor[(size_t)i * 3 + 0], dcolor[(size_t)i * 3 + 1], dcolor[(size_t)i * 3 + 2]};
+        float dsig[6], dalb[3];
+        sample_backward(p, l, ratio, mode, mode == kLambertian ? albedo + (size_t)i * 3 : nullptr, g,
+                        dnormal ? dnormal + (size_t)i * 3 : nullptr, dorient[i], e, dsig, dalb);
+        dsigma7[i] = 0.f;  // the centre density only feeds the compositor
+#pragma unroll
+        for (uint32_t r = 0; r < 6; r++) dsigma7[(size_t)(r + 1) * cap + i] = dsig[r];
+        if (dalbedo) { dalbedo[(size_t)i * 3 + 0] = dalb[0]; dalbedo[(size_t)i * 3 + 1] = dalb[1]; dalbedo[(size_t)i * 3 + 2] = dalb[2]; }
     }
 }
 

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "../../stable-dreamfusion_amd/csrc/sdfx_math.h"
+#include "../../stable-dreamfusion_amd/csrc/shade_math.h"
 
 using namespace sdfx;
 
@@ -83,6 +84,40 @@ void hm_march_count_wave(const float* rays_o, const float* rays_d, const uint8_t
             }
         }
         counts[n] = (int32_t)step;
+    }
+}
+
+// bodies of k_shade_forward / k_shade_backward over all rays (same per-sample source as the kernels: shade_math.h)
+void hm_shade_forward(const float* sigma7, const float* albedo, const float* dirs, const int32_t* rays, const float* rays_o,
+                      const float* light_off, float ratio, int mode, float e, uint32_t cap, uint32_t n_rays, float* color,
+                      float* normal, float* orient) {
+    using namespace sdfx::shade;
+    for (uint32_t n = 0; n < n_rays; n++) {
+        const Vec3 l = ray_light(rays_o, light_off, n);
+        for (uint32_t k = 0; k < (uint32_t)rays[n * 2 + 1]; k++) {
+            const uint32_t i = (uint32_t)rays[n * 2] + k;
+            const Sample p = load_sample(sigma7, dirs, cap, i, e, l);
+            sample_forward(p, ratio, mode, mode == kLambertian ? albedo + (size_t)i * 3 : nullptr, color + (size_t)i * 3, orient[i]);
+            normal[(size_t)i * 3 + 0] = p.n.x; normal[(size_t)i * 3 + 1] = p.n.y; normal[(size_t)i * 3 + 2] = p.n.z;
+        }
+    }
+}
+
+void hm_shade_backward(const float* sigma7, const float* albedo, const float* dirs, const int32_t* rays, const float* rays_o,
+                       const float* light_off, float ratio, int mode, float e, uint32_t cap, uint32_t n_rays,
+                       const float* dcolor, const float* dorient, float* dsigma7, float* dalbedo) {
+    using namespace sdfx::shade;
+    for (uint32_t n = 0; n < n_rays; n++) {
+        const Vec3 l = ray_light(rays_o, light_off, n);
+        for (uint32_t k = 0; k < (uint32_t)rays[n * 2 + 1]; k++) {
+            const uint32_t i = (uint32_t)rays[n * 2] + k;
+            const Sample p = load_sample(sigma7, dirs, cap, i, e, l);
+            float dsig[6];
+            sample_backward(p, l, ratio, mode, mode == kLambertian ? albedo + (size_t)i * 3 : nullptr, dcolor + (size_t)i * 3,
+                            nullptr, dorient[i], e, dsig, dalbedo + (size_t)i * 3);
+            dsigma7[i] = 0.f;
+            for (uint32_t r = 0; r < 6; r++) dsigma7[(size_t)(r + 1) * cap + i] = dsig[r];
+        }
     }
 }
 

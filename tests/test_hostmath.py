@@ -141,3 +141,33 @@ def test_half_fixed_point_is_exact_for_every_finite_half(hostmath):
     exact = float(np.sum(vals[pick]))                                                # float64 sums of these are exact too
     assert total * 2.0 ** -24 == exact
     assert hostmath.hm_fixed_to_float(total) == np.float32(exact)                    # one rounding on the way back
+
+
+@pytest.mark.parametrize("shading,mode", [("lambertian", 1), ("textureless", 2), ("normal", 3)])
+def test_shade_kernel_source_matches_reference_forward_and_autograd(hostmath, shading, mode):
+    """csrc/shade_math.h — the per-sample source the HIP kernels k_shade_forward / k_shade_backward are built from —
+    compiled for the host and compared with tests/golden/shade_ref.npz (the reference's own NeRFNetwork.forward and its
+    autograd gradient)."""
+    import os
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "shade_ref.npz"))
+    s7, alb, dirs = (np.ascontiguousarray(g[k], np.float32) for k in ("sigma7", "albedo", "dirs_raw"))
+    rays, rays_o, off = np.ascontiguousarray(g["rays"], np.int32), np.ascontiguousarray(g["rays_o"], np.float32), g["light_offset"]
+    M = s7.shape[1]
+    color, normal, orient = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros(M, np.float32)
+    hostmath.hm_shade_forward(_p(s7), _p(alb), _p(dirs), _p(rays), _p(rays_o), _p(np.ascontiguousarray(off, np.float32)),
+                              f32(float(g["ratio"])), i32(mode), f32(float(g["epsilon"])), u32(M), u32(rays.shape[0]),
+                              _p(color), _p(normal), _p(orient))
+    assert np.allclose(color, g[f"{shading}_color"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(normal, g[f"{shading}_normal"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(orient, g[f"{shading}_orient"], rtol=1e-5, atol=1e-6)
+    ds7, dalb = np.zeros_like(s7), np.zeros_like(alb)
+    gc, go = np.ascontiguousarray(g["gc"], np.float32), np.ascontiguousarray(g["go"], np.float32)
+    hostmath.hm_shade_backward(_p(s7), _p(alb), _p(dirs), _p(rays), _p(rays_o), _p(np.ascontiguousarray(off, np.float32)),
+                               f32(float(g["ratio"])), i32(mode), f32(float(g["epsilon"])), u32(M), u32(rays.shape[0]),
+                               _p(gc), _p(go), _p(ds7), _p(dalb))
+    ref = g[f"{shading}_dsigma7"]
+    ok = np.isfinite(ref).all(0) & np.isfinite(ds7).all(0)
+    assert (~ok).sum() <= 2
+    assert np.abs(ds7[:, ok] - ref[:, ok]).max() <= 2e-5 * np.abs(ref[:, ok]).max()
+    assert np.allclose(dalb, g[f"{shading}_dalbedo"], rtol=1e-5, atol=1e-6)
