@@ -8,6 +8,7 @@
 
 #include "../../stable-dreamfusion_amd/csrc/sdfx_math.h"
 #include "../../stable-dreamfusion_amd/csrc/shade_math.h"
+#include "../../stable-dreamfusion_amd/csrc/optim_math.h"
 
 using namespace sdfx;
 
@@ -118,6 +119,30 @@ void hm_shade_backward(const float* sigma7, const float* albedo, const float* di
             dsigma7[i] = 0.f;
             for (uint32_t r = 0; r < 6; r++) dsigma7[(size_t)(r + 1) * cap + i] = dsig[r];
         }
+    }
+}
+
+// One iteration of the device-resident optimiser tail over `tensors` parameter tensors, as csrc/optim.hip runs it:
+// k_grad_stats (sum of squares in double + non-finite flag), k_adan_prepare, k_adan_update (same source: optim_math.h).
+void hm_adan_iteration(uint32_t tensors, float** params, const float** grads, float** m, float** v, float** nn, float** prev,
+                       const uint64_t* counts, const float* lrs, const float* wds, float* ctl, float b1, float b2, float b3,
+                       float max_grad_norm, float eps, float growth, float backoff, float growth_interval, int no_prox) {
+    using namespace sdfx::optim;
+    double sumsq = 0.0, bad = 0.0;
+    for (uint32_t t = 0; t < tensors; t++)
+        for (uint64_t i = 0; i < counts[t]; i++) {
+            const float g = grads[t][i];
+            if (!(fabsf(g) <= 3.402823466e38f)) bad = 1.0;
+            sumsq += (double)g * (double)g;
+        }
+    adan_prepare(ctl, sumsq, bad, b1, b2, b3, max_grad_norm, eps, growth, backoff, growth_interval);
+    if (ctl[5] != 0.f) return;
+    const float unscale = ctl[3] * ctl[4];
+    const bool first = ctl[2] == 1.0f;
+    for (uint32_t t = 0; t < tensors; t++) {
+        const AdanHyper h{lrs[t], wds[t], eps, b1, b2, b3, no_prox};
+        for (uint64_t i = 0; i < counts[t]; i++)
+            adan_one(params[t][i], grads[t][i], m[t][i], v[t][i], nn[t][i], prev[t][i], unscale, first, ctl[6], ctl[7], ctl[8], h);
     }
 }
 

@@ -171,3 +171,50 @@ def test_shade_kernel_source_matches_reference_forward_and_autograd(hostmath, sh
     assert (~ok).sum() <= 2
     assert np.abs(ds7[:, ok] - ref[:, ok]).max() <= 2e-5 * np.abs(ref[:, ok]).max()
     assert np.allclose(dalb, g[f"{shading}_dalbedo"], rtol=1e-5, atol=1e-6)
+
+
+def test_optimizer_kernel_source_matches_reference_adan_and_gradscaler(hostmath):
+    """csrc/optim_math.h — what k_adan_prepare / k_adan_update are built from — compiled for the host: six steps against
+    tests/golden/adan_ref.npz (the reference's own optimizer.Adan) with the gradients scaled by a loss scale as the AMP
+    backward leaves them, an overflowed iteration in between (skipped, scale halved, no step counted) and the growth of
+    the scale after `growth_interval` clean iterations."""
+    import ctypes
+    import os
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "adan_ref.npz"))
+    T = 3
+    params = [np.ascontiguousarray(g[f"p0_{i}"], np.float32).copy() for i in range(T)]
+    state = [[np.zeros_like(p) for p in params] for _ in range(4)]     # m, v, n, prev
+    counts = (ctypes.c_uint64 * T)(*[p.size for p in params])
+    lrs = (ctypes.c_float * T)(5e-2, 5e-3, 5e-3)
+    wds = (ctypes.c_float * T)(2e-5, 2e-5, 2e-5)
+    ctl = np.zeros(16, np.float32)
+    ctl[0] = 1024.0
+    PP = ctypes.POINTER(ctypes.c_float)
+    arr = lambda xs: (PP * T)(*[x.ctypes.data_as(PP) for x in xs])
+
+    def iterate(grads):
+        gs = [np.ascontiguousarray(x, np.float32) for x in grads]
+        hostmath.hm_adan_iteration(u32(T), arr(params), arr(gs), arr(state[0]), arr(state[1]), arr(state[2]), arr(state[3]),
+                                   counts, lrs, wds, _p(ctl), f32(0.98), f32(0.92), f32(0.99), f32(5.0), f32(1e-8), f32(2.0),
+                                   f32(0.5), f32(4.0), i32(0))
+
+    scale, tracker = 1024.0, 0
+    for k in range(6):
+        if k == 3:                                            # an overflowed iteration between the reference's steps 3 and 4
+            bad = [g[f"g{k}_{i}"] * np.float32(scale) for i in range(T)]
+            bad[1] = bad[1].copy(); bad[1].flat[7] = np.inf
+            before = [p.copy() for p in params]
+            iterate(bad)
+            assert ctl[5] == 1 and ctl[0] == scale / 2 and ctl[10] == 1 and ctl[2] == k
+            assert all(np.array_equal(a, b) for a, b in zip(before, params))
+            scale, tracker = scale / 2, 0
+        iterate([g[f"g{k}_{i}"] * np.float32(scale) for i in range(T)])
+        assert ctl[5] == 0 and ctl[2] == k + 1
+        tracker += 1
+        if tracker == 4:
+            scale, tracker = scale * 2, 0
+        assert ctl[0] == scale and ctl[1] == tracker
+        for i in range(T):
+            ref = g[f"p{k + 1}_{i}"]
+            assert np.abs(params[i] - ref).max() <= 3e-5 * np.abs(ref).max() + 1e-7, (k, i)
