@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
     ap.add_argument("--no-nerf-only", action="store_true", help="skip the second timed pass without the SD-1.5 UNet")
+    ap.add_argument("--phase", default="latent", choices=["latent", "rgb"],
+                    help="latent: iterations 0.. of a run (the first 20 %%: 64x64 latents straight from the renderer, 'normal' "
+                         "shading); rgb: start after the latent phase (RGB render -> 512^2 -> VAE encoder with gradient, "
+                         "lambertian / textureless shading, random backgrounds). Default latent; rgb is not yet measured.")
     ap.add_argument("--cpu-rays", type=int, default=256, help="rays in the CPU-oracle baseline sample")
     return ap.parse_args()
 
@@ -346,6 +350,9 @@ def main():
         prior = G.synthetic_prior(dev, opt.fp16)
         guidance_kind = "synthetic"
     step = TrainStep(opt, model, prior, dev, seed=seed)
+    if args.phase == "rgb":
+        step.global_step = int(opt.iters * opt.latent_iter_ratio) + 1   # first iteration after the latent warm-up phase
+        step.graph_prime_span = 1.15   # four (shading, background) kinds instead of one: prime fewer neighbours per miss
     # skip the as_latent warm-start phase of the schedule? No: global_step advances as in training, and the
     # first 20 % of a 10k-iteration run uses 'normal' shading + as_latent (nerf/utils.py:503-507).
     if args.grid == "trained-proxy":
@@ -499,7 +506,8 @@ def main():
                    "guidance": guidance_kind + (" (SD-1.5 UNet + VAE-encoder architecture, 860 M + 34 M parameters, random weights, evaluated in full; its damped output is added to the consistent stand-in; diffusers/hub weights absent)"
                                                 if guidance_kind == "sd15_random" else
                                                 " (consistent-denoiser stand-in for the frozen prior; diffusers/hub weights absent)"),
-                   "rays_per_iter": 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid},
+                   "rays_per_iter": 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid,
+                   "phase": args.phase},
         "rays_per_s": world * args.steps * 4096 / elapsed,
         "samples_per_iter": samples / max(args.steps, 1),
         "iters_per_sec_without_unet": nerf_only,
