@@ -59,7 +59,10 @@ struct AdanHyper {
 SDFX_HD void adan_one(float& p, float gs, float& m, float& v, float& nn, float& prev, float unscale, bool first, float bc1,
                       float bc2, float bc3, const AdanHyper& h) {
     const float g = gs * unscale;                       // unscale and clip (optimizer.py:154 grad.mul_(clip))
-    const float diff = first ? 0.f : g - prev;          // optimizer.py:145-148: pre_grad := grad on the first step
+    // optimizer.py:145-148: the first time a parameter has a gradient, pre_grad := grad (difference 0). `prev` is
+    // allocated as NaN, so this also holds for a tensor that joins later (e.g. the background MLP, unused while the
+    // schedule draws random background colours); overflowed iterations never get here, so NaN is a safe "unset" mark
+    const float diff = (first || prev != prev) ? 0.f : g - prev;
     m = m * h.b1 + (1.f - h.b1) * g;                    // exp_avg
     v = v * h.b2 + (1.f - h.b2) * diff;                 // exp_avg_diff
     const float u = g + h.b2 * diff;

@@ -112,7 +112,8 @@ class DeviceAdan:
         for g in self.param_groups:
             for p in g["params"]:
                 assert p.dtype == torch.float32 and p.is_contiguous(), "DeviceAdan: float32 contiguous parameters"
-                self.state[p] = tuple(torch.zeros_like(p) for _ in range(4))  # exp_avg, exp_avg_diff, exp_avg_sq, pre_grad
+                # exp_avg, exp_avg_diff, exp_avg_sq, pre_grad (NaN = "no previous gradient yet", see csrc/optim_math.h)
+                self.state[p] = (torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p), torch.full_like(p, float("nan")))
 
     def parameters(self):
         return [p for g in self.param_groups for p in g["params"]]

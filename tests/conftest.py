@@ -43,8 +43,8 @@ def hostmath():
     d = os.path.join(TESTS, "hostmath")
     so = os.path.join(d, "libhostmath.so")
     src = os.path.join(d, "hostmath.cpp")
-    hdr = os.path.join(ROOT, "stable-dreamfusion_amd", "csrc", "sdfx_math.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(ROOT, "stable-dreamfusion_amd", "csrc", h) for h in ("sdfx_math.h", "shade_math.h", "optim_math.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", so, src])
     return ctypes.CDLL(so)
 

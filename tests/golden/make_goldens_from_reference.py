@@ -231,7 +231,7 @@ def make_shade():
 def make_adan():
     from optimizer import Adan
     g = torch.Generator().manual_seed(33)
-    shapes = [(1001,), (8, 5), (3,)]
+    shapes = [(1001,), (8, 5), (3,), (17,)]
     params = [torch.nn.Parameter(torch.randn(s, generator=g) * 0.1) for s in shapes]
     out = {f"p0_{i}": p.detach().numpy().copy() for i, p in enumerate(params)}
     opt = Adan([{"params": params[:1], "lr": 5e-2}, {"params": params[1:], "lr": 5e-3}], eps=1e-8, weight_decay=2e-5,
@@ -241,7 +241,9 @@ def make_adan():
         for i, p in enumerate(params):
             gr = torch.randn(p.shape, generator=g) * mag
             out[f"g{k}_{i}"] = gr.numpy().copy()
-            p.grad = gr.clone()
+            # the last tensor joins late: no gradient during the first two steps (as the background MLP while the
+            # schedule draws random background colours) -> its pre_grad is initialised at its own first step
+            p.grad = None if (i == 3 and k < 2) else gr.clone()
         opt.step()
         for i, p in enumerate(params):
             out[f"p{k + 1}_{i}"] = p.detach().numpy().copy()

@@ -182,22 +182,23 @@ def test_optimizer_kernel_source_matches_reference_adan_and_gradscaler(hostmath)
     import os
     from conftest import ROOT
     g = np.load(os.path.join(ROOT, "tests", "golden", "adan_ref.npz"))
-    T = 3
+    T = 4
     params = [np.ascontiguousarray(g[f"p0_{i}"], np.float32).copy() for i in range(T)]
-    state = [[np.zeros_like(p) for p in params] for _ in range(4)]     # m, v, n, prev
-    counts = (ctypes.c_uint64 * T)(*[p.size for p in params])
-    lrs = (ctypes.c_float * T)(5e-2, 5e-3, 5e-3)
-    wds = (ctypes.c_float * T)(2e-5, 2e-5, 2e-5)
+    state = [[np.zeros_like(p) for p in params] for _ in range(3)] + [[np.full_like(p, np.nan) for p in params]]   # m, v, n, prev
+    lr_all = (5e-2, 5e-3, 5e-3, 5e-3)
     ctl = np.zeros(16, np.float32)
     ctl[0] = 1024.0
     PP = ctypes.POINTER(ctypes.c_float)
-    arr = lambda xs: (PP * T)(*[x.ctypes.data_as(PP) for x in xs])
 
-    def iterate(grads):
-        gs = [np.ascontiguousarray(x, np.float32) for x in grads]
-        hostmath.hm_adan_iteration(u32(T), arr(params), arr(gs), arr(state[0]), arr(state[1]), arr(state[2]), arr(state[3]),
-                                   counts, lrs, wds, _p(ctl), f32(0.98), f32(0.92), f32(0.99), f32(5.0), f32(1e-8), f32(2.0),
-                                   f32(0.5), f32(4.0), i32(0))
+    def iterate(grads, k):
+        live = [i for i in range(T) if not (i == 3 and k < 2)]            # tensor 3 has no gradient before step 3
+        n = len(live)
+        arr = lambda xs: (PP * n)(*[xs[i].ctypes.data_as(PP) for i in live])
+        gs = {i: np.ascontiguousarray(grads[i], np.float32) for i in live}
+        hostmath.hm_adan_iteration(u32(n), arr(params), (PP * n)(*[gs[i].ctypes.data_as(PP) for i in live]), arr(state[0]),
+                                   arr(state[1]), arr(state[2]), arr(state[3]), (ctypes.c_uint64 * n)(*[params[i].size for i in live]),
+                                   (ctypes.c_float * n)(*[lr_all[i] for i in live]), (ctypes.c_float * n)(*[2e-5] * n), _p(ctl),
+                                   f32(0.98), f32(0.92), f32(0.99), f32(5.0), f32(1e-8), f32(2.0), f32(0.5), f32(4.0), i32(0))
 
     scale, tracker = 1024.0, 0
     for k in range(6):
@@ -205,11 +206,11 @@ def test_optimizer_kernel_source_matches_reference_adan_and_gradscaler(hostmath)
             bad = [g[f"g{k}_{i}"] * np.float32(scale) for i in range(T)]
             bad[1] = bad[1].copy(); bad[1].flat[7] = np.inf
             before = [p.copy() for p in params]
-            iterate(bad)
+            iterate(bad, k)
             assert ctl[5] == 1 and ctl[0] == scale / 2 and ctl[10] == 1 and ctl[2] == k
             assert all(np.array_equal(a, b) for a, b in zip(before, params))
             scale, tracker = scale / 2, 0
-        iterate([g[f"g{k}_{i}"] * np.float32(scale) for i in range(T)])
+        iterate([g[f"g{k}_{i}"] * np.float32(scale) for i in range(T)], k)
         assert ctl[5] == 0 and ctl[2] == k + 1
         tracker += 1
         if tracker == 4:

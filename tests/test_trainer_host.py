@@ -223,16 +223,17 @@ def test_sds_guidance_half_precision_path_is_dtype_consistent(mods, as_latent):
 
 def test_foreach_adan_reproduces_the_reference_optimizer(mods):
     """tests/golden/adan_ref.npz: parameters after each of six steps of the reference's own optimizer.Adan (two groups,
-    weight decay, global-norm clipping on the even steps), generated in the build container."""
+    weight decay, global-norm clipping on the even steps, one tensor without a gradient during the first two steps),
+    generated in the build container."""
     import os
     from conftest import ROOT
     g = np.load(os.path.join(ROOT, "tests", "golden", "adan_ref.npz"))
-    params = [torch.nn.Parameter(torch.from_numpy(g[f"p0_{i}"].copy())) for i in range(3)]
+    params = [torch.nn.Parameter(torch.from_numpy(g[f"p0_{i}"].copy())) for i in range(4)]
     opt = mods.optim.Adan([{"params": params[:1], "lr": 5e-2}, {"params": params[1:], "lr": 5e-3}], eps=1e-8, weight_decay=2e-5,
                           max_grad_norm=5.0)
     for k in range(6):
         for i, p in enumerate(params):
-            p.grad = torch.from_numpy(g[f"g{k}_{i}"].copy())
+            p.grad = None if (i == 3 and k < 2) else torch.from_numpy(g[f"g{k}_{i}"].copy())   # tensor 3 joins at step 3
         opt.step()
         for i, p in enumerate(params):
             assert np.allclose(p.detach().numpy(), g[f"p{k + 1}_{i}"], rtol=1e-5, atol=1e-7), (k, i)
