@@ -154,9 +154,9 @@ __global__ __launch_bounds__(64) void k_march_count(const float* __restrict__ ra
     rays[n * 2 + 1] = (int32_t)step;
 }
 
-// Pass 1, one WAVE per ray (experimental, off by default: sdfx_march_set_impl(1) / SDFX_MARCH_WAVE=1; validated lane by
-// lane on the CPU in tests/hostmath — hm_march_count_wave reproduces the serial march bit for bit — but not yet on the
-// GPU). Every ray time the march visits lies on one occupancy-independent lattice (march_advance), so 64 consecutive
+// Pass 1, one WAVE per ray (the default since round 2: 107-184 us against 250-330 us for the thread-per-ray kernel on
+// the init / blobs / full grids, identical counts, offsets and sample times on the MI355X — tests/test_gpu_parity.py,
+// tools/march_bench.py; sdfx_march_set_impl(0) / SDFX_MARCH_WAVE=0 select the thread-per-ray kernel). Every ray time the march visits lies on one occupancy-independent lattice (march_advance), so 64 consecutive
 // lattice points are probed at once — each lane: is my cell occupied, and if not, how many lattice points does the
 // serial march skip from here (the literal do-while of raymarching.cu:459-462)? — and the serial decision chain is
 // then replayed over the 64 results with scalar ballots / readlanes. The dependent global loads of the bitfield, which
@@ -603,10 +603,10 @@ __global__ __launch_bounds__(kCompactBlock) void k_compact_scatter(const int32_t
 // C ABI
 // =========================================================================================
 namespace {
-int g_march_impl = -1;  // -1: follow SDFX_MARCH_WAVE (default 0 = thread per ray), 0 / 1 forced by sdfx_march_set_impl
+int g_march_impl = -1;  // -1: follow SDFX_MARCH_WAVE (default 1 = wave per ray), 0 / 1 forced by sdfx_march_set_impl
 bool march_wave_impl() {
     if (g_march_impl >= 0) return g_march_impl == 1;
-    static const bool env = [] { const char* e = getenv("SDFX_MARCH_WAVE"); return e && atoi(e) == 1; }();
+    static const bool env = [] { const char* e = getenv("SDFX_MARCH_WAVE"); return !e || atoi(e) != 0; }();
     return env;
 }
 }  // namespace

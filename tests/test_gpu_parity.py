@@ -545,8 +545,6 @@ def test_fused_field_network_matches_unfused(oracle, dev):
     assert torch.abs(ge1 - ge0).max().item() < 3e-2 * ge0.abs().max().item()
 
 
-@pytest.mark.skipif(os.environ.get("SDFX_TEST_EXPERIMENTAL") != "1",
-                    reason="wave-per-ray counting pass: verified on the CPU (tests/test_hostmath.py), GPU run pending")
 @pytest.mark.parametrize("gridname", ["init", "blobs", "full"])
 def test_wave_per_ray_march_matches_thread_per_ray(oracle, dev, gridname):
     import raymarching
@@ -568,9 +566,6 @@ def test_wave_per_ray_march_matches_thread_per_ray(oracle, dev, gridname):
         assert torch.equal(a, b)
 
 
-@pytest.mark.skipif(os.environ.get("SDFX_TEST_EXPERIMENTAL") != "1",
-                    reason="run-to-run bit reproducibility of the binned scatter: expected by construction (exact integer sums), "
-                           "enabled after its first GPU run")
 def test_binned_table_gradient_is_bit_reproducible(oracle, dev):
     import _gridencoder as B
     offsets_np, pls = oracle.grid_offsets(desired_resolution=2048)

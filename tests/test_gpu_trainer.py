@@ -223,9 +223,6 @@ def test_fused_entropy_matches_torch(dev):
     assert torch.allclose(gf, w.grad, rtol=1e-5, atol=1e-6) and float(gf[M:].abs().sum()) == 0
 
 
-@pytest.mark.skipif(os.environ.get("SDFX_TEST_EXPERIMENTAL") != "1",
-                    reason="direct HIP-vs-reference-golden comparison: enabled after its first GPU run (the same chain is "
-                           "already covered by HIP == torch_shade on the GPU and torch_shade == golden on the CPU)")
 @pytest.mark.parametrize("shading", ["lambertian", "textureless", "normal"])
 def test_fused_shade_matches_reference_golden(dev, shading):
     importlib.import_module("stable-dreamfusion_amd")
