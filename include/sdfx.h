@@ -131,6 +131,22 @@ uint64_t sdfx_compact_rays_scratch_bytes(uint32_t n);
 
 /* ------------------------------------------------------------------------- gridencoder */
 
+/* testing / measurement aid: switches of the D = 3, C = 2 forward (csrc/gridencoder_fwd.hip); -1 = default / environment.
+ *   fwd_impl            0 = generic kernel (any D, C), 1 = k_grid_fwd where it applies (default; env SDFX_GRID_FWD)
+ *   pairs               1 = a gather-bound fine level shares its workgroup range with a small dense level, alternating
+ *                       (default), 0 = every level on its own (env SDFX_GRID_PAIRS)
+ *   points_per_thread   1, 2 (default) or 4 (env SDFX_GRID_POINTS)
+ *   balance             1 = cut the level sequence into 8 per-XCD ranges of equal modelled COST (default; needs a step hint),
+ *                       0 = equal tile counts (env SDFX_GRID_BALANCE)
+ * Results are identical for every setting. */
+void sdfx_grid_set_impl(int fwd_impl, int pairs, int points_per_thread, int balance);
+
+/* Host-only (no GPU work): the per-XCD work list sdfx_grid_encode_forward_hint would use for these arguments, 5 integers per
+ * segment (xcd, level_a, level_b or -1 for a single level, first tile column, columns). A pair segment alternates workgroups
+ * of level_a and level_b over the same columns. Returns the number of segments, < 0 on error. */
+int sdfx_grid_forward_plan(const int32_t* offsets_host, uint32_t max_level, float S, uint32_t H, int is_half, uint32_t B,
+                           uint32_t slabs, float step, int32_t* segments, uint32_t max_segments, uint32_t* columns_per_level);
+
 /*
  * gridencoder.cu:467-490 grid_encode_forward.
  *   inputs [B,D] f32 in [0,1]; embeddings [sum, C] f32|f16; offsets [L+1] i32 (device);
@@ -144,6 +160,20 @@ int sdfx_grid_encode_forward(const float* inputs, const void* embeddings, const 
                              const int32_t* offsets_host, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                              uint32_t max_level, float S, uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners,
                              uint32_t interp, int is_half, int out_layout, sdfx_stream_t stream);
+
+/*
+ * Extension — sdfx_grid_encode_forward with locality hints; the outputs are identical, only speed depends on them.
+ *   slabs  1, or 7: the B points are 7 slabs of B/7 points and points i, i + B/7, ..., i + 6B/7 are the finite-difference
+ *          stencil of one sample (x, x +- e along each axis; nerf/network_grid.py:81-96 evaluated in one call). The seven
+ *          points are then processed by neighbouring lanes, which share table lines at every level.
+ *   step   expected distance, in input units ([0,1]), between consecutive points of a slab when they are consecutive
+ *          samples of a ray (dt_min / (2 bound)); 0 = unknown. Drives the per-XCD split of the levels (cost model).
+ */
+int sdfx_grid_encode_forward_hint(const float* inputs, const void* embeddings, const int32_t* offsets,
+                             const int32_t* offsets_host, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                             uint32_t max_level, float S, uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners,
+                             uint32_t interp, int is_half, int out_layout, uint32_t slabs, float step,
+                                  sdfx_stream_t stream);
 
 /*
  * gridencoder.cu:492-522 grid_encode_backward.  grad [L,B,C] (grad_layout 0) or [B,L*C]

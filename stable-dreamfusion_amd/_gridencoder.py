@@ -10,21 +10,20 @@ import torch
 import _sdfx as S
 
 _FLOATS = (torch.float32, torch.float16)
-_OFFSETS_HOST = {}
 
 
 def offsets_host(offsets: torch.Tensor):
-    """Host copy of the level offsets (cached per device buffer; the launch plan needs the
-    level sizes on the host, and the buffer never changes after GridEncoder.__init__)."""
-    key = (offsets.data_ptr(), offsets.numel())
-    hit = _OFFSETS_HOST.get(key)
-    if hit is None:
+    """Host copy of the level offsets: the launch plan needs the level sizes on the host. The copy lives ON the tensor
+    object (PyTorch keeps a tensor's Python object, attributes included, alive with its TensorImpl — the buffer
+    registered by GridEncoder and the tensor autograd hands back in backward are the same object), stamped with the
+    tensor's version counter: it dies with the buffer and is re-read after an in-place update (load_state_dict), so a
+    later encoder whose buffer lands on a recycled address can never see another encoder's level sizes."""
+    hit = getattr(offsets, "_sdfx_offsets_host", None)
+    if hit is None or hit[0] != offsets._version or hit[1] != offsets.numel():
         vals = [int(v) for v in offsets.detach().cpu().tolist()]
-        hit = (C.c_int32 * len(vals))(*vals)
-        if len(_OFFSETS_HOST) > 64:
-            _OFFSETS_HOST.clear()
-        _OFFSETS_HOST[key] = hit
-    return hit
+        hit = (offsets._version, offsets.numel(), (C.c_int32 * len(vals))(*vals))
+        offsets._sdfx_offsets_host = hit
+    return hit[2]
 
 
 def _table(t, name):
@@ -38,7 +37,8 @@ def _same(a, b, na, nb):
 
 
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C_, L, max_level, S_, H, dy_dx, gridtype,
-                        align_corners, interp, out_layout=0):
+                        align_corners, interp, out_layout=0, slabs=1, step=0.0):
+    """`slabs`, `step` (extensions): locality hints of sdfx_grid_encode_forward_hint; outputs do not depend on them."""
     S.check_tensor(inputs, "inputs", torch.float32)
     _table(embeddings, "embeddings")
     S.check_tensor(offsets, "offsets", torch.int32)
@@ -47,30 +47,29 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C_, L, max_l
     if dy_dx is not None:
         _table(dy_dx, "dy_dx")
         _same(embeddings, dy_dx, "embeddings", "dy_dx")
-    S.call("sdfx_grid_encode_forward", S.ptr(inputs), S.ptr(embeddings), S.ptr(offsets), offsets_host(offsets),
+    S.call("sdfx_grid_encode_forward_hint", S.ptr(inputs), S.ptr(embeddings), S.ptr(offsets), offsets_host(offsets),
            S.ptr(outputs), B, D, C_, L, max_level, float(S_), H, S.ptr(dy_dx), gridtype, int(bool(align_corners)), interp,
-           int(embeddings.dtype == torch.float16), out_layout, S.stream())
+           int(embeddings.dtype == torch.float16), out_layout, int(slabs), float(step), S.stream())
 
 
 # ---- binned scatter (D = 3, C = 2): persistent scratch per device -----------------------------------
 _BINNED = int(os.environ.get("SDFX_GRID_BWD_BINNED", "1"))
 _BINNED_CHUNK_POINTS = int(os.environ.get("SDFX_GRID_BWD_CHUNK", str(1 << 22)))
-_BINNED_SCRATCH = {}
+_BINNED_SCRATCH = {}   # device index -> list of buffers, the last one is the current (largest) one
 
 
 def _binned_scratch(device, offsets, L, max_level, S_, H, is_half):
-    key = (device.index, offsets.data_ptr(), max_level, is_half)
-    hit = _BINNED_SCRATCH.get(key)
-    if hit is None:
-        nbytes = int(S.lib().sdfx_grid_encode_backward_binned_scratch_bytes(offsets_host(offsets), L, max_level, float(S_), H,
-                                                                           _BINNED_CHUNK_POINTS, is_half))
-        if nbytes <= 0:
-            return None
-        hit = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        if len(_BINNED_SCRATCH) > 8:
-            _BINNED_SCRATCH.clear()
-        _BINNED_SCRATCH[key] = hit
-    return hit
+    """Persistent scratch of the binned scatter: ONE buffer per device, sized for the largest request seen. It is plain
+    bytes (every launch re-initialises what it uses), so encoders and dtypes share it. Buffers are never freed: a
+    captured HIP graph has the address baked in, so an outgrown buffer stays alive beside its replacement."""
+    nbytes = int(S.lib().sdfx_grid_encode_backward_binned_scratch_bytes(offsets_host(offsets), L, max_level, float(S_), H,
+                                                                       _BINNED_CHUNK_POINTS, is_half))
+    if nbytes <= 0:
+        return None
+    bufs = _BINNED_SCRATCH.setdefault(device.index, [])
+    if not bufs or bufs[-1].numel() < nbytes:
+        bufs.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
+    return bufs[-1]
 
 
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C_, L, max_level, S_, H, dy_dx,

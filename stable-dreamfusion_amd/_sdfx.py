@@ -37,6 +37,8 @@ _SIGNATURES = {
     "sdfx_compact_rays_scratch_bytes": [_u32],
     "sdfx_grid_encode_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32,
                                  _int, _u32, _int, _int, _ptr],
+    "sdfx_grid_encode_forward_hint": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32,
+                                 _int, _u32, _int, _int, _u32, _f32, _ptr],
     "sdfx_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _ptr,
                                   _ptr, _u32, _int, _u32, _int, _int, _ptr],
     "sdfx_grid_encode_backward_binned": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
@@ -62,6 +64,8 @@ _SIGNATURES = {
     "sdfx_entropy_forward": [_ptr, _u32, _ptr, _ptr, _ptr],
     "sdfx_entropy_backward": [_ptr, _u32, _ptr, _ptr, _ptr, _ptr],
     "sdfx_march_set_impl": [_int],
+    "sdfx_grid_set_impl": [_int, _int, _int, _int],
+    "sdfx_grid_forward_plan": [_ptr, _u32, _f32, _u32, _int, _u32, _u32, _f32, _ptr, _u32, _ptr],
     "sdfx_adan_ctl_words": [],
     "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],
     "sdfx_adan_prepare": [_ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _u32, _ptr],

@@ -69,13 +69,20 @@ inline uint32_t plan_grid_size(const GridPlan& p) {
 // workgroup -> (level, tile); false when this workgroup has no item
 __device__ __forceinline__ bool plan_item(const GridPlan& p, uint32_t& level, uint32_t& tile) {
     const uint32_t xcd = blockIdx.x % kXcds;
-    const uint32_t item = p.start[xcd] + blockIdx.x / kXcds;
-    if (item >= p.end[xcd]) return false;
+    const uint32_t local = blockIdx.x / kXcds;
+    if (local >= p.end[xcd] - p.start[xcd]) return false;
+    const uint32_t item = p.start[xcd] + local;
     const uint32_t virt = item / p.tiles;
     level = p.order[virt];
     tile = item - virt * p.tiles;
     return true;
 }
+
+// ---- forward of the hot-path configuration (gridencoder_fwd.hip) ----
+bool fast_forward_enabled();
+void launch_forward_d3c2(const float* inputs, const void* table, const int32_t* offsets_host, void* outputs, uint32_t B,
+                         uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                         uint32_t interp, int is_half, int out_layout, uint32_t slabs, float step, hipStream_t st);
 
 // ---- table element types ----------------------------------------------------------------
 template <bool HALF> struct Elem;

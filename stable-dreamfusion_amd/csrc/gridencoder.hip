@@ -441,10 +441,11 @@ bool aligned_for(const void* p, uint32_t C, uint32_t elem_bytes) {
 // =========================================================================================
 extern "C" {
 
-int sdfx_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
+int sdfx_grid_encode_forward_hint(const float* inputs, const void* embeddings, const int32_t* offsets,
                              const int32_t* offsets_host, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                              uint32_t max_level, float S, uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners,
-                             uint32_t interp, int is_half, int out_layout, sdfx_stream_t stream) {
+                             uint32_t interp, int is_half, int out_layout, uint32_t slabs, float step,
+                                  sdfx_stream_t stream) {
     (void)offsets;
     SDFX_REQUIRE(inputs && embeddings && offsets_host && outputs, "grid_encode_forward: null pointer");
     if (!supported_dc(D, C)) {  // gridencoder.cu:392,409 throw std::runtime_error here
@@ -458,6 +459,11 @@ int sdfx_grid_encode_forward(const float* inputs, const void* embeddings, const 
     SDFX_REQUIRE(aligned_for(embeddings, C, eb) && aligned_for(outputs, C, eb) && (!dy_dx || aligned_for(dy_dx, C, eb)),
                  "grid_encode_forward: embeddings/outputs/dy_dx must be aligned to min(16, C*sizeof(elem)) bytes");
     if (B == 0) return SDFX_OK;
+    if (D == 3 && C == 2 && !dy_dx && fast_forward_enabled()) {
+        launch_forward_d3c2(inputs, embeddings, offsets_host, outputs, B, L, max_level, S, H, gridtype, align_corners, interp,
+                            is_half, out_layout, slabs, step, as_stream(stream));
+        return check_launch("grid_encode_forward");
+    }
     FwdArgs a;
     a.inputs = inputs; a.table = embeddings; a.outputs = outputs; a.B = B; a.L = L;
     a.plan = make_plan(offsets_host, max_level, S, H, C, eb, B);
@@ -467,6 +473,14 @@ int sdfx_grid_encode_forward(const float* inputs, const void* embeddings, const 
     a.out_layout = out_layout; a.st = as_stream(stream); a.grid = plan_grid_size(a.plan);
     if (is_half) { SDFX_DISPATCH_DC(true, launch_forward, a) } else { SDFX_DISPATCH_DC(false, launch_forward, a) }
     return check_launch("grid_encode_forward");
+}
+
+int sdfx_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
+                             const int32_t* offsets_host, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                             uint32_t max_level, float S, uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners,
+                             uint32_t interp, int is_half, int out_layout, sdfx_stream_t stream) {
+    return sdfx_grid_encode_forward_hint(inputs, embeddings, offsets, offsets_host, outputs, B, D, C, L, max_level, S, H, dy_dx,
+                                         gridtype, align_corners, interp, is_half, out_layout, 1u, 0.0f, stream);
 }
 
 int sdfx_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,

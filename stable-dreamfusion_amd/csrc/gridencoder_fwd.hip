@@ -1,0 +1,499 @@
+// gridencoder_fwd.hip — the forward of the hash / tiled grid encoder for the configuration of the hot path
+// (D = 3, C = 2, no dy_dx): same arithmetic as k_grid_forward (gridencoder.hip; reference gridencoder.cu:82-249),
+// bit for bit, organised around what bounds it on MI355X.
+//
+// What bounds it (tools/ubench/gather_width.hip, gather_policy.hip; profiles/README.md): a divergent gather costs the
+// CU's vector memory pipe ~2.4 cycles per DISTINCT 128-byte line per wave instruction — whatever the access width
+// (4 / 8 / 16 bytes per lane), whatever the cache policy (sc0 / sc1 / nt), and whether the line hits in L1 or not.
+// The eight corners of a sample at a hashed level are 4 such lines (the x-pair shares one), so the kernel's time is
+// (distinct lines per wave, summed over its gathers) x 2.4 cycles, on the XCD that got the most of them. Therefore:
+//
+//   * fewer distinct lines per wave: the seven points of a finite-difference stencil (x, x +- e along each axis;
+//     network_grid.py:81-96) are evaluated by NEIGHBOURING LANES — 9 samples x 7 points per wave — when the caller
+//     says the batch is `slabs` = 7 slabs of B/7 points. x +- e land in the same 128-byte line as x at every level (the
+//     x prime of the spatial hash is 1) and the other four share the coarse cells: -30 % lines on ray-ordered samples
+//     (1657 instead of 2353 per 64 points over the 16 levels). Only the lane -> point map changes; layouts do not.
+//   * one big table per XCD at a time, the same load on every XCD: a hashed level is a 2 MiB fp16 table and an XCD's
+//     L2 is 4 MiB, shared with the streamed coordinates and features — two hashed levels in flight on one XCD thrash it
+//     (measured: walking a fine and a 2 MiB coarse level alternately costs +20 %; fp32 tables, 4 MiB a level: +50 %).
+//     So the levels form a SEQUENCE OF UNITS that every XCD walks in order, one unit at a time: a unit is either one
+//     level, or a fine level paired with one of the small dense levels (20 KB ... 0.8 MB), whose tiles alternate so that
+//     the gather-bound fine waves and the VALU-bound coarse waves overlap on every CU. The sequence is cut into 8
+//     ranges of equal COST (not equal tile count): cost per wave = max(distinct lines x 2.4 cycles, VALU cycles), lines
+//     from a model of ray-ordered samples (lines_per_wave) evaluated at the caller's step hint; without a hint every
+//     level costs the same and the split is the even one.
+//   * VALU off the critical path: level constants in scalar registers from one 32-byte record, hash / stride terms shared
+//     by the x-pair, packed half arithmetic (v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f16: bit-identical to at::Half's
+//     round-after-every-operation, see Acc2), fine and coarse tiles alternating on every CU so gather-bound and
+//     VALU-bound waves overlap, and P points per thread so the launch / scalar-load prologue is paid once per P tiles and
+//     4 P gathers are in flight per lane.
+#include "grid_common.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+using namespace sdfx;
+using namespace sdfx::grid;
+
+namespace {
+
+constexpr uint32_t kMaxSegs = 6;       // per XCD
+constexpr uint32_t kNoLevel = 0xffffffffu;
+constexpr uint32_t kGroup = 7;         // points per stencil
+constexpr uint32_t kGroupsPerWave = 9; // 9 x 7 = 63 lanes
+
+struct LevelConst {   // 32 bytes, one s_load_dwordx8
+    uint32_t res, row0, size, m1, m2, flags, pad0, pad1;   // flags: 1 = hashed, 2 = size is a power of two
+};
+// tile columns [first, first + count) of level_a — and of level_b when it is a pair: the workgroups of a pair segment
+// alternate a, b, a, b ... over the same columns
+struct Seg { uint32_t level_a, level_b, first, count; };
+struct FwdPlan {
+    LevelConst lv[kMaxLevels];
+    Seg seg[kXcds][kMaxSegs];
+    uint32_t ntiles[kXcds];   // workgroups of each XCD (sum over its segments of count x (pair ? 2 : 1))
+    uint32_t vec16;           // table base 16-byte aligned: paired gathers allowed
+    uint32_t slabs;           // 1, or 7 = stencil batch [7, B/7, 3] evaluated with the 7 points of a sample in neighbouring lanes
+    uint32_t slab_points;     // B / slabs
+};
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// results[ch] += w * grid[index + ch] with results and grid of the table's type (gridencoder.cu:168-195).
+// Half tables: the reference converts the float32 product to at::Half, then adds two at::Half values — in float32,
+// rounded to half again. v_cvt_pk_f16_f32 is the first rounding (kept opaque so hipcc cannot fuse product and rounding
+// into v_fma_mixlo_f16, which rounds the exact product once). v_pk_add_f16 is the second: the float32 sum of two halves
+// rounded to half equals the correctly rounded half sum, because float32's 24 significand bits >= 2 * 11 + 2 (double
+// rounding is innocuous; tests/test_hostmath.py checks the identity over all exponent pairs).
+template <bool HALF> struct Acc2;
+template <> struct Acc2<true> {
+    half2_t acc = {(_Float16)0.0f, (_Float16)0.0f};
+    __device__ __forceinline__ void add(float w, uint32_t row) {
+        const half2_t g = __builtin_bit_cast(half2_t, row);
+        const float2_t gf = {(float)g.x, (float)g.y};
+        const float2_t p = gf * w;
+        half2_t ph;
+        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(p.x), "v"(p.y));
+        acc = acc + ph;
+    }
+    __device__ __forceinline__ void store(__half* out, bool zero) const {
+        *reinterpret_cast<uint32_t*>(out) = zero ? 0u : __builtin_bit_cast(uint32_t, acc);
+    }
+};
+template <> struct Acc2<false> {
+    float a0 = 0.0f, a1 = 0.0f;
+    __device__ __forceinline__ void add(float w, uint2 row) {
+        a0 = a0 + w * __uint_as_float(row.x);
+        a1 = a1 + w * __uint_as_float(row.y);
+    }
+    __device__ __forceinline__ void store(float* out, bool zero) const {
+        *reinterpret_cast<float2*>(out) = zero ? make_float2(0.f, 0.f) : make_float2(a0, a1);
+    }
+};
+
+__device__ __forceinline__ uint32_t pick4(const uint4& b, uint32_t j) {   // dword j (0..3) of a 16-byte block
+    const uint32_t lo = (j & 2u) ? b.z : b.x;
+    const uint32_t hi = (j & 2u) ? b.w : b.y;
+    return (j & 1u) ? hi : lo;
+}
+
+// workgroup -> (level, tile) through the XCD's segment list (walked in order); false when there is nothing to do
+__device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint32_t& tile) {
+    const uint32_t xcd = blockIdx.x % kXcds;
+    uint32_t local = blockIdx.x / kXcds;
+    if (local >= p.ntiles[xcd]) return false;
+#pragma unroll
+    for (uint32_t s = 0; s < kMaxSegs; s++) {
+        const Seg sg = p.seg[xcd][s];
+        const bool pair = sg.level_b != kNoLevel;
+        const uint32_t n = pair ? 2u * sg.count : sg.count;
+        if (local < n) {
+            level = (pair && (local & 1u)) ? sg.level_b : sg.level_a;
+            tile = sg.first + (pair ? (local >> 1) : local);
+            return true;
+        }
+        local -= n;
+    }
+    return false;
+}
+
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, uint32_t P>
+__global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ inputs,
+                                                     const typename Elem<HALF>::type* __restrict__ table,
+                                                     typename Elem<HALF>::type* __restrict__ outputs, uint32_t B, uint32_t L,
+                                                     FwdPlan plan, int out_layout) {
+    using T = typename Elem<HALF>::type;
+    constexpr uint32_t C = 2;
+    constexpr uint32_t RB = HALF ? 4u : 2u;   // rows per 16-byte block
+    using RowT = typename std::conditional<HALF, uint32_t, uint2>::type;
+    uint32_t level, tile;
+    if (!fwd_item(plan, level, tile)) return;
+
+    const LevelConst lc = plan.lv[level];
+    const bool hashed = HASHGRID && (lc.flags & 1u);
+    const bool pow2 = (lc.flags & 2u) != 0u;
+    const T* tab = table + (size_t)lc.row0 * C;
+
+    // ---- slots of this thread -> points ----
+    uint32_t pt[P];
+    bool live[P];
+#pragma unroll
+    for (uint32_t j = 0; j < P; j++) {
+        const uint32_t slot = (tile * P + j) * kTile + threadIdx.x;
+        if (plan.slabs == kGroup) {   // lane = 7 * (sample within the wave) + stencil point; lane 63 idles
+            const uint32_t lane = slot & 63u, g = lane / kGroup;
+            const uint32_t sample = (slot >> 6) * kGroupsPerWave + g;
+            live[j] = lane < kGroup * kGroupsPerWave && sample < plan.slab_points;
+            pt[j] = (lane - g * kGroup) * plan.slab_points + sample;
+        } else {
+            live[j] = slot < B;
+            pt[j] = slot;
+        }
+        if (!live[j]) pt[j] = 0;   // a valid address to load from; nothing is stored
+    }
+
+    float xin[P][3];
+#pragma unroll
+    for (uint32_t j = 0; j < P; j++) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) xin[j][d] = inputs[(size_t)pt[j] * 3 + d];
+    }
+
+    auto wrap = [&](uint32_t idx) -> uint32_t {   // index % hashmap_size (gridencoder.cu:78)
+        if (pow2) return idx & (lc.size - 1u);
+        return idx < lc.size ? idx : idx % lc.size;
+    };
+
+    // Phase 1: cell, weights and the row indices of the 4 x-pairs of every point (no memory access)
+    float ax[P][2], ay[P][2], az[P][2];
+    uint32_t r0[P][4], r1[P][4];
+    bool oob[P];
+#pragma unroll
+    for (uint32_t j = 0; j < P; j++) {
+        oob[j] = xin[j][0] < 0 || xin[j][0] > 1 || xin[j][1] < 0 || xin[j][1] > 1 || xin[j][2] < 0 || xin[j][2] > 1;  // gridencoder.cu:105
+        float pos[3], deriv;
+        uint32_t pg[3], pn[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            grid_locate_axis(xin[j][d], lc.res, ALIGN, INTERP, pos[d], deriv, pg[d]);
+            // an out-of-range or NaN coordinate must still give an in-range vertex (its loads are issued, its result is not used)
+            pg[d] = min(pg[d], lc.res - 1u);
+            pn[d] = min(pg[d] + 1u, lc.res - 1u);   // the "+1" vertex (gridencoder.cu:181)
+        }
+        (void)deriv;
+        ax[j][0] = 1 - pos[0]; ax[j][1] = pos[0];
+        ay[j][0] = 1 - pos[1]; ay[j][1] = pos[1];
+        az[j][0] = 1 - pos[2]; az[j][1] = pos[2];
+        uint32_t yz[4];   // (y, z) part of the row index for the four (y, z) corners (gridencoder.cu:45-79)
+        if (hashed) {
+            const uint32_t hy[2] = {pg[1] * 2654435761u, pn[1] * 2654435761u};
+            const uint32_t hz[2] = {pg[2] * 805459861u, pn[2] * 805459861u};
+#pragma unroll
+            for (int k = 0; k < 4; k++) yz[k] = hy[k & 1] ^ hz[k >> 1];
+        } else {
+            const uint32_t sy[2] = {pg[1] * lc.m1, pn[1] * lc.m1};
+            const uint32_t sz[2] = {pg[2] * lc.m2, pn[2] * lc.m2};
+#pragma unroll
+            for (int k = 0; k < 4; k++) yz[k] = sy[k & 1] + sz[k >> 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r0[j][k] = wrap(hashed ? (pg[0] ^ yz[k]) : (pg[0] + yz[k]));
+            r1[j][k] = wrap(hashed ? (pn[0] ^ yz[k]) : (pn[0] + yz[k]));
+        }
+    }
+
+    // Phase 2: every gather of the thread is issued before the first result is touched (4 P in flight per lane, plus the
+    // second gathers of x-pairs that straddle two 16-byte blocks)
+    RowT v0[P][4], v1[P][4];
+    if (plan.vec16) {
+        // rows r0 and r1 = row(x + 1) nearly always share an aligned 16-byte block (the hash's x prime is 1, dense
+        // levels are x-major): one gather serves both corners of the pair
+        uint4 blk[P][4];
+#pragma unroll
+        for (uint32_t j = 0; j < P; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) blk[j][k] = *reinterpret_cast<const uint4*>(tab + (size_t)(r0[j][k] & ~(RB - 1)) * C);
+        }
+        RowT extra[P][4];
+#pragma unroll
+        for (uint32_t j = 0; j < P; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((r0[j][k] ^ r1[j][k]) >= RB) extra[j][k] = *reinterpret_cast<const RowT*>(tab + (size_t)r1[j][k] * C);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < P; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if constexpr (HALF) {
+                    v0[j][k] = pick4(blk[j][k], r0[j][k] & 3u);
+                    v1[j][k] = pick4(blk[j][k], r1[j][k] & 3u);
+                } else {
+                    v0[j][k] = (r0[j][k] & 1u) ? make_uint2(blk[j][k].z, blk[j][k].w) : make_uint2(blk[j][k].x, blk[j][k].y);
+                    v1[j][k] = (r1[j][k] & 1u) ? make_uint2(blk[j][k].z, blk[j][k].w) : make_uint2(blk[j][k].x, blk[j][k].y);
+                }
+                if ((r0[j][k] ^ r1[j][k]) >= RB) v1[j][k] = extra[j][k];
+            }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < P; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v0[j][k] = *reinterpret_cast<const RowT*>(tab + (size_t)r0[j][k] * C);
+                v1[j][k] = *reinterpret_cast<const RowT*>(tab + (size_t)r1[j][k] * C);
+            }
+        }
+    }
+
+    // Phase 3: accumulate in the reference's corner order and store
+#pragma unroll
+    for (uint32_t j = 0; j < P; j++) {
+        Acc2<HALF> acc;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {   // corner order of gridencoder.cu:168-195 (x fastest); weights ((1 * a_x) * a_y) * a_z
+            const float wy = ay[j][k & 1], wz = az[j][k >> 1];
+            acc.add(((1 * ax[j][0]) * wy) * wz, v0[j][k]);
+            acc.add(((1 * ax[j][1]) * wy) * wz, v1[j][k]);
+        }
+        if (live[j]) {
+            T* out = out_layout == 0 ? outputs + ((size_t)level * B + pt[j]) * C : outputs + ((size_t)pt[j] * L + level) * C;
+            acc.store(out, oob[j]);
+        }
+    }
+}
+
+// ---- host: the plan -------------------------------------------------------------------------------------------------
+
+// Distinct 128-byte table lines per wave (64 lanes: 9 samples x 7 stencil points, or 64 consecutive samples) as a
+// function of u = grid cells per sample step, for ray-ordered samples: measured by simulating the kernel's addresses on
+// the samples of a 4096-ray view (the finite-difference stencil of network_grid.py:81, e = 0.01, step 1/591 of the unit
+// cube; profiles/README.md). Piecewise linear in log u. Includes the second gather of an x-pair that straddles two
+// 16-byte blocks (a quarter of the lanes).
+double lines_per_wave(double u, bool stencil) {
+    static const double us[16] = {0.0271, 0.0389, 0.0525, 0.0728, 0.0998, 0.137, 0.190, 0.261, 0.360, 0.499, 0.689, 0.951, 1.315, 1.816, 2.509, 3.465};
+    static const double st7[16] = {7.6, 9.7, 11.8, 14.6, 18.9, 25.9, 36.3, 52.8, 79.9, 106.6, 136.7, 181.3, 212.8, 242.1, 252.8, 267.4};
+    static const double ray[16] = {14.3, 19.0, 23.3, 30.1, 38.4, 50.0, 65.9, 87.3, 116.5, 155.3, 205.3, 269.2, 320.1, 319.6, 319.6, 319.3};
+    const double* c = stencil ? st7 : ray;
+    if (u <= us[0]) return c[0];
+    if (u >= us[15]) return c[15];
+    const double lu = log(u);
+    for (int i = 0; i < 15; i++) {
+        if (u <= us[i + 1]) {
+            const double t = (lu - log(us[i])) / (log(us[i + 1]) - log(us[i]));
+            return c[i] + t * (c[i + 1] - c[i]);
+        }
+    }
+    return c[15];
+}
+
+constexpr uint32_t kBigTable = 1u << 20;   // bytes: a level this large wants the XCD's L2 for itself
+
+struct Unit { uint32_t a, b; double cost; };   // levels (b = kNoLevel: single) and cost per tile column
+
+FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uint32_t H, uint32_t elem_bytes, uint32_t B,
+                      uint32_t slabs, float step, uint32_t P, bool balance, bool pairs, double valu_lines) {
+    FwdPlan p;
+    memset(&p, 0, sizeof(p));
+    double lines[kMaxLevels];
+    uint32_t bytes[kMaxLevels];
+    for (uint32_t l = 0; l < levels; l++) {
+        LevelConst& c = p.lv[l];
+        c.res = level_resolution(l, S, H);
+        c.row0 = (uint32_t)offsets_host[l];
+        c.size = (uint32_t)offsets_host[l + 1] - c.row0;
+        uint64_t stride = 1;   // gridencoder.cu:61-79: dense index while the strides fit (d = 0 always does)
+        stride *= c.res;
+        if (stride <= c.size) { c.m1 = (uint32_t)stride; stride *= c.res; }
+        if (stride <= c.size) { c.m2 = (uint32_t)stride; stride *= c.res; }
+        c.flags = (stride > c.size ? 1u : 0u) | ((c.size & (c.size - 1u)) == 0u ? 2u : 0u);
+        bytes[l] = c.size * 2u * elem_bytes;
+        lines[l] = lines_per_wave((double)c.res * step, slabs == kGroup);
+    }
+    p.slabs = slabs == kGroup && B % kGroup == 0 ? kGroup : 1u;
+    p.slab_points = B / p.slabs;
+    const uint64_t slots = p.slabs == kGroup ? (uint64_t)div_up(p.slab_points, kGroupsPerWave) * 64u : B;
+    const uint32_t T = div_up(slots, (uint64_t)kTile * P);   // tile columns per level
+
+    // ---- units ----
+    Unit units[kMaxLevels];
+    uint32_t nu = 0;
+    const bool modelled = balance && step > 0.f;
+    if (!modelled) {   // no information: every level costs the same; the order [L-1, 0, L-2, 1, ...] of GridPlan
+        for (uint32_t v = 0, lo = 0, hi = levels; v < levels; v++) units[nu++] = {(v & 1u) ? lo++ : --hi, kNoLevel, 1.0};
+    } else {
+        bool used[kMaxLevels] = {};
+        // gather-bound levels, most expensive first, each paired with a small VALU-bound level while there are any
+        uint32_t heavy[kMaxLevels], nh = 0;
+        for (uint32_t l = 0; l < levels; l++) if (lines[l] > valu_lines) heavy[nh++] = l;
+        for (uint32_t i = 0; i < nh; i++) for (uint32_t j = i + 1; j < nh; j++) if (lines[heavy[j]] > lines[heavy[i]]) { const uint32_t t = heavy[i]; heavy[i] = heavy[j]; heavy[j] = t; }
+        uint32_t next_small = 0;
+        for (uint32_t i = 0; i < nh; i++) {
+            const uint32_t h = heavy[i];
+            uint32_t partner = kNoLevel;
+            if (pairs) {
+                while (next_small < levels && (used[next_small] || bytes[next_small] >= kBigTable || lines[next_small] > valu_lines)) next_small++;
+                // the pair must leave room in the 4 MiB L2 (fp32 tables: a fine level is 4 MiB on its own — no pairs)
+                if (next_small < levels && (uint64_t)bytes[h] + bytes[next_small] <= (7u << 19)) partner = next_small;
+            }
+            used[h] = true;
+            if (partner != kNoLevel) {
+                used[partner] = true;
+                const double both = lines[h] + lines[partner];
+                units[nu++] = {h, partner, both > 2 * valu_lines ? both : 2 * valu_lines};
+            } else {
+                units[nu++] = {h, kNoLevel, lines[h]};
+            }
+        }
+        for (uint32_t l = levels; l-- > 0;) {   // the rest: VALU-bound singles (largest tables first, the small ones last)
+            if (!used[l]) units[nu++] = {l, kNoLevel, lines[l] > valu_lines ? lines[l] : valu_lines};
+        }
+    }
+
+    // ---- cut the sequence into 8 ranges of equal cost ----
+    double total = 0;
+    for (uint32_t u = 0; u < nu; u++) total += units[u].cost * T;
+    // position of boundary k as (unit, column): the same function closes XCD k-1 and opens XCD k
+    uint32_t bu[kXcds + 1], bc[kXcds + 1];
+    for (uint32_t k = 0; k <= kXcds; k++) {
+        const double target = total * k / kXcds;
+        double cum = 0;
+        uint32_t u = 0;
+        while (u + 1 < nu && cum + units[u].cost * T <= target) { cum += units[u].cost * T; u++; }
+        double col = (target - cum) / units[u].cost;
+        if (k == kXcds) { u = nu - 1; col = T; }
+        bu[k] = u;
+        bc[k] = col <= 0 ? 0u : (col >= T ? T : (uint32_t)(col + 0.5));
+    }
+    for (uint32_t k = 0; k < kXcds; k++) {
+        uint32_t ns = 0;
+        for (uint32_t u = bu[k]; u <= bu[k + 1] && u < nu; u++) {
+            const uint32_t first = u == bu[k] ? bc[k] : 0u;
+            const uint32_t last = u == bu[k + 1] ? bc[k + 1] : T;
+            if (last <= first) continue;
+            if (ns == kMaxSegs) {   // cannot happen with <= 32 levels on 8 XCDs unless costs are degenerate: fold into the last one's XCD
+                break;
+            }
+            p.seg[k][ns++] = {units[u].a, units[u].b, first, last - first};
+            p.ntiles[k] += (last - first) * (units[u].b != kNoLevel ? 2u : 1u);
+        }
+    }
+    return p;
+}
+
+uint32_t fwd_grid_size(const FwdPlan& p) {
+    uint32_t longest = 0;
+    for (uint32_t k = 0; k < kXcds; k++) longest = p.ntiles[k] > longest ? p.ntiles[k] : longest;
+    return longest * kXcds;
+}
+
+// ---- implementation switches (testing / measurement aid; sdfx_grid_set_impl) ----
+int g_fwd_impl = -1, g_pairs = -1, g_points = -1, g_balance = -1;
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+int sw(int forced, const char* env, int dflt) {
+    return forced >= 0 ? forced : env_int(env, dflt);
+}
+
+template <bool HALF, uint32_t P>
+void launch(const float* inputs, const void* table, void* outputs, uint32_t B, uint32_t L, const FwdPlan& plan, uint32_t gridtype,
+            int align_corners, uint32_t interp, int out_layout, hipStream_t st) {
+    using T = typename Elem<HALF>::type;
+    const uint32_t grid = fwd_grid_size(plan);
+#define SDFX_FWD(INTERP_, ALIGN_, HASH_)                                                                               \
+    hipLaunchKernelGGL((k_grid_fwd<HALF, INTERP_, ALIGN_, HASH_, P>), dim3(grid), dim3(kTile), 0, st, inputs,            \
+                       static_cast<const T*>(table), static_cast<T*>(outputs), B, L, plan, out_layout)
+    const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
+    switch (sel) {
+        case 0: SDFX_FWD(0u, false, false); break;
+        case 1: SDFX_FWD(0u, false, true); break;
+        case 2: SDFX_FWD(0u, true, false); break;
+        case 3: SDFX_FWD(0u, true, true); break;
+        case 4: SDFX_FWD(1u, false, false); break;
+        case 5: SDFX_FWD(1u, false, true); break;
+        case 6: SDFX_FWD(1u, true, false); break;
+        default: SDFX_FWD(1u, true, true); break;
+    }
+#undef SDFX_FWD
+}
+
+}  // namespace
+
+namespace sdfx {
+namespace grid {
+
+bool fast_forward_enabled() { return sw(g_fwd_impl, "SDFX_GRID_FWD", 1) == 1; }
+
+// D = 3, C = 2, no dy_dx. `slabs`, `step`: locality hints (sdfx_grid_encode_forward_hint); results do not depend on them.
+void launch_forward_d3c2(const float* inputs, const void* table, const int32_t* offsets_host, void* outputs, uint32_t B,
+                         uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                         uint32_t interp, int is_half, int out_layout, uint32_t slabs, float step, hipStream_t st) {
+    const uint32_t eb = is_half ? 2u : 4u;
+    // points per thread: 1 measured best (2: -2 %, 4: -10 %: more lines in flight per CU than its L1 holds)
+    uint32_t P = (uint32_t)sw(g_points, "SDFX_GRID_POINTS", 1);
+    if (P != 1 && P != 2 && P != 4) P = 1;
+    // SDFX_GRID_VALU_LINES: VALU time of one wave of one level in units of table lines (232 instructions / 2.4 cycles a line)
+    static const double valu_lines = (double)env_int("SDFX_GRID_VALU_LINES", 97);
+    FwdPlan plan = make_fwd_plan(offsets_host, max_level, S, H, eb, B, slabs, step, P, sw(g_balance, "SDFX_GRID_BALANCE", 1) == 1,
+                                 sw(g_pairs, "SDFX_GRID_PAIRS", 1) == 1, valu_lines);
+    plan.vec16 = (reinterpret_cast<uintptr_t>(table) % 16) == 0 ? 1u : 0u;
+    if (env_int("SDFX_GRID_PLAN_DEBUG", 0)) {   // one line per XCD: its segments (level: tiles) and modelled load
+        for (uint32_t k = 0; k < kXcds; k++) {
+            fprintf(stderr, "[grid plan] B=%u P=%u slabs=%u step=%g xcd %u: %u workgroups:", B, P, plan.slabs, (double)step, k,
+                    plan.ntiles[k]);
+            for (uint32_t sgi = 0; sgi < kMaxSegs; sgi++) {
+                const Seg& sg = plan.seg[k][sgi];
+                if (!sg.count) continue;
+                if (sg.level_b != kNoLevel) fprintf(stderr, "  L%u+L%u[%u,+%u)", sg.level_a, sg.level_b, sg.first, sg.count);
+                else fprintf(stderr, "  L%u[%u,+%u)", sg.level_a, sg.first, sg.count);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+#define SDFX_LAUNCH_P(P_)                                                                                               \
+    if (is_half) launch<true, P_>(inputs, table, outputs, B, L, plan, gridtype, align_corners, interp, out_layout, st);   \
+    else launch<false, P_>(inputs, table, outputs, B, L, plan, gridtype, align_corners, interp, out_layout, st)
+    if (P == 1) { SDFX_LAUNCH_P(1u); } else if (P == 2) { SDFX_LAUNCH_P(2u); } else { SDFX_LAUNCH_P(4u); }
+#undef SDFX_LAUNCH_P
+}
+
+}  // namespace grid
+}  // namespace sdfx
+
+// Host-only: the per-XCD segments the forward would use, 5 integers per segment (xcd, level_a, level_b or -1, first tile
+// column, columns); returns the number of segments (<= max_segments), tile columns per level in *columns_per_level.
+extern "C" int sdfx_grid_forward_plan(const int32_t* offsets_host, uint32_t max_level, float S, uint32_t H, int is_half, uint32_t B,
+                                      uint32_t slabs, float step, int32_t* segments, uint32_t max_segments,
+                                      uint32_t* columns_per_level) {
+    if (!offsets_host || !segments || max_level < 1 || max_level > kMaxLevels || B == 0) return -1;
+    uint32_t P = (uint32_t)sw(g_points, "SDFX_GRID_POINTS", 1);
+    if (P != 1 && P != 2 && P != 4) P = 1;
+    const FwdPlan plan = make_fwd_plan(offsets_host, max_level, S, H, is_half ? 2u : 4u, B, slabs, step, P,
+                                       sw(g_balance, "SDFX_GRID_BALANCE", 1) == 1, sw(g_pairs, "SDFX_GRID_PAIRS", 1) == 1,
+                                       (double)env_int("SDFX_GRID_VALU_LINES", 97));
+    const uint64_t slots = plan.slabs == kGroup ? (uint64_t)div_up(plan.slab_points, kGroupsPerWave) * 64u : B;
+    if (columns_per_level) *columns_per_level = div_up(slots, (uint64_t)kTile * P);
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < kXcds; k++) {
+        for (uint32_t sgi = 0; sgi < kMaxSegs; sgi++) {
+            const Seg& sg = plan.seg[k][sgi];
+            if (!sg.count) continue;
+            if (n == max_segments) return -2;
+            int32_t* o = segments + 5 * n++;
+            o[0] = (int32_t)k; o[1] = (int32_t)sg.level_a; o[2] = sg.level_b == kNoLevel ? -1 : (int32_t)sg.level_b;
+            o[3] = (int32_t)sg.first; o[4] = (int32_t)sg.count;
+        }
+    }
+    return (int)n;
+}
+
+extern "C" void sdfx_grid_set_impl(int fwd_impl, int pairs, int points_per_thread, int balance) {
+    g_fwd_impl = fwd_impl; g_pairs = pairs; g_points = points_per_thread; g_balance = balance;
+}

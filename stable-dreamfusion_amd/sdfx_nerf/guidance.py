@@ -16,6 +16,8 @@ The frozen 2D prior itself (UNet / VAE / text encoder) is third-party code the r
 """
 from __future__ import annotations
 
+import hashlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -94,7 +96,10 @@ class SDSGuidance(nn.Module):
         """The CLIP text encoder is not available; embeddings are seeded from the prompt text."""
         outs = []
         for p in prompt:
-            g = torch.Generator().manual_seed(abs(hash(p)) % (2 ** 31))
+            # a stable digest: Python's str hash is salted per process, which made the stand-in embeddings (and with them
+            # the loss trajectory) differ between runs and between the ranks of one job
+            seed = int.from_bytes(hashlib.sha256(p.encode("utf-8")).digest()[:4], "little") % (2 ** 31)
+            g = torch.Generator().manual_seed(seed)
             outs.append(torch.randn(1, self.ctx_len, self.ctx_dim, generator=g))
         return torch.cat(outs).to(self.device, self.precision_t)
 

@@ -47,6 +47,11 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
   encmodule_ref.npz  freqencoder/freq.py FreqEncoder and shencoder/sphere_harmonics.py SHEncoder modules (prefix-shape
                  handling, output_dim, the `size` scaling of SHEncoder, backward through dy_dx) run by the reference code
                  over the oracle backends -> pins this repository's two encoder wrappers.
+  o2_ref.npz     the `-O2` path (BASELINE.json configs[0]): nerf/network.py NeRFNetwork (vanilla backbone, FreqEncoder_torch,
+                 ResBlock MLP, autograd normals) rendered by nerf/renderer.py NeRFRenderer.run (64 stratified + 32 importance
+                 samples, sample_pdf, cumprod compositing, orientation loss, background MLP) on 256 rays of camera 0, training
+                 mode with perturbation, 'albedo' and 'lambertian' shading, forward + backward -> pins oracle/o2_path.py, the
+                 CPU baseline bench.py times beside the GPU numbers.
   sh_ref.npz     the literal expressions of shencoder/src/shencoder.cu:45-352 parsed out of the source
                  text and evaluated in float64 -> pins the SH oracle and kernel (values + Jacobian).
 """
@@ -624,6 +629,43 @@ def make_encmodule():
     print("encmodule_ref.npz", out["freq_y"].shape, out["sh8_y"].shape)
 
 
+def make_o2():
+    import argparse
+    from nerf.network import NeRFNetwork
+    opt = argparse.Namespace(bound=1.0, dmtet=False, cuda_ray=False, taichi_ray=False, min_near=0.01, density_thresh=10.0,
+                             density_activation="exp", blob_density=5.0, blob_radius=0.2, bg_radius=1.4, num_steps=64,
+                             upsample_steps=32, lambda_orient=1e-2, lambda_3d_normal_smooth=0, lambda_2d_normal_smooth=0,
+                             lambda_normal=0)
+    torch.manual_seed(31)
+    net = NeRFNetwork(opt).train()
+    cams = np.load(os.path.join(OUT, "cams_ref.npz"))
+    sel = np.linspace(0, 4095, 256).astype(np.int64)
+    rays_o = torch.from_numpy(cams["rays_o0"].reshape(-1, 3)[sel].copy())
+    rays_d = torch.from_numpy(cams["rays_d0"].reshape(-1, 3)[sel].copy())
+    g = torch.Generator().manual_seed(33)
+    gi, gd, gw = torch.randn(256, 3, generator=g), torch.randn(256, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
+    out = {"rays_o": rays_o.numpy(), "rays_d": rays_d.numpy(), "gi": gi.numpy(), "gd": gd.numpy(), "gw": gw.numpy(),
+           "n_params": np.int64(sum(p.numel() for p in net.parameters()))}
+    for k, v in net.state_dict().items():
+        out["w_" + k] = v.numpy().copy()
+    for shading, ratio in (("albedo", 1.0), ("lambertian", 0.35)):
+        torch.manual_seed(32)
+        net.zero_grad()
+        r = net.run(rays_o[None], rays_d[None], ambient_ratio=ratio, shading=shading, perturb=True)
+        loss = (r["image"][0] * gi).sum() + (r["depth"][0] * gd).sum() + (r["weights_sum"][0] * gw).sum()
+        if "loss_orient" in r:
+            loss = loss + opt.lambda_orient * r["loss_orient"]
+            out[f"{shading}_loss_orient"] = np.float64(r["loss_orient"].item())
+        loss.backward()
+        out.update({f"{shading}_image": r["image"][0].detach().numpy(), f"{shading}_depth": r["depth"][0].detach().numpy(),
+                    f"{shading}_weights_sum": r["weights_sum"][0].detach().numpy(),
+                    f"{shading}_weights": r["weights"].detach().numpy()[::8].copy()})
+        for n, p in net.named_parameters():
+            out[f"{shading}_g_{n}"] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "o2_ref.npz"), **out)
+    print("o2_ref.npz", int(out["n_params"]), "parameters")
+
+
 def make_sh():
     src = open(os.path.join(REF, "shencoder/src/shencoder.cu")).read()
     body = src[src.index("auto write_sh = [&]()"):src.index("template <typename scalar_t>\n__global__ void kernel_sh_backward")]
@@ -682,6 +724,9 @@ if __name__ == "__main__":
     if "--only-rmwrap" in sys.argv:
         make_rmwrap()
         sys.exit(0)
+    if "--only-o2" in sys.argv:
+        make_o2()
+        sys.exit(0)
     if "--only-encmodule" in sys.argv:
         make_encmodule()
         sys.exit(0)
@@ -694,6 +739,7 @@ if __name__ == "__main__":
     make_network()
     make_rmwrap()
     make_encmodule()
+    make_o2()
     make_renderer()      # last: it monkey-patches torch.Tensor.cuda
     make_freq()
     make_run_composite()

@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
-"""Standalone launch loop of the hash-grid encode forward (for rocprofv3 --pmc passes).
-usage: python tools/encode_bench.py [uniform|ray] [f16|f32] [launches]"""
+"""Standalone launch loop of the hash-grid encode forward (timing per implementation switch, and for rocprofv3 --pmc).
+usage: python tools/encode_bench.py [uniform|ray|stencil] [f16|f32] [launches] [impl,pairs,points,balance,hint ...]
+  uniform  2^21 uniform random points (the occupancy refresh's shape)
+  ray      the samples of one 4096-ray view through S-grid-init, in ray order
+  stencil  those samples and their six finite-difference neighbours, batched [7, M, 3] as the iteration does
+Each variant = the four switches of sdfx_grid_set_impl (-1 = default) + hint (0: none, 1: slabs = 7 / step = 1/591 where
+they apply); every variant is timed (rounds interleaved) and its output compared bit for bit with the first one."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 importlib.import_module("stable-dreamfusion_amd")
-import _gridencoder, synth, oracle as O
+import _gridencoder, _sdfx, synth, oracle as O
 kind = sys.argv[1] if len(sys.argv) > 1 else "uniform"
 dt = torch.float16 if (len(sys.argv) < 3 or sys.argv[2] == "f16") else torch.float32
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+variants = [tuple(int(v) for v in a.split(",")) for a in sys.argv[4:]] or [(0, -1, -1, -1, 0), (1, 0, 1, 0, 0), (1, -1, -1, -1, 1)]
 dev = torch.device("cuda:0")
 offsets_np, pls = O.grid_offsets(desired_resolution=2048)
 offsets = torch.from_numpy(offsets_np).to(dev)
@@ -22,16 +28,38 @@ else:
     bf = synth.s_grid_init()[2]
     o, d = synth.s_rays(0)
     nears, fars = O.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
-    xyzs = O.march_rays_train(o, d, 1.0, bf, 1, 128, nears, fars, synth.s_noises(4096))[0]
-    x = torch.from_numpy(((xyzs + 1) / 2).astype(np.float32)).to(dev)
+    xyzs = torch.from_numpy(O.march_rays_train(o, d, 1.0, bf, 1, 128, nears, fars, synth.s_noises(4096))[0]).to(dev)
+    if kind == "stencil":
+        e = 1e-2
+        offs = torch.tensor([[0, 0, 0], [e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]], device=dev)
+        xyzs = (xyzs.unsqueeze(0) + offs.unsqueeze(1)).clamp(-1, 1).reshape(-1, 3)      # [7, M, 3]
+    x = ((xyzs + 1) / 2).contiguous()
 B = x.shape[0]
-out = torch.empty(16, B, 2, device=dev, dtype=dt)
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for i in range(n + 2):
-    if i == 2:
-        s.record()
-    _gridencoder.grid_encode_forward(x, table, offsets, out, B, 3, 2, 16, 16, S, 16, None, 0, False, 1, 0)
-e.record(); torch.cuda.synchronize()
-ms = s.elapsed_time(e) / n
 bpp = 588 if dt == torch.float16 else 1164
-print(f"encode_fwd {kind} {dt} B={B}: {ms*1e3:.1f} us/launch, {B/ms/1e6:.2f} Gpts/s, {B*bpp/ms/1e6:.0f} GB/s algorithmic")
+first = None
+view = torch.int16 if dt == torch.float16 else torch.int32
+STEP = 1.0 / 591.0
+times = {v: [] for v in variants}
+outs = {}
+for rnd in range(3):            # rounds interleaved so that clock / thermal drift hits every variant alike
+    for var in variants:
+        impl, inter, pts, bal, hint = var   # inter = pairs switch
+        _sdfx.lib().sdfx_grid_set_impl(impl, inter, pts, bal)
+        slabs = 7 if (hint and kind == "stencil") else 1
+        step = STEP if (hint and kind != "uniform") else 0.0
+        out = torch.empty(16, B, 2, device=dev, dtype=dt)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(n + 2):
+            if i == 2:
+                s.record()
+            _gridencoder.grid_encode_forward(x, table, offsets, out, B, 3, 2, 16, 16, S, 16, None, 0, False, 1, 0, slabs, step)
+        e.record(); torch.cuda.synchronize()
+        times[var].append(s.elapsed_time(e) / n)
+        outs[var] = out.view(view)
+for var in variants:
+    ms = min(times[var])
+    same = bool(torch.equal(outs[var], outs[variants[0]]))
+    print(f"encode_fwd {kind} {dt} B={B} impl,pairs,points,balance,hint={var}: {ms*1e3:.1f} us/launch (min of 3 rounds; "
+          f"{[round(t*1e3) for t in times[var]]}), {B/ms/1e6:.2f} Gpts/s, {B*bpp/ms/1e6:.0f} GB/s algorithmic "
+          f"({B*bpp/ms/1e6/8000:.3f} of 8 TB/s)  identical to first: {same}", flush=True)
+_sdfx.lib().sdfx_grid_set_impl(-1, -1, -1, -1)

@@ -17,7 +17,10 @@ nears, fars = O.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.floa
 xyzs = O.march_rays_train(o, d, 1.0, bf, 1, 128, nears, fars, synth.s_noises(4096))[0]
 e = 1e-2
 offs = np.array([[0, 0, 0], [e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]], np.float32)
-pts = np.clip(xyzs[None] + offs[:, None], -1, 1).reshape(-1, 3)
+if os.environ.get("STENCIL_ORDER", "stencil") == "sample":   # [M, 7, 3]: the seven points of a sample are neighbours
+    pts = np.clip(xyzs[:, None] + offs[None], -1, 1).reshape(-1, 3)
+else:                                                        # [7, M, 3]
+    pts = np.clip(xyzs[None] + offs[:, None], -1, 1).reshape(-1, 3)
 x = torch.from_numpy(((pts + 1) / 2).astype(np.float32)).to(dev)
 B = x.shape[0]
 grad = (torch.randn(16, B, 2, device=dev) * 0.01).half()
@@ -29,7 +32,7 @@ for i in range(n + 1):
         s.record()
     _gridencoder.grid_encode_backward(grad, x, table, offsets, gt, B, 3, 2, 16, 16, S, 16, None, None, 0, False, 1, 0)
 e_.record(); torch.cuda.synchronize()
-print(f"grid bwd binned B={B}: {s.elapsed_time(e_)/n*1e3:.1f} us/call")
+print(f"grid bwd binned B={B} order={os.environ.get('STENCIL_ORDER', 'stencil')}: {s.elapsed_time(e_)/n*1e3:.1f} us/call")
 if os.environ.get("PER_LEVEL"):
     prev = 0.0
     for ml in range(1, 17):
