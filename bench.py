@@ -8,12 +8,17 @@
 One step = one full `-O` training iteration (BASELINE.json configs[1]): 64x64 = 4096 rays from the
 reference's camera sampler, 128^3 occupancy grid, <= 1024 steps per ray, 16-level fp16 hash grid,
 finite-difference normals (7 field evaluations), compositing, SDS loss, AMP backward, Adan step,
-density-grid refresh every 16 steps. Multi-GPU = independent prompts/seeds, one process per GPU,
-RCCL only for the barriers and one MAX reduction of the elapsed time ("weak" scaling).
+density-grid refresh every 16 steps. The K timed steps are the mix of a default 10 000-iteration run
+(nerf/utils.py:503-521, main.py:58-60): the first 20 % of them in the latent phase (64x64 latents straight from the
+renderer, 'normal' shading), the other 80 % in the RGB phase (render -> 512^2 -> VAE encoder with gradient,
+lambertian / textureless shading, random backgrounds); `phases` in the JSON gives each phase on its own.
+Multi-GPU = independent prompts/seeds, one process per GPU, RCCL only for the barriers and one MAX reduction of the
+elapsed time ("weak" scaling).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      the dominant kernel (hash-grid encode forward): algorithmic bytes / event-timed launch time
-  cpu_baseline  the CPU oracle port of the same iteration, timed on this host on a bounded ray sample
+  cpu_baseline  the reference's `-O2` vanilla-NeRF path on this host's cores: the reference's own code when
+                /root/reference is mounted, else oracle/o2_path.py (pinned to it by tests/golden/o2_ref.npz)
 """
 from __future__ import annotations
 
@@ -50,11 +55,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
     ap.add_argument("--no-nerf-only", action="store_true", help="skip the second timed pass without the SD-1.5 UNet")
-    ap.add_argument("--phase", default="latent", choices=["latent", "rgb"],
-                    help="latent: iterations 0.. of a run (the first 20 %%: 64x64 latents straight from the renderer, 'normal' "
-                         "shading); rgb: start after the latent phase (RGB render -> 512^2 -> VAE encoder with gradient, "
-                         "lambertian / textureless shading, random backgrounds). Default latent; rgb is not yet measured.")
-    ap.add_argument("--cpu-rays", type=int, default=256, help="rays in the CPU-oracle baseline sample")
+    ap.add_argument("--phase", default="mix", choices=["mix", "latent", "rgb"],
+                    help="mix (default): 20 %% of the timed steps in the latent phase, 80 %% in the RGB phase, as in a default run; "
+                         "latent / rgb: that phase only")
+    ap.add_argument("--no-reference-flow", action="store_true", help="skip the pass with the reference's host flow "
+                                                                     "(GradScaler + foreach Adan, no graph replay)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="control-path test without a GPU: gloo instead of RCCL, a stub iteration; exercises the rank "
+                         "agreement, barriers, MAX reduction, rank-0-only output and teardown of the N > 1 path")
     return ap.parse_args()
 
 
@@ -113,7 +121,25 @@ def install_timers(timer):
     def comp_bwd_bytes(gw, gws, gd, gi, sigmas, rgbs, ts, rays, ws, depth, image, M, N, *rest, **k):
         return M * COMPOSITE_BWD_BYTES[0] + N * COMPOSITE_BWD_BYTES[1]
 
-    timer.wrap(_gridencoder, "grid_encode_forward", "grid_encode_forward", enc_fwd_bytes)
+    # the iteration's launches (7-point stencil batches of ray-ordered samples, hinted) and the occupancy refresh's (2^21
+    # jittered cell centres, no hint) are different workloads: separate lines, the roofline object quotes the first
+    inner_fwd = _gridencoder.grid_encode_forward
+
+    def fwd_stencil(*a, **k):
+        return inner_fwd(*a, **k)
+
+    def fwd_plain(*a, **k):
+        return inner_fwd(*a, **k)
+
+    _gridencoder._fwd_stencil, _gridencoder._fwd_plain = fwd_stencil, fwd_plain
+    timer.wrap(_gridencoder, "_fwd_stencil", "grid_encode_forward", enc_fwd_bytes)
+    timer.wrap(_gridencoder, "_fwd_plain", "grid_encode_forward_unhinted", enc_fwd_bytes)
+
+    def dispatch(*a, **k):
+        slabs = k.get("slabs", a[16] if len(a) > 16 else 1)
+        return (_gridencoder._fwd_stencil if slabs == 7 else _gridencoder._fwd_plain)(*a, **k)
+
+    _gridencoder.grid_encode_forward = dispatch
     timer.wrap(_gridencoder, "grid_encode_backward", "grid_encode_backward", enc_bwd_bytes)
     timer.wrap(_raymarching, "composite_rays_train_forward", "composite_rays_train_forward", comp_fwd_bytes)
     timer.wrap(_raymarching, "composite_rays_train_backward", "composite_rays_train_backward", comp_bwd_bytes)
@@ -138,12 +164,13 @@ def kernel_microbench(dev):
     import _gridencoder
     import raymarching
     import synth
-    import oracle as O
+    from gridencoder import GridEncoder
     out = {}
-    offsets_np, pls = O.grid_offsets(desired_resolution=2048)
-    offsets = torch.from_numpy(offsets_np).to(dev)
-    S = float(np.log2(pls))
-    rows = int(offsets_np[-1])
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048,
+                      interpolation="smoothstep")     # the -O configuration: level offsets and growth factor from the module
+    offsets = enc.offsets.to(dev)
+    S = float(np.log2(enc.per_level_scale))
+    rows = int(enc.offsets[-1])
     g = torch.Generator(device="cpu").manual_seed(3)
     table32 = (torch.randn(rows, 2, generator=g) * 0.1).to(dev)
     for name, table in (("f16", table32.half()), ("f32", table32)):
@@ -226,42 +253,96 @@ def kernel_microbench(dev):
     return out
 
 
-def cpu_baseline(n_rays):
-    """The CPU oracle port of one iteration (shading 'normal': 7 field evaluations, fwd + bwd) on the first
-    n_rays rays of S-rays view 0 through the S-grid-init occupancy; single thread."""
-    import oracle as O
+def _reference_o2_model():
+    """The reference's own `-O2` network + renderer, imported from /root/reference with the unused third-party imports
+    stubbed. Only possible where the checkout is mounted (the build container; never the GPU box)."""
+    import argparse
+    import types
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "nerf")):
+        return None
+    sys.dont_write_bytecode = True
+
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return self
+        def __getattr__(self, k): return _Any()
+    for n in ["cv2", "trimesh", "mcubes", "pymeshlab", "imageio", "xatlas", "nvdiffrast", "nvdiffrast.torch", "tensorboardX",
+              "torchvision", "torchvision.transforms", "torchvision.transforms.functional", "torchvision.utils", "torchmetrics",
+              "torch_ema"]:
+        if n not in sys.modules:
+            m = types.ModuleType(n)
+            m.__getattr__ = lambda k: _Any      # any other attribute: a do-nothing class
+            sys.modules[n] = m
+            if "." in n:                        # `import a.b.c as x` walks the attributes
+                parent, child = n.rsplit(".", 1)
+                setattr(sys.modules[parent], child, m)
+    sys.path.insert(0, ref)
+    try:
+        from nerf.network import NeRFNetwork
+    finally:
+        sys.path.remove(ref)
+    opt = argparse.Namespace(bound=1.0, dmtet=False, cuda_ray=False, taichi_ray=False, min_near=0.01, density_thresh=10.0,
+                             density_activation="exp", blob_density=5.0, blob_radius=0.2, bg_radius=1.4, num_steps=64,
+                             upsample_steps=32, lambda_orient=1e-2, lambda_3d_normal_smooth=0, lambda_2d_normal_smooth=0,
+                             lambda_normal=0)
+    return NeRFNetwork(opt).train()
+
+
+def cpu_baseline(budget_s=30.0):
+    """BASELINE.md §3 / SURVEY.md §8(d): the `-O2` vanilla-NeRF path (4096 rays x (64 + 32) samples, render + backward with a
+    dummy SDS gradient, fp32, perturb=True) on ALL host cores: 1 warm-up + up to 5 timed iterations per shading, stopping
+    when the budget is spent. kind = "reference" when the reference's own code ran, "port" for oracle/o2_path.py."""
     import synth
+    from oracle import o2_path
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
     o, d = synth.s_rays(0)
-    sel = np.linspace(0, 4095, n_rays).astype(np.int64)
-    o, d = o[sel], d[sel]
-    bf = synth.s_grid_init()[2]
-    offsets, pls = O.grid_offsets(desired_resolution=2048)
-    table = synth.s_table(int(offsets[-1]), 2, "init", np.float16)
-    ws_, bs_ = synth.s_mlp()
-    t0 = time.perf_counter()
-    nears, fars = O.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
-    xyzs, dirs, ts, rays = O.march_rays_train(o, d, 1.0, bf, 1, 128, nears, fars, synth.s_noises(n_rays))
-    M = xyzs.shape[0]
-    eps = np.float32(1e-2)
-    offs = [np.zeros(3, np.float32)] + [s * e for e in np.eye(3, dtype=np.float32) * eps for s in (1, -1)]
-    sig0 = None
-    for k, off in enumerate(offs):
-        x01 = ((np.clip(xyzs + off, -1, 1) + np.float32(1)) / np.float32(2)).astype(np.float32)
-        enc, _, _ = O.grid_encode_forward(x01, table, offsets, pls, 16, False, 0, False, 1)
-        sigma, albedo = O.field_forward(enc.astype(np.float32), xyzs + off, ws_, bs_)
-        if k == 0:
-            sig0, alb0 = sigma, albedo
-    w, wsum, depth, image = O.composite_rays_train_forward(sig0, alb0, ts, rays)
-    gs, gc = O.composite_rays_train_backward(np.zeros_like(w), np.ones_like(wsum), np.zeros_like(depth), np.ones_like(image),
-                                             sig0, alb0, ts, rays, wsum, depth, image)
-    g_enc = np.random.default_rng(0).normal(size=(M, 32)).astype(np.float16)
-    for k, off in enumerate(offs):
-        x01 = ((np.clip(xyzs + off, -1, 1) + np.float32(1)) / np.float32(2)).astype(np.float32)
-        # MLP backward: two extra GEMM passes, the same cost as the forward's three
-        O.mlp_forward(g_enc.astype(np.float32), ws_, bs_)
-        O.grid_encode_backward(g_enc, x01, table, offsets, pls, 16, None, 0, False, 1)
-    dt = time.perf_counter() - t0
-    return {"rays": n_rays, "samples": int(M), "seconds": dt, "rays_per_s": n_rays / dt, "iters_per_s": n_rays / dt / 4096.0}
+    ro, rd = torch.from_numpy(o), torch.from_numpy(d)
+    model, kind = None, "port"
+    try:
+        model = _reference_o2_model()
+        if model is not None:
+            kind = "reference"
+    except Exception:  # noqa: BLE001 — any import problem: time the pinned restatement instead
+        model = None
+    if model is None:
+        torch.manual_seed(0)
+        model = o2_path.VanillaNeRF().train()
+
+    def iteration(shading):
+        model.zero_grad()
+        if kind == "reference":
+            out = model.run(ro[None], rd[None], ambient_ratio=1.0 if shading == "albedo" else 0.5, shading=shading, perturb=True)
+            image = out["image"][0]
+        else:
+            out = model.render(ro, rd, ambient_ratio=1.0 if shading == "albedo" else 0.5, shading=shading, perturb=True)
+            image = out["image"]
+        loss = (image * torch.randn_like(image)).sum()
+        if "loss_orient" in out:
+            loss = loss + 1e-2 * out["loss_orient"]
+        loss.backward()
+
+    res, t_begin = {}, time.perf_counter()
+    for shading, share in (("albedo", 0.4), ("lambertian", 1.0)):
+        times = []
+        for it in range(6):
+            t0 = time.perf_counter()
+            iteration(shading)
+            if it >= 1:
+                times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_begin > budget_s * share and times:
+                break
+        res[shading] = {"s_per_iter_median": float(np.median(times)), "s_per_iter_min": float(min(times)), "iters": len(times),
+                        "rays_per_s": 4096.0 / float(np.median(times))}
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"kind": kind, "cores": int(torch.get_num_threads()), "os_cpu_count": cores, "cpu_model": cpu_model, "shadings": res,
+            "seconds": time.perf_counter() - t_begin}
 
 
 # ---- multi-GPU control path (independent prompts, one process per GPU) ------------------------------
@@ -289,193 +370,301 @@ def job_throughput(world: int, steps: int, elapsed: float) -> float:
     return world * steps / elapsed
 
 
+def agree(ok: bool, dist, device) -> bool:
+    """True only if every rank says so (all ranks must time the same configuration and take the same barriers)."""
+    if dist is None:
+        return ok
+    t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def phase_plan(phase: str, steps: int):
+    """[(phase name, steps)] of the timed region: the 20 / 80 mix of a default run, or one phase."""
+    if phase != "mix":
+        return [(phase, steps)]
+    k_lat = min(max(1, round(0.2 * steps)), steps)
+    return [(n, k) for n, k in (("latent", k_lat), ("rgb", steps - k_lat)) if k > 0]
+
+
+class DryJob:
+    """Stand-in for the GPU job (--dry-run-cpu): the same control path — prior agreement, priming, barriers, timed phases,
+    MAX reduction, rank-0-only output — around a stub iteration, so that it can run under gloo on CPUs."""
+    train_mode, guidance_kind = "dry-run", "none"
+
+    def __init__(self, args, rank, world, dev):
+        self.rank, self.x, self.n = rank, torch.zeros(64, 64), 0
+        self.prior_ok = os.environ.get("SDFX_DRY_PRIOR_FAIL_RANK", "") != str(rank)   # test hook: one rank loses the big prior
+
+    def use_synthetic_prior(self): self.guidance_kind = "synthetic"
+    def build(self): pass
+    def calibrate(self): return 0
+    def prime(self, phase): pass
+    def set_phase(self, phase): self.phase = phase
+    def sync(self): pass
+    def applied(self): return self.n
+
+    def step(self, i):
+        self.x = (self.x @ self.x.T).tanh() + 1e-3 * i
+        self.n += 1
+        return 1000
+
+
+class GpuJob:
+    def __init__(self, args, rank, world, dev):
+        importlib.import_module("stable-dreamfusion_amd")
+        import synth
+        from sdfx_nerf.network_grid import NeRFNetwork
+        from sdfx_nerf.options import default_opt
+        self.args, self.rank, self.world, self.dev = args, rank, world, dev
+        seed = rank_seed(rank)                       # independent prompt / seed per rank
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        self.seed, self.opt = seed, default_opt()
+        self.model = NeRFNetwork(self.opt).to(dev)
+        self.prior, self.guidance_kind, self.prior_ok = None, args.guidance, True
+        if args.guidance in ("auto", "sd15_random"):
+            try:
+                from sdfx_nerf.sd15_arch import sd15_random_prior
+                self.prior = sd15_random_prior(dev, self.opt.fp16)
+                # one call of the SDS glue through the big network before anything depends on it (MIOpen's solver search for its
+                # convolution shapes happens here, per rank, a few seconds — outside every timed region); both phases, so the
+                # VAE encoder's shapes are searched too. Any failure falls back to the synthetic prior on ALL ranks.
+                with torch.autocast("cuda", dtype=torch.float16, enabled=self.opt.fp16):
+                    z = torch.cat([self.prior.get_text_embeds(["uncond"]), self.prior.get_text_embeds(["front"])])
+                    probe = self.prior.train_step(z, torch.rand(1, 4, 64, 64, device=dev), as_latent=True)
+                    x = torch.rand(1, 3, 64, 64, device=dev, requires_grad=True)
+                    probe2 = self.prior.train_step(z, x, as_latent=False)
+                    probe2.backward()
+                if not (bool(torch.isfinite(probe)) and bool(torch.isfinite(probe2))):
+                    raise RuntimeError("non-finite SDS loss from the SD-1.5-architecture prior")
+                self.guidance_kind = "sd15_random"
+            except Exception as exc:  # noqa: BLE001
+                if args.guidance == "sd15_random":
+                    raise
+                self.prior, self.prior_ok = None, False
+                if rank == 0:
+                    print(f"[bench] SD-1.5-architecture prior unavailable ({type(exc).__name__}: {exc}); synthetic prior", file=sys.stderr)
+        else:
+            self.prior_ok = False
+        poses, fovy = synth.reference_cameras()
+        self.views = []
+        for v in range(len(poses)):
+            o, d = synth.get_rays(poses[v], float(fovy[v]))
+            az = float(np.degrees(np.arctan2(poses[v][0, 3], poses[v][2, 3])))
+            self.views.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), az))
+        self.phase_step = {}
+        self.phase = None
+
+    def use_synthetic_prior(self):
+        from sdfx_nerf import guidance as G
+        self.prior = G.synthetic_prior(self.dev, self.opt.fp16)
+        self.guidance_kind = "synthetic"
+
+    def build(self, mode=None):
+        from sdfx_nerf.trainer import TrainStep
+        self.step_obj = TrainStep(self.opt, self.model, self.prior, self.dev, seed=self.seed, mode=mode)
+        self.step_obj.graph_prime_span = 1.25   # several (phase, background) kinds: prime fewer neighbours per miss
+        if self.args.grid == "trained-proxy":    # start from a trained-scene-like occupancy instead of the empty grid
+            import synth
+            dens = np.unpackbits(synth.s_grid_blobs(), bitorder="little").astype(np.float32) * 20.0
+            self.model.density_grid.copy_(torch.from_numpy(dens).view(1, -1).to(self.dev))
+        self.phase_step = {"latent": 0, "rgb": int(self.opt.iters * self.opt.latent_iter_ratio) + 1}
+        self.phase = None
+        self.set_phase("latent" if self.args.phase != "rgb" else "rgb")
+
+    @property
+    def train_mode(self):
+        return self.step_obj.mode
+
+    def set_phase(self, phase):
+        """Continue `phase` where it stopped: the schedule (shading, as_latent, backgrounds) is a function of global_step."""
+        st = self.step_obj
+        if self.phase is not None:
+            self.phase_step[self.phase] = st.global_step
+        self.phase = phase
+        st.global_step = self.phase_step[phase]   # (a count prefetched for the other phase's next step no longer matches: recounted)
+
+    def step(self, i):
+        ro, rd, az = self.views[rank_view(self.rank, i, len(self.views))]
+        nxt = self.views[rank_view(self.rank, i + 1, len(self.views))]      # what a data loader knows: the next camera's rays
+        self.step_obj.step(ro, rd, azimuth=az, next_rays=(nxt[0], nxt[1]))
+        return self.step_obj.last["num_samples"]
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def applied(self):
+        return self.step_obj.applied_steps()
+
+    def calibrate(self):
+        """GradScaler calibration, untimed: torch's GradScaler starts at 2^16 and SKIPS the optimiser step while the fp16
+        backward overflows (what the reference's first iterations do, nerf/utils.py:1050). Timing those iterations would
+        time a loop without its optimiser step, so iterate until the scale has settled."""
+        n = 0
+        while n < 64:
+            before = self.applied()
+            self.step(n)
+            n += 1
+            if self.applied() > before and n >= 2:
+                break
+        return n
+
+    def prime(self, phase):
+        """Run `phase` over the camera set until a whole pass needed no capture and no eager iteration (graph mode): every
+        (capacity, background kind) this phase meets has its graph. Bounded: 4 passes."""
+        self.set_phase(phase)
+        st = self.step_obj
+        for _ in range(4):
+            before = (st.stats["captures"], st.stats["eager"])
+            for v in range(len(self.views)):
+                self.step(v)
+            if st.mode != "graph" or (st.stats["captures"], st.stats["eager"]) == before:
+                break
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.dry_run_cpu
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used for barriers + one reduction only
-
-    importlib.import_module("stable-dreamfusion_amd")
-    import synth
-    from sdfx_nerf.network_grid import NeRFNetwork
-    from sdfx_nerf.options import default_opt
-    from sdfx_nerf.trainer import TrainStep
-    from sdfx_nerf import guidance as G
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used for barriers + two small reductions only
 
     timer = KernelTimer()
-    install_timers(timer)
-
-    # independent prompt/seed per rank
-    seed = rank_seed(rank)
-    torch.manual_seed(seed)
-    np.random.seed(seed)
-    opt = default_opt()
-    model = NeRFNetwork(opt).to(dev)
-    guidance_kind = args.guidance
-    prior = None
-    if guidance_kind in ("auto", "sd15_random"):
-        try:
-            from sdfx_nerf.sd15_arch import sd15_random_prior
-            prior = sd15_random_prior(dev, opt.fp16)
-            # one call of the SDS glue through the big network before anything depends on it (MIOpen's solver search for
-            # its 36 convolution shapes happens here, a few seconds); any failure falls back to the synthetic prior
-            with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
-                z = torch.cat([prior.get_text_embeds(["uncond"]), prior.get_text_embeds(["front"])])
-                probe = prior.train_step(z, torch.rand(1, 4, 64, 64, device=dev), as_latent=True)
-            if not bool(torch.isfinite(probe)):
-                raise RuntimeError("non-finite SDS loss from the SD-1.5-architecture prior")
-            del z, probe
-            guidance_kind = "sd15_random"
-        except Exception as exc:  # noqa: BLE001
-            if args.guidance == "sd15_random":
-                raise
-            prior = None
-            if rank == 0:
-                print(f"[bench] SD-1.5-architecture prior unavailable ({type(exc).__name__}: {exc}); synthetic prior",
-                      file=sys.stderr)
-    if dist is not None:   # every rank must time the same configuration (and take the same barriers)
-        ok = torch.tensor([0 if prior is None else 1], device=dev, dtype=torch.int32)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            prior = None
-    if prior is None:
-        prior = G.synthetic_prior(dev, opt.fp16)
-        guidance_kind = "synthetic"
-    step = TrainStep(opt, model, prior, dev, seed=seed)
-    if args.phase == "rgb":
-        step.global_step = int(opt.iters * opt.latent_iter_ratio) + 1   # first iteration after the latent warm-up phase
-        step.graph_prime_span = 1.15   # four (shading, background) kinds instead of one: prime fewer neighbours per miss
-    # skip the as_latent warm-start phase of the schedule? No: global_step advances as in training, and the
-    # first 20 % of a 10k-iteration run uses 'normal' shading + as_latent (nerf/utils.py:503-507).
-    if args.grid == "trained-proxy":
-        # start from a trained-scene-like occupancy (S-grid-blobs density) instead of the empty grid
-        bf = synth.s_grid_blobs()
-        dens = np.unpackbits(bf, bitorder="little").astype(np.float32) * 20.0
-        model.density_grid.copy_(torch.from_numpy(dens).view(1, -1).to(dev))
-
-    poses, fovy = synth.reference_cameras()
-    views = []
-    for v in range(len(poses)):
-        o, d = synth.get_rays(poses[v], float(fovy[v]))
-        az = float(np.degrees(np.arctan2(poses[v][0, 3], poses[v][2, 3])))
-        views.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), az))
-
-    verbose = os.environ.get("SDFX_BENCH_TRACE") == "2"   # diagnosis only: loss scale / overflow flag of every iteration
-
-    def one_step(i):
-        ro, rd, az = views[rank_view(rank, i, len(views))]
-        nxt = views[rank_view(rank, i + 1, len(views))]      # what a data loader knows: the next camera's rays
-        out = step.step(ro, rd, azimuth=az, next_rays=(nxt[0], nxt[1]))
-        if verbose and step.mode != "reference":
-            c = step.optimizer.ctl.tolist()
-            print(f"[it {step.global_step}] view={rank_view(rank, i, len(views))} S={c[0]:g} skip={int(c[5])} norm={c[9]:.3g} "
-                  f"loss={float(out):.3g} M={step.last['num_samples']} {step.stats}", file=sys.stderr)
-            if int(c[5]) and step.mode == "graph" and getattr(step, "last_key", None) in step.graphs and step.global_step > 20:
-                grads = step.graphs[step.last_key][4]
-                names = [n for n, _ in model.named_parameters()]
-                bad = [(names[k] if k < len(names) else k, int(torch.isnan(g).sum()), int(torch.isinf(g).sum()), g.numel())
-                       for k, g in enumerate(grads) if g is not None and not bool(torch.isfinite(g).all())]
-                print(f"      key={step.last_key[:2]} non-finite grads (name, nan, inf, numel): {bad}", file=sys.stderr)
-                g = grads[0]
-                if g is not None and g.dim() == 2 and not bool(torch.isfinite(g).all()):
-                    offs = model.encoder.offsets.tolist()
-                    rows = (~torch.isfinite(g)).any(1).nonzero().flatten()
-                    per = [int(((rows >= offs[l]) & (rows < offs[l + 1])).sum()) for l in range(16)]
-                    fin = g[torch.isfinite(g).all(1)]
-                    print(f"      bad rows per level: {per}; finite |g| max {float(fin.abs().max()):.3g}; first bad rows {rows[:6].tolist()} "
-                          f"values {g[rows[:3]].tolist()}", file=sys.stderr)
-        return out
-
-    # GradScaler calibration, untimed and before the warmup: torch's GradScaler starts at 2^16 and SKIPS the optimiser
-    # step while the fp16 backward overflows (exactly what the reference's first iterations do, nerf/utils.py:1050).
-    # Timing those iterations would time a loop without its optimiser step, so iterate until the scale has settled.
-    def applied():
-        return step.applied_steps()
-
-    calib = 0
-    while calib < 64:
-        before = applied()
-        one_step(calib)
-        calib += 1
-        if applied() > before and calib >= 2:
-            break
-    if step.mode == "graph":
-        # one pass over the camera set, so that the sample-count buckets these views need have their graphs
-        # (a bucket met for the first time costs one eager iteration plus a capture)
-        for v in range(len(views)):
-            one_step(v)
-            calib += 1
+    job = (DryJob if dry else GpuJob)(args, rank, world, dev)
+    if not dry:
+        install_timers(timer)
+    if not agree(job.prior_ok, dist, dev):      # one rank without the big prior: nobody uses it
+        job.use_synthetic_prior()
+    job.build()
+    calib = job.calibrate()
+    plan = phase_plan(args.phase, args.steps)
+    for name, _ in plan:
+        job.prime(name)
+    job.set_phase(plan[0][0])
     for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    applied_before = applied()
+        job.step(i)
+    job.sync()
+    applied_before = job.applied()
+
+    # ---- the timed region: EXACTLY args.steps steps between two barrier + synchronize pairs ----
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    job.sync()
     timer.enabled = True
-    samples = 0
+    samples, marks = 0, []
     t0 = time.perf_counter()
-    trace = os.environ.get("SDFX_BENCH_TRACE") == "1"   # diagnosis only: synchronises every iteration
-    for i in range(args.steps):
-        if trace:
-            torch.cuda.synchronize()
-            ts0 = time.perf_counter()
-        one_step(args.warmup + i)
-        samples += step.last["num_samples"]
-        if trace:
-            torch.cuda.synchronize()
-            print(f"[trace] step {i}: {(time.perf_counter() - ts0) * 1e3:.2f} ms  M={step.last['num_samples']} {step.stats}",
-                  file=sys.stderr)
-    torch.cuda.synchronize()
+    i = args.warmup
+    for name, k in plan:
+        job.set_phase(name)
+        for _ in range(k):
+            samples += job.step(i)
+            i += 1
+        if len(plan) > 1:
+            job.sync()                             # phase boundary: one device synchronisation inside the region
+        marks.append((name, k, time.perf_counter()))
+    job.sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    job.sync()
+    elapsed_local = time.perf_counter() - t0
     timer.enabled = False
-    applied_in_timed = applied() - applied_before
-    stats_timed = dict(step.stats)
+    applied_in_timed = job.applied() - applied_before
+    elapsed = job_elapsed(elapsed_local, dist, dev)
+    phases, prev = {}, t0
+    for name, k, t in marks:
+        dt = job_elapsed(t - prev, dist, dev)
+        phases[name] = {"steps": k, "iters_per_sec": job_throughput(world, k, dt), "ms_per_step": dt / k * 1e3}
+        prev = t
+    result = {
+        "metric": "sds_iters_per_sec", "value": job_throughput(world, args.steps, elapsed), "unit": "iters/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16 table/features, f32 coordinates+compositing", "data": "synthetic",
+        "phases": phases, "rays_per_s": world * args.steps * 4096 / elapsed, "samples_per_iter": samples / max(args.steps, 1),
+        "optimizer_steps_applied": applied_in_timed, "scaler_calibration_iters": calib, "train_mode": job.train_mode,
+    }
+    if dry:
+        result["config"] = {"workload": "dry run of the control path (no GPU work)", "parallelism": f"independent-prompts x{world}",
+                            "guidance": job.guidance_kind}
+        result["dry_run"] = True
+        if rank == 0:
+            print(json.dumps(result))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    step = job.step_obj
+    result["grad_scale"] = step.get_scale()
+    result["graph_stats"] = dict(step.stats)
     roofline_pass = "timed region"
     if step.mode == "graph":
-        # Launches inside a replayed HIP graph do not pass through Python, so the per-kernel HIP events are taken
-        # in a second, untimed pass over the next iterations of the same run with the graph switched off (same
-        # kernels, same launch sizes up to the capacity padding). rocprofv3 sees the replayed kernels directly:
-        # profiles/ holds that trace for comparison.
+        # Launches inside a replayed HIP graph do not pass through Python, so the per-kernel HIP events are taken in a
+        # second, untimed pass over the next iterations of the same run with the graph switched off (same kernels, same
+        # launch sizes up to the capacity padding). rocprofv3 sees the replayed kernels directly: profiles/ holds that
+        # trace of this command for comparison (tools/gpu_profile_round.sh).
         step.mode = "device"
         timer.enabled = True
-        for i in range(min(args.steps, 8)):
-            one_step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
+        n_eager = min(args.steps, 8)
+        for j in range(n_eager):
+            job.step(i + j)
+        job.sync()
         timer.enabled = False
         step.mode = "graph"
-        roofline_pass = f"{min(args.steps, 8)} eager iterations after the timed region (graph replay hides launches from Python)"
-    elapsed = job_elapsed(elapsed, dist, dev)
+        roofline_pass = f"{n_eager} eager iterations after the timed region (graph replay hides launches from Python)"
 
-    # second figure, same run: the iteration without the frozen prior's UNet (the part of it this repository implements)
-    nerf_only = None
-    if guidance_kind == "sd15_random" and not args.no_nerf_only:
-        prior.unet.skip_unet = True
-        step.graphs.clear(); step.graph_uses.clear(); step._warm.clear()
-        for v in range(len(views) + 2):
-            one_step(v)
-        torch.cuda.synchronize()
+    def timed_pass():
+        """The same phase mix once more, barrier-bracketed, for the secondary figures."""
+        job.sync()
         if dist is not None:
             dist.barrier()
         t1 = time.perf_counter()
-        for i in range(args.steps):
-            one_step(args.warmup + i)
-        torch.cuda.synchronize()
+        j = args.warmup
+        for name, k in plan:
+            job.set_phase(name)
+            for _ in range(k):
+                job.step(j)
+                j += 1
+        job.sync()
         if dist is not None:
             dist.barrier()
-        nerf_only = job_throughput(world, args.steps, job_elapsed(time.perf_counter() - t1, dist, dev))
-        prior.unet.skip_unet = False
+        return job_throughput(world, args.steps, job_elapsed(time.perf_counter() - t1, dist, dev))
+
+    # second figure, same run: the iteration without the frozen prior's UNet (the part of it this repository implements)
+    nerf_only = None
+    if job.guidance_kind == "sd15_random" and not args.no_nerf_only:
+        job.prior.unet.skip_unet = True
+        step.graphs.clear(); step.graph_uses.clear(); step._warm.clear()
+        for name, _ in plan:
+            job.prime(name)
+        nerf_only = timed_pass()
+        job.prior.unet.skip_unet = False
+        step.graphs.clear(); step.graph_uses.clear(); step._warm.clear()
+    # third figure: the reference's host flow (torch.amp.GradScaler + foreach Adan, no device-side tail, no graph replay,
+    # nerf/utils.py:1032-1072) on the same kernels — what an unchanged main.py gets from the drop-in operators
+    ref_flow = None
+    if not args.no_reference_flow:
+        graph_step = job.step_obj
+        job.build(mode="reference")
+        job.calibrate()
+        ref_flow = timed_pass()
+        job.step_obj = graph_step
+    result["iters_per_sec_without_unet"] = nerf_only
+    result["iters_per_sec_reference_flow"] = ref_flow
 
     if rank != 0:
         if dist is not None:
@@ -484,44 +673,34 @@ def main():
         return
 
     ksum = timer.summary()
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the number comes
-    # from the committed summary of `tools/gpu_profile_round.sh` over this same command (FETCH_SIZE doubled: on
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the number comes from the
+    # committed summary of `tools/gpu_profile_round.sh` over this same command, taken this round (FETCH_SIZE doubled: on
     # gfx950 it tallies 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM"); null when the file is absent.
-    traffic = None
+    traffic, traffic_file = None, "profiles/r02_pmc_traffic.json"
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")) as f:
-            pm = json.load(f)["k_grid_forward"]
+        with open(os.path.join(ROOT, traffic_file)) as f:
+            pm = json.load(f)["k_grid_fwd"]
         traffic = (2.0 * pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]) * 1024.0
     except (OSError, KeyError, ValueError):
         pass
     enc = ksum.get("grid_encode_forward", {"GBps": 0.0, "avg_us": 0.0, "launches": 0, "bytes": 0})
-    iters_per_s = job_throughput(world, args.steps, elapsed)
-    result = {
-        "metric": "sds_iters_per_sec", "value": iters_per_s, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f16 table/features, f32 coordinates+compositing", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: Instant-NGP -O iteration, 4096 rays (64x64), 128^3 occupancy grid, "
-                               "<=1024 steps/ray, 16-level hash grid (2^19 x 2 fp16), 7 field evals/sample, SDS loss, AMP "
-                               "backward, Adan step, grid refresh every 16 iters",
-                   "guidance": guidance_kind + (" (SD-1.5 UNet + VAE-encoder architecture, 860 M + 34 M parameters, random weights, evaluated in full; its damped output is added to the consistent stand-in; diffusers/hub weights absent)"
-                                                if guidance_kind == "sd15_random" else
-                                                " (consistent-denoiser stand-in for the frozen prior; diffusers/hub weights absent)"),
-                   "rays_per_iter": 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid,
-                   "phase": args.phase},
-        "rays_per_s": world * args.steps * 4096 / elapsed,
-        "samples_per_iter": samples / max(args.steps, 1),
-        "iters_per_sec_without_unet": nerf_only,
-        "optimizer_steps_applied": applied_in_timed, "scaler_calibration_iters": calib,
-        "grad_scale": step.get_scale(), "train_mode": step.mode, "graph_stats": stats_timed,
-        "roofline": {"bound": "hbm", "kernel": "k_grid_forward<3,2,half>", "achieved": enc["GBps"], "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": enc["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_unit": "bytes per launch (profiles/r01_v5_pmc_traffic.json)",
-                     "algorithmic_bytes_per_launch": (enc["bytes"] / enc["launches"]) if enc.get("launches") else None,
-                     "avg_launch_us": enc["avg_us"], "launches": enc["launches"], "measured_in": roofline_pass,
-                     "algorithmic_bytes_per_point": 588},
-        "kernels_in_step": {k: {"GBps": round(v["GBps"], 1), "avg_us": round(v["avg_us"], 1), "launches": v["launches"]}
-                            for k, v in ksum.items()},
-    }
+    result["config"] = {
+        "workload": "BASELINE configs[1]: Instant-NGP -O iteration, 4096 rays (64x64), 128^3 occupancy grid, <=1024 steps/ray, "
+                    "16-level hash grid (2^19 x 2 fp16), 7 field evals/sample, SDS loss, AMP backward, Adan step, grid refresh "
+                    "every 16 iters; timed steps = " + " + ".join(f"{k} {n}" for n, k in plan),
+        "guidance": job.guidance_kind + (" (SD-1.5 UNet + VAE-encoder architecture, 860 M + 34 M parameters, random weights, evaluated in full; "
+                                         "its damped output is added to the consistent stand-in; diffusers/hub weights absent)"
+                                         if job.guidance_kind == "sd15_random" else
+                                         " (consistent-denoiser stand-in for the frozen prior; diffusers/hub weights absent)"),
+        "rays_per_iter": 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid, "phase": args.phase}
+    result["roofline"] = {
+        "bound": "hbm", "kernel": "k_grid_fwd<half> (7-point stencil batches of the iteration)", "achieved": enc["GBps"],
+        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": enc["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
+        "traffic_unit": f"bytes per launch ({traffic_file})",
+        "algorithmic_bytes_per_launch": (enc["bytes"] / enc["launches"]) if enc.get("launches") else None,
+        "avg_launch_us": enc["avg_us"], "launches": enc["launches"], "measured_in": roofline_pass, "algorithmic_bytes_per_point": 588}
+    result["kernels_in_step"] = {k: {"GBps": round(v["GBps"], 1), "avg_us": round(v["avg_us"], 1), "launches": v["launches"]}
+                                 for k, v in ksum.items()}
     if not args.no_kernel_bench:
         try:
             kb = kernel_microbench(dev)
@@ -531,14 +710,19 @@ def main():
             result["kernels_standalone"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            cb = cpu_baseline(args.cpu_rays)
-            result["cpu_baseline"] = {"value": cb["iters_per_s"], "unit": "iters/s", "cores": 1, "kind": "port",
-                                      "sample": f"{cb['rays']} of 4096 rays ({cb['samples']} samples) of S-rays view 0 through "
-                                                f"S-grid-init, one fwd+bwd iteration of the CPU oracle (C, -O2, no FMA), "
-                                                f"{cb['seconds']:.1f} s; rays/s = {cb['rays_per_s']:.1f}; "
-                                                f"host cpus = {os.cpu_count()}"}
+            cb = cpu_baseline()
+            lam = cb["shadings"]["lambertian"]
+            result["cpu_baseline"] = {
+                "value": 1.0 / lam["s_per_iter_median"], "unit": "iters/s", "cores": cb["cores"],
+                "kind": cb["kind"] + " -O2",
+                "sample": f"the reference's -O2 vanilla-NeRF path ({'its own code, /root/reference' if cb['kind'] == 'reference' else 'oracle/o2_path.py, pinned to it by tests/golden/o2_ref.npz'}): "
+                          f"4096 rays x (64 + 32) samples, render + backward with a dummy SDS gradient, fp32, "
+                          f"torch threads = {cb['cores']} (os.cpu_count() = {cb['os_cpu_count']}, {cb['cpu_model']}); value = 'lambertian' "
+                          f"shading (autograd normals, as 80 % of a run): median of {lam['iters']} iterations {lam['s_per_iter_median']:.2f} s; "
+                          f"'albedo': {cb['shadings']['albedo']['s_per_iter_median']:.2f} s; {cb['seconds']:.0f} s of CPU work in total",
+                "rays_per_s": {k: round(v["rays_per_s"], 1) for k, v in cb["shadings"].items()}}
         except Exception as exc:  # noqa: BLE001
-            result["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 1, "kind": "port",
+            result["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port -O2",
                                       "sample": f"failed: {type(exc).__name__}: {exc}"}
     print(json.dumps(result))
     if dist is not None:

@@ -132,20 +132,16 @@ uint64_t sdfx_compact_rays_scratch_bytes(uint32_t n);
 /* ------------------------------------------------------------------------- gridencoder */
 
 /* testing / measurement aid: switches of the D = 3, C = 2 forward (csrc/gridencoder_fwd.hip); -1 = default / environment.
- *   fwd_impl            0 = generic kernel (any D, C), 1 = k_grid_fwd where it applies (default; env SDFX_GRID_FWD)
- *   pairs               1 = a gather-bound fine level shares its workgroup range with a small dense level, alternating
- *                       (default), 0 = every level on its own (env SDFX_GRID_PAIRS)
- *   points_per_thread   1, 2 (default) or 4 (env SDFX_GRID_POINTS)
- *   balance             1 = cut the level sequence into 8 per-XCD ranges of equal modelled COST (default; needs a step hint),
- *                       0 = equal tile counts (env SDFX_GRID_BALANCE)
+ *   fwd_impl   0 = generic kernel (any D, C) always, 1 = k_grid_fwd for hinted batches (default; env SDFX_GRID_FWD)
+ *   balance    1 = cut the level sequence into 8 per-XCD ranges of equal modelled COST (default; needs a step hint),
+ *              0 = equal tile counts (env SDFX_GRID_BALANCE)
  * Results are identical for every setting. */
-void sdfx_grid_set_impl(int fwd_impl, int pairs, int points_per_thread, int balance);
+void sdfx_grid_set_impl(int fwd_impl, int balance);
 
-/* Host-only (no GPU work): the per-XCD work list sdfx_grid_encode_forward_hint would use for these arguments, 5 integers per
- * segment (xcd, level_a, level_b or -1 for a single level, first tile column, columns). A pair segment alternates workgroups
- * of level_a and level_b over the same columns. Returns the number of segments, < 0 on error. */
+/* Host-only (no GPU work): the per-XCD work list sdfx_grid_encode_forward_hint would use for these arguments, 4 integers per
+ * segment (xcd, level, first tile, tiles); an XCD walks its segments in order. Returns the number of segments, < 0 on error. */
 int sdfx_grid_forward_plan(const int32_t* offsets_host, uint32_t max_level, float S, uint32_t H, int is_half, uint32_t B,
-                           uint32_t slabs, float step, int32_t* segments, uint32_t max_segments, uint32_t* columns_per_level);
+                           uint32_t slabs, float step, int32_t* segments, uint32_t max_segments, uint32_t* tiles_per_level);
 
 /*
  * gridencoder.cu:467-490 grid_encode_forward.
@@ -288,6 +284,31 @@ int sdfx_shade_backward(const float* sigma7, const float* albedo, const float* d
                         const float* light_offset, const float* ratio, int mode, float epsilon, uint32_t capacity,
                         uint32_t n_rays, const int32_t* total, const float* dcolor, const float* dnormal, const float* dorient,
                         float* dsigma7, float* dalbedo, sdfx_stream_t stream);
+
+/*
+ * Extension — shading + compositing + regulariser sums of a training iteration in one kernel each way (csrc/render.hip):
+ * sdfx_shade_forward -> sdfx_composite_rays_train_forward -> sdfx_entropy_forward and the orientation term of
+ * nerf/renderer.py:744-746, with the same arithmetic (csrc/shade_math.h; raymarching.cu:500-706), one wavefront per ray.
+ *   sigma7 [7, capacity] densities at x, x+e_x, x-e_x, x+e_y, x-e_y, x+e_z, x-e_z; albedo [capacity, 3] at x; dirs [capacity, 3]
+ *   un-normalised; ts [capacity, 2]; rays [n_rays, 2] (offset, count); rays_o [n_rays, 3]; light_offset [3]; ratio: device
+ *   scalar; mode_dev: device scalar holding 1 / 2 / 3 as a float (lambertian / textureless / normal) or NULL -> `mode`;
+ *   total [1]: number of valid rows (rows in [total, capacity) are padding: zero weight, zero gradient).
+ *   forward out: weights [capacity], weights_sum / depth [n_rays], image [n_rays, 3],
+ *                ray_sums [n_rays, 2] = (sum_i H(clamp(w_i, 1e-5, 1 - 1e-5)) in bits, sum_i w_i clamp(n_i . d_i, 0)^2) over the ray's samples.
+ *   backward in: the forward's weights_sum / depth / image and the gradients of weights_sum, depth (NULL = 0), image and
+ *                ray_sums (NULL = 0); out: dsigma7 [7, capacity], dalbedo [capacity, 3] (every row written).
+ */
+int sdfx_render_train_forward(const float* sigma7, const float* albedo, const float* dirs, const float* ts, const int32_t* rays,
+                              const float* rays_o, const float* light_offset, const float* ratio, const float* mode_dev,
+                              int mode, float epsilon, float T_thresh, uint32_t capacity, uint32_t n_rays, const int32_t* total,
+                              float* weights, float* weights_sum, float* depth, float* image, float* ray_sums,
+                              sdfx_stream_t stream);
+int sdfx_render_train_backward(const float* sigma7, const float* albedo, const float* dirs, const float* ts, const int32_t* rays,
+                               const float* rays_o, const float* light_offset, const float* ratio, const float* mode_dev,
+                               int mode, float epsilon, float T_thresh, uint32_t capacity, uint32_t n_rays, const int32_t* total,
+                               const float* weights_sum, const float* depth, const float* image, const float* grad_weights_sum,
+                               const float* grad_depth, const float* grad_image, const float* grad_ray_sums, float* dsigma7,
+                               float* dalbedo, sdfx_stream_t stream);
 
 /*
  * Extension — the entropy regulariser of Trainer.train_step (nerf/utils.py:571-575) on the compositing weights:

@@ -56,14 +56,19 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C_, L, max_l
 _BINNED = int(os.environ.get("SDFX_GRID_BWD_BINNED", "1"))
 _BINNED_CHUNK_POINTS = int(os.environ.get("SDFX_GRID_BWD_CHUNK", str(1 << 22)))
 _BINNED_SCRATCH = {}   # device index -> list of buffers, the last one is the current (largest) one
+_BINNED_BYTES = {}     # (level layout, ...) -> scratch bytes
 
 
 def _binned_scratch(device, offsets, L, max_level, S_, H, is_half):
     """Persistent scratch of the binned scatter: ONE buffer per device, sized for the largest request seen. It is plain
     bytes (every launch re-initialises what it uses), so encoders and dtypes share it. Buffers are never freed: a
     captured HIP graph has the address baked in, so an outgrown buffer stays alive beside its replacement."""
-    nbytes = int(S.lib().sdfx_grid_encode_backward_binned_scratch_bytes(offsets_host(offsets), L, max_level, float(S_), H,
-                                                                       _BINNED_CHUNK_POINTS, is_half))
+    host = offsets_host(offsets)
+    key = (tuple(host), L, max_level, float(S_), H, is_half)     # the size depends on the level layout only (17 ints: cheap to hash)
+    nbytes = _BINNED_BYTES.get(key)
+    if nbytes is None:
+        nbytes = _BINNED_BYTES[key] = int(S.lib().sdfx_grid_encode_backward_binned_scratch_bytes(host, L, max_level, float(S_), H,
+                                                                                                _BINNED_CHUNK_POINTS, is_half))
     if nbytes <= 0:
         return None
     bufs = _BINNED_SCRATCH.setdefault(device.index, [])

@@ -61,10 +61,14 @@ _SIGNATURES = {
     "sdfx_shade_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _f32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_shade_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _f32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                             _ptr],
+    "sdfx_render_train_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _f32, _f32, _u32, _u32, _ptr,
+                                  _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_render_train_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _f32, _f32, _u32, _u32, _ptr,
+                                   _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_entropy_forward": [_ptr, _u32, _ptr, _ptr, _ptr],
     "sdfx_entropy_backward": [_ptr, _u32, _ptr, _ptr, _ptr, _ptr],
     "sdfx_march_set_impl": [_int],
-    "sdfx_grid_set_impl": [_int, _int, _int, _int],
+    "sdfx_grid_set_impl": [_int, _int],
     "sdfx_grid_forward_plan": [_ptr, _u32, _f32, _u32, _int, _u32, _u32, _f32, _ptr, _u32, _ptr],
     "sdfx_adan_ctl_words": [],
     "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],

@@ -80,7 +80,7 @@ __device__ __forceinline__ bool plan_item(const GridPlan& p, uint32_t& level, ui
 
 // ---- forward of the hot-path configuration (gridencoder_fwd.hip) ----
 bool fast_forward_enabled();
-void launch_forward_d3c2(const float* inputs, const void* table, const int32_t* offsets_host, void* outputs, uint32_t B,
+bool launch_forward_d3c2(const float* inputs, const void* table, const int32_t* offsets_host, void* outputs, uint32_t B,
                          uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
                          uint32_t interp, int is_half, int out_layout, uint32_t slabs, float step, hipStream_t st);
 

@@ -459,9 +459,11 @@ int sdfx_grid_encode_forward_hint(const float* inputs, const void* embeddings, c
     SDFX_REQUIRE(aligned_for(embeddings, C, eb) && aligned_for(outputs, C, eb) && (!dy_dx || aligned_for(dy_dx, C, eb)),
                  "grid_encode_forward: embeddings/outputs/dy_dx must be aligned to min(16, C*sizeof(elem)) bytes");
     if (B == 0) return SDFX_OK;
-    if (D == 3 && C == 2 && !dy_dx && fast_forward_enabled()) {
+    // the D = 3, C = 2 kernel (gridencoder_fwd.hip) where the caller described its batch (a step hint); a batch without a
+    // hint (e.g. the 2^21 jittered cell centres of the occupancy refresh) keeps k_grid_forward, which is 6 % faster there
+    if (D == 3 && C == 2 && !dy_dx && fast_forward_enabled() && (step > 0.f || slabs > 1) &&
         launch_forward_d3c2(inputs, embeddings, offsets_host, outputs, B, L, max_level, S, H, gridtype, align_corners, interp,
-                            is_half, out_layout, slabs, step, as_stream(stream));
+                            is_half, out_layout, slabs, step, as_stream(stream))) {
         return check_launch("grid_encode_forward");
     }
     FwdArgs a;

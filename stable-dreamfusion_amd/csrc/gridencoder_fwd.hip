@@ -13,20 +13,20 @@
 //     says the batch is `slabs` = 7 slabs of B/7 points. x +- e land in the same 128-byte line as x at every level (the
 //     x prime of the spatial hash is 1) and the other four share the coarse cells: -30 % lines on ray-ordered samples
 //     (1657 instead of 2353 per 64 points over the 16 levels). Only the lane -> point map changes; layouts do not.
-//   * one big table per XCD at a time, the same load on every XCD: a hashed level is a 2 MiB fp16 table and an XCD's
-//     L2 is 4 MiB, shared with the streamed coordinates and features — two hashed levels in flight on one XCD thrash it
-//     (measured: walking a fine and a 2 MiB coarse level alternately costs +20 %; fp32 tables, 4 MiB a level: +50 %).
-//     So the levels form a SEQUENCE OF UNITS that every XCD walks in order, one unit at a time: a unit is either one
-//     level, or a fine level paired with one of the small dense levels (20 KB ... 0.8 MB), whose tiles alternate so that
-//     the gather-bound fine waves and the VALU-bound coarse waves overlap on every CU. The sequence is cut into 8
-//     ranges of equal COST (not equal tile count): cost per wave = max(distinct lines x 2.4 cycles, VALU cycles), lines
-//     from a model of ray-ordered samples (lines_per_wave) evaluated at the caller's step hint; without a hint every
-//     level costs the same and the split is the even one.
+//   * one level per XCD at a time, the same load on every XCD: a hashed level is a 2 MiB fp16 table, an XCD's L2 is 4 MiB
+//     and is shared with the streamed coordinates and features. Measured on ray-ordered stencil batches (B = 1.8 M):
+//     an XCD walking two levels with alternating tiles is 15-20 % slower than walking them one after the other, even when
+//     the second table is 20 KB (the gather-bound fine waves hold the wave slots the latency-bound coarse waves need);
+//     fp32 tables (4 MiB a level) +50 %. So the levels form ONE SEQUENCE that is cut into 8 per-XCD ranges of equal
+//     modelled COST (not equal tile count), each XCD walking its range in order: cost per wave =
+//     max(distinct lines, VALU time in line units), lines from a model of ray-ordered samples (lines_per_wave) at the
+//     caller's step hint. A level then costs 267 lines per wave at the fine end and 97 at the coarse end, and the even
+//     two-levels-per-XCD split (275 vs 133 lines) becomes 8 equal shares: 335 -> 287 us. Without a hint every level
+//     costs the same and the split is the even one.
 //   * VALU off the critical path: level constants in scalar registers from one 32-byte record, hash / stride terms shared
 //     by the x-pair, packed half arithmetic (v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f16: bit-identical to at::Half's
-//     round-after-every-operation, see Acc2), fine and coarse tiles alternating on every CU so gather-bound and
-//     VALU-bound waves overlap, and P points per thread so the launch / scalar-load prologue is paid once per P tiles and
-//     4 P gathers are in flight per lane.
+//     round-after-every-operation, see Acc2), and all gathers of a lane issued before the first result is touched
+//     (more points per thread were measured slower: 2 -> -2 %, 4 -> -10 %).
 #include "grid_common.h"
 
 #include <math.h>
@@ -40,20 +40,17 @@ using namespace sdfx::grid;
 namespace {
 
 constexpr uint32_t kMaxSegs = 6;       // per XCD
-constexpr uint32_t kNoLevel = 0xffffffffu;
 constexpr uint32_t kGroup = 7;         // points per stencil
 constexpr uint32_t kGroupsPerWave = 9; // 9 x 7 = 63 lanes
 
 struct LevelConst {   // 32 bytes, one s_load_dwordx8
     uint32_t res, row0, size, m1, m2, flags, pad0, pad1;   // flags: 1 = hashed, 2 = size is a power of two
 };
-// tile columns [first, first + count) of level_a — and of level_b when it is a pair: the workgroups of a pair segment
-// alternate a, b, a, b ... over the same columns
-struct Seg { uint32_t level_a, level_b, first, count; };
+struct Seg { uint32_t level, first, count, pad; };   // tiles [first, first + count) of `level`
 struct FwdPlan {
     LevelConst lv[kMaxLevels];
     Seg seg[kXcds][kMaxSegs];
-    uint32_t ntiles[kXcds];   // workgroups of each XCD (sum over its segments of count x (pair ? 2 : 1))
+    uint32_t ntiles[kXcds];   // workgroups of each XCD (sum of its segments)
     uint32_t vec16;           // table base 16-byte aligned: paired gathers allowed
     uint32_t slabs;           // 1, or 7 = stencil batch [7, B/7, 3] evaluated with the 7 points of a sample in neighbouring lanes
     uint32_t slab_points;     // B / slabs
@@ -108,19 +105,13 @@ __device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint
 #pragma unroll
     for (uint32_t s = 0; s < kMaxSegs; s++) {
         const Seg sg = p.seg[xcd][s];
-        const bool pair = sg.level_b != kNoLevel;
-        const uint32_t n = pair ? 2u * sg.count : sg.count;
-        if (local < n) {
-            level = (pair && (local & 1u)) ? sg.level_b : sg.level_a;
-            tile = sg.first + (pair ? (local >> 1) : local);
-            return true;
-        }
-        local -= n;
+        if (local < sg.count) { level = sg.level; tile = sg.first + local; return true; }
+        local -= sg.count;
     }
     return false;
 }
 
-template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, uint32_t P>
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
 __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ inputs,
                                                      const typename Elem<HALF>::type* __restrict__ table,
                                                      typename Elem<HALF>::type* __restrict__ outputs, uint32_t B, uint32_t L,
@@ -129,6 +120,7 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
     constexpr uint32_t C = 2;
     constexpr uint32_t RB = HALF ? 4u : 2u;   // rows per 16-byte block
     using RowT = typename std::conditional<HALF, uint32_t, uint2>::type;
+    constexpr uint32_t P = 1;   // points per thread (the loops below are written for any P; 2 and 4 were measured slower)
     uint32_t level, tile;
     if (!fwd_item(plan, level, tile)) return;
 
@@ -292,16 +284,14 @@ double lines_per_wave(double u, bool stencil) {
     return c[15];
 }
 
-constexpr uint32_t kBigTable = 1u << 20;   // bytes: a level this large wants the XCD's L2 for itself
-
-struct Unit { uint32_t a, b; double cost; };   // levels (b = kNoLevel: single) and cost per tile column
+struct Unit { uint32_t level; double cost; };   // cost per tile
 
 FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uint32_t H, uint32_t elem_bytes, uint32_t B,
-                      uint32_t slabs, float step, uint32_t P, bool balance, bool pairs, double valu_lines) {
+                      uint32_t slabs, float step, bool balance, double valu_lines) {
+    constexpr uint32_t P = 1;
     FwdPlan p;
     memset(&p, 0, sizeof(p));
     double lines[kMaxLevels];
-    uint32_t bytes[kMaxLevels];
     for (uint32_t l = 0; l < levels; l++) {
         LevelConst& c = p.lv[l];
         c.res = level_resolution(l, S, H);
@@ -312,47 +302,21 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
         if (stride <= c.size) { c.m1 = (uint32_t)stride; stride *= c.res; }
         if (stride <= c.size) { c.m2 = (uint32_t)stride; stride *= c.res; }
         c.flags = (stride > c.size ? 1u : 0u) | ((c.size & (c.size - 1u)) == 0u ? 2u : 0u);
-        bytes[l] = c.size * 2u * elem_bytes;
         lines[l] = lines_per_wave((double)c.res * step, slabs == kGroup);
     }
+    (void)elem_bytes;
     p.slabs = slabs == kGroup && B % kGroup == 0 ? kGroup : 1u;
     p.slab_points = B / p.slabs;
     const uint64_t slots = p.slabs == kGroup ? (uint64_t)div_up(p.slab_points, kGroupsPerWave) * 64u : B;
-    const uint32_t T = div_up(slots, (uint64_t)kTile * P);   // tile columns per level
+    const uint32_t T = div_up(slots, (uint64_t)kTile * P);   // tiles per level
 
-    // ---- units ----
+    // ---- the sequence of levels and what a tile of each costs ----
     Unit units[kMaxLevels];
     uint32_t nu = 0;
-    const bool modelled = balance && step > 0.f;
-    if (!modelled) {   // no information: every level costs the same; the order [L-1, 0, L-2, 1, ...] of GridPlan
-        for (uint32_t v = 0, lo = 0, hi = levels; v < levels; v++) units[nu++] = {(v & 1u) ? lo++ : --hi, kNoLevel, 1.0};
-    } else {
-        bool used[kMaxLevels] = {};
-        // gather-bound levels, most expensive first, each paired with a small VALU-bound level while there are any
-        uint32_t heavy[kMaxLevels], nh = 0;
-        for (uint32_t l = 0; l < levels; l++) if (lines[l] > valu_lines) heavy[nh++] = l;
-        for (uint32_t i = 0; i < nh; i++) for (uint32_t j = i + 1; j < nh; j++) if (lines[heavy[j]] > lines[heavy[i]]) { const uint32_t t = heavy[i]; heavy[i] = heavy[j]; heavy[j] = t; }
-        uint32_t next_small = 0;
-        for (uint32_t i = 0; i < nh; i++) {
-            const uint32_t h = heavy[i];
-            uint32_t partner = kNoLevel;
-            if (pairs) {
-                while (next_small < levels && (used[next_small] || bytes[next_small] >= kBigTable || lines[next_small] > valu_lines)) next_small++;
-                // the pair must leave room in the 4 MiB L2 (fp32 tables: a fine level is 4 MiB on its own — no pairs)
-                if (next_small < levels && (uint64_t)bytes[h] + bytes[next_small] <= (7u << 19)) partner = next_small;
-            }
-            used[h] = true;
-            if (partner != kNoLevel) {
-                used[partner] = true;
-                const double both = lines[h] + lines[partner];
-                units[nu++] = {h, partner, both > 2 * valu_lines ? both : 2 * valu_lines};
-            } else {
-                units[nu++] = {h, kNoLevel, lines[h]};
-            }
-        }
-        for (uint32_t l = levels; l-- > 0;) {   // the rest: VALU-bound singles (largest tables first, the small ones last)
-            if (!used[l]) units[nu++] = {l, kNoLevel, lines[l] > valu_lines ? lines[l] : valu_lines};
-        }
+    if (!(balance && step > 0.f)) {   // no information: every level costs the same; the order [L-1, 0, L-2, 1, ...] of GridPlan
+        for (uint32_t v = 0, lo = 0, hi = levels; v < levels; v++) units[nu++] = {(v & 1u) ? lo++ : --hi, 1.0};
+    } else {                          // fine to coarse; a tile costs its gathers or its VALU work, whichever is longer
+        for (uint32_t l = levels; l-- > 0;) units[nu++] = {l, lines[l] > valu_lines ? lines[l] : valu_lines};
     }
 
     // ---- cut the sequence into 8 ranges of equal cost ----
@@ -376,11 +340,9 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
             const uint32_t first = u == bu[k] ? bc[k] : 0u;
             const uint32_t last = u == bu[k + 1] ? bc[k + 1] : T;
             if (last <= first) continue;
-            if (ns == kMaxSegs) {   // cannot happen with <= 32 levels on 8 XCDs unless costs are degenerate: fold into the last one's XCD
-                break;
-            }
-            p.seg[k][ns++] = {units[u].a, units[u].b, first, last - first};
-            p.ntiles[k] += (last - first) * (units[u].b != kNoLevel ? 2u : 1u);
+            if (ns == kMaxSegs) { p.ntiles[0] = 0xffffffffu; return p; }   // more levels in one range than a Seg list holds: caller falls back
+            p.seg[k][ns++] = {units[u].level, first, last - first, 0u};
+            p.ntiles[k] += last - first;
         }
     }
     return p;
@@ -393,7 +355,7 @@ uint32_t fwd_grid_size(const FwdPlan& p) {
 }
 
 // ---- implementation switches (testing / measurement aid; sdfx_grid_set_impl) ----
-int g_fwd_impl = -1, g_pairs = -1, g_points = -1, g_balance = -1;
+int g_fwd_impl = -1, g_balance = -1;
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -402,13 +364,13 @@ int sw(int forced, const char* env, int dflt) {
     return forced >= 0 ? forced : env_int(env, dflt);
 }
 
-template <bool HALF, uint32_t P>
+template <bool HALF>
 void launch(const float* inputs, const void* table, void* outputs, uint32_t B, uint32_t L, const FwdPlan& plan, uint32_t gridtype,
             int align_corners, uint32_t interp, int out_layout, hipStream_t st) {
     using T = typename Elem<HALF>::type;
     const uint32_t grid = fwd_grid_size(plan);
 #define SDFX_FWD(INTERP_, ALIGN_, HASH_)                                                                               \
-    hipLaunchKernelGGL((k_grid_fwd<HALF, INTERP_, ALIGN_, HASH_, P>), dim3(grid), dim3(kTile), 0, st, inputs,            \
+    hipLaunchKernelGGL((k_grid_fwd<HALF, INTERP_, ALIGN_, HASH_>), dim3(grid), dim3(kTile), 0, st, inputs,            \
                        static_cast<const T*>(table), static_cast<T*>(outputs), B, L, plan, out_layout)
     const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
     switch (sel) {
@@ -432,68 +394,57 @@ namespace grid {
 bool fast_forward_enabled() { return sw(g_fwd_impl, "SDFX_GRID_FWD", 1) == 1; }
 
 // D = 3, C = 2, no dy_dx. `slabs`, `step`: locality hints (sdfx_grid_encode_forward_hint); results do not depend on them.
-void launch_forward_d3c2(const float* inputs, const void* table, const int32_t* offsets_host, void* outputs, uint32_t B,
+// Returns false when the plan does not fit (more than kMaxSegs levels in one XCD's range): the caller uses k_grid_forward.
+bool launch_forward_d3c2(const float* inputs, const void* table, const int32_t* offsets_host, void* outputs, uint32_t B,
                          uint32_t L, uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
                          uint32_t interp, int is_half, int out_layout, uint32_t slabs, float step, hipStream_t st) {
-    const uint32_t eb = is_half ? 2u : 4u;
-    // points per thread: 1 measured best (2: -2 %, 4: -10 %: more lines in flight per CU than its L1 holds)
-    uint32_t P = (uint32_t)sw(g_points, "SDFX_GRID_POINTS", 1);
-    if (P != 1 && P != 2 && P != 4) P = 1;
-    // SDFX_GRID_VALU_LINES: VALU time of one wave of one level in units of table lines (232 instructions / 2.4 cycles a line)
+    // SDFX_GRID_VALU_LINES: VALU time of one wave of one level in units of table lines (232 instructions / 2.4 cycles a
+    // line = 97; measured optimum of the split on MI355X: 75 -> 315 us, 97 -> 287 us, 120 -> 308 us at B = 1.8 M)
     static const double valu_lines = (double)env_int("SDFX_GRID_VALU_LINES", 97);
-    FwdPlan plan = make_fwd_plan(offsets_host, max_level, S, H, eb, B, slabs, step, P, sw(g_balance, "SDFX_GRID_BALANCE", 1) == 1,
-                                 sw(g_pairs, "SDFX_GRID_PAIRS", 1) == 1, valu_lines);
+    FwdPlan plan = make_fwd_plan(offsets_host, max_level, S, H, is_half ? 2u : 4u, B, slabs, step,
+                                 sw(g_balance, "SDFX_GRID_BALANCE", 1) == 1, valu_lines);
+    if (plan.ntiles[0] == 0xffffffffu) return false;
     plan.vec16 = (reinterpret_cast<uintptr_t>(table) % 16) == 0 ? 1u : 0u;
-    if (env_int("SDFX_GRID_PLAN_DEBUG", 0)) {   // one line per XCD: its segments (level: tiles) and modelled load
+    if (env_int("SDFX_GRID_PLAN_DEBUG", 0)) {   // one line per XCD: its segments
         for (uint32_t k = 0; k < kXcds; k++) {
-            fprintf(stderr, "[grid plan] B=%u P=%u slabs=%u step=%g xcd %u: %u workgroups:", B, P, plan.slabs, (double)step, k,
-                    plan.ntiles[k]);
+            fprintf(stderr, "[grid plan] B=%u slabs=%u step=%g xcd %u: %u workgroups:", B, plan.slabs, (double)step, k, plan.ntiles[k]);
             for (uint32_t sgi = 0; sgi < kMaxSegs; sgi++) {
                 const Seg& sg = plan.seg[k][sgi];
-                if (!sg.count) continue;
-                if (sg.level_b != kNoLevel) fprintf(stderr, "  L%u+L%u[%u,+%u)", sg.level_a, sg.level_b, sg.first, sg.count);
-                else fprintf(stderr, "  L%u[%u,+%u)", sg.level_a, sg.first, sg.count);
+                if (sg.count) fprintf(stderr, "  L%u[%u,+%u)", sg.level, sg.first, sg.count);
             }
             fprintf(stderr, "\n");
         }
     }
-#define SDFX_LAUNCH_P(P_)                                                                                               \
-    if (is_half) launch<true, P_>(inputs, table, outputs, B, L, plan, gridtype, align_corners, interp, out_layout, st);   \
-    else launch<false, P_>(inputs, table, outputs, B, L, plan, gridtype, align_corners, interp, out_layout, st)
-    if (P == 1) { SDFX_LAUNCH_P(1u); } else if (P == 2) { SDFX_LAUNCH_P(2u); } else { SDFX_LAUNCH_P(4u); }
-#undef SDFX_LAUNCH_P
+    if (is_half) launch<true>(inputs, table, outputs, B, L, plan, gridtype, align_corners, interp, out_layout, st);
+    else launch<false>(inputs, table, outputs, B, L, plan, gridtype, align_corners, interp, out_layout, st);
+    return true;
 }
 
 }  // namespace grid
 }  // namespace sdfx
 
-// Host-only: the per-XCD segments the forward would use, 5 integers per segment (xcd, level_a, level_b or -1, first tile
-// column, columns); returns the number of segments (<= max_segments), tile columns per level in *columns_per_level.
+// Host-only: the per-XCD work list the forward would use, 4 integers per segment (xcd, level, first tile, tiles);
+// returns the number of segments (<= max_segments), tiles per level in *tiles_per_level.
 extern "C" int sdfx_grid_forward_plan(const int32_t* offsets_host, uint32_t max_level, float S, uint32_t H, int is_half, uint32_t B,
                                       uint32_t slabs, float step, int32_t* segments, uint32_t max_segments,
-                                      uint32_t* columns_per_level) {
+                                      uint32_t* tiles_per_level) {
     if (!offsets_host || !segments || max_level < 1 || max_level > kMaxLevels || B == 0) return -1;
-    uint32_t P = (uint32_t)sw(g_points, "SDFX_GRID_POINTS", 1);
-    if (P != 1 && P != 2 && P != 4) P = 1;
-    const FwdPlan plan = make_fwd_plan(offsets_host, max_level, S, H, is_half ? 2u : 4u, B, slabs, step, P,
-                                       sw(g_balance, "SDFX_GRID_BALANCE", 1) == 1, sw(g_pairs, "SDFX_GRID_PAIRS", 1) == 1,
-                                       (double)env_int("SDFX_GRID_VALU_LINES", 97));
+    const FwdPlan plan = make_fwd_plan(offsets_host, max_level, S, H, is_half ? 2u : 4u, B, slabs, step,
+                                       sw(g_balance, "SDFX_GRID_BALANCE", 1) == 1, (double)env_int("SDFX_GRID_VALU_LINES", 97));
+    if (plan.ntiles[0] == 0xffffffffu) return -3;
     const uint64_t slots = plan.slabs == kGroup ? (uint64_t)div_up(plan.slab_points, kGroupsPerWave) * 64u : B;
-    if (columns_per_level) *columns_per_level = div_up(slots, (uint64_t)kTile * P);
+    if (tiles_per_level) *tiles_per_level = div_up(slots, (uint64_t)kTile);
     uint32_t n = 0;
     for (uint32_t k = 0; k < kXcds; k++) {
         for (uint32_t sgi = 0; sgi < kMaxSegs; sgi++) {
             const Seg& sg = plan.seg[k][sgi];
             if (!sg.count) continue;
             if (n == max_segments) return -2;
-            int32_t* o = segments + 5 * n++;
-            o[0] = (int32_t)k; o[1] = (int32_t)sg.level_a; o[2] = sg.level_b == kNoLevel ? -1 : (int32_t)sg.level_b;
-            o[3] = (int32_t)sg.first; o[4] = (int32_t)sg.count;
+            int32_t* o = segments + 4 * n++;
+            o[0] = (int32_t)k; o[1] = (int32_t)sg.level; o[2] = (int32_t)sg.first; o[3] = (int32_t)sg.count;
         }
     }
     return (int)n;
 }
 
-extern "C" void sdfx_grid_set_impl(int fwd_impl, int pairs, int points_per_thread, int balance) {
-    g_fwd_impl = fwd_impl; g_pairs = pairs; g_points = points_per_thread; g_balance = balance;
-}
+extern "C" void sdfx_grid_set_impl(int fwd_impl, int balance) { g_fwd_impl = fwd_impl; g_balance = balance; }

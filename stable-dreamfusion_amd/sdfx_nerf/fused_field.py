@@ -22,7 +22,7 @@ class _fused_field(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, x, embeddings, offsets, w1, b1, w2, b2, w3, b3, bound, per_level_scale, base_resolution, gridtype,
-                align_corners, interp, blob_density, blob_radius):
+                align_corners, interp, blob_density, blob_radius, slabs, step):
         x = x.float().contiguous()
         B = x.shape[0]
         inputs = ((x + bound) / (2 * bound)).contiguous()       # GridEncoder.forward's map to [0, 1] (grid.py:157)
@@ -32,7 +32,7 @@ class _fused_field(Function):
         emb = embeddings.to(torch.half).contiguous()             # autocast: fp16 table (grid.py:46-47)
         enc = torch.empty(L, B, C, device=x.device, dtype=torch.half)
         _gridencoder.grid_encode_forward(inputs, emb, offsets, enc, B, 3, C, L, L, S, base_resolution, None, gridtype,
-                                         align_corners, interp, 0)
+                                         align_corners, interp, 0, slabs, step)
         packed = torch.empty(_field.packed_words(), dtype=torch.int32, device=x.device)
         _field.pack(w1.detach().float().contiguous(), b1.detach().float().contiguous(), w2.detach().float().contiguous(),
                     b2.detach().float().contiguous(), w3.detach().float().contiguous(), b3.detach().float().contiguous(), packed)
@@ -60,7 +60,7 @@ class _fused_field(Function):
         grad_emb = torch.zeros(emb_shape, dtype=torch.half, device=dev)
         _gridencoder.grid_encode_backward(denc, inputs, grad_emb, offsets, grad_emb, B, 3, C, L, L, S, H, None, None, gridtype,
                                           align_corners, interp, 0)
-        return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 8
+        return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 10
 
 
 def supported(encoder, sigma_net, x, density_activation, max_level) -> bool:
@@ -70,8 +70,11 @@ def supported(encoder, sigma_net, x, density_activation, max_level) -> bool:
             and sigma_net.net[0].bias is not None)
 
 
-def fused_field(x, encoder, sigma_net, bound, blob_density, blob_radius):
+def fused_field(x, encoder, sigma_net, bound, blob_density, blob_radius, slabs=1, step=0.0):
+    """`slabs`, `step`: locality hints for the encoder (include/sdfx.h, sdfx_grid_encode_forward_hint): slabs = 7 when x is the
+    [7, N, 3] batch of a finite-difference stencil, step = distance between consecutive ray samples in the unit cube."""
     n = sigma_net.net
     return _fused_field.apply(x, encoder.embeddings, encoder.offsets, n[0].weight, n[0].bias, n[1].weight, n[1].bias,
                               n[2].weight, n[2].bias, bound, encoder.per_level_scale, encoder.base_resolution,
-                              encoder.gridtype_id, encoder.align_corners, encoder.interp_id, blob_density, blob_radius)
+                              encoder.gridtype_id, encoder.align_corners, encoder.interp_id, blob_density, blob_radius,
+                              int(slabs), float(step))

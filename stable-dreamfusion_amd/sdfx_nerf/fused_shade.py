@@ -74,6 +74,67 @@ def fused_shade(sigma7, albedo0, dirs, rays, rays_o, light_offset, ratio, total,
                               MODES[shading], epsilon)
 
 
+class _fused_render(Function):
+    """Shading + compositing + regulariser sums (csrc/render.hip; include/sdfx.h sdfx_render_train_*).
+
+        weights, weights_sum, depth, image, ray_sums = fused_render(sigma7, albedo0, dirs, ts, rays, rays_o, light_offset,
+                                                                     ratio, mode, total, T_thresh)
+
+    `mode`: a shading name, or a 0-dim float32 device tensor holding 1 / 2 / 3 (so that a captured graph serves every mode).
+    `weights` [cap] is returned detached (its consumers — the entropy and orientation terms — are inside: ray_sums [N, 2])."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, sigma7, albedo0, dirs, ts, rays, rays_o, light_offset, ratio, mode, total, T_thresh, epsilon):
+        sigma7, albedo0, dirs, ts = sigma7.contiguous(), albedo0.contiguous(), dirs.contiguous(), ts.contiguous()
+        rays_o = rays_o.contiguous().view(-1, 3)
+        cap, n_rays, dev = dirs.shape[0], rays.shape[0], sigma7.device
+        assert sigma7.numel() == 7 * cap and albedo0.shape[0] == cap
+        mode_dev = mode if torch.is_tensor(mode) else None
+        mode_int = 0 if mode_dev is not None else MODES[mode]
+        f = dict(dtype=_F32, device=dev)
+        weights = torch.empty(cap, **f)
+        weights_sum, depth = torch.empty(n_rays, **f), torch.empty(n_rays, **f)
+        image, ray_sums = torch.empty(n_rays, 3, **f), torch.empty(n_rays, 2, **f)
+        S.call("sdfx_render_train_forward", S.ptr(S.check_tensor(sigma7, "sigma7", _F32)), S.ptr(S.check_tensor(albedo0, "albedo", _F32)),
+               S.ptr(S.check_tensor(dirs, "dirs", _F32)), S.ptr(S.check_tensor(ts, "ts", _F32)),
+               S.ptr(S.check_tensor(rays, "rays", torch.int32)), S.ptr(S.check_tensor(rays_o, "rays_o", _F32)),
+               S.ptr(S.check_tensor(light_offset, "light_offset", _F32)), S.ptr(S.check_tensor(ratio, "ratio", _F32)),
+               S.ptr(None if mode_dev is None else S.check_tensor(mode_dev, "mode", _F32)), mode_int, float(epsilon), float(T_thresh),
+               cap, n_rays, S.ptr(S.check_tensor(total, "total", torch.int32)), S.ptr(weights), S.ptr(weights_sum), S.ptr(depth),
+               S.ptr(image), S.ptr(ray_sums), S.stream())
+        ctx.save_for_backward(sigma7, albedo0, dirs, ts, rays, rays_o, light_offset, ratio, mode_dev, total, weights_sum, depth, image)
+        ctx.meta = (mode_int, float(epsilon), float(T_thresh), cap, n_rays)
+        ctx.mark_non_differentiable(weights)
+        ctx.set_materialize_grads(False)
+        return weights, weights_sum, depth, image, ray_sums
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, _gw, g_ws, g_depth, g_image, g_sums):
+        sigma7, albedo0, dirs, ts, rays, rays_o, light_offset, ratio, mode_dev, total, weights_sum, depth, image = ctx.saved_tensors
+        mode_int, epsilon, T_thresh, cap, n_rays = ctx.meta
+        dev = sigma7.device
+        z = lambda g, shape: torch.zeros(shape, dtype=_F32, device=dev) if g is None else g.float().contiguous()
+        g_ws, g_image = z(g_ws, (n_rays,)), z(g_image, (n_rays, 3))
+        g_depth = None if g_depth is None else g_depth.float().contiguous()
+        g_sums = None if g_sums is None else g_sums.float().contiguous()
+        dsigma7 = torch.empty(7 * cap, dtype=_F32, device=dev)
+        dalbedo = torch.empty(cap, 3, dtype=_F32, device=dev)
+        S.call("sdfx_render_train_backward", S.ptr(sigma7), S.ptr(albedo0), S.ptr(dirs), S.ptr(ts), S.ptr(rays), S.ptr(rays_o),
+               S.ptr(light_offset), S.ptr(ratio), S.ptr(mode_dev), mode_int, epsilon, T_thresh, cap, n_rays, S.ptr(total),
+               S.ptr(weights_sum), S.ptr(depth), S.ptr(image), S.ptr(g_ws), S.ptr(g_depth), S.ptr(g_image), S.ptr(g_sums),
+               S.ptr(dsigma7), S.ptr(dalbedo), S.stream())
+        return (dsigma7, dalbedo) + (None,) * 10
+
+
+def fused_render(sigma7, albedo0, dirs, ts, rays, rays_o, light_offset, ratio, mode, total, T_thresh=1e-4, epsilon=1e-2):
+    if not torch.is_tensor(ratio):
+        ratio = torch.tensor(float(ratio), dtype=_F32, device=sigma7.device)
+    return _fused_render.apply(sigma7.reshape(-1), albedo0, dirs, ts, rays, rays_o, light_offset, ratio.to(_F32), mode, total,
+                               T_thresh, epsilon)
+
+
 class _weights_entropy(Function):
     """sum_{i < total} H(clamp(w_i, 1e-5, 1 - 1e-5)) in bits — the un-normalised lambda_entropy term (nerf/utils.py:571-575)."""
 

@@ -25,6 +25,8 @@ _FUSED = int(os.environ.get("SDFX_FUSED_FIELD", "1"))
 _BATCH_STENCIL = int(os.environ.get("SDFX_BATCH_STENCIL", "1"))
 # normal / shading / orientation glue between the field and the compositor in one HIP kernel each way
 _FUSED_SHADE = int(os.environ.get("SDFX_FUSED_SHADE", "1"))
+# ... and the compositor and the entropy / orientation sums in the same kernel (csrc/render.hip)
+_FUSED_RENDER = int(os.environ.get("SDFX_FUSED_RENDER", "1"))
 # The background MLP (4096 rays x 1.4 k MACs) is evaluated in float32 even under autocast: its gradient is the image
 # gradient times the loss scale, un-attenuated by compositing weights, and is what overflows fp16 first — in half it
 # caps the loss scale ~64x lower (field gradients underflow) and costs a GradScaler skip every ~12 iterations.
@@ -99,11 +101,15 @@ class NeRFNetwork(NeRFRenderer):
         self.register_buffer("_fd_offsets", torch.tensor([[e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]],
                                                          dtype=torch.float32), persistent=False)
 
-    def common_forward(self, x):
+    def common_forward(self, x, slabs=1, ray_ordered=False):
+        """`slabs` = 7: x is the [7, N, 3] batch of a finite-difference stencil; `ray_ordered`: consecutive rows are
+        consecutive samples of a ray. Both only steer the encoder's work split (same values either way)."""
         if _FUSED and _ff.supported(self.encoder, self.sigma_net, x, self.opt.density_activation, self.max_level):
             shape = x.shape[:-1]
+            # sample spacing in the encoder's unit cube: dt_min = 2 sqrt(3) / max_steps (raymarching.cu:385) over 2 bound
+            step = (3.0 ** 0.5) / (self.opt.max_steps * self.bound) if ray_ordered else 0.0
             sigma, albedo = _ff.fused_field(x.reshape(-1, 3), self.encoder, self.sigma_net, self.bound,
-                                            self.opt.blob_density, self.opt.blob_radius)
+                                            self.opt.blob_density, self.opt.blob_radius, slabs, step)
             return sigma.view(*shape), albedo.view(*shape, 3)
         enc = self.encoder(x, bound=self.bound, max_level=self.max_level)
         h = self.sigma_net(enc)
@@ -136,7 +142,7 @@ class NeRFNetwork(NeRFRenderer):
         offs = self._fd_offsets if e == 1e-2 else self._fd_offsets * (e / 1e-2)
         neigh = (x.unsqueeze(0) + offs.unsqueeze(1)).clamp(-self.bound, self.bound)      # [6, N, 3]
         pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
-        sigma_all, albedo_all = self.common_forward(pts)
+        sigma_all, albedo_all = self.common_forward(pts, slabs=7, ray_ordered=self.training)
         s = sigma_all.view(7, N)
         normal = -torch.stack([0.5 * (s[1] - s[2]) / e, 0.5 * (s[3] - s[4]) / e, 0.5 * (s[5] - s[6]) / e], dim=-1)
         return s[0], albedo_all.view(7, N, 3)[0], normal
@@ -148,10 +154,22 @@ class NeRFNetwork(NeRFRenderer):
         N = x.shape[0]
         neigh = (x.unsqueeze(0) + self._fd_offsets.unsqueeze(1)).clamp(-self.bound, self.bound)
         pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
-        sigma_all, albedo_all = self.common_forward(pts)
+        sigma_all, albedo_all = self.common_forward(pts, slabs=7, ray_ordered=True)
         color, normal, orient = _fs.fused_shade(sigma_all, albedo_all[:N] if shading == "lambertian" else None, dirs, rays,
                                                 rays_o, light_offset, ratio, total, shading)
         return sigma_all[:N], color, normal, orient
+
+    def forward_render(self, x, dirs, ts, rays, rays_o, light_offset, total, ratio=1, shading="lambertian", T_thresh=1e-4):
+        """Field at the 7 stencil points -> ONE kernel for normal, shading, compositing and the two regulariser sums
+        (csrc/render.hip). `shading`: a name, or a 0-dim device tensor holding 1 / 2 / 3 (lambertian / textureless / normal).
+        Returns weights (detached), weights_sum, depth, image, ray_sums [N, 2] = per-ray (entropy sum, orientation sum)."""
+        neigh = (x.unsqueeze(0) + self._fd_offsets.unsqueeze(1)).clamp(-self.bound, self.bound)
+        pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
+        sigma_all, albedo_all = self.common_forward(pts, slabs=7, ray_ordered=True)
+        return _fs.fused_render(sigma_all, albedo_all[:x.shape[0]], dirs, ts, rays, rays_o, light_offset, ratio, shading, total, T_thresh)
+
+    def fused_render_available(self, shading):
+        return bool(_FUSED_RENDER and _FUSED_SHADE and _BATCH_STENCIL and (torch.is_tensor(shading) or shading in _fs.MODES))
 
     def fused_shade_available(self, shading):
         return bool(_FUSED_SHADE and _BATCH_STENCIL and shading in _fs.MODES)

@@ -64,7 +64,7 @@ class NeRFRenderer(nn.Module):
 
     # --------------------------------------------------------------------------- run_cuda
     def run_cuda(self, rays_o, rays_d, light_d=None, ambient_ratio=1.0, shading="albedo", bg_color=None, perturb=False,
-                 T_thresh=1e-4, binarize=False, marched=None, **kwargs):
+                 T_thresh=1e-4, binarize=False, marched=None, shading_dev=None, **kwargs):
         """`marched` (extension): (xyzs, dirs, ts, rays, n_valid) from raymarching.march_rays_train_count/_write when
         the caller has already marched into fixed-capacity buffers; n_valid is the device-side sample total and
         replaces the buffer length wherever the reference averages over samples."""
@@ -97,7 +97,20 @@ class NeRFRenderer(nn.Module):
                                                                     self.cascade, self.grid_size, nears, fars, perturb,
                                                                     self.opt.dt_gamma, self.opt.max_steps)
             orient = None
-            if fused:
+            rendered = (fused and not binarize and hasattr(self, "fused_render_available") and self.fused_render_available(shading))
+            if rendered:   # field -> [normal, shading, compositing, entropy and orientation sums] in one kernel
+                if total is None:
+                    total = (rays[-1, 0] + rays[-1, 1]).reshape(1).to(torch.int32)
+                weights, weights_sum, depth, image, ray_sums = self.forward_render(
+                    xyzs, dirs, ts, rays, rays_o, light_offset, total, ratio=ambient_ratio,
+                    shading=shading if shading_dev is None else shading_dev, T_thresh=T_thresh)
+                sums = ray_sums.sum(0)
+                denom = n_valid if n_valid is not None else float(max(xyzs.shape[0], 1))
+                results["entropy_sum"] = sums[0]          # sum over samples of H(clamp(w)); the trainer divides by the sample count
+                if self.opt.lambda_orient > 0:
+                    results["loss_orient"] = sums[1] / denom
+                normals = None
+            elif fused:
                 if total is None:  # offsets are the exclusive prefix sum of the counts in ray order
                     total = (rays[-1, 0] + rays[-1, 1]).reshape(1).to(torch.int32)
                 sigmas, rgbs, normals, orient = self.forward_fused(xyzs, dirs, rays, rays_o, light_offset, total,
@@ -108,7 +121,8 @@ class NeRFRenderer(nn.Module):
                     flatten_rays = raymarching.flatten_rays(rays, xyzs.shape[0]).long()
                     light_d = light_d[flatten_rays]
                 sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
-            weights, weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ts, rays, T_thresh, binarize)
+            if not rendered:
+                weights, weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ts, rays, T_thresh, binarize)
 
             if self.opt.lambda_orient > 0 and normals is not None:
                 if orient is None:

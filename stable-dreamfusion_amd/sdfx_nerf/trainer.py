@@ -14,9 +14,11 @@ Three ways of driving the same arithmetic (`mode`, default from SDFX_TRAIN_MODE,
                by marching into fixed-capacity buffers (raymarching.march_rays_train_write) — the capacity is the
                total rounded up to the next step of a capacity ladder, padded rows carry zero weight — and the
                per-iteration scalars of the schedule (ambient ratio, background colour, text-embedding weights,
-               regulariser weights) are read from a small device block refreshed by one H2D copy. Graphs are
-               captured per (capacity, shading, as_latent, background kind); capacities come from a geometric ladder
-               (ratio 1.1) and a miss captures the neighbouring ladder steps too, since the sample total drifts.
+               regulariser weights, the shading mode of the fused render kernel) are read from a small device block
+               refreshed by one H2D copy. Graphs are captured per (capacity, shading class, as_latent, background kind) —
+               'lambertian', 'textureless' and 'normal' are one class: csrc/render.hip reads the mode from the block —
+               and all captures share one memory pool; capacities come from a geometric ladder (ratio 1.1) and a miss
+               captures the neighbouring ladder steps too, since the sample total drifts.
 """
 from __future__ import annotations
 
@@ -28,6 +30,7 @@ import torch
 
 import raymarching
 
+from .fused_shade import MODES as _SHADE_MODES
 from .fused_shade import weights_entropy_sum
 from .optim import Adan, DeviceAdan
 
@@ -36,7 +39,7 @@ _PREFETCH = int(os.environ.get("SDFX_PREFETCH", "1"))      # counting pass of th
 _STEP_SYNC = int(os.environ.get("SDFX_STEP_SYNC", "0"))    # debugging aid: device-wide synchronisation after every step
 
 # layout of the per-iteration scalar block
-_SC_AMBIENT, _SC_BG, _SC_WF, _SC_WS, _SC_WB, _SC_ENTROPY, _SC_WORDS = 0, 1, 4, 5, 6, 7, 8
+_SC_AMBIENT, _SC_BG, _SC_WF, _SC_WS, _SC_WB, _SC_ENTROPY, _SC_MODE, _SC_WORDS = 0, 1, 4, 5, 6, 7, 8, 12
 
 
 class TrainStep:
@@ -48,6 +51,10 @@ class TrainStep:
         self.rng = random.Random(seed)
         if opt.optim != "adan" and self.mode != "reference":
             self.mode = "reference"  # the device-side tail implements Adan only
+        if (opt.grad_clip >= 0 or opt.lambda_tv > 0 or opt.lambda_wd > 0) and self.mode != "reference":
+            # these act on UNSCALED gradients between backward and step (nerf/utils.py:1055-1066): only the host flow does that
+            warnings.warn("grad_clip / lambda_tv / lambda_wd need the reference host flow: TrainStep(mode='reference')")
+            self.mode = "reference"
         if self.mode == "reference":
             if opt.optim == "adan":
                 self.optimizer = Adan(model.get_params(5 * opt.lr), eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0)
@@ -84,7 +91,9 @@ class TrainStep:
         self.graph_prime_span = 1.5      # on a miss, capture every ladder step within this factor of the need
         self.max_graphs = int(os.environ.get("SDFX_MAX_GRAPHS", "64"))
         self._warm = set()               # kinds that have run eagerly once
-        self.graphs = {}                 # (capacity, shading, as_latent, bg_kind) -> (CUDAGraph, loss tensor)
+        self.graphs = {}                 # (capacity, shading class, as_latent, bg_kind, H, W, lr signature) -> captured stages
+        self.graph_pool = None           # one memory pool for every capture (replays are serial)
+        self.lr_changes = 0
         self.graph_uses = {}
         self.stats = {"replays": 0, "captures": 0, "eager": 0, "prefetched": 0}
 
@@ -111,6 +120,7 @@ class TrainStep:
                 for k in range(3):
                     sc[_SC_BG + k] = self.rng.random()
         sc[_SC_AMBIENT] = ambient_ratio
+        sc[_SC_MODE] = float(_SHADE_MODES.get(shading, 0))
         # text_z: r * start + (1 - r) * end between (front, side) or (side, back)
         if -90 <= azimuth < 90:
             r = 1 - azimuth / 90 if azimuth >= 0 else 1 + azimuth / 90
@@ -133,8 +143,12 @@ class TrainStep:
         B = 1
         H, W = self.hw
         bg_color = None if bg_kind == "net" else sc[_SC_BG:_SC_BG + 3]
+        shading_dev = None
+        if shading == "fd":   # the class of the three finite-difference shadings: the kernel reads which one from the block
+            shading, shading_dev = "lambertian", sc[_SC_MODE]
         outputs = self.model.render(self.rays_o, self.rays_d, None, H, W, staged=False, perturb=True, bg_color=bg_color,
-                                    ambient_ratio=sc[_SC_AMBIENT], shading=shading, binarize=False, marched=marched)
+                                    ambient_ratio=sc[_SC_AMBIENT], shading=shading, binarize=False, marched=marched,
+                                    shading_dev=shading_dev)
         self._num_samples = outputs.get("num_samples", 0)
         if as_latent:
             pred_rgb = torch.cat([outputs["image"], outputs["weights_sum"].unsqueeze(-1)], dim=-1).reshape(B, H, W, 4)
@@ -148,7 +162,9 @@ class TrainStep:
             loss = loss + opt.lambda_opacity * (outputs["weights_sum"] ** 2).mean()
         if opt.lambda_entropy > 0:
             n_valid = outputs["num_valid"]
-            if n_valid is not None and _FUSED_ENTROPY:   # fixed-capacity buffers: one kernel each way, padding excluded
+            if "entropy_sum" in outputs:                 # summed inside the fused render kernel
+                loss_entropy = outputs["entropy_sum"] / (n_valid if n_valid is not None else float(max(self._num_samples, 1)))
+            elif n_valid is not None and _FUSED_ENTROPY:   # fixed-capacity buffers: one kernel each way, padding excluded
                 loss_entropy = weights_entropy_sum(outputs["weights"], outputs["num_total"]) / n_valid
             else:
                 alphas = outputs["weights"].clamp(1e-5, 1 - 1e-5)
@@ -185,8 +201,6 @@ class TrainStep:
         with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
             loss = self.train_step((xyzs, dirs, ts, self.cur_rays, self.n_valid, self.cur_total), shading, as_latent, bg_kind)
         (loss * self.optimizer.scale).backward()
-        if opt.grad_clip >= 0 or opt.lambda_tv > 0 or opt.lambda_wd > 0:
-            raise NotImplementedError("grad_clip / lambda_tv / lambda_wd act on unscaled gradients: use mode='reference'")
         self.optimizer.step()
         return loss.detach()
 
@@ -255,11 +269,13 @@ class TrainStep:
             del self.graphs[victim]
             self.graph_uses.pop(victim, None)
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
+        if self.graph_pool is None:
+            self.graph_pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g1, pool=self.graph_pool):
             marched = self._stage_march(key[0])
         self.optimizer.zero_grad()
-        with torch.cuda.graph(g2):
-            loss = self._stage_train(marched, *key[1:])
+        with torch.cuda.graph(g2, pool=self.graph_pool):
+            loss = self._stage_train(marched, *key[1:6])
         # (the gradient buffers of this graph are kept reachable for diagnostics: Python's p.grad only names the
         # buffers of the most recent capture)
         self.graphs[key] = (g1, g2, loss, marched, [p.grad for p in self.optimizer.parameters()])
@@ -293,11 +309,23 @@ class TrainStep:
             return self._step_reference(rays_o, rays_d, kinds)
 
         M = self._count(rays_o, rays_d)
+        if kinds[0] in _SHADE_MODES and getattr(self.model, "fused_render_available", lambda s: False)(kinds[0]):
+            kinds = ("fd",) + kinds[1:]      # one graph for the three finite-difference shadings (mode read on the device)
         if self.mode == "device":
             loss = self._body(M, *kinds)
             self.stats["eager"] += 1
         else:
-            kinds = kinds + (H, W)
+            # learning rates are kernel arguments of the captured optimiser step: part of the key. The -O schedule is
+            # constant (main.py: LambdaLR(lambda iter: 1)); a scheduler that moves them every step falls back to 'device'.
+            lr_sig = tuple(g["lr"] for g in self.optimizer.param_groups)
+            if getattr(self, "_lr_sig", lr_sig) != lr_sig:
+                self.lr_changes += 1
+                if self.lr_changes > 8:
+                    warnings.warn("learning rates change every few steps: HIP-graph replay disabled (mode='device')")
+                    self.mode = "device"
+                    self.graphs.clear(); self.graph_uses.clear()
+            self._lr_sig = lr_sig
+            kinds = kinds + (H, W, lr_sig)
             key = (self._ladder(M),) + kinds
             first = kinds not in self._warm
             if first:

@@ -258,6 +258,45 @@ def test_grid_forward_fp32_bit_exact(oracle, dev, interp, gridtype, align):
         assert np.array_equal(N_(dy), dy_ref)
 
 
+@pytest.mark.parametrize("is_half", [True, False])
+@pytest.mark.parametrize("interp,gridtype,align", [(1, 0, False), (0, 1, True)])
+def test_grid_forward_hinted_kernel_bit_exact(oracle, dev, is_half, interp, gridtype, align):
+    """sdfx_grid_encode_forward_hint -> k_grid_fwd (csrc/gridencoder_fwd.hip): stencil-neighbour lanes (slabs = 7), the
+    cost-balanced per-XCD split (step hint) and the packed half arithmetic must not change a single bit against the
+    oracle (gridencoder.cu:82-249) — on a ray-ordered stencil batch, on a batch whose size is not a multiple of 7,
+    on tiny batches, with out-of-range points, both output layouts, and for max_level < L."""
+    import _gridencoder as B
+    dtype = np.float16 if is_half else np.float32
+    offsets, pls, table = _grid_setup(oracle, dtype=dtype, desired_resolution=2048)
+    bf = synth.s_grid_init()[2]
+    o, d = synth.s_rays(2)
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    xyzs = oracle.march_rays_train(o, d, 1.0, bf, 1, 128, nears, fars, synth.s_noises(4096))[0][:9001]
+    e = np.float32(1e-2)
+    offs = np.array([[0, 0, 0], [e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]], np.float32)
+    pts = np.clip(xyzs[None] + offs[:, None], -1, 1).reshape(-1, 3)               # [7, M, 3]
+    x = ((pts + np.float32(1)) / np.float32(2)).astype(np.float32)
+    x[3] = [1.5, 0.2, 0.2]; x[11] = [0.3, -0.1, 0.5]                              # outside [0, 1]: zero features
+    S = np.log2(pls)
+    L, C = 16, 2
+    step = 1.0 / 591.0
+    cases = [(x, 7, step, L), (x, 7, 0.0, L), (x, 1, step, L), (x[:-3], 7, step, L), (x[:7 * 5], 7, step, L), (x[:1], 1, step, L),
+             (x, 7, step, 9)]
+    for xs, slabs, st, max_level in cases:
+        Bn = xs.shape[0]
+        out_ref, lbc_ref, _ = oracle.grid_encode_forward(xs, table, offsets, pls, 16, False, gridtype, align, interp)
+        if max_level < L:       # levels >= max_level are not written: compare the computed ones, the rest keeps the fill
+            lbc_ref = lbc_ref.copy(); lbc_ref[max_level:] = 0
+            out_ref = np.ascontiguousarray(np.transpose(lbc_ref, (1, 0, 2)).reshape(Bn, L * C))
+        for layout in (0, 1):
+            out = torch.zeros((L, Bn, C) if layout == 0 else (Bn, L * C), device=dev, dtype=torch.float16 if is_half else torch.float32)
+            B.grid_encode_forward(T(xs, dev), T(table, dev), T(offsets, dev), out, Bn, 3, C, L, max_level, S, 16, None, gridtype,
+                                  align, interp, layout, slabs, st)
+            got, ref = N_(out), (lbc_ref if layout == 0 else out_ref)
+            view = np.uint16 if is_half else np.uint32
+            assert np.array_equal(got.view(view), ref.view(view)), (Bn, slabs, st, max_level, layout)
+
+
 def test_grid_module_forward_backward_fp32(oracle, dev):
     """GridEncoder module (the encoding.py / network_grid.py call surface): forward bit-exact,
     table gradient within float-atomic reordering noise, input gradient bit-exact."""

@@ -1,0 +1,52 @@
+"""Host-side work split of the hinted hash-grid forward (csrc/gridencoder_fwd.hip, sdfx_grid_forward_plan): every tile of
+every level is handed to exactly one XCD, whatever the batch size, level count, hint or table type; with a step hint
+the modelled cost of the eight ranges is even. No GPU work."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+importlib.import_module("stable-dreamfusion_amd")
+import _sdfx as S
+
+
+def _plan(offsets, pls, L, half, B, slabs, step):
+    off = (C.c_int32 * len(offsets))(*[int(v) for v in offsets])
+    seg = (C.c_int32 * (4 * 128))()
+    tiles = C.c_uint32()
+    n = S.lib().sdfx_grid_forward_plan(off, L, float(np.log2(pls)), 16, half, B, slabs, step, seg, 128, C.byref(tiles))
+    assert n > 0, n
+    return np.array(seg[:4 * n]).reshape(n, 4), int(tiles.value)
+
+
+@pytest.mark.parametrize("B", [1, 100, 4096 * 7, 1810900, 1 << 21])
+@pytest.mark.parametrize("slabs,step", [(1, 0.0), (7, 0.0), (1, 1 / 591.0), (7, 1 / 591.0), (7, 1e-5), (7, 0.05)])
+@pytest.mark.parametrize("L,half", [(16, 1), (16, 0), (9, 1), (1, 1)])
+def test_every_tile_is_assigned_once(oracle, B, slabs, step, L, half):
+    offsets, pls = oracle.grid_offsets(desired_resolution=2048)
+    seg, T = _plan(offsets, pls, L, half, B, slabs, step)
+    groups = B % 7 == 0 and slabs == 7
+    slots = -(-(B // 7) // 9) * 64 if groups else B
+    assert T == -(-slots // 256)
+    for level in range(L):
+        mine = sorted((int(f), int(f + c)) for x, l, f, c in seg if l == level)
+        assert mine and mine[0][0] == 0 and mine[-1][1] == T, (level, mine)
+        assert all(a[1] == b[0] for a, b in zip(mine, mine[1:])), (level, mine)
+    assert set(seg[:, 1].tolist()) == set(range(L)) and (seg[:, 3] > 0).all() and set(seg[:, 0].tolist()) <= set(range(8))
+    per_xcd = [int(seg[seg[:, 0] == k, 3].sum()) for k in range(8)]
+    assert sum(per_xcd) == L * T
+
+
+def test_step_hint_balances_the_modelled_cost(oracle):
+    """With the ray-ordered stencil model a fine level costs ~267 lines per wave and a coarse one the VALU floor (97):
+    equal tile counts would give the XCD holding (L15, L0) twice the load of the one holding (L8, L7)."""
+    offsets, pls = oracle.grid_offsets(desired_resolution=2048)
+    seg, T = _plan(offsets, pls, 16, 1, 1810900, 7, 1 / 591.0)
+    st7 = [7.6, 9.7, 11.8, 14.6, 18.9, 25.9, 36.3, 52.8, 79.9, 106.6, 136.7, 181.3, 212.8, 242.1, 252.8, 267.4]
+    cost = [max(c, 97.0) for c in st7]
+    load = [sum(cost[l] * c for x, l, f, c in seg if x == k) for k in range(8)]
+    assert max(load) <= 1.02 * min(load), load
+    even, _ = _plan(offsets, pls, 16, 1, 1810900, 7, 0.0)
+    load_even = [sum(cost[l] * c for x, l, f, c in even if x == k) for k in range(8)]
+    assert max(load_even) > 1.5 * min(load_even)

@@ -219,3 +219,28 @@ def test_optimizer_kernel_source_matches_reference_adan_and_gradscaler(hostmath)
         for i in range(T):
             ref = g[f"p{k + 1}_{i}"]
             assert np.abs(params[i] - ref).max() <= 3e-5 * np.abs(ref).max() + 1e-7, (k, i)
+
+
+def test_half_sum_double_rounding_is_innocuous():
+    """csrc/gridencoder_fwd.hip accumulates half tables with v_pk_add_f16 (one correctly rounded half addition) where the
+    reference adds two at::Half values in float32 and rounds the sum to half (gridencoder.cu:191). The two agree for
+    every pair of halves because float32 carries 24 >= 2 * 11 + 2 significand bits. Checked here against the exact sum
+    (float64 holds the sum of two halves exactly) over every (sign, exponent) pair x 1500 mantissa pairs incl. the edges."""
+    rng = np.random.default_rng(7)
+    edge = np.array([0, 1, 2, 3, 511, 512, 513, 1021, 1022, 1023], np.uint16)
+    mant = np.concatenate([edge, rng.integers(0, 1024, 90).astype(np.uint16)])            # 100 mantissas
+    ma, mb = np.meshgrid(mant, mant, indexing="ij")                                          # 10 000 pairs, subsample
+    keep = rng.choice(ma.size, 1500, replace=False)
+    keep[:100] = np.arange(100) * 101                                                        # the diagonal incl. edges
+    ma, mb = ma.reshape(-1)[keep], mb.reshape(-1)[keep]
+    exps = np.arange(0, 31, dtype=np.uint16)                                                 # 31 = inf/nan, excluded
+    bad = 0
+    for sa in (0, 0x8000):
+        for sb in (0, 0x8000):
+            ea, eb = np.meshgrid(exps, exps, indexing="ij")
+            a = (sa | (ea.reshape(-1, 1) << 10) | ma.reshape(1, -1)).astype(np.uint16).view(np.float16)
+            b = (sb | (eb.reshape(-1, 1) << 10) | mb.reshape(1, -1)).astype(np.uint16).view(np.float16)
+            via32 = (a.astype(np.float32) + b.astype(np.float32)).astype(np.float16)
+            exact = (a.astype(np.float64) + b.astype(np.float64)).astype(np.float16)
+            bad += int((via32.view(np.uint16) != exact.view(np.uint16)).sum())
+    assert bad == 0

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Standalone launch loop of the hash-grid encode forward (timing per implementation switch, and for rocprofv3 --pmc).
-usage: python tools/encode_bench.py [uniform|ray|stencil] [f16|f32] [launches] [impl,pairs,points,balance,hint ...]
+usage: python tools/encode_bench.py [uniform|ray|stencil] [f16|f32] [launches] [impl,balance,hint ...]
   uniform  2^21 uniform random points (the occupancy refresh's shape)
   ray      the samples of one 4096-ray view through S-grid-init, in ray order
   stencil  those samples and their six finite-difference neighbours, batched [7, M, 3] as the iteration does
-Each variant = the four switches of sdfx_grid_set_impl (-1 = default) + hint (0: none, 1: slabs = 7 / step = 1/591 where
+Each variant = the two switches of sdfx_grid_set_impl (-1 = default) + hint (0: none, 1: slabs = 7 / step = 1/591 where
 they apply); every variant is timed (rounds interleaved) and its output compared bit for bit with the first one."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ import _gridencoder, _sdfx, synth, oracle as O
 kind = sys.argv[1] if len(sys.argv) > 1 else "uniform"
 dt = torch.float16 if (len(sys.argv) < 3 or sys.argv[2] == "f16") else torch.float32
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-variants = [tuple(int(v) for v in a.split(",")) for a in sys.argv[4:]] or [(0, -1, -1, -1, 0), (1, 0, 1, 0, 0), (1, -1, -1, -1, 1)]
+variants = [tuple(int(v) for v in a.split(",")) for a in sys.argv[4:]] or [(0, -1, 0), (1, 0, 1), (1, 1, 1)]
 dev = torch.device("cuda:0")
 offsets_np, pls = O.grid_offsets(desired_resolution=2048)
 offsets = torch.from_numpy(offsets_np).to(dev)
@@ -43,8 +43,8 @@ times = {v: [] for v in variants}
 outs = {}
 for rnd in range(3):            # rounds interleaved so that clock / thermal drift hits every variant alike
     for var in variants:
-        impl, inter, pts, bal, hint = var   # inter = pairs switch
-        _sdfx.lib().sdfx_grid_set_impl(impl, inter, pts, bal)
+        impl, bal, hint = var
+        _sdfx.lib().sdfx_grid_set_impl(impl, bal)
         slabs = 7 if (hint and kind == "stencil") else 1
         step = STEP if (hint and kind != "uniform") else 0.0
         out = torch.empty(16, B, 2, device=dev, dtype=dt)
@@ -59,7 +59,7 @@ for rnd in range(3):            # rounds interleaved so that clock / thermal dri
 for var in variants:
     ms = min(times[var])
     same = bool(torch.equal(outs[var], outs[variants[0]]))
-    print(f"encode_fwd {kind} {dt} B={B} impl,pairs,points,balance,hint={var}: {ms*1e3:.1f} us/launch (min of 3 rounds; "
+    print(f"encode_fwd {kind} {dt} B={B} impl,balance,hint={var}: {ms*1e3:.1f} us/launch (min of 3 rounds; "
           f"{[round(t*1e3) for t in times[var]]}), {B/ms/1e6:.2f} Gpts/s, {B*bpp/ms/1e6:.0f} GB/s algorithmic "
           f"({B*bpp/ms/1e6/8000:.3f} of 8 TB/s)  identical to first: {same}", flush=True)
-_sdfx.lib().sdfx_grid_set_impl(-1, -1, -1, -1)
+_sdfx.lib().sdfx_grid_set_impl(-1, -1)

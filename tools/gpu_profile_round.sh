@@ -6,7 +6,7 @@ TAG=${1:-round}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
-CMD="python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-bench"
+CMD="python $REPO/bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-kernel-bench --no-reference-flow --no-nerf-only"
 # The counter passes serialise every kernel: with the 860 M-parameter UNet of the default prior (thousands of stock
 # PyTorch kernels per iteration, plus MIOpen's one-off solver search) one pass takes > 10 minutes. The kernels of this
 # repository are the same with the synthetic prior, so the PMC passes run that.
@@ -29,8 +29,9 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] != C:
                 continue
             n = r["Kernel_Name"]
-            for key in ("k_grid_forward", "k_grid_bwd_bin", "k_grid_bwd_reduce", "k_field_backward_mma", "k_field_forward_mma",
-                        "k_composite_train_fwd", "k_composite_train_bwd", "k_march_count", "k_adan_update"):
+            for key in ("k_grid_fwd", "k_grid_forward", "k_grid_bwd_bin", "k_grid_bwd_reduce", "k_field_backward_mma", "k_field_forward_mma",
+                        "k_render_train_fwd", "k_render_train_bwd", "k_composite_train_fwd", "k_composite_train_bwd", "k_march_count",
+                        "k_adan_update"):
                 if key in n:
                     per[key].append(float(r["Counter_Value"]))
         for k, v in per.items():
