@@ -129,6 +129,41 @@ int sdfx_compact_rays(const int32_t* rays_alive_in, uint32_t n, int32_t* rays_al
                       void* scratch, sdfx_stream_t stream);
 uint64_t sdfx_compact_rays_scratch_bytes(uint32_t n);
 
+/*
+ * Extension — the occupancy-grid refresh of NeRFRenderer.update_extra_state (nerf/renderer.py:1102-1149) without index tensors
+ * and without reading the mean density back to the host (csrc/occupancy.hip):
+ *   sdfx_occupancy_points   xyzs[m] = jittered sample position of cell m of the MORTON-ordered grid of one cascade
+ *                           (renderer.py:1123-1133; bound_cascade = min(2^cascade, bound)); jitter from `noise` [H^3, 3]
+ *                           (in the reference's meshgrid order n = (x H + y) H + z) or, when NULL, from Philox4x32-10 keyed
+ *                           by (seed, cascade) with counter n. The density of point m is then the new value of cell m.
+ *   sdfx_occupancy_update   grid = max(grid * decay, sigmas) where grid >= 0 (renderer.py:1137-1139); stats[0] += sum,
+ *                           stats[1] += count of those cells (doubles; zeroed first when reset_stats != 0).
+ *   sdfx_occupancy_pack     bitfield = packbits(grid, min(stats[0] / stats[1], density_thresh)) (renderer.py:1140-1147,
+ *                           raymarching.cu:267-300); mean_out[0] (optional) = the mean, for reporting.
+ */
+int sdfx_occupancy_points(uint32_t H, double bound_cascade, const float* noise, uint64_t seed, uint32_t cascade, float* xyzs,
+                          sdfx_stream_t stream);
+int sdfx_occupancy_update(float* density_grid_cascade, const float* sigmas, uint32_t n_cells, float decay, double* stats,
+                          int reset_stats, sdfx_stream_t stream);
+int sdfx_occupancy_pack(const float* density_grid, uint32_t n_cells, const double* stats, float density_thresh, uint8_t* bitfield,
+                        float* mean_out, sdfx_stream_t stream);
+
+/*
+ * Extension — the test-time renderer of NeRFRenderer.run_cuda (nerf/renderer.py:759-794: march_rays -> field -> composite_rays
+ * -> mask compaction, in a host loop) as ONE persistent kernel for 'albedo' shading and the -O field (16 x 2 half hash grid,
+ * 32-64-64-4 MLP): one lane per ray from start to finish, finished lanes pull the next ray from `next_ray_counter` (device,
+ * 4 bytes; zeroed by the call). Per ray the operations and their order are the reference loop's.
+ *   rays_o / rays_d [N, 3], nears / fars [N]; noises [N] or NULL (the perturb=True start jitter of raymarching.cu:756-757);
+ *   embeddings_half: the float16 table; offsets_host: L + 1 level offsets on the host; field_packed: sdfx_field_pack output;
+ *   out: weights_sum / depth [N], image [N, 3] (without background), n_samples [N] or NULL (samples taken per ray).
+ */
+int sdfx_render_infer(const float* rays_o, const float* rays_d, const float* nears, const float* fars, const float* noises,
+                      const uint8_t* density_bitfield, float bound, int contract, float dt_gamma, uint32_t max_steps, uint32_t N,
+                      uint32_t C, uint32_t H, const void* embeddings_half, const int32_t* offsets_host, uint32_t num_levels, float S,
+                      uint32_t base_resolution, uint32_t gridtype, int align_corners, uint32_t interp, const uint32_t* field_packed,
+                      float blob_density, float blob_radius, float T_thresh, uint32_t* next_ray_counter, float* weights_sum,
+                      float* depth, float* image, int32_t* n_samples, sdfx_stream_t stream);
+
 /* ------------------------------------------------------------------------- gridencoder */
 
 /* testing / measurement aid: switches of the D = 3, C = 2 forward (csrc/gridencoder_fwd.hip); -1 = default / environment.

@@ -61,6 +61,11 @@ _SIGNATURES = {
     "sdfx_shade_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _f32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_shade_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _f32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                             _ptr],
+    "sdfx_render_infer": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _int, _f32, _u32, _u32, _u32, _u32, _ptr, _ptr, _u32, _f32, _u32,
+                          _u32, _int, _u32, _ptr, _f32, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_occupancy_points": [_u32, C.c_double, _ptr, _u64, _u32, _ptr, _ptr],
+    "sdfx_occupancy_update": [_ptr, _ptr, _u32, _f32, _ptr, _int, _ptr],
+    "sdfx_occupancy_pack": [_ptr, _u32, _ptr, _f32, _ptr, _ptr, _ptr],
     "sdfx_render_train_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _f32, _f32, _u32, _u32, _ptr,
                                   _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_render_train_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _f32, _f32, _u32, _u32, _ptr,

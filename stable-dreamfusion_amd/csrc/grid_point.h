@@ -1,0 +1,143 @@
+// grid_point.h — pieces of the D = 3, C = 2 hash-grid forward shared by csrc/gridencoder_fwd.hip (one (point, level) per
+// thread, level-major over the XCDs) and csrc/infer.hip (all levels of a sample in one thread): the per-level constants, the
+// reference-exact accumulation (gridencoder.cu:168-195) and the evaluation of one level at one point.
+#pragma once
+
+#include "grid_common.h"
+
+namespace sdfx {
+namespace grid {
+
+struct LevelConst {   // 32 bytes, one s_load_dwordx8
+    uint32_t res, row0, size, m1, m2, flags, pad0, pad1;   // flags: 1 = hashed, 2 = size is a power of two
+};
+
+// per-level constants from the host copy of `offsets` (gridencoder.cu:61-79, 133)
+inline LevelConst make_level_const(const int32_t* offsets_host, uint32_t level, float S, uint32_t H) {
+    LevelConst c;
+    memset(&c, 0, sizeof(c));
+    c.res = level_resolution(level, S, H);
+    c.row0 = (uint32_t)offsets_host[level];
+    c.size = (uint32_t)offsets_host[level + 1] - c.row0;
+    uint64_t stride = 1;   // dense index while the strides fit (d = 0 always does)
+    stride *= c.res;
+    if (stride <= c.size) { c.m1 = (uint32_t)stride; stride *= c.res; }
+    if (stride <= c.size) { c.m2 = (uint32_t)stride; stride *= c.res; }
+    c.flags = (stride > c.size ? 1u : 0u) | ((c.size & (c.size - 1u)) == 0u ? 2u : 0u);
+    return c;
+}
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// results[ch] += w * grid[index + ch] with results and grid of the table's type (gridencoder.cu:168-195).
+// Half tables: the reference converts the float32 product to at::Half, then adds two at::Half values — in float32,
+// rounded to half again. v_cvt_pk_f16_f32 is the first rounding (kept opaque so hipcc cannot fuse product and rounding
+// into v_fma_mixlo_f16, which rounds the exact product once). v_pk_add_f16 is the second: the float32 sum of two halves
+// rounded to half equals the correctly rounded half sum, because float32's 24 significand bits >= 2 * 11 + 2 (double
+// rounding is innocuous; tests/test_hostmath.py checks the identity over all exponent pairs).
+template <bool HALF> struct Acc2;
+template <> struct Acc2<true> {
+    half2_t acc = {(_Float16)0.0f, (_Float16)0.0f};
+    __device__ __forceinline__ void add(float w, uint32_t row) {
+        const half2_t g = __builtin_bit_cast(half2_t, row);
+        const float2_t gf = {(float)g.x, (float)g.y};
+        const float2_t p = gf * w;
+        half2_t ph;
+        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(p.x), "v"(p.y));
+        acc = acc + ph;
+    }
+    __device__ __forceinline__ void store(__half* out, bool zero) const {
+        *reinterpret_cast<uint32_t*>(out) = zero ? 0u : __builtin_bit_cast(uint32_t, acc);
+    }
+};
+template <> struct Acc2<false> {
+    float a0 = 0.0f, a1 = 0.0f;
+    __device__ __forceinline__ void add(float w, uint2 row) {
+        a0 = a0 + w * __uint_as_float(row.x);
+        a1 = a1 + w * __uint_as_float(row.y);
+    }
+    __device__ __forceinline__ void store(float* out, bool zero) const {
+        *reinterpret_cast<float2*>(out) = zero ? make_float2(0.f, 0.f) : make_float2(a0, a1);
+    }
+};
+
+__device__ __forceinline__ uint32_t pick4(const uint4& b, uint32_t j) {   // dword j (0..3) of a 16-byte block
+    const uint32_t lo = (j & 2u) ? b.z : b.x;
+    const uint32_t hi = (j & 2u) ? b.w : b.y;
+    return (j & 1u) ? hi : lo;
+}
+
+
+// Features (2 halves, packed) of one point at one level of a half table: the eight corners in the reference's order, x-pairs
+// fetched with one 16-byte gather where both rows share an aligned block. `x` in [0, 1]^3 (the caller handles out-of-range
+// points: gridencoder.cu:105-130 writes zeros for them).
+template <uint32_t INTERP, bool ALIGN, bool HASHGRID>
+__device__ __forceinline__ uint32_t encode_level_half(const __half* __restrict__ table, const LevelConst& lc, const float x[3],
+                                                      bool vec16) {
+    const bool hashed = HASHGRID && (lc.flags & 1u);
+    const bool pow2 = (lc.flags & 2u) != 0u;
+    const __half* tab = table + (size_t)lc.row0 * 2;
+    float pos[3], deriv;
+    uint32_t pg[3], pn[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        grid_locate_axis(x[d], lc.res, ALIGN, INTERP, pos[d], deriv, pg[d]);
+        pg[d] = min(pg[d], lc.res - 1u);
+        pn[d] = min(pg[d] + 1u, lc.res - 1u);
+    }
+    (void)deriv;
+    uint32_t yz[4];
+    if (hashed) {
+        const uint32_t hy[2] = {pg[1] * 2654435761u, pn[1] * 2654435761u};
+        const uint32_t hz[2] = {pg[2] * 805459861u, pn[2] * 805459861u};
+#pragma unroll
+        for (int k = 0; k < 4; k++) yz[k] = hy[k & 1] ^ hz[k >> 1];
+    } else {
+        const uint32_t sy[2] = {pg[1] * lc.m1, pn[1] * lc.m1};
+        const uint32_t sz[2] = {pg[2] * lc.m2, pn[2] * lc.m2};
+#pragma unroll
+        for (int k = 0; k < 4; k++) yz[k] = sy[k & 1] + sz[k >> 1];
+    }
+    auto wrap = [&](uint32_t idx) -> uint32_t {
+        if (pow2) return idx & (lc.size - 1u);
+        return idx < lc.size ? idx : idx % lc.size;
+    };
+    uint32_t r0[4], r1[4], v0[4], v1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        r0[k] = wrap(hashed ? (pg[0] ^ yz[k]) : (pg[0] + yz[k]));
+        r1[k] = wrap(hashed ? (pn[0] ^ yz[k]) : (pn[0] + yz[k]));
+    }
+    if (vec16) {
+        uint4 blk[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) blk[k] = *reinterpret_cast<const uint4*>(tab + (size_t)(r0[k] & ~3u) * 2);
+        uint32_t extra[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 4; k++) if ((r0[k] ^ r1[k]) >= 4u) extra[k] = *reinterpret_cast<const uint32_t*>(tab + (size_t)r1[k] * 2);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v0[k] = pick4(blk[k], r0[k] & 3u);
+            v1[k] = (r0[k] ^ r1[k]) >= 4u ? extra[k] : pick4(blk[k], r1[k] & 3u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v0[k] = *reinterpret_cast<const uint32_t*>(tab + (size_t)r0[k] * 2);
+            v1[k] = *reinterpret_cast<const uint32_t*>(tab + (size_t)r1[k] * 2);
+        }
+    }
+    const float ax[2] = {1 - pos[0], pos[0]}, ay[2] = {1 - pos[1], pos[1]}, az[2] = {1 - pos[2], pos[2]};
+    Acc2<true> acc;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float wy = ay[k & 1], wz = az[k >> 1];
+        acc.add(((1 * ax[0]) * wy) * wz, v0[k]);
+        acc.add(((1 * ax[1]) * wy) * wz, v1[k]);
+    }
+    return __builtin_bit_cast(uint32_t, acc.acc);
+}
+
+}  // namespace grid
+}  // namespace sdfx

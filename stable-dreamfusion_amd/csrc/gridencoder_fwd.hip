@@ -27,7 +27,7 @@
 //     by the x-pair, packed half arithmetic (v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f16: bit-identical to at::Half's
 //     round-after-every-operation, see Acc2), and all gathers of a lane issued before the first result is touched
 //     (more points per thread were measured slower: 2 -> -2 %, 4 -> -10 %).
-#include "grid_common.h"
+#include "grid_point.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -43,9 +43,6 @@ constexpr uint32_t kMaxSegs = 6;       // per XCD
 constexpr uint32_t kGroup = 7;         // points per stencil
 constexpr uint32_t kGroupsPerWave = 9; // 9 x 7 = 63 lanes
 
-struct LevelConst {   // 32 bytes, one s_load_dwordx8
-    uint32_t res, row0, size, m1, m2, flags, pad0, pad1;   // flags: 1 = hashed, 2 = size is a power of two
-};
 struct Seg { uint32_t level, first, count, pad; };   // tiles [first, first + count) of `level`
 struct FwdPlan {
     LevelConst lv[kMaxLevels];
@@ -55,47 +52,6 @@ struct FwdPlan {
     uint32_t slabs;           // 1, or 7 = stencil batch [7, B/7, 3] evaluated with the 7 points of a sample in neighbouring lanes
     uint32_t slab_points;     // B / slabs
 };
-
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-typedef float float2_t __attribute__((ext_vector_type(2)));
-
-// results[ch] += w * grid[index + ch] with results and grid of the table's type (gridencoder.cu:168-195).
-// Half tables: the reference converts the float32 product to at::Half, then adds two at::Half values — in float32,
-// rounded to half again. v_cvt_pk_f16_f32 is the first rounding (kept opaque so hipcc cannot fuse product and rounding
-// into v_fma_mixlo_f16, which rounds the exact product once). v_pk_add_f16 is the second: the float32 sum of two halves
-// rounded to half equals the correctly rounded half sum, because float32's 24 significand bits >= 2 * 11 + 2 (double
-// rounding is innocuous; tests/test_hostmath.py checks the identity over all exponent pairs).
-template <bool HALF> struct Acc2;
-template <> struct Acc2<true> {
-    half2_t acc = {(_Float16)0.0f, (_Float16)0.0f};
-    __device__ __forceinline__ void add(float w, uint32_t row) {
-        const half2_t g = __builtin_bit_cast(half2_t, row);
-        const float2_t gf = {(float)g.x, (float)g.y};
-        const float2_t p = gf * w;
-        half2_t ph;
-        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(p.x), "v"(p.y));
-        acc = acc + ph;
-    }
-    __device__ __forceinline__ void store(__half* out, bool zero) const {
-        *reinterpret_cast<uint32_t*>(out) = zero ? 0u : __builtin_bit_cast(uint32_t, acc);
-    }
-};
-template <> struct Acc2<false> {
-    float a0 = 0.0f, a1 = 0.0f;
-    __device__ __forceinline__ void add(float w, uint2 row) {
-        a0 = a0 + w * __uint_as_float(row.x);
-        a1 = a1 + w * __uint_as_float(row.y);
-    }
-    __device__ __forceinline__ void store(float* out, bool zero) const {
-        *reinterpret_cast<float2*>(out) = zero ? make_float2(0.f, 0.f) : make_float2(a0, a1);
-    }
-};
-
-__device__ __forceinline__ uint32_t pick4(const uint4& b, uint32_t j) {   // dword j (0..3) of a 16-byte block
-    const uint32_t lo = (j & 2u) ? b.z : b.x;
-    const uint32_t hi = (j & 2u) ? b.w : b.y;
-    return (j & 1u) ? hi : lo;
-}
 
 // workgroup -> (level, tile) through the XCD's segment list (walked in order); false when there is nothing to do
 __device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint32_t& tile) {
@@ -293,15 +249,8 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
     memset(&p, 0, sizeof(p));
     double lines[kMaxLevels];
     for (uint32_t l = 0; l < levels; l++) {
-        LevelConst& c = p.lv[l];
-        c.res = level_resolution(l, S, H);
-        c.row0 = (uint32_t)offsets_host[l];
-        c.size = (uint32_t)offsets_host[l + 1] - c.row0;
-        uint64_t stride = 1;   // gridencoder.cu:61-79: dense index while the strides fit (d = 0 always does)
-        stride *= c.res;
-        if (stride <= c.size) { c.m1 = (uint32_t)stride; stride *= c.res; }
-        if (stride <= c.size) { c.m2 = (uint32_t)stride; stride *= c.res; }
-        c.flags = (stride > c.size ? 1u : 0u) | ((c.size & (c.size - 1u)) == 0u ? 2u : 0u);
+        p.lv[l] = make_level_const(offsets_host, l, S, H);
+        const LevelConst& c = p.lv[l];
         lines[l] = lines_per_wave((double)c.res * step, slabs == kGroup);
     }
     (void)elem_bytes;

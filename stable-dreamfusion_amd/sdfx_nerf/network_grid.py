@@ -27,6 +27,8 @@ _BATCH_STENCIL = int(os.environ.get("SDFX_BATCH_STENCIL", "1"))
 _FUSED_SHADE = int(os.environ.get("SDFX_FUSED_SHADE", "1"))
 # ... and the compositor and the entropy / orientation sums in the same kernel (csrc/render.hip)
 _FUSED_RENDER = int(os.environ.get("SDFX_FUSED_RENDER", "1"))
+# test-time frames: march + field + compositing + compaction of nerf/renderer.py:759-794 in one persistent kernel (csrc/infer.hip)
+_FUSED_INFER = int(os.environ.get("SDFX_FUSED_INFER", "1"))
 # The background MLP (4096 rays x 1.4 k MACs) is evaluated in float32 even under autocast: its gradient is the image
 # gradient times the loss scale, un-attenuated by compositing weights, and is what overflows fp16 first — in half it
 # caps the loss scale ~64x lower (field gradients underflow) and costs a GradScaler skip every ~12 iterations.
@@ -167,6 +169,41 @@ class NeRFNetwork(NeRFRenderer):
         pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
         sigma_all, albedo_all = self.common_forward(pts, slabs=7, ray_ordered=True)
         return _fs.fused_render(sigma_all, albedo_all[:x.shape[0]], dirs, ts, rays, rays_o, light_offset, ratio, shading, total, T_thresh)
+
+    def infer_fused_available(self, shading, light_d=None):
+        """The persistent inference kernel (csrc/infer.hip) covers 'albedo' shading of the -O field under fp16 autocast."""
+        return bool(_FUSED_INFER and shading == "albedo" and self.density_bitfield.is_cuda and torch.is_autocast_enabled("cuda")
+                    and self.opt.density_activation == "exp" and self.max_level is None and self.encoder.num_levels == 16
+                    and self.encoder.level_dim == 2 and self.encoder.input_dim == 3 and self.sigma_net.num_layers == 3
+                    and self.sigma_net.dim_hidden == 64)
+
+    @torch.no_grad()
+    def render_infer_fused(self, rays_o, rays_d, nears, fars, noises=None, T_thresh=1e-4, return_samples=False):
+        """weights_sum [N], depth [N], image [N, 3] of the eval loop of nerf/renderer.py:759-794 from one kernel launch."""
+        import numpy as np
+        import _field
+        import _gridencoder
+        import _sdfx as S
+        dev, N = rays_o.device, rays_o.shape[0]
+        n = self.sigma_net.net
+        packed = torch.empty(_field.packed_words(), dtype=torch.int32, device=dev)
+        _field.pack(*[t.detach().float().contiguous() for t in (n[0].weight, n[0].bias, n[1].weight, n[1].bias, n[2].weight, n[2].bias)],
+                    packed)
+        emb = self.encoder.embeddings.detach().to(torch.half).contiguous()          # autocast: fp16 table (grid.py:46-47)
+        f = dict(dtype=torch.float32, device=dev)
+        ws, depth, image = torch.empty(N, **f), torch.empty(N, **f), torch.empty(N, 3, **f)
+        counter = torch.empty(1, dtype=torch.int32, device=dev)
+        ns = torch.empty(N, dtype=torch.int32, device=dev) if return_samples else None
+        chk = lambda t, name: S.check_tensor(t.contiguous(), name, torch.float32)
+        S.call("sdfx_render_infer", S.ptr(chk(rays_o, "rays_o")), S.ptr(chk(rays_d, "rays_d")), S.ptr(chk(nears, "nears")),
+               S.ptr(chk(fars, "fars")), S.ptr(None if noises is None else chk(noises, "noises")),
+               S.ptr(S.check_tensor(self.density_bitfield, "density_bitfield", torch.uint8)), float(self.bound), 0,
+               float(self.opt.dt_gamma), int(self.opt.max_steps), N, self.cascade, self.grid_size, S.ptr(emb),
+               _gridencoder.offsets_host(self.encoder.offsets), 16, float(np.log2(self.encoder.per_level_scale)),
+               int(self.encoder.base_resolution), self.encoder.gridtype_id, int(bool(self.encoder.align_corners)), self.encoder.interp_id,
+               S.ptr(packed), float(self.opt.blob_density), float(self.opt.blob_radius), float(T_thresh), S.ptr(counter), S.ptr(ws),
+               S.ptr(depth), S.ptr(image), S.ptr(ns), S.stream())
+        return (ws, depth, image, ns) if return_samples else (ws, depth, image)
 
     def fused_render_available(self, shading):
         return bool(_FUSED_RENDER and _FUSED_SHADE and _BATCH_STENCIL and (torch.is_tensor(shading) or shading in _fs.MODES))

@@ -8,11 +8,16 @@ reference's, so its checkpoints load.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 import raymarching
+
+# occupancy refresh through csrc/occupancy.hip (Morton-ordered sample points generated on the device, EMA + mean +
+# packbits without a host read); SDFX_FUSED_OCCUPANCY=0 keeps the reference's tensor-by-tensor flow
+_FUSED_OCC = int(os.environ.get("SDFX_FUSED_OCCUPANCY", "1"))
 
 
 def safe_normalize(x, eps=1e-20):
@@ -40,9 +45,10 @@ class NeRFRenderer(nn.Module):
         density_bitfield = torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8)
         self.register_buffer("density_grid", density_grid)
         self.register_buffer("density_bitfield", density_bitfield)
-        self.mean_density = 0
+        self._mean_density, self._mean_density_dev = 0, None
         self.iter_density = 0
-        self._grid_coords = None  # (morton indices, cell-centre coords), built once per device
+        self._grid_coords = None  # (morton indices, cell-centre coords), built once per device (unfused refresh only)
+        self._occ_buffers = None  # (sample points, [sum, count], mean) of the fused refresh
 
     @torch.no_grad()
     def density_blob(self, x):
@@ -141,6 +147,10 @@ class NeRFRenderer(nn.Module):
             results["num_samples"] = xyzs.shape[0]
             results["num_valid"] = n_valid
             results["num_total"] = total
+        elif (hasattr(self, "infer_fused_available") and self.infer_fused_available(shading) and not binarize):
+            # one persistent kernel instead of the host-paced loop below (csrc/infer.hip): same per-ray operations
+            noises = torch.rand(N, dtype=torch.float32, device=device) if perturb else None
+            weights_sum, depth, image = self.render_infer_fused(rays_o, rays_d, nears, fars, noises, T_thresh)
         else:
             dtype = torch.float32
             weights_sum = torch.zeros(N, dtype=dtype, device=device)
@@ -175,11 +185,28 @@ class NeRFRenderer(nn.Module):
         return results
 
     # ----------------------------------------------------------------- update_extra_state
+    @property
+    def mean_density(self):
+        """Mean of the valid density-grid cells after the last refresh. The fused refresh leaves it on the device (nothing in
+        the training loop needs it on the host); reading it here synchronises."""
+        if self._mean_density_dev is not None:
+            self._mean_density = float(self._mean_density_dev.item())
+            self._mean_density_dev = None
+        return self._mean_density
+
+    @mean_density.setter
+    def mean_density(self, v):
+        self._mean_density, self._mean_density_dev = v, None
+
     @torch.no_grad()
-    def update_extra_state(self, decay=0.95, S=128):
-        """Refresh density_grid (EMA-max of jittered field samples, Morton order) and repack the
-        occupancy bitfield; called every opt.update_extra_interval iterations."""
+    def update_extra_state(self, decay=0.95, S=128, noise=None):
+        """Refresh density_grid (EMA-max of jittered field samples, Morton order) and repack the occupancy bitfield; called
+        every opt.update_extra_interval iterations (nerf/renderer.py:1102-1149).
+        `noise` (extension, for tests): [cascade, H^3, 3] uniform numbers in the order of the reference's
+        torch.rand_like(cas_xyzs) (meshgrid index), instead of drawing them."""
         device = self.aabb_train.device
+        if _FUSED_OCC and device.type == "cuda":
+            return self._update_extra_state_fused(decay, noise)
         tmp_grid = -torch.ones_like(self.density_grid)
         if self._grid_coords is None or self._grid_coords[0].device != device:
             ar = torch.arange(self.grid_size, dtype=torch.int32, device=device)
@@ -194,7 +221,8 @@ class NeRFRenderer(nn.Module):
             bound = min(2 ** cas, self.bound)
             half_grid_size = bound / self.grid_size
             cas_xyzs = xyzs * (bound - half_grid_size)
-            cas_xyzs = cas_xyzs + (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
+            u = torch.rand_like(cas_xyzs) if noise is None else noise[cas].to(cas_xyzs)
+            cas_xyzs = cas_xyzs + (u * 2 - 1) * half_grid_size
             sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach()
             tmp_grid[cas, indices] = sigmas.to(tmp_grid.dtype)
 
@@ -205,6 +233,34 @@ class NeRFRenderer(nn.Module):
 
         density_thresh = min(self.mean_density, self.density_thresh)
         self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+
+    def _update_extra_state_fused(self, decay, noise):
+        """The same refresh on csrc/occupancy.hip: per cascade [points in Morton order -> density -> EMA-max + sum/count],
+        then the threshold min(mean, density_thresh) and the bit packing on the device. No coords / indices tensors, no
+        scatter, no host read (the reference reads the mean with .item())."""
+        import _sdfx as S
+        device = self.density_grid.device
+        H, n = self.grid_size, self.grid_size ** 3
+        if self._occ_buffers is None or self._occ_buffers[0].device != device:
+            self._occ_buffers = (torch.empty(n, 3, dtype=torch.float32, device=device),
+                                 torch.zeros(2, dtype=torch.float64, device=device),
+                                 torch.zeros(1, dtype=torch.float32, device=device))
+        pts, stats, mean = self._occ_buffers
+        grid = S.check_tensor(self.density_grid, "density_grid", torch.float32)
+        # the seed comes from torch's CPU generator: reproducible under torch.manual_seed, no device synchronisation
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        for cas in range(self.cascade):
+            bound = min(2 ** cas, self.bound)
+            nz = None if noise is None else S.check_tensor(noise[cas].to(device=device, dtype=torch.float32).contiguous(), "noise",
+                                                           torch.float32)
+            S.call("sdfx_occupancy_points", H, float(bound), S.ptr(nz), seed, cas, S.ptr(pts), S.stream())
+            sigmas = self.density(pts)["sigma"].reshape(-1).detach().float().contiguous()
+            S.call("sdfx_occupancy_update", grid.data_ptr() + cas * n * 4, S.ptr(sigmas), n, float(decay), S.ptr(stats),
+                   int(cas == 0), S.stream())
+        S.call("sdfx_occupancy_pack", S.ptr(grid), self.cascade * n, S.ptr(stats), float(self.density_thresh),
+               S.ptr(S.check_tensor(self.density_bitfield, "density_bitfield", torch.uint8)), S.ptr(mean), S.stream())
+        self._mean_density_dev = mean
+        self.iter_density += 1
 
     def render(self, rays_o, rays_d, mvp=None, h=None, w=None, staged=False, max_ray_batch=4096, **kwargs):
         return self.run_cuda(rays_o, rays_d, **kwargs)

@@ -17,8 +17,8 @@ Three ways of driving the same arithmetic (`mode`, default from SDFX_TRAIN_MODE,
                regulariser weights, the shading mode of the fused render kernel) are read from a small device block
                refreshed by one H2D copy. Graphs are captured per (capacity, shading class, as_latent, background kind) —
                'lambertian', 'textureless' and 'normal' are one class: csrc/render.hip reads the mode from the block —
-               and all captures share one memory pool; capacities come from a geometric ladder (ratio 1.1) and a miss
-               captures the neighbouring ladder steps too, since the sample total drifts.
+               capacities come from a geometric ladder (ratio 1.1) and a miss captures the neighbouring ladder steps too,
+               since the sample total drifts.
 """
 from __future__ import annotations
 
@@ -89,10 +89,9 @@ class TrainStep:
         self.graph_bucket = int(os.environ.get("SDFX_GRAPH_BUCKET", "32768"))
         self.graph_ratio = float(os.environ.get("SDFX_GRAPH_RATIO", "1.1"))   # capacity ladder: <= 10 % padding
         self.graph_prime_span = 1.5      # on a miss, capture every ladder step within this factor of the need
-        self.max_graphs = int(os.environ.get("SDFX_MAX_GRAPHS", "64"))
+        self.max_graphs = int(os.environ.get("SDFX_MAX_GRAPHS", "32"))
         self._warm = set()               # kinds that have run eagerly once
         self.graphs = {}                 # (capacity, shading class, as_latent, bg_kind, H, W, lr signature) -> captured stages
-        self.graph_pool = None           # one memory pool for every capture (replays are serial)
         self.lr_changes = 0
         self.graph_uses = {}
         self.stats = {"replays": 0, "captures": 0, "eager": 0, "prefetched": 0}
@@ -268,13 +267,14 @@ class TrainStep:
             victim = min(old, key=lambda k: self.graph_uses.get(k, 0))
             del self.graphs[victim]
             self.graph_uses.pop(victim, None)
+        # (each capture keeps its private memory pool: one pool shared by all captures — torch.cuda.graph(pool=...) — tripped
+        # an allocator assert on ROCm 7.2 / PyTorch 2.10, "use_count > 0" in HIPCachingAllocator, as soon as the frozen prior's
+        # VAE was part of a capture; memory is bounded instead by max_graphs and the narrow prime span)
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        if self.graph_pool is None:
-            self.graph_pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g1, pool=self.graph_pool):
+        with torch.cuda.graph(g1):
             marched = self._stage_march(key[0])
         self.optimizer.zero_grad()
-        with torch.cuda.graph(g2, pool=self.graph_pool):
+        with torch.cuda.graph(g2):
             loss = self._stage_train(marched, *key[1:6])
         # (the gradient buffers of this graph are kept reachable for diagnostics: Python's p.grad only names the
         # buffers of the most recent capture)

@@ -39,7 +39,7 @@ def test_ctypes_signatures_match_header_prototypes():
     import _sdfx
     text = open(os.path.join(ROOT, "include", "sdfx.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    protos = re.findall(r"\b(?:int|uint64_t|uint32_t|const char\*)\s+(sdfx_[a-zA-Z0-9_]+)\s*\(([^)]*)\)\s*;", text)
+    protos = re.findall(r"\b(?:int|void|uint64_t|uint32_t|const char\*)\s+(sdfx_[a-zA-Z0-9_]+)\s*\(([^)]*)\)\s*;", text)
     assert len(protos) >= 24
     def ctype(decl):
         decl = decl.strip()
@@ -48,7 +48,7 @@ def test_ctypes_signatures_match_header_prototypes():
         if "*" in decl or decl.startswith("sdfx_stream_t"):
             return C.c_void_p
         base = decl.split()[0] if not decl.startswith("const") else decl.split()[1]
-        return {"uint32_t": C.c_uint32, "float": C.c_float, "int": C.c_int, "uint64_t": C.c_uint64}[base]
+        return {"uint32_t": C.c_uint32, "float": C.c_float, "double": C.c_double, "int": C.c_int, "uint64_t": C.c_uint64}[base]
     for name, params in protos:
         want = [c for c in (ctype(d) for d in params.split(",")) if c is not None]
         if name in ("sdfx_last_error", "sdfx_build_info"):

@@ -1,0 +1,121 @@
+"""csrc/infer.hip — the test-time renderer (nerf/renderer.py:759-794) as one persistent kernel — against
+  (1) the host-paced loop of sdfx_nerf/renderer.py run with the SAME field arithmetic (v_dot2 kernels): per ray the
+      operations and their order are identical, so the frame agrees to float rounding;
+  (2) the reference loop restated with the ORACLE operators (oracle.march_rays / grid_encode_forward on the half table /
+      field_forward / composite_rays + numpy mask compaction) on a ray subset of an 800 x 800 frame: tolerance of the fp16
+      MLP (the oracle's MLP is float32 on half-rounded features)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+AABB = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+
+
+def _model(dev, seed=0):
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf import network_grid as ng
+    from sdfx_nerf.options import default_opt
+    torch.manual_seed(seed)
+    model = ng.NeRFNetwork(default_opt()).to(dev).eval()
+    with torch.no_grad():
+        model.encoder.embeddings.uniform_(-0.3, 0.3)          # structure beyond the density blob
+        model.density_bitfield.copy_(torch.from_numpy(synth.s_grid_blobs()).to(dev))
+    return model, ng
+
+
+def _frame_rays(hw, view=3):
+    poses, fovy = synth.reference_cameras()
+    return synth.get_rays(poses[view], float(fovy[view]), hw, hw)
+
+
+def test_persistent_kernel_equals_host_loop(dev, oracle):
+    model, ng = _model(dev)
+    import _sdfx as S
+    o, d = synth.s_rays(5)
+    ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    out = {}
+    try:
+        S.lib().sdfx_field_set_impl(1)                         # v_dot2 field kernels: the arithmetic csrc/infer.hip inlines
+        for fused in (1, 0):
+            ng._FUSED_INFER = fused
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                r = model.render(ro[None], rd[None], None, 64, 64, staged=False, perturb=False, bg_color=1.0, ambient_ratio=1.0,
+                                 shading="albedo")
+            out[fused] = (r["image"].float().clone(), r["depth"].float().clone(), r["weights_sum"].float().clone())
+    finally:
+        S.lib().sdfx_field_set_impl(-1)
+        ng._FUSED_INFER = 1
+    for a, b in zip(out[1], out[0]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), float((a - b).abs().max())
+    assert float(out[1][2].max()) > 0.5                        # the frame is not empty
+
+
+def test_800x800_frame_against_the_oracle_loop_on_a_ray_subset(dev, oracle):
+    model, ng = _model(dev, seed=1)
+    import _gridencoder
+    o, d = _frame_rays(800)
+    N = o.shape[0]
+    assert N == 640000
+    ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        import raymarching
+        nears, fars = raymarching.near_far_from_aabb(ro, rd, model.aabb_infer)
+        ws, depth, image, ns = model.render_infer_fused(ro, rd, nears, fars, None, 1e-4, return_samples=True)
+    ws, depth, image, ns = (t.cpu().numpy() for t in (ws, depth, image, ns))
+    assert ns.max() <= 1024 and (ns > 0).mean() > 0.02
+    # ---- the reference loop with the oracle operators on every 331st ray ----
+    sel = np.arange(0, N, 331)
+    so, sd = o[sel], d[sel]
+    n = so.shape[0]
+    bf = synth.s_grid_blobs()
+    nr, fr = oracle.near_far_from_aabb(so, sd, AABB, 0.2)
+    assert np.array_equal(nr, nears.cpu().numpy()[sel])
+    offsets, pls = oracle.grid_offsets(desired_resolution=2048)
+    table = model.encoder.embeddings.detach().cpu().numpy().astype(np.float16)
+    net = model.sigma_net.net
+    Ws = [net[i].weight.detach().cpu().numpy() for i in range(3)]
+    Bs = [net[i].bias.detach().cpu().numpy() for i in range(3)]
+    ws_r = np.zeros(n, np.float32); dp_r = np.zeros(n, np.float32); im_r = np.zeros((n, 3), np.float32)
+    alive = np.arange(n, dtype=np.int32); t_r = nr.copy()
+    step, taken = 0, np.zeros(n, np.int64)
+    while step < 1024 and alive.shape[0] > 0:
+        n_alive = alive.shape[0]
+        n_step = max(min(n // n_alive, 8), 1)
+        x, _, ts = oracle.march_rays(n_alive, n_step, alive, t_r, so, sd, 1.0, bf, 1, 128, nr, fr, np.zeros(n_alive, np.float32))
+        x01 = ((x + np.float32(1)) / np.float32(2)).astype(np.float32)
+        enc, _, _ = oracle.grid_encode_forward(x01, table, offsets, pls, 16, False, 0, False, 1)
+        sigma, albedo = oracle.field_forward(enc.astype(np.float32), x, Ws, Bs)
+        oracle.composite_rays(n_alive, n_step, alive, t_r, sigma, albedo, ts, ws_r, dp_r, im_r, 1e-4)
+        alive = alive[alive >= 0]
+        step += n_step
+    # fp16 MLP (kernel) vs float32 MLP on half features (oracle): 2e-3-level differences per sample, accumulated along a ray
+    assert np.abs(ws[sel] - ws_r).max() < 2e-2 and np.abs(image[sel] - im_r).max() < 2e-2
+    assert np.abs(depth[sel] - dp_r).max() < 5e-2
+    assert np.abs(ws[sel] - ws_r).mean() < 1e-3 and np.abs(image[sel] - im_r).mean() < 1e-3
+    hit = ws_r > 0.5
+    assert hit.sum() > 20 and np.abs(ws[sel][hit] - ws_r[hit]).max() < 5e-3
+
+
+def test_perturbed_start_and_step_cap(dev, oracle):
+    """noises shift the first sample exactly as raymarching.cu:756-757; max_steps bounds the samples of a ray."""
+    model, ng = _model(dev, seed=2)
+    o, d = synth.s_rays(6, 32, 32)
+    ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    import raymarching
+    nears, fars = raymarching.near_far_from_aabb(ro, rd, model.aabb_infer)
+    noises = torch.rand(ro.shape[0], device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = model.render_infer_fused(ro, rd, nears, fars, None, 1e-4, return_samples=True)
+        b = model.render_infer_fused(ro, rd, nears, fars, noises, 1e-4, return_samples=True)
+        model.opt.max_steps, keep = 16, model.opt.max_steps
+        try:
+            c = model.render_infer_fused(ro, rd, nears, fars, None, 1e-4, return_samples=True)
+        finally:
+            model.opt.max_steps = keep
+    assert not torch.equal(a[2], b[2]) and torch.allclose(a[0], b[0], atol=0.15)
+    assert int(c[3].max()) <= 16 and int(a[3].max()) > 16
