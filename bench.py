@@ -41,6 +41,8 @@ ENCODE_FWD_BYTES_PER_POINT = {2: 588, 4: 1164}   # 4*D + L*2^D
 ENCODE_BWD_BYTES_PER_POINT = {2: 1100, 4: 2188}
 COMPOSITE_FWD_BYTES = (28, 28)                   # per sample, per ray
 COMPOSITE_BWD_BYTES = (44, 48)
+RENDER_FWD_BYTES = (64, 48)                      # csrc/render.hip: per sample (capacity row), per ray
+RENDER_BWD_BYTES = (100, 96)
 
 
 def parse():
@@ -143,6 +145,13 @@ def install_timers(timer):
     timer.wrap(_gridencoder, "grid_encode_backward", "grid_encode_backward", enc_bwd_bytes)
     timer.wrap(_raymarching, "composite_rays_train_forward", "composite_rays_train_forward", comp_fwd_bytes)
     timer.wrap(_raymarching, "composite_rays_train_backward", "composite_rays_train_backward", comp_bwd_bytes)
+    # shading + compositing + regulariser sums in one kernel (csrc/render.hip): per sample 7*4 + 12 + 12 + 8 in, 4 out
+    # forward; 60 in, 7*4 + 12 out backward; per ray 8 + 12 in, 4 + 4 + 12 + 8 out forward (+ gradients backward)
+    import _render
+    timer.wrap(_render, "train_forward", "render_train_forward",
+               lambda sigma7, albedo, dirs, ts, rays, *r, **k: dirs.shape[0] * RENDER_FWD_BYTES[0] + rays.shape[0] * RENDER_FWD_BYTES[1])
+    timer.wrap(_render, "train_backward", "render_train_backward",
+               lambda sigma7, albedo, dirs, ts, rays, *r, **k: dirs.shape[0] * RENDER_BWD_BYTES[0] + rays.shape[0] * RENDER_BWD_BYTES[1])
     # the operator packages bound `_backend` at import time to the module objects, so they see the wrappers
 
 
@@ -217,39 +226,41 @@ def kernel_microbench(dev):
                                                                               ws, dep, img, M, 4096, 1e-4, False, gs, gc), iters=20)
         out[f"composite_bwd_{gname}"] = {"ms": ms, "M": M, "Mrays_per_s": 4096 / ms / 1e3,
                                          "GBps": (M * 44 + 4096 * 48) / ms / 1e6}
-    # inference operators (march_rays / composite_rays / compact_rays, renderer.py:759-794) with synthetic densities:
-    # the loop the reference runs at test time, n_step samples per alive ray and round, until every ray is done
-    for gname, bf in (("init", synth.s_grid_init()[2]),):
-        bfd = to(bf)
-        N = od.shape[0]
+    return out
 
-        def infer():
-            ws, dep, img = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
-            alive = torch.arange(N, dtype=torch.int32, device=dev)
-            rays_t = nears.clone()
-            step_i, rounds = 0, 0
-            while step_i < 1024 and alive.shape[0] > 0:
-                n_alive = alive.shape[0]
-                n_step = max(min(N // n_alive, 8), 1)
-                xyzs, dirs, ts = raymarching.march_rays(n_alive, n_step, alive, rays_t, od, dd, 1.0, bfd, 1, 128, nears, fars,
-                                                        False, 0, 1024)
-                sig = torch.full((xyzs.shape[0],), 8.0, device=dev)
-                rgb = xyzs * 0.5 + 0.5
-                raymarching.composite_rays(n_alive, n_step, alive, rays_t, sig, rgb, ts, ws, dep, img, 1e-4)
-                alive = raymarching.compact_rays(alive)
-                step_i += n_step
-                rounds += 1
-            return rounds
 
-        rounds = infer()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            infer()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 3 * 1e3
-        out[f"infer_loop_{gname}"] = {"ms": ms, "rounds": rounds, "Mrays_per_s": N / ms / 1e3,
-                                      "note": "4096 rays to termination, sigma = 8 everywhere occupied; host-paced (one sync per round)"}
+def inference_bench(model, dev):
+    """A test-time frame at the reference's default resolution (800 x 800 = 640 000 rays, main.py:151-152; its only published
+    figure is "~10 FPS at 800x800", readme.md:28) through the model the timed region just trained: the persistent kernel
+    (csrc/infer.hip) and the host-paced loop of nerf/renderer.py:759-794 on the same operators."""
+    import synth
+    from sdfx_nerf import network_grid as ng
+    poses, fovy = synth.reference_cameras()
+    o, d = synth.get_rays(poses[3], float(fovy[3]), 800, 800)
+    ro, rd = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+    was_training = model.training
+    model.eval()
+    out = {}
+    try:
+        for name, fused, n in (("persistent_kernel", 1, 5), ("host_paced_loop", 0, 1)):
+            ng._FUSED_INFER = fused
+
+            def frame():
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                    return model.render(ro, rd, None, 800, 800, staged=False, perturb=False, bg_color=1.0, ambient_ratio=1.0,
+                                        shading="albedo")
+            r = frame()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                r = frame()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / n * 1e3
+            out[f"infer_800x800_{name}"] = {"ms_per_frame": ms, "fps": 1e3 / ms, "Mrays_per_s": 640000 / ms / 1e3,
+                                             "pixels_covered": float((r["weights_sum"] > 0.5).float().mean())}
+    finally:
+        ng._FUSED_INFER = 1
+        model.train(was_training)
     return out
 
 
@@ -291,12 +302,14 @@ def _reference_o2_model():
 
 def cpu_baseline(budget_s=30.0):
     """BASELINE.md §3 / SURVEY.md §8(d): the `-O2` vanilla-NeRF path (4096 rays x (64 + 32) samples, render + backward with a
-    dummy SDS gradient, fp32, perturb=True) on ALL host cores: 1 warm-up + up to 5 timed iterations per shading, stopping
-    when the budget is spent. kind = "reference" when the reference's own code ran, "port" for oracle/o2_path.py."""
+    dummy SDS gradient, fp32, perturb=True) on the host cores. The thread count is PROBED (32, 64, 128, all cores: one
+    iteration each while it keeps getting faster) and the fastest is used and reported as `cores` — handing all 256 hardware
+    threads of the GPU box's EPYC to PyTorch's intra-op pools made an iteration 40x slower than 32 threads (70 s vs < 2 s:
+    the tensors of this path are a few MB, the pools spin). Then 1 warm-up + up to 5 timed iterations per shading within the
+    budget. kind = "reference" when the reference's own code ran, "port" for oracle/o2_path.py."""
     import synth
     from oracle import o2_path
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     o, d = synth.s_rays(0)
     ro, rd = torch.from_numpy(o), torch.from_numpy(d)
     model, kind = None, "port"
@@ -323,8 +336,23 @@ def cpu_baseline(budget_s=30.0):
             loss = loss + 1e-2 * out["loss_orient"]
         loss.backward()
 
-    res, t_begin = {}, time.perf_counter()
-    for shading, share in (("albedo", 0.4), ("lambertian", 1.0)):
+    t_begin = time.perf_counter()
+    probe, best = {}, None
+    for n in sorted({min(c, ncpu) for c in (32, 64, 128, ncpu)}):
+        torch.set_num_threads(n)
+        t0 = time.perf_counter()
+        iteration("albedo")
+        probe[n] = time.perf_counter() - t0
+        if best is not None and probe[n] > 1.15 * probe[best]:
+            break                                  # more threads made it slower: stop climbing
+        if best is None or probe[n] < probe[best]:
+            best = n
+        if time.perf_counter() - t_begin > 0.3 * budget_s:
+            break
+    torch.set_num_threads(best)
+    cores = ncpu
+    res = {}
+    for shading, share in (("albedo", 0.6), ("lambertian", 1.0)):
         times = []
         for it in range(6):
             t0 = time.perf_counter()
@@ -342,7 +370,7 @@ def cpu_baseline(budget_s=30.0):
     except OSError:
         pass
     return {"kind": kind, "cores": int(torch.get_num_threads()), "os_cpu_count": cores, "cpu_model": cpu_model, "shadings": res,
-            "seconds": time.perf_counter() - t_begin}
+            "thread_probe_s_per_albedo_iter": {str(k): round(v, 2) for k, v in probe.items()}, "seconds": time.perf_counter() - t_begin}
 
 
 # ---- multi-GPU control path (independent prompts, one process per GPU) ------------------------------
@@ -544,22 +572,32 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used for barriers + two small reductions only
 
+    t_start = time.perf_counter()
+
+    def stage(name):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f} s] {name}", file=sys.stderr, flush=True)
+
     timer = KernelTimer()
     job = (DryJob if dry else GpuJob)(args, rank, world, dev)
+    stage("model and prior built")
     if not dry:
         install_timers(timer)
     if not agree(job.prior_ok, dist, dev):      # one rank without the big prior: nobody uses it
         job.use_synthetic_prior()
     job.build()
     calib = job.calibrate()
+    stage(f"loss scale calibrated ({calib} iterations)")
     plan = phase_plan(args.phase, args.steps)
     for name, _ in plan:
         job.prime(name)
+        stage(f"phase {name} primed")
     job.set_phase(plan[0][0])
     for i in range(args.warmup):
         job.step(i)
     job.sync()
     applied_before = job.applied()
+    stats_before = dict(getattr(getattr(job, "step_obj", None), "stats", {}))
 
     # ---- the timed region: EXACTLY args.steps steps between two barrier + synchronize pairs ----
     if dist is not None:
@@ -583,7 +621,9 @@ def main():
     job.sync()
     elapsed_local = time.perf_counter() - t0
     timer.enabled = False
+    stage("timed region done")
     applied_in_timed = job.applied() - applied_before
+    stats_timed = {k: v - stats_before.get(k, 0) for k, v in getattr(getattr(job, "step_obj", None), "stats", {}).items()}
     elapsed = job_elapsed(elapsed_local, dist, dev)
     phases, prev = {}, t0
     for name, k, t in marks:
@@ -611,6 +651,7 @@ def main():
     step = job.step_obj
     result["grad_scale"] = step.get_scale()
     result["graph_stats"] = dict(step.stats)
+    result["graph_stats_timed_region"] = stats_timed
     roofline_pass = "timed region"
     if step.mode == "graph":
         # Launches inside a replayed HIP graph do not pass through Python, so the per-kernel HIP events are taken in a
@@ -663,6 +704,7 @@ def main():
         job.calibrate()
         ref_flow = timed_pass()
         job.step_obj = graph_step
+    stage("secondary passes done")
     result["iters_per_sec_without_unet"] = nerf_only
     result["iters_per_sec_reference_flow"] = ref_flow
 
@@ -704,6 +746,7 @@ def main():
     if not args.no_kernel_bench:
         try:
             kb = kernel_microbench(dev)
+            kb.update(inference_bench(job.model, dev))
             result["kernels_standalone"] = {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                                             for k, v in kb.items()}
         except Exception as exc:  # noqa: BLE001
@@ -717,7 +760,8 @@ def main():
                 "kind": cb["kind"] + " -O2",
                 "sample": f"the reference's -O2 vanilla-NeRF path ({'its own code, /root/reference' if cb['kind'] == 'reference' else 'oracle/o2_path.py, pinned to it by tests/golden/o2_ref.npz'}): "
                           f"4096 rays x (64 + 32) samples, render + backward with a dummy SDS gradient, fp32, "
-                          f"torch threads = {cb['cores']} (os.cpu_count() = {cb['os_cpu_count']}, {cb['cpu_model']}); value = 'lambertian' "
+                          f"torch threads = {cb['cores']} = the fastest of the probe {cb['thread_probe_s_per_albedo_iter']} s per 'albedo' iteration "
+                          f"(os.cpu_count() = {cb['os_cpu_count']}, {cb['cpu_model']}); value = 'lambertian' "
                           f"shading (autograd normals, as 80 % of a run): median of {lam['iters']} iterations {lam['s_per_iter_median']:.2f} s; "
                           f"'albedo': {cb['shadings']['albedo']['s_per_iter_median']:.2f} s; {cb['seconds']:.0f} s of CPU work in total",
                 "rays_per_s": {k: round(v["rays_per_s"], 1) for k, v in cb["shadings"].items()}}

@@ -69,15 +69,24 @@ __device__ __forceinline__ uint32_t pick4(const uint4& b, uint32_t j) {   // dwo
 }
 
 
-// Features (2 halves, packed) of one point at one level of a half table: the eight corners in the reference's order, x-pairs
-// fetched with one 16-byte gather where both rows share an aligned block. `x` in [0, 1]^3 (the caller handles out-of-range
-// points: gridencoder.cu:105-130 writes zeros for them).
+// One level at one point, in three phases so that a caller can keep the gathers of SEVERAL levels in flight together:
+//   level_prepare  cell, interpolation weights and the row indices of the four x-pairs (no memory access)
+//   level_gather   the gathers (one 16-byte block per x-pair + the odd second row)
+//   level_reduce   the reference-exact accumulation (gridencoder.cu:168-195), corners in the reference's order
+// `x` in [0, 1]^3 (the caller handles out-of-range points: gridencoder.cu:105-130 writes zeros for them).
+struct LevelPoint {
+    uint32_t r0[4], r1[4];     // rows of the corners (x, y, z) and (x + 1, y, z) for the four (y, z) corners
+    float ax1, ay1, az1;       // interpolation weights of the "+1" vertices (the others are 1 - these)
+};
+struct LevelData {
+    uint4 blk[4];
+    uint32_t extra[4];
+};
+
 template <uint32_t INTERP, bool ALIGN, bool HASHGRID>
-__device__ __forceinline__ uint32_t encode_level_half(const __half* __restrict__ table, const LevelConst& lc, const float x[3],
-                                                      bool vec16) {
+__device__ __forceinline__ void level_prepare(const LevelConst& lc, const float x[3], LevelPoint& p) {
     const bool hashed = HASHGRID && (lc.flags & 1u);
     const bool pow2 = (lc.flags & 2u) != 0u;
-    const __half* tab = table + (size_t)lc.row0 * 2;
     float pos[3], deriv;
     uint32_t pg[3], pn[3];
 #pragma unroll
@@ -87,54 +96,63 @@ __device__ __forceinline__ uint32_t encode_level_half(const __half* __restrict__
         pn[d] = min(pg[d] + 1u, lc.res - 1u);
     }
     (void)deriv;
-    uint32_t yz[4];
-    if (hashed) {
-        const uint32_t hy[2] = {pg[1] * 2654435761u, pn[1] * 2654435761u};
-        const uint32_t hz[2] = {pg[2] * 805459861u, pn[2] * 805459861u};
-#pragma unroll
-        for (int k = 0; k < 4; k++) yz[k] = hy[k & 1] ^ hz[k >> 1];
-    } else {
-        const uint32_t sy[2] = {pg[1] * lc.m1, pn[1] * lc.m1};
-        const uint32_t sz[2] = {pg[2] * lc.m2, pn[2] * lc.m2};
-#pragma unroll
-        for (int k = 0; k < 4; k++) yz[k] = sy[k & 1] + sz[k >> 1];
-    }
-    auto wrap = [&](uint32_t idx) -> uint32_t {
-        if (pow2) return idx & (lc.size - 1u);
-        return idx < lc.size ? idx : idx % lc.size;
-    };
-    uint32_t r0[4], r1[4], v0[4], v1[4];
+    p.ax1 = pos[0]; p.ay1 = pos[1]; p.az1 = pos[2];
+    // Branch-free in the level's kind (both the hashed and the dense index are formed and one is masked in): this function is
+    // inlined once per level of a batch, and control flow on per-level flags made the compiler unswitch the batch loop into
+    // every combination of kinds (12 000 instructions, more than the instruction cache holds).
+    const uint32_t hm = hashed ? 0xffffffffu : 0u;
+    const uint32_t wm = pow2 ? lc.size - 1u : 0xffffffffu;
+    const uint32_t hy[2] = {pg[1] * 2654435761u, pn[1] * 2654435761u};
+    const uint32_t hz[2] = {pg[2] * 805459861u, pn[2] * 805459861u};
+    const uint32_t sy[2] = {pg[1] * lc.m1, pn[1] * lc.m1};
+    const uint32_t sz[2] = {pg[2] * lc.m2, pn[2] * lc.m2};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        r0[k] = wrap(hashed ? (pg[0] ^ yz[k]) : (pg[0] + yz[k]));
-        r1[k] = wrap(hashed ? (pn[0] ^ yz[k]) : (pn[0] + yz[k]));
+        const uint32_t yh = hy[k & 1] ^ hz[k >> 1], yd = sy[k & 1] + sz[k >> 1];
+        uint32_t i0 = (((pg[0] ^ yh) & hm) | ((pg[0] + yd) & ~hm)) & wm;
+        uint32_t i1 = (((pn[0] ^ yh) & hm) | ((pn[0] + yd) & ~hm)) & wm;
+        if (i0 >= lc.size) i0 %= lc.size;   // index % hashmap_size (gridencoder.cu:78): only a non-power-of-two level whose
+        if (i1 >= lc.size) i1 %= lc.size;   // dense index overruns its size ever gets here
+        p.r0[k] = i0; p.r1[k] = i1;
     }
+}
+
+__device__ __forceinline__ void level_gather(const __half* __restrict__ table, const LevelConst& lc, const LevelPoint& p, bool vec16,
+                                             LevelData& d) {
+    const __half* tab = table + (size_t)lc.row0 * 2;
     if (vec16) {
-        uint4 blk[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) blk[k] = *reinterpret_cast<const uint4*>(tab + (size_t)(r0[k] & ~3u) * 2);
-        uint32_t extra[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k = 0; k < 4; k++) if ((r0[k] ^ r1[k]) >= 4u) extra[k] = *reinterpret_cast<const uint32_t*>(tab + (size_t)r1[k] * 2);
+        for (int k = 0; k < 4; k++) d.blk[k] = *reinterpret_cast<const uint4*>(tab + (size_t)(p.r0[k] & ~3u) * 2);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            v0[k] = pick4(blk[k], r0[k] & 3u);
-            v1[k] = (r0[k] ^ r1[k]) >= 4u ? extra[k] : pick4(blk[k], r1[k] & 3u);
+            d.extra[k] = 0u;
+            if ((p.r0[k] ^ p.r1[k]) >= 4u) d.extra[k] = *reinterpret_cast<const uint32_t*>(tab + (size_t)p.r1[k] * 2);
         }
-    } else {
+    } else {   // table not 16-byte aligned: one gather per corner; blk[k].x / .y carry the two rows
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            v0[k] = *reinterpret_cast<const uint32_t*>(tab + (size_t)r0[k] * 2);
-            v1[k] = *reinterpret_cast<const uint32_t*>(tab + (size_t)r1[k] * 2);
+            d.blk[k].x = *reinterpret_cast<const uint32_t*>(tab + (size_t)p.r0[k] * 2);
+            d.blk[k].y = *reinterpret_cast<const uint32_t*>(tab + (size_t)p.r1[k] * 2);
+            d.extra[k] = 0u;
         }
     }
-    const float ax[2] = {1 - pos[0], pos[0]}, ay[2] = {1 - pos[1], pos[1]}, az[2] = {1 - pos[2], pos[2]};
+}
+
+__device__ __forceinline__ uint32_t level_reduce(const LevelPoint& p, const LevelData& d, bool vec16) {
+    const float ax[2] = {1 - p.ax1, p.ax1}, ay[2] = {1 - p.ay1, p.ay1}, az[2] = {1 - p.az1, p.az1};
     Acc2<true> acc;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 4; k++) {   // corner order of gridencoder.cu:168-195 (x fastest); weights ((1 * a_x) * a_y) * a_z
+        uint32_t v0, v1;
+        if (vec16) {
+            v0 = pick4(d.blk[k], p.r0[k] & 3u);
+            v1 = (p.r0[k] ^ p.r1[k]) >= 4u ? d.extra[k] : pick4(d.blk[k], p.r1[k] & 3u);
+        } else {
+            v0 = d.blk[k].x; v1 = d.blk[k].y;
+        }
         const float wy = ay[k & 1], wz = az[k >> 1];
-        acc.add(((1 * ax[0]) * wy) * wz, v0[k]);
-        acc.add(((1 * ax[1]) * wy) * wz, v1[k]);
+        acc.add(((1 * ax[0]) * wy) * wz, v0);
+        acc.add(((1 * ax[1]) * wy) * wz, v1);
     }
     return __builtin_bit_cast(uint32_t, acc.acc);
 }

@@ -23,6 +23,7 @@
 // of expf / __expf ordering that both share (tests/test_gpu_infer.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sdfx.h"
 #include "sdfx_common.h"
@@ -42,17 +43,24 @@ struct InferArgs {
     const float* rays_o; const float* rays_d; const float* nears; const float* fars; const float* noises;   // noises nullable
     const uint8_t* bitfield;
     MarchParams mp;
-    const __half* table;
     LevelConst lv[kLevels];
-    const uint32_t* packed;      // field_mlp.h parameter block
     float bound, blob_density, inv_2r2, T_thresh;
     uint32_t n_rays, max_steps, vec16;
     uint32_t* next_ray;          // device counter, starts at 0
     float* weights_sum; float* depth; float* image; int32_t* n_samples;   // n_samples nullable: samples taken per ray
 };
 
-template <uint32_t INTERP, bool ALIGN, bool HASHGRID>
-__global__ __launch_bounds__(kThreads) void k_render_infer(InferArgs a) {
+// WAVES: minimum waves per SIMD the register allocation must allow (2: 198 VGPRs, 4 levels per gather round; 3 and 4: 124 VGPRs,
+// 2 levels per round). The kernel is latency-bound — a sample step is a chain of dependent gather rounds — so occupancy is traded
+// against gathers in flight per lane. Measured on an 800 x 800 frame (52 M samples): 37.1 / 31.3 / 31.3 ms for 2 / 3 / 4
+// (tools/infer_bench.py, SDFX_INFER_WAVES); default 3.
+template <uint32_t INTERP, bool ALIGN, bool HASHGRID, int WAVES>
+__global__ __launch_bounds__(kThreads, WAVES) void k_render_infer(InferArgs a, const uint32_t* __restrict__ P,
+                                                                       const __half* __restrict__ table) {
+    // (P and table are separate __restrict__ parameters, not members of `a`: only then may the compiler assume that the
+    // kernel's stores do not alias them and fetch the wave-uniform MLP weights with scalar loads — as members they were
+    // 849 vector loads + 1100 v_readlane per sample step)
+    __shared__ uint32_t enc_lds[kLevels][kThreads];   // feature pairs of the thread's current sample, [level][thread]
     const int lane = lane_id();
     uint32_t ray = 0xffffffffu;
     bool active = false, exhausted = false;
@@ -106,12 +114,26 @@ __global__ __launch_bounds__(kThreads) void k_render_infer(InferArgs a) {
 #pragma unroll
             for (int d = 0; d < 3; d++) x01[d] = (pw[d] + a.bound) / (2 * a.bound);            // GridEncoder.forward, grid.py:157
             const bool oob = x01[0] < 0 || x01[0] > 1 || x01[1] < 0 || x01[1] > 1 || x01[2] < 0 || x01[2] > 1;
-#pragma unroll 4
-            for (uint32_t l = 0; l < kLevels; l++) {
-                const uint32_t f = encode_level_half<INTERP, ALIGN, HASHGRID>(a.table, a.lv[l], x01, a.vec16 != 0);
-                acts.enc[l] = as_h2(oob ? 0u : f);
+            // kBatch levels at a time: their 4 kBatch gathers are all issued before the first is consumed — a sample step is a
+            // chain of dependent memory round trips, so more levels per round = fewer rounds (at ~30 VGPRs a level). The loop
+            // over the batches is NOT unrolled (16 unrolled levels x their hashed / dense variants were 160 KB of code, more
+            // than the instruction cache); the features go through a per-thread LDS column so that the MLP still gets them
+            // in statically indexed registers (a dynamically indexed register array would live in scratch).
+            constexpr uint32_t kBatch = WAVES <= 2 ? 4u : 2u;
+#pragma unroll 1
+            for (uint32_t l0 = 0; l0 < kLevels; l0 += kBatch) {
+                LevelPoint lp[kBatch];
+                LevelData ld[kBatch];
+#pragma unroll
+                for (uint32_t j = 0; j < kBatch; j++) level_prepare<INTERP, ALIGN, HASHGRID>(a.lv[l0 + j], x01, lp[j]);
+#pragma unroll
+                for (uint32_t j = 0; j < kBatch; j++) level_gather(table, a.lv[l0 + j], lp[j], true, ld[j]);
+#pragma unroll
+                for (uint32_t j = 0; j < kBatch; j++) enc_lds[l0 + j][threadIdx.x] = oob ? 0u : level_reduce(lp[j], ld[j], true);
             }
-            mlp_forward(a.packed, acts);
+#pragma unroll
+            for (uint32_t l = 0; l < kLevels; l++) acts.enc[l] = as_h2(enc_lds[l][threadIdx.x]);
+            mlp_forward(P, acts);
             const float z = acts.h3[0] + a.blob_density * expf(-(px * px + py * py + pz * pz) * a.inv_2r2);
             const float sigma = expf(z);                                     // trunc_exp forward
             const float alb[3] = {1.0f / (1.0f + expf(-acts.h3[1])), 1.0f / (1.0f + expf(-acts.h3[2])), 1.0f / (1.0f + expf(-acts.h3[3]))};
@@ -148,23 +170,31 @@ int sdfx_render_infer(const float* rays_o, const float* rays_d, const float* nea
     SDFX_REQUIRE(num_levels == kLevels, "render_infer: the fused field needs the 16-level, 2-feature hash grid of the -O configuration");
     SDFX_REQUIRE(gridtype <= 1 && interp <= 1, "render_infer: bad enum");
     SDFX_REQUIRE(blob_radius > 0.f && bound > 0.f, "render_infer: blob_radius and bound must be positive");
+    SDFX_REQUIRE((reinterpret_cast<uintptr_t>(embeddings_half) % 16) == 0, "render_infer: the table must be 16-byte aligned");
     if (N == 0) return SDFX_OK;
     hipStream_t st = as_stream(stream);
     InferArgs a;
     memset(&a, 0, sizeof(a));
     a.rays_o = rays_o; a.rays_d = rays_d; a.nears = nears; a.fars = fars; a.noises = noises; a.bitfield = density_bitfield;
     a.mp = make_march_params(bound, contract, dt_gamma, max_steps, C, H);
-    a.table = static_cast<const __half*>(embeddings_half);
     for (uint32_t l = 0; l < kLevels; l++) a.lv[l] = make_level_const(offsets_host, l, S, base_resolution);
-    a.packed = field_packed; a.bound = bound; a.blob_density = blob_density; a.inv_2r2 = 1.0f / (2.0f * blob_radius * blob_radius);
+    a.bound = bound; a.blob_density = blob_density; a.inv_2r2 = 1.0f / (2.0f * blob_radius * blob_radius);
     a.T_thresh = T_thresh; a.n_rays = N; a.max_steps = max_steps;
     a.vec16 = (reinterpret_cast<uintptr_t>(embeddings_half) % 16) == 0 ? 1u : 0u;
     a.next_ray = next_ray_counter; a.weights_sum = weights_sum; a.depth = depth; a.image = image; a.n_samples = n_samples;
     zero_device(next_ray_counter, sizeof(uint32_t), st);
-    // persistent workgroups: enough waves to fill the chip (256 CUs x 2 workgroups of 4 waves), never more than the rays need
-    const uint32_t blocks = div_up(N, kThreads) < 512u ? div_up(N, kThreads) : 512u;
-#define SDFX_INFER(INTERP_, ALIGN_, HASH_) \
-    hipLaunchKernelGGL((k_render_infer<INTERP_, ALIGN_, HASH_>), dim3(blocks), dim3(kThreads), 0, st, a)
+    const uint32_t* P_ = field_packed;
+    const __half* T_ = static_cast<const __half*>(embeddings_half);
+    static const int waves = [] { const char* e = getenv("SDFX_INFER_WAVES"); const int w = e ? atoi(e) : 3; return w < 2 ? 2 : (w > 4 ? 4 : w); }();
+    // persistent workgroups: enough waves to fill the chip at the chosen occupancy, never more than the rays need
+    const uint32_t max_blocks = 256u * (uint32_t)waves;
+    const uint32_t blocks = div_up(N, kThreads) < max_blocks ? div_up(N, kThreads) : max_blocks;
+#define SDFX_INFER(INTERP_, ALIGN_, HASH_)                                                                                    \
+    do {                                                                                                                      \
+        if (waves == 2) hipLaunchKernelGGL((k_render_infer<INTERP_, ALIGN_, HASH_, 2>), dim3(blocks), dim3(kThreads), 0, st, a, P_, T_);      \
+        else if (waves == 3) hipLaunchKernelGGL((k_render_infer<INTERP_, ALIGN_, HASH_, 3>), dim3(blocks), dim3(kThreads), 0, st, a, P_, T_); \
+        else hipLaunchKernelGGL((k_render_infer<INTERP_, ALIGN_, HASH_, 4>), dim3(blocks), dim3(kThreads), 0, st, a, P_, T_);                 \
+    } while (0)
     const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
     switch (sel) {
         case 0: SDFX_INFER(0u, false, false); break;

@@ -18,6 +18,7 @@ import torch
 from torch.amp import custom_bwd, custom_fwd
 from torch.autograd import Function
 
+import _render
 import _sdfx as S
 
 MODES = {"lambertian": 1, "textureless": 2, "normal": 3}
@@ -96,13 +97,8 @@ class _fused_render(Function):
         weights = torch.empty(cap, **f)
         weights_sum, depth = torch.empty(n_rays, **f), torch.empty(n_rays, **f)
         image, ray_sums = torch.empty(n_rays, 3, **f), torch.empty(n_rays, 2, **f)
-        S.call("sdfx_render_train_forward", S.ptr(S.check_tensor(sigma7, "sigma7", _F32)), S.ptr(S.check_tensor(albedo0, "albedo", _F32)),
-               S.ptr(S.check_tensor(dirs, "dirs", _F32)), S.ptr(S.check_tensor(ts, "ts", _F32)),
-               S.ptr(S.check_tensor(rays, "rays", torch.int32)), S.ptr(S.check_tensor(rays_o, "rays_o", _F32)),
-               S.ptr(S.check_tensor(light_offset, "light_offset", _F32)), S.ptr(S.check_tensor(ratio, "ratio", _F32)),
-               S.ptr(None if mode_dev is None else S.check_tensor(mode_dev, "mode", _F32)), mode_int, float(epsilon), float(T_thresh),
-               cap, n_rays, S.ptr(S.check_tensor(total, "total", torch.int32)), S.ptr(weights), S.ptr(weights_sum), S.ptr(depth),
-               S.ptr(image), S.ptr(ray_sums), S.stream())
+        _render.train_forward(sigma7, albedo0, dirs, ts, rays, rays_o, light_offset, ratio, mode_dev, mode_int, epsilon, T_thresh, total,
+                              weights, weights_sum, depth, image, ray_sums)
         ctx.save_for_backward(sigma7, albedo0, dirs, ts, rays, rays_o, light_offset, ratio, mode_dev, total, weights_sum, depth, image)
         ctx.meta = (mode_int, float(epsilon), float(T_thresh), cap, n_rays)
         ctx.mark_non_differentiable(weights)
@@ -121,10 +117,8 @@ class _fused_render(Function):
         g_sums = None if g_sums is None else g_sums.float().contiguous()
         dsigma7 = torch.empty(7 * cap, dtype=_F32, device=dev)
         dalbedo = torch.empty(cap, 3, dtype=_F32, device=dev)
-        S.call("sdfx_render_train_backward", S.ptr(sigma7), S.ptr(albedo0), S.ptr(dirs), S.ptr(ts), S.ptr(rays), S.ptr(rays_o),
-               S.ptr(light_offset), S.ptr(ratio), S.ptr(mode_dev), mode_int, epsilon, T_thresh, cap, n_rays, S.ptr(total),
-               S.ptr(weights_sum), S.ptr(depth), S.ptr(image), S.ptr(g_ws), S.ptr(g_depth), S.ptr(g_image), S.ptr(g_sums),
-               S.ptr(dsigma7), S.ptr(dalbedo), S.stream())
+        _render.train_backward(sigma7, albedo0, dirs, ts, rays, rays_o, light_offset, ratio, mode_dev, mode_int, epsilon, T_thresh, total,
+                               weights_sum, depth, image, g_ws, g_depth, g_image, g_sums, dsigma7, dalbedo)
         return (dsigma7, dalbedo) + (None,) * 10
 
 

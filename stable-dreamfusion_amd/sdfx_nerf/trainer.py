@@ -89,8 +89,9 @@ class TrainStep:
         self.graph_bucket = int(os.environ.get("SDFX_GRAPH_BUCKET", "32768"))
         self.graph_ratio = float(os.environ.get("SDFX_GRAPH_RATIO", "1.1"))   # capacity ladder: <= 10 % padding
         self.graph_prime_span = 1.5      # on a miss, capture every ladder step within this factor of the need
-        self.max_graphs = int(os.environ.get("SDFX_MAX_GRAPHS", "32"))
+        self.max_graphs = int(os.environ.get("SDFX_MAX_GRAPHS", "64"))
         self._warm = set()               # kinds that have run eagerly once
+        self._priming = set()            # keys captured by the _prime call in progress
         self.graphs = {}                 # (capacity, shading class, as_latent, bg_kind, H, W, lr signature) -> captured stages
         self.lr_changes = 0
         self.graph_uses = {}
@@ -262,8 +263,8 @@ class TrainStep:
         """Record the iteration body for `key` = (capacity, shading, as_latent, bg_kind, H, W). Capturing executes
         nothing, so it needs no valid sample data — only that the lazy initialisations behind the body (MIOpen
         find, hipBLASLt heuristics, scratch allocations) have happened in an earlier eager iteration."""
-        if len(self.graphs) >= self.max_graphs:   # evict the least used graph (never one captured for the current kinds just now)
-            old = [k for k in self.graphs if self.graph_uses.get(k, 0) > 0 or k[1:] != key[1:]] or list(self.graphs)
+        if len(self.graphs) >= self.max_graphs:   # evict the least used graph — never one captured by the _prime call in progress
+            old = [k for k in self.graphs if k not in self._priming] or list(self.graphs)
             victim = min(old, key=lambda k: self.graph_uses.get(k, 0))
             del self.graphs[victim]
             self.graph_uses.pop(victim, None)
@@ -280,16 +281,26 @@ class TrainStep:
         # buffers of the most recent capture)
         self.graphs[key] = (g1, g2, loss, marched, [p.grad for p in self.optimizer.parameters()])
         self.graph_uses[key] = 0
+        self._priming.add(key)
         self.stats["captures"] += 1
 
     def _prime(self, key):
         """Capture `key` and the ladder steps around it (the sample total drifts as the scene trains)."""
         cap, kinds = key[0], key[1:]
+        self._priming = set()
+        # outside the latent phase the background alternates at random between the network and a random colour
+        # (nerf/utils.py:509-521): capture both kinds together, or every capacity is missed twice
+        variants = [kinds]
+        if not kinds[1]:
+            other = (kinds[0], kinds[1], "rand" if kinds[2] == "net" else "net") + kinds[3:]
+            if other in self._warm:      # only a kind that has run eagerly once (lazy library initialisations cannot be captured)
+                variants.append(other)
         lo, hi = cap / self.graph_prime_span, cap * self.graph_prime_span
         c = self._ladder(max(int(lo), 1))
         while c <= hi:
-            if (c,) + kinds not in self.graphs:
-                self._capture((c,) + kinds)
+            for kv in variants:
+                if (c,) + kv not in self.graphs:
+                    self._capture((c,) + kv)
             c = self._ladder(c + 1)
 
     def step(self, rays_o, rays_d, azimuth=0.0, H=64, W=64, next_rays=None):

@@ -10,9 +10,8 @@ import synth
 from sdfx_nerf import network_grid as ng
 from sdfx_nerf.options import default_opt
 dev = torch.device("cuda:0")
-HW = int(os.environ.get("HW", "800"))
 poses, fovy = synth.reference_cameras()
-for scene in ("init", "blobs"):
+for HW, scene in [(int(h), sc) for h in os.environ.get("HW", "800").split(",") for sc in os.environ.get("SCENES", "init,blobs").split(",")]:
     torch.manual_seed(0)
     model = ng.NeRFNetwork(default_opt()).to(dev).eval()
     with torch.no_grad():
@@ -37,6 +36,14 @@ for scene in ("init", "blobs"):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
         cover = float((r["weights_sum"] > 0.5).float().mean())
+        extra = ""
+        if fused:   # samples the frame takes (for samples/s of the in-lane field evaluation)
+            import raymarching
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                nears, fars = raymarching.near_far_from_aabb(ro[0], rd[0], model.aabb_infer)
+                ns = model.render_infer_fused(ro[0], rd[0], nears, fars, None, 1e-4, return_samples=True)[3]
+            tot = int(ns.sum())
+            extra = f", {tot/1e6:.2f} M samples ({tot/ms/1e6:.3f} G samples/s)"
         print(f"{scene:6s} {HW}x{HW} {'persistent kernel' if fused else 'host-paced loop  '}: {ms:8.2f} ms/frame = {1e3/ms:7.1f} FPS, "
-              f"{o.shape[0]/ms/1e3:7.2f} Mrays/s, coverage {cover:.3f}", flush=True)
+              f"{o.shape[0]/ms/1e3:7.2f} Mrays/s, coverage {cover:.3f}{extra}", flush=True)
     ng._FUSED_INFER = 1
