@@ -446,6 +446,8 @@ __device__ __forceinline__ uint32_t masked_pack(uint32_t act, float g0, float g1
     return as_u32(pack(a.x > (_Float16)0 ? g0 : 0.f, a.y > (_Float16)0 ? g1 : 0.f));
 }
 
+// (Register allocation: 256 VGPRs + 242 AGPRs = one wave per SIMD, one workgroup per CU. Capping it at 256 registers with
+// __launch_bounds__(256, 2) — two workgroups per CU — spills 189 dwords to scratch and is SLOWER: 714 -> 989 us at B = 3 M.)
 __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t* __restrict__ enc, int enc_layout,
                                                                   const float* __restrict__ x,
                                                                   const uint32_t* __restrict__ P, uint32_t B,

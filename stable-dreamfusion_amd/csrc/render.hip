@@ -66,6 +66,30 @@ struct RenderArgs {
 
 __device__ __forceinline__ int shading_mode(const RenderArgs& a) { return a.mode_p ? (int)a.mode_p[0] : a.mode; }
 
+// what one lane reads for one sample: loaded a chunk AHEAD of its use, so that the memory round trip of chunk k + 1 overlaps the
+// scan of chunk k (a ray is a chain of dependent 64-sample chunks: tools/ubench/launch_floor.hip prices a round trip at ~1.2 us)
+struct Raw {
+    float s[7], alb[3], d[3], t, dt;
+};
+__device__ __forceinline__ Raw load_raw(const RenderArgs& a, uint32_t i, bool valid, bool want_albedo) {
+    Raw r;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) r.s[k] = a.sigma7[(size_t)k * a.cap + i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) r.d[k] = a.dirs[(size_t)i * 3 + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) r.alb[k] = want_albedo ? a.albedo[(size_t)i * 3 + k] : 0.f;
+        const float2 tt = reinterpret_cast<const float2*>(a.ts)[i];
+        r.t = tt.x; r.dt = tt.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 7; k++) r.s[k] = 0.f;
+        r.alb[0] = r.alb[1] = r.alb[2] = 0.f; r.d[0] = r.d[1] = r.d[2] = 0.f; r.t = r.dt = 0.f;
+    }
+    return r;
+}
+
 __global__ __launch_bounds__(kThreads) void k_render_train_fwd(RenderArgs a, float* __restrict__ weights,
                                                                 float* __restrict__ weights_sum, float* __restrict__ depth,
                                                                 float* __restrict__ image, float* __restrict__ ray_sums) {
@@ -93,6 +117,8 @@ __global__ __launch_bounds__(kThreads) void k_render_train_fwd(RenderArgs a, flo
     float T_carry = 1.0f;
     float r = 0, g = 0, b = 0, ws = 0, d = 0, ent = 0, ori = 0;
     bool done = false;
+    const bool lamb = mode == kLambertian;
+    Raw nxt = load_raw(a, offset + (uint32_t)lane, (uint32_t)lane < count, lamb);
     for (uint32_t base = 0; base < count; base += kWave) {
         const uint32_t k = base + lane;
         const bool valid = k < count;
@@ -101,13 +127,14 @@ __global__ __launch_bounds__(kThreads) void k_render_train_fwd(RenderArgs a, flo
             if (valid) { weights[i] = 0.f; ent += entropy_bits(0.f); }
             continue;
         }
+        const Raw cur = nxt;
+        nxt = load_raw(a, i + kWave, k + kWave < count, lamb);            // the next chunk's loads are in flight during this scan
         float alpha = 0.f, t = 0.f, c[3] = {0.f, 0.f, 0.f}, o = 0.f;
         if (valid) {
-            const Sample p = load_sample(a.sigma7, a.dirs, a.cap, i, a.e, l);
-            sample_forward(p, ratio, mode, mode == kLambertian ? a.albedo + (size_t)i * 3 : nullptr, c, o);
-            const float2 tt = reinterpret_cast<const float2*>(a.ts)[i];
-            t = tt.x;
-            alpha = 1.0f - __expf(-a.sigma7[i] * tt.y);   // raymarching.cu:543 (binarize = false on the training path)
+            const Sample p = make_sample(cur.s, cur.d, a.e, l);
+            sample_forward(p, ratio, mode, lamb ? cur.alb : nullptr, c, o);
+            t = cur.t;
+            alpha = 1.0f - __expf(-cur.s[0] * cur.dt);   // raymarching.cu:543 (binarize = false on the training path)
         }
         const float incl = wave_incl_prod(1.0f - alpha, lane);
         float excl = __shfl_up(incl, 1, kWave);
@@ -170,6 +197,8 @@ __global__ __launch_bounds__(kThreads) void k_render_train_bwd(RenderArgs a, con
 
     float T_carry = 1.0f, r_c = 0, g_c = 0, b_c = 0, ws_c = 0, d_c = 0;
     bool done = false;
+    const bool lamb = mode == kLambertian;
+    Raw nxt = load_raw(a, offset + (uint32_t)lane, (uint32_t)lane < count, lamb);
     for (uint32_t base = 0; base < count; base += kWave) {
         const uint32_t k = base + lane;
         const bool valid = k < count;
@@ -178,14 +207,15 @@ __global__ __launch_bounds__(kThreads) void k_render_train_bwd(RenderArgs a, con
             if (valid) zero_row(i);
             continue;
         }
+        const Raw cur = nxt;
+        nxt = load_raw(a, i + kWave, k + kWave < count, lamb);
         float alpha = 0.f, t = 0.f, dt = 0.f, c[3] = {0.f, 0.f, 0.f}, o = 0.f;
         Sample p = {};
         if (valid) {
-            p = load_sample(a.sigma7, a.dirs, a.cap, i, a.e, l);
-            sample_forward(p, ratio, mode, mode == kLambertian ? a.albedo + (size_t)i * 3 : nullptr, c, o);
-            const float2 tt = reinterpret_cast<const float2*>(a.ts)[i];
-            t = tt.x; dt = tt.y;
-            alpha = 1.0f - __expf(-a.sigma7[i] * dt);
+            p = make_sample(cur.s, cur.d, a.e, l);
+            sample_forward(p, ratio, mode, lamb ? cur.alb : nullptr, c, o);
+            t = cur.t; dt = cur.dt;
+            alpha = 1.0f - __expf(-cur.s[0] * dt);
         }
         const float incl = wave_incl_prod(1.0f - alpha, lane);
         float excl = __shfl_up(incl, 1, kWave);
@@ -212,8 +242,7 @@ __global__ __launch_bounds__(kThreads) void k_render_train_bwd(RenderArgs a, con
                                      gd * (T * t - (d_final - d)));
             // shading + orientation term (weights are detached in loss_orient: d/d orient_i = g * w_i)
             float dsig[6], dalb[3];
-            sample_backward(p, l, ratio, mode, mode == kLambertian ? a.albedo + (size_t)i * 3 : nullptr, grgb, nullptr, g_ori * w, a.e,
-                            dsig, dalb);
+            sample_backward(p, l, ratio, mode, lamb ? cur.alb : nullptr, grgb, nullptr, g_ori * w, a.e, dsig, dalb);
             dsigma7[i] = gsig;
 #pragma unroll
             for (uint32_t s = 0; s < 6; s++) dsigma7[(size_t)(s + 1) * cap + i] = dsig[s];

@@ -44,23 +44,30 @@ struct Sample {
     float ndl, ndd;
 };
 
-// sigma7: [7, cap] densities at x, x+e_x, x-e_x, x+e_y, x-e_y, x+e_z, x-e_z; dirs: [cap, 3] un-normalised
-SDFX_HD Sample load_sample(const float* sigma7, const float* dirs, uint32_t cap, uint32_t i, float e, const Vec3& l) {
+// from the seven stencil densities (x, x+e_x, x-e_x, x+e_y, x-e_y, x+e_z, x-e_z) and the un-normalised view direction
+SDFX_HD Sample make_sample(const float s[7], const float dir[3], float e, const Vec3& l) {
     Sample p;
-    const float* s = sigma7 + i;
-    p.raw.x = -(0.5f * (s[1 * (size_t)cap] - s[2 * (size_t)cap]) / e);   // network_grid.py:90-96
-    p.raw.y = -(0.5f * (s[3 * (size_t)cap] - s[4 * (size_t)cap]) / e);
-    p.raw.z = -(0.5f * (s[5 * (size_t)cap] - s[6 * (size_t)cap]) / e);
+    p.raw.x = -(0.5f * (s[1] - s[2]) / e);   // network_grid.py:90-96
+    p.raw.y = -(0.5f * (s[3] - s[4]) / e);
+    p.raw.z = -(0.5f * (s[5] - s[6]) / e);
     p.q = p.raw.x * p.raw.x + p.raw.y * p.raw.y + p.raw.z * p.raw.z;
     p.s = sqrtf(fmaxf(p.q, kNormEps));
     p.y = {p.raw.x / p.s, p.raw.y / p.s, p.raw.z / p.s};
     p.n = {nan_to_num_(p.y.x), nan_to_num_(p.y.y), nan_to_num_(p.y.z)};
-    const float dx = dirs[(size_t)i * 3 + 0], dy = dirs[(size_t)i * 3 + 1], dz = dirs[(size_t)i * 3 + 2];
+    const float dx = dir[0], dy = dir[1], dz = dir[2];
     const float ds = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, kNormEps));
     p.d = {dx / ds, dy / ds, dz / ds};
     p.ndl = p.n.x * l.x + p.n.y * l.y + p.n.z * l.z;
     p.ndd = p.n.x * p.d.x + p.n.y * p.d.y + p.n.z * p.d.z;
     return p;
+}
+
+// sigma7: [7, cap] densities at x, x+e_x, x-e_x, x+e_y, x-e_y, x+e_z, x-e_z; dirs: [cap, 3] un-normalised
+SDFX_HD Sample load_sample(const float* sigma7, const float* dirs, uint32_t cap, uint32_t i, float e, const Vec3& l) {
+    float s[7], d[3];
+    for (int k = 0; k < 7; k++) s[k] = sigma7[(size_t)k * cap + i];
+    d[0] = dirs[(size_t)i * 3 + 0]; d[1] = dirs[(size_t)i * 3 + 1]; d[2] = dirs[(size_t)i * 3 + 2];
+    return make_sample(s, d, e, l);
 }
 
 // color (network_grid.py:117-130) and the per-sample factor of loss_orient (renderer.py:745); albedo3 only read for mode 1
