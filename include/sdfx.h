@@ -346,6 +346,56 @@ int sdfx_render_train_backward(const float* sigma7, const float* albedo, const f
                                float* dalbedo, sdfx_stream_t stream);
 
 /*
+ * Extension — everything between the compositor's per-ray outputs and the guidance network's input in one kernel each way
+ * (csrc/head.hip): background = sigmoid(MLP(FreqEncoder_6(rays_d))) (nerf/network_grid.py:132-153; W1 [32, 39], b1 [32], W2 [3, 32],
+ * b2 [3] float32) or the colour bg_color [3] when W1 is NULL; image + (1 - weights_sum) * background (nerf/renderer.py:797-806);
+ * pred [C, N] = that image (+ weights_sum as 4th channel when C = 4), i.e. the [1, C, H, W] tensor of nerf/utils.py:533-541;
+ * loss_reg [1] = lambda_opacity mean(weights_sum^2) + (lambda_entropy ray_sums[:, 0] + lambda_orient ray_sums[:, 1]).sum() / n_valid
+ * (nerf/utils.py:563-575, nerf/renderer.py:744-746). lambda_entropy and n_valid are device scalars; ray_sums may be NULL.
+ * backward: gradients with respect to image_raw, weights_sum, ray_sums and the four network tensors from grad_pred [C, N] and
+ * grad_loss_reg [1] (NULL = 0). scratch: sdfx_head_scratch_bytes(N) bytes.
+ */
+uint64_t sdfx_head_scratch_bytes(uint32_t N);
+int sdfx_head_forward(const float* image_raw, const float* weights_sum, const float* ray_sums, const float* rays_d, const float* W1,
+                      const float* b1, const float* W2, const float* b2, const float* bg_color, const float* lambda_entropy,
+                      const float* n_valid, float lambda_opacity, float lambda_orient, uint32_t N, uint32_t C, float* pred,
+                      float* loss_reg, void* scratch, sdfx_stream_t stream);
+int sdfx_head_backward(const float* image_raw, const float* weights_sum, const float* ray_sums, const float* rays_d, const float* W1,
+                       const float* b1, const float* W2, const float* b2, const float* bg_color, const float* lambda_entropy,
+                       const float* n_valid, float lambda_opacity, float lambda_orient, uint32_t N, uint32_t C, const float* grad_pred,
+                       const float* grad_loss_reg, float* grad_image, float* grad_weights_sum, float* grad_ray_sums, float* dW1,
+                       float* db1, float* dW2, float* db2, void* scratch, sdfx_stream_t stream);
+
+/*
+ * Extension — the elementwise arithmetic of StableDiffusion.train_step either side of the frozen UNet
+ * (guidance/sd_utils.py:86-159), B items of per_item = C * h * w latent elements each.
+ * sdfx_sds_add_noise: latents = x * 2 - 1 if affine (latent phase, float32 x, written to latents_out) else x (float32, or
+ * float16 when is_half: the VAE's output); model_input [2B, per_item] float16 = [noisy, noisy] with
+ * noisy = sqrt(abar[t]) latents + sqrt(1 - abar[t]) noise (sd_utils.py:104-106), tt [2B] = [t, t] (sd_utils.py:107).
+ * noise has the dtype of the latents (torch.randn_like), t is int64 [B], alphas_cumprod float32 [1000].
+ * sdfx_sds_loss: noise_pred float16 [2B, per_item] = (unconditional, text) halves; classifier-free guidance, w(t) = 1 - abar[t],
+ * grad = nan_to_num(grad_scale w (eps - noise)), loss[0] = 0.5 sum (latents - (latents - grad))^2 / B (sd_utils.py:111-159) and
+ * grad_latents (dtype of the latents) = out_scale * dloss/dlatents (out_scale = 2 folds the latent phase's x * 2 - 1).
+ * sdfx_sds_text_mix: out [2, n] float16 = (uncond, w_front front + w_side side + w_back back), the interpolated text
+ * embedding of nerf/utils.py:448-470 stacked under the unconditional one; the weights are device float32 scalars.
+ * Float16 intermediates are rounded where PyTorch's tensor expressions round them.
+ */
+int sdfx_sds_add_noise(const void* x, int is_half, int affine, const void* noise, const int64_t* t, const float* alphas_cumprod,
+                       uint32_t B, uint32_t per_item, float* latents_out, void* model_input, int64_t* tt, sdfx_stream_t stream);
+int sdfx_sds_loss(const void* noise_pred, const void* noise, const void* latents, int is_half, const int64_t* t,
+                  const float* alphas_cumprod, float guidance_scale, float grad_scale, float out_scale, uint32_t B, uint32_t per_item,
+                  float* loss, void* grad_latents, sdfx_stream_t stream);
+/* Bilinear resampling [planes, H, W] -> [planes, OH, OW] with PyTorch's align_corners=False arithmetic (sd_utils.py:93), optionally
+ * followed by encode_imgs' 2 x - 1 (sd_utils.py:285; affine) and the cast to float16 (out_half); the backward is the exact
+ * adjoint as a gather (no atomics: deterministic), grad_out float16 (grad_half) or float32, times 2 when affine. */
+int sdfx_sds_upsample_forward(const float* x, uint32_t planes, uint32_t H, uint32_t W, uint32_t OH, uint32_t OW, int affine, int out_half,
+                              void* out, sdfx_stream_t stream);
+int sdfx_sds_upsample_backward(const void* grad_out, int grad_half, uint32_t planes, uint32_t H, uint32_t W, uint32_t OH, uint32_t OW,
+                               int affine, float* grad_x, sdfx_stream_t stream);
+int sdfx_sds_text_mix(const void* uncond, const void* front, const void* side, const void* back, const float* w_front,
+                      const float* w_side, const float* w_back, uint32_t n, void* out, sdfx_stream_t stream);
+
+/*
  * Extension — the entropy regulariser of Trainer.train_step (nerf/utils.py:571-575) on the compositing weights:
  * sum_out[0] = sum over rows < total of H(clamp(w, 1e-5, 1 - 1e-5)), H the binary entropy in bits (double; the
  * caller divides by the sample total for the reference's .mean()); backward: grad_weights = grad_sum[0] * dH/dw

@@ -31,3 +31,40 @@ def train_backward(sigma7, albedo, dirs, ts, rays, rays_o, light_offset, ratio, 
            _f(image, "image"), _f(g_weights_sum, "grad_weights_sum"), None if g_depth is None else _f(g_depth, "grad_depth"),
            _f(g_image, "grad_image"), None if g_ray_sums is None else _f(g_ray_sums, "grad_ray_sums"), _f(dsigma7, "dsigma7"),
            _f(dalbedo, "dalbedo"), S.stream())
+
+
+# ---- image head (csrc/head.hip): background + mix + [1, C, H, W] layout + regulariser sum ----
+_HEAD_SCRATCH = {}
+
+
+def _head_scratch(device, N):
+    key = (device.index, N)
+    buf = _HEAD_SCRATCH.get(key)
+    if buf is None:
+        buf = _HEAD_SCRATCH[key] = torch.empty(int(S.lib().sdfx_head_scratch_bytes(N)), dtype=torch.uint8, device=device)
+    return buf
+
+
+def _opt(t, name):
+    return None if t is None else _f(t, name)
+
+
+def head_forward(image_raw, ws, ray_sums, rays_d, net, bg_color, lam_entropy, n_valid, lam_opacity, lam_orient, C_, pred, loss_reg):
+    N = ws.shape[0]
+    W1, b1, W2, b2 = net if net is not None else (None,) * 4
+    S.call("sdfx_head_forward", _f(image_raw, "image_raw"), _f(ws, "weights_sum"), _opt(ray_sums, "ray_sums"), _opt(rays_d, "rays_d"),
+           _opt(W1, "W1"), _opt(b1, "b1"), _opt(W2, "W2"), _opt(b2, "b2"), _opt(bg_color, "bg_color"), _f(lam_entropy, "lambda_entropy"),
+           _f(n_valid, "n_valid"), float(lam_opacity), float(lam_orient), N, C_, _f(pred, "pred"), _f(loss_reg, "loss_reg"),
+           S.ptr(_head_scratch(ws.device, N)), S.stream())
+
+
+def head_backward(image_raw, ws, ray_sums, rays_d, net, bg_color, lam_entropy, n_valid, lam_opacity, lam_orient, C_, g_pred, g_reg, g_image,
+                  g_ws, g_sums, dnet):
+    N = ws.shape[0]
+    W1, b1, W2, b2 = net if net is not None else (None,) * 4
+    dW1, db1, dW2, db2 = dnet if dnet is not None else (None,) * 4
+    S.call("sdfx_head_backward", _f(image_raw, "image_raw"), _f(ws, "weights_sum"), _opt(ray_sums, "ray_sums"), _opt(rays_d, "rays_d"),
+           _opt(W1, "W1"), _opt(b1, "b1"), _opt(W2, "W2"), _opt(b2, "b2"), _opt(bg_color, "bg_color"), _f(lam_entropy, "lambda_entropy"),
+           _f(n_valid, "n_valid"), float(lam_opacity), float(lam_orient), N, C_, _f(g_pred, "grad_pred"), _opt(g_reg, "grad_loss_reg"),
+           _f(g_image, "grad_image"), _f(g_ws, "grad_weights_sum"), _opt(g_sums, "grad_ray_sums"), _opt(dW1, "dW1"), _opt(db1, "db1"),
+           _opt(dW2, "dW2"), _opt(db2, "db2"), S.ptr(_head_scratch(ws.device, N)), S.stream())

@@ -61,6 +61,14 @@ _SIGNATURES = {
     "sdfx_shade_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _f32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_shade_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _f32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                             _ptr],
+    "sdfx_head_scratch_bytes": [_u32],
+    "sdfx_head_forward": [_ptr] * 11 + [_f32, _f32, _u32, _u32, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_head_backward": [_ptr] * 11 + [_f32, _f32, _u32, _u32] + [_ptr] * 11,
+    "sdfx_sds_add_noise": [_ptr, _int, _int, _ptr, _ptr, _ptr, _u32, _u32, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_sds_loss": [_ptr, _ptr, _ptr, _int, _ptr, _ptr, _f32, _f32, _f32, _u32, _u32, _ptr, _ptr, _ptr],
+    "sdfx_sds_upsample_forward": [_ptr, _u32, _u32, _u32, _u32, _u32, _int, _int, _ptr, _ptr],
+    "sdfx_sds_upsample_backward": [_ptr, _int, _u32, _u32, _u32, _u32, _u32, _int, _ptr, _ptr],
+    "sdfx_sds_text_mix": [_ptr] * 7 + [_u32, _ptr, _ptr],
     "sdfx_render_infer": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _int, _f32, _u32, _u32, _u32, _u32, _ptr, _ptr, _u32, _f32, _u32,
                           _u32, _int, _u32, _ptr, _f32, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_occupancy_points": [_u32, C.c_double, _ptr, _u64, _u32, _ptr, _ptr],
@@ -83,6 +91,7 @@ _SIGNATURES = {
 _RESTYPES = {
     "sdfx_march_rays_train_scratch_bytes": _u64,
     "sdfx_compact_rays_scratch_bytes": _u64,
+    "sdfx_head_scratch_bytes": _u64,
     "sdfx_grid_encode_backward_binned_scratch_bytes": _u64,
     "sdfx_field_packed_words": _u32,
     "sdfx_field_backward_scratch_bytes": _u64,

@@ -447,6 +447,7 @@ int sdfx_grid_encode_forward_hint(const float* inputs, const void* embeddings, c
                              uint32_t interp, int is_half, int out_layout, uint32_t slabs, float step,
                                   sdfx_stream_t stream) {
     (void)offsets;
+    if (B == 0) return SDFX_OK;   // an empty batch (a view that hits no occupied cell) is a no-op, whatever the pointers
     SDFX_REQUIRE(inputs && embeddings && offsets_host && outputs, "grid_encode_forward: null pointer");
     if (!supported_dc(D, C)) {  // gridencoder.cu:392,409 throw std::runtime_error here
         set_error("GridEncoding: D must be 2, 3, 4 or 5 and C must be 1, 2, 4, 8, 16 or 32 (got D=%u C=%u)", D, C);

@@ -275,11 +275,12 @@ int sdfx_render_train_forward(const float* sigma7, const float* albedo, const fl
                               int mode, float epsilon, float T_thresh, uint32_t capacity, uint32_t n_rays, const int32_t* total,
                               float* weights, float* weights_sum, float* depth, float* image, float* ray_sums,
                               sdfx_stream_t stream) {
-    SDFX_REQUIRE(sigma7 && albedo && dirs && ts && rays && rays_o && light_offset && ratio && total && weights && weights_sum &&
-                     depth && image && ray_sums, "render_train_forward: null pointer");
+    SDFX_REQUIRE(rays && rays_o && light_offset && ratio && total && weights_sum && depth && image && ray_sums,
+                 "render_train_forward: null pointer");
+    SDFX_REQUIRE(capacity == 0 || (sigma7 && albedo && dirs && ts && weights), "render_train_forward: null sample buffer");
     SDFX_REQUIRE(mode_dev || (mode >= kLambertian && mode <= kNormal), "render_train_forward: mode must be 1, 2 or 3 (or given on the device)");
     SDFX_REQUIRE(epsilon > 0.f, "render_train_forward: epsilon must be positive");
-    if (capacity == 0 || n_rays == 0) return SDFX_OK;
+    if (n_rays == 0) return SDFX_OK;   // (capacity 0 = a view without samples: every ray has count 0 and gets zero outputs)
     RenderArgs a;
     fill_args(a, sigma7, albedo, dirs, ts, rays, rays_o, light_offset, ratio, mode_dev, mode, epsilon, T_thresh, capacity, n_rays, total);
     hipLaunchKernelGGL(k_render_train_fwd, dim3(a.ray_blocks + kPadBlocks), dim3(kThreads), 0, as_stream(stream), a, weights,
@@ -293,8 +294,9 @@ int sdfx_render_train_backward(const float* sigma7, const float* albedo, const f
                                const float* weights_sum, const float* depth, const float* image, const float* grad_weights_sum,
                                const float* grad_depth, const float* grad_image, const float* grad_ray_sums, float* dsigma7,
                                float* dalbedo, sdfx_stream_t stream) {
-    SDFX_REQUIRE(sigma7 && albedo && dirs && ts && rays && rays_o && light_offset && ratio && total && weights_sum && depth &&
-                     image && grad_weights_sum && grad_image && dsigma7 && dalbedo, "render_train_backward: null pointer");
+    SDFX_REQUIRE(rays && rays_o && light_offset && ratio && total && weights_sum && depth && image && grad_weights_sum && grad_image,
+                 "render_train_backward: null pointer");
+    SDFX_REQUIRE(capacity == 0 || (sigma7 && albedo && dirs && ts && dsigma7 && dalbedo), "render_train_backward: null sample buffer");
     SDFX_REQUIRE(mode_dev || (mode >= kLambertian && mode <= kNormal), "render_train_backward: mode must be 1, 2 or 3 (or given on the device)");
     if (capacity == 0 || n_rays == 0) return SDFX_OK;
     RenderArgs a;

@@ -25,6 +25,9 @@ class _fused_field(Function):
                 align_corners, interp, blob_density, blob_radius, slabs, step):
         x = x.float().contiguous()
         B = x.shape[0]
+        if B == 0:   # a view that hits no occupied cell: nothing to evaluate, nothing to differentiate
+            ctx.meta = None
+            return x.new_zeros(0), x.new_zeros(0, 3)
         inputs = ((x + bound) / (2 * bound)).contiguous()       # GridEncoder.forward's map to [0, 1] (grid.py:157)
         L = offsets.shape[0] - 1
         C = embeddings.shape[1]
@@ -46,6 +49,8 @@ class _fused_field(Function):
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, dsigma, dalbedo):
+        if ctx.meta is None:
+            return (None,) * 19
         x, inputs, offsets, enc, packed = ctx.saved_tensors
         B, C, L, S, H, gridtype, align_corners, interp, blob_density, blob_radius, emb_shape = ctx.meta
         dev = x.device

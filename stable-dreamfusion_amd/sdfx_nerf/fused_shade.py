@@ -129,6 +129,64 @@ def fused_render(sigma7, albedo0, dirs, ts, rays, rays_o, light_offset, ratio, m
                                T_thresh, epsilon)
 
 
+class _image_head(Function):
+    """Background (network or colour) + `image + (1 - weights_sum) bg` + the [1, C, H, W] layout the guidance wants + the sum of
+    the three per-ray regularisers, one kernel each way (csrc/head.hip; include/sdfx.h sdfx_head_*).
+
+        pred, loss_reg = image_head(image_raw, weights_sum, ray_sums, rays_d, bg_net, bg_color, lam_entropy, n_valid,
+                                    lam_opacity, lam_orient, C, H, W)
+
+    bg_net: the model's 2-layer background MLP (sdfx_nerf.network_grid.MLP(39, 3, 32, 2)) or None -> bg_color [3] (device).
+    lam_entropy, n_valid: 0-dim float32 device tensors (read at execution time: replay-safe)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, image_raw, ws, ray_sums, rays_d, W1, b1, W2, b2, bg_color, lam_entropy, n_valid, lam_opacity, lam_orient, C, H, W):
+        image_raw, ws = image_raw.contiguous().view(-1, 3), ws.contiguous().view(-1)
+        N, dev = ws.shape[0], ws.device
+        assert N == H * W
+        net = None if W1 is None else tuple(t.contiguous() for t in (W1, b1, W2, b2))
+        rays_d = None if rays_d is None else rays_d.contiguous().view(-1, 3)
+        ray_sums = None if ray_sums is None else ray_sums.contiguous()
+        bg_color = None if bg_color is None else bg_color.contiguous()
+        pred = torch.empty(1, C, H, W, dtype=_F32, device=dev)
+        loss_reg = torch.empty((), dtype=_F32, device=dev)
+        _render.head_forward(image_raw, ws, ray_sums, rays_d, net, bg_color, lam_entropy, n_valid, lam_opacity, lam_orient, C, pred, loss_reg)
+        ctx.save_for_backward(image_raw, ws, ray_sums, rays_d, W1 if net is None else net[0], None if net is None else net[1],
+                              None if net is None else net[2], None if net is None else net[3], bg_color, lam_entropy, n_valid)
+        ctx.meta = (float(lam_opacity), float(lam_orient), C, N)
+        ctx.set_materialize_grads(False)
+        return pred, loss_reg
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g_pred, g_reg):
+        image_raw, ws, ray_sums, rays_d, W1, b1, W2, b2, bg_color, lam_entropy, n_valid = ctx.saved_tensors
+        lam_opacity, lam_orient, C, N = ctx.meta
+        dev = ws.device
+        f = dict(dtype=_F32, device=dev)
+        g_pred = torch.zeros(1, C, N, **f) if g_pred is None else g_pred.float().contiguous()
+        g_reg = None if g_reg is None else g_reg.float().contiguous()
+        g_image, g_ws = torch.empty(N, 3, **f), torch.empty(N, **f)
+        g_sums = None if ray_sums is None else torch.empty(N, 2, **f)
+        net = None if W1 is None else (W1, b1, W2, b2)
+        dnet = None if net is None else tuple(torch.empty_like(t) for t in net)
+        _render.head_backward(image_raw, ws, ray_sums, rays_d, net, bg_color, lam_entropy, n_valid, lam_opacity, lam_orient, C, g_pred, g_reg,
+                              g_image, g_ws, g_sums, dnet)
+        dW1, db1, dW2, db2 = dnet if dnet is not None else (None,) * 4
+        return (g_image, g_ws, g_sums, None, dW1, db1, dW2, db2) + (None,) * 8
+
+
+def image_head(image_raw, ws, ray_sums, rays_d, bg_net, bg_color, lam_entropy, n_valid, lam_opacity, lam_orient, C, H, W):
+    if bg_net is not None:
+        n = bg_net.net
+        W1, b1, W2, b2 = n[0].weight, n[0].bias, n[1].weight, n[1].bias
+    else:
+        W1 = b1 = W2 = b2 = None
+    return _image_head.apply(image_raw, ws, ray_sums, rays_d, W1, b1, W2, b2, bg_color, lam_entropy, n_valid, lam_opacity, lam_orient,
+                             C, H, W)
+
+
 class _weights_entropy(Function):
     """sum_{i < total} H(clamp(w_i, 1e-5, 1 - 1e-5)) in bits — the un-normalised lambda_entropy term (nerf/utils.py:571-575)."""
 

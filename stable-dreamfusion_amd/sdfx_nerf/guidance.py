@@ -17,6 +17,7 @@ The frozen 2D prior itself (UNet / VAE / text encoder) is third-party code the r
 from __future__ import annotations
 
 import hashlib
+import os
 
 import torch
 import torch.nn as nn
@@ -49,16 +50,21 @@ class SyntheticUNet(nn.Module):
         blob = torch.exp(-(xx ** 2 + yy ** 2) / (2 * 0.35 ** 2))
         target = torch.stack([blob * (0.5 + 0.5 * xx), blob * (0.5 - 0.5 * yy), blob * 0.6, blob], dim=0) * 2 - 1
         self.register_buffer("target", target[None])
-        self.register_buffer("alphas", ddim_alphas_cumprod())
+        abar = ddim_alphas_cumprod()
+        self.register_buffer("alphas", abar)
+        a, b = abar.sqrt(), (1 - abar).sqrt()
+        # per-timestep coefficients of forward(), one gathered row per call: 1 / b, -a / b, 0.02 cos(1e-3 t)
+        self.register_buffer("coef", torch.stack([1 / b, -a / b, 0.02 * torch.cos(torch.arange(1000, dtype=torch.float32) * 1e-3)], dim=1))
 
     def forward(self, x, t, encoder_hidden_states):
-        abar = self.alphas[t].to(x.dtype)[:, None, None, None]
-        a, b = abar.sqrt(), (1 - abar).sqrt()
+        c = self.coef[t].to(x.dtype)
+        inv_b, neg_a_over_b, k = (c[:, i, None, None, None] for i in range(3))
         # text-conditioned and unconditional targets differ by ~1e-3 per channel: times guidance_scale = 100 that is the
         # O(0.1) shift classifier-free guidance applies
-        shift = 1e-3 * torch.tanh(self.ctx(encoder_hidden_states.mean(dim=1).to(x.dtype)))[:, :, None, None]
-        tgt = self.target.to(x.dtype) + shift
-        return (x - a * tgt) / b + 0.02 * self.conv(x) * torch.cos(t.to(x.dtype) * 1e-3)[:, None, None, None]
+        shift = torch.tanh(self.ctx(encoder_hidden_states.mean(dim=1).to(x.dtype)))[:, :, None, None]
+        tgt = torch.add(self.target.to(x.dtype), shift, alpha=1e-3)
+        # (x - a tgt) / b + 0.02 cos(1e-3 t) conv(x)
+        return torch.addcmul(torch.addcmul(x * inv_b, tgt, neg_a_over_b), self.conv(x), k)
 
 
 class SyntheticVAE(nn.Module):
@@ -111,12 +117,27 @@ class SDSGuidance(nn.Module):
         a = self.alphas[t].to(latents.dtype)
         return a.sqrt()[:, None, None, None] * latents + (1 - a).sqrt()[:, None, None, None] * noise
 
+    def _fused_ok(self, x):
+        return (_FUSED_SDS and x.is_cuda and self.precision_t == torch.float16 and x.dtype in (torch.float32, torch.float16)
+                and x.dim() == 4)
+
     def train_step(self, text_embeddings, pred_rgb, guidance_scale=100, as_latent=False, grad_scale=1):
+        if as_latent and self._fused_ok(pred_rgb) and pred_rgb.dtype == torch.float32:
+            # bilinear resampling to the size the tensor already has is the identity (source index = destination index, weight 1)
+            x = pred_rgb if tuple(pred_rgb.shape[-2:]) == (64, 64) else F.interpolate(pred_rgb, (64, 64), mode="bilinear",
+                                                                                      align_corners=False)
+            return _FusedSDS.apply(x.contiguous(), self, text_embeddings, float(guidance_scale), float(grad_scale), True)
         if as_latent:
             latents = F.interpolate(pred_rgb, (64, 64), mode="bilinear", align_corners=False) * 2 - 1
+        elif self._fused_ok(pred_rgb) and pred_rgb.dtype == torch.float32:
+            # bilinear 512^2 + `2 x - 1` + cast to the VAE's dtype in one kernel each way (csrc/sds.hip)
+            imgs = _UpsampleToVAE.apply(pred_rgb.contiguous(), 512, 512)
+            latents = self.vae.encode_sample(imgs) * self.vae.scaling_factor
         else:
             pred_rgb_512 = F.interpolate(pred_rgb, (512, 512), mode="bilinear", align_corners=False)
             latents = self.encode_imgs(pred_rgb_512)
+        if not as_latent and self._fused_ok(latents):
+            return _FusedSDS.apply(latents.contiguous(), self, text_embeddings, float(guidance_scale), float(grad_scale), False)
 
         t = torch.randint(self.min_step, self.max_step + 1, (latents.shape[0],), dtype=torch.long, device=self.device)
         with torch.no_grad():
@@ -139,6 +160,84 @@ class SDSGuidance(nn.Module):
         grad = torch.nan_to_num(grad)
         targets = (latents - grad).detach()
         return 0.5 * F.mse_loss(latents.float(), targets, reduction="sum") / latents.shape[0]
+
+
+_FUSED_SDS = int(os.environ.get("SDFX_FUSED_SDS", "1"))
+
+
+class _UpsampleToVAE(torch.autograd.Function):
+    """float16(2 * bilinear(x -> OH x OW) - 1): sd_utils.py:93 + encode_imgs' first line (sd_utils.py:285) + the cast to the frozen
+    VAE's dtype; the backward is the adjoint gather (deterministic, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        import _sdfx as S
+        S.check_tensor(x, "pred_rgb", torch.float32)
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, OH, OW, dtype=torch.float16, device=x.device)
+        S.call("sdfx_sds_upsample_forward", S.ptr(x), B * C, H, W, OH, OW, 1, 1, S.ptr(out), S.stream())
+        ctx.shape = (B, C, H, W, OH, OW)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import _sdfx as S
+        B, C, H, W, OH, OW = ctx.shape
+        g = S.check_tensor(g.contiguous(), "grad", torch.float16, torch.float32)
+        gx = torch.empty(B, C, H, W, dtype=torch.float32, device=g.device)
+        S.call("sdfx_sds_upsample_backward", S.ptr(g), int(g.dtype == torch.float16), B * C, H, W, OH, OW, 1, S.ptr(gx), S.stream())
+        return gx, None, None
+
+
+class _FusedSDS(torch.autograd.Function):
+    """SDSGuidance.train_step from the latents on (sd_utils.py:97-159) with csrc/sds.hip either side of the frozen network:
+    randint, randn, k_sds_add_noise, UNet, k_sds_loss; the backward is one multiplication by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, x, g, text_embeddings, guidance_scale, grad_scale, affine):
+        import _sdfx as S
+        B, per = x.shape[0], x[0].numel()
+        half = x.dtype == torch.float16
+        t = torch.randint(g.min_step, g.max_step + 1, (B,), dtype=torch.long, device=x.device)
+        noise = torch.randn_like(x)
+        latents = torch.empty_like(x) if affine else x
+        model_input = torch.empty((2 * B,) + tuple(x.shape[1:]), dtype=torch.float16, device=x.device)
+        tt = torch.empty(2 * B, dtype=torch.long, device=x.device)
+        alphas = S.check_tensor(g.alphas, "alphas_cumprod", torch.float32)
+        S.call("sdfx_sds_add_noise", S.ptr(x), int(half), int(affine), S.ptr(noise), S.ptr(t), S.ptr(alphas), B, per,
+               S.ptr(latents) if affine else None, S.ptr(model_input), S.ptr(tt), S.stream())
+        with torch.autocast("cuda", enabled=False):     # see train_step: the frozen network runs outside the trainer's autocast
+            noise_pred = g.unet(model_input, tt, encoder_hidden_states=text_embeddings.to(torch.float16))
+        noise_pred = S.check_tensor(noise_pred.contiguous(), "noise_pred", torch.float16)
+        if tuple(noise_pred.shape) != tuple(model_input.shape):
+            raise ValueError(f"noise predictor returned {tuple(noise_pred.shape)} for an input of {tuple(model_input.shape)}")
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        S.call("sdfx_sds_loss", S.ptr(noise_pred), S.ptr(noise), S.ptr(latents), int(half), S.ptr(t), S.ptr(alphas), guidance_scale,
+               grad_scale, 2.0 if affine else 1.0, B, per, S.ptr(loss), S.ptr(dx), S.stream())
+        ctx.save_for_backward(dx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (dx,) = ctx.saved_tensors
+        return dx * grad_loss.to(dx.dtype), None, None, None, None, None
+
+
+def text_mix(uncond, front, side, back, w_front, w_side, w_back):
+    """[uncond; w_front front + w_side side + w_back back] — the interpolated text embedding of nerf/utils.py:448-470 stacked
+    under the unconditional one, float16 rounding as in the tensor expressions (csrc/sds.hip)."""
+    import _sdfx as S
+    out = torch.empty((2,) + tuple(front.shape[1:]), dtype=torch.float16, device=front.device)
+    h = lambda t, n: S.ptr(S.check_tensor(t, n, torch.float16))
+    f = lambda t, n: S.ptr(S.check_tensor(t, n, torch.float32))
+    S.call("sdfx_sds_text_mix", h(uncond, "uncond"), h(front, "front"), h(side, "side"), h(back, "back"), f(w_front, "w_front"),
+           f(w_side, "w_side"), f(w_back, "w_back"), front.numel(), S.ptr(out), S.stream())
+    return out
+
+
+def fused_text_mix_available(e):
+    return bool(_FUSED_SDS and e.is_cuda and e.dtype == torch.float16 and e.shape[0] == 1)
 
 
 def synthetic_prior(device, fp16=True):

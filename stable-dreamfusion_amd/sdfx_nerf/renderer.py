@@ -70,7 +70,7 @@ class NeRFRenderer(nn.Module):
 
     # --------------------------------------------------------------------------- run_cuda
     def run_cuda(self, rays_o, rays_d, light_d=None, ambient_ratio=1.0, shading="albedo", bg_color=None, perturb=False,
-                 T_thresh=1e-4, binarize=False, marched=None, shading_dev=None, **kwargs):
+                 T_thresh=1e-4, binarize=False, marched=None, shading_dev=None, defer_head=False, **kwargs):
         """`marched` (extension): (xyzs, dirs, ts, rays, n_valid) from raymarching.march_rays_train_count/_write when
         the caller has already marched into fixed-capacity buffers; n_valid is the device-side sample total and
         replaces the buffer length wherever the reference averages over samples."""
@@ -110,6 +110,10 @@ class NeRFRenderer(nn.Module):
                 weights, weights_sum, depth, image, ray_sums = self.forward_render(
                     xyzs, dirs, ts, rays, rays_o, light_offset, total, ratio=ambient_ratio,
                     shading=shading if shading_dev is None else shading_dev, T_thresh=T_thresh)
+                if defer_head:   # background, [1, C, H, W] layout and the regulariser sum are the caller's one kernel
+                    results.update(deferred=True, image_raw=image, ray_sums=ray_sums, weights=weights, weights_sum=weights_sum,
+                                   depth=depth, num_samples=xyzs.shape[0], num_valid=n_valid, num_total=total)
+                    return results
                 sums = ray_sums.sum(0)
                 denom = n_valid if n_valid is not None else float(max(xyzs.shape[0], 1))
                 results["entropy_sum"] = sums[0]          # sum over samples of H(clamp(w)); the trainer divides by the sample count

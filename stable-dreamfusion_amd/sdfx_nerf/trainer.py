@@ -31,10 +31,13 @@ import torch
 import raymarching
 
 from .fused_shade import MODES as _SHADE_MODES
-from .fused_shade import weights_entropy_sum
+from .fused_shade import image_head, weights_entropy_sum
+from .guidance import fused_text_mix_available, text_mix
 from .optim import Adan, DeviceAdan
 
 _FUSED_ENTROPY = int(os.environ.get("SDFX_FUSED_ENTROPY", "1"))
+# background network + background mix + [1, C, H, W] layout + the three regulariser terms in one kernel each way (csrc/head.hip)
+_FUSED_HEAD = int(os.environ.get("SDFX_FUSED_HEAD", "1"))
 _PREFETCH = int(os.environ.get("SDFX_PREFETCH", "1"))      # counting pass of the next iteration on a second stream
 _STEP_SYNC = int(os.environ.get("SDFX_STEP_SYNC", "0"))    # debugging aid: device-wide synchronisation after every step
 
@@ -133,11 +136,24 @@ class TrainStep:
 
     def text_z(self):
         e, sc = self.embeddings, self.sc
+        if fused_text_mix_available(e["front"]):
+            return text_mix(e["uncond"], e["front"], e["side"], e["back"], sc[_SC_WF], sc[_SC_WS], sc[_SC_WB])
         dt = e["front"].dtype
         z = sc[_SC_WF].to(dt) * e["front"] + sc[_SC_WS].to(dt) * e["side"] + sc[_SC_WB].to(dt) * e["back"]
         return torch.cat([e["uncond"], z], dim=0)
 
     # ------------------------------------------------------------------------------ loss (device)
+    def _head_ok(self, bg_kind):
+        """csrc/head.hip covers the -O configuration: a 39-32-3 background MLP evaluated in float32 (or a colour), B = 1."""
+        if not _FUSED_HEAD or self.device.type != "cuda":
+            return False
+        if bg_kind != "net":
+            return True
+        from . import network_grid as ng
+        net = getattr(self.model, "bg_net", None)
+        return bool(ng._BG_FP32 and net is not None and net.num_layers == 2 and net.dim_in == 39 and net.dim_hidden == 32
+                    and net.dim_out == 3 and net.net[0].bias is not None)
+
     def train_step(self, marched, shading, as_latent, bg_kind):
         opt, sc = self.opt, self.sc
         B = 1
@@ -148,8 +164,18 @@ class TrainStep:
             shading, shading_dev = "lambertian", sc[_SC_MODE]
         outputs = self.model.render(self.rays_o, self.rays_d, None, H, W, staged=False, perturb=True, bg_color=bg_color,
                                     ambient_ratio=sc[_SC_AMBIENT], shading=shading, binarize=False, marched=marched,
-                                    shading_dev=shading_dev)
+                                    shading_dev=shading_dev, defer_head=self._head_ok(bg_kind))
         self._num_samples = outputs.get("num_samples", 0)
+        if outputs.get("deferred"):
+            n_valid = outputs["num_valid"]
+            if n_valid is None:
+                n_valid = torch.full((), float(max(self._num_samples, 1)), dtype=torch.float32, device=self.device)
+            pred_rgb, loss_reg = image_head(outputs["image_raw"], outputs["weights_sum"], outputs["ray_sums"], self.rays_d,
+                                            self.model.bg_net if bg_kind == "net" else None, bg_color, sc[_SC_ENTROPY], n_valid,
+                                            max(opt.lambda_opacity, 0.0), max(opt.lambda_orient, 0.0), 4 if as_latent else 3, H, W)
+            loss = self.guidance.train_step(self.text_z(), pred_rgb, as_latent=as_latent, guidance_scale=opt.guidance_scale,
+                                            grad_scale=opt.lambda_guidance)
+            return loss + loss_reg
         if as_latent:
             pred_rgb = torch.cat([outputs["image"], outputs["weights_sum"].unsqueeze(-1)], dim=-1).reshape(B, H, W, 4)
         else:

@@ -1,6 +1,7 @@
 """-m gpu: the HIP path (Python operator packages -> ctypes -> C ABI -> gfx950 kernels) against the
 CPU oracle on identical seeded inputs. Integer / index outputs and fp32 grid features are compared
 bit-exactly; compositing and fp16 / atomic paths within the stated tolerances."""
+import importlib
 import os
 
 import numpy as np
@@ -582,6 +583,51 @@ def test_fused_field_network_matches_unfused(oracle, dev):
     assert torch.abs(c1 - c0).max().item() < 2e-2
     assert torch.abs(gw1 - gw0).max().item() < 3e-2 * gw0.abs().max().item()
     assert torch.abs(ge1 - ge0).max().item() < 3e-2 * ge0.abs().max().item()
+
+
+def test_stencil_batched_field_matches_seven_oracle_evaluations(oracle, dev):
+    """NeRFNetwork._stencil_forward evaluates x and its six finite-difference neighbours as ONE [7, N, 3] batch (hinted encode:
+    stencil lanes + cost-balanced split, MFMA field). The reference makes seven separate common_forward calls
+    (network_grid.py:81-96, 108-115). Oracle side: seven separate evaluations — oracle.grid_encode_forward on the half table
+    (bit-exact features), then the MLP / trunc_exp / blob of oracle.field_forward in float32 on those half features."""
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf import network_grid as ng
+    from sdfx_nerf.options import default_opt
+    torch.manual_seed(3)
+    model = ng.NeRFNetwork(default_opt()).to(dev).train()
+    offsets, pls = oracle.grid_offsets(desired_resolution=2048)
+    table = synth.s_table(int(offsets[-1]), 2, "trained", np.float32)
+    with torch.no_grad():
+        model.encoder.embeddings.copy_(T(table, dev))
+    o, d = synth.s_rays(4)
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    xyzs = oracle.march_rays_train(o, d, 1.0, synth.s_grid_init()[2], 1, 128, nears, fars, synth.s_noises(4096))[0][:30000]
+    xyzs[:3] = [[0.999, -0.999, 0.5], [-1.0, 1.0, -1.0], [0.0, 0.0, 0.0]]      # neighbours clamped at the box faces
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        sigma, albedo, normal = model._stencil_forward(T(xyzs, dev))
+    net = model.sigma_net.net
+    Ws = [net[i].weight.detach().cpu().numpy() for i in range(3)]
+    Bs = [net[i].bias.detach().cpu().numpy() for i in range(3)]
+    th = table.astype(np.float16)
+    e = np.float32(1e-2)
+    offs = np.array([[0, 0, 0], [e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]], np.float32)
+    sig_ref = []
+    for k in range(7):                                                       # seven separate evaluations
+        pts = np.clip(xyzs + offs[k], -1, 1).astype(np.float32)
+        x01 = ((pts + np.float32(1)) / np.float32(2)).astype(np.float32)
+        enc, _, _ = oracle.grid_encode_forward(x01, th, offsets, pls, 16, False, 0, False, 1)
+        s_k, a_k = oracle.field_forward(enc.astype(np.float32), pts, Ws, Bs)
+        sig_ref.append(s_k)
+        if k == 0:
+            alb_ref = a_k
+    sig_ref = np.stack(sig_ref)
+    n_ref = -np.stack([0.5 * (sig_ref[1] - sig_ref[2]) / e, 0.5 * (sig_ref[3] - sig_ref[4]) / e, 0.5 * (sig_ref[5] - sig_ref[6]) / e], -1)
+    s, a, n = N_(sigma.float()), N_(albedo.float()), N_(normal.float())
+    # fp16 MLP (kernel: half activations between layers, as autocast) vs float32 MLP on the same half features
+    assert np.abs(s - sig_ref[0]).max() <= 1e-2 * np.abs(sig_ref[0]).max() and np.median(np.abs(s - sig_ref[0]) / sig_ref[0]) < 2e-3
+    assert np.abs(a - alb_ref).max() < 1e-2
+    scale = np.abs(n_ref).max()
+    assert np.abs(n - n_ref).max() <= 6e-2 * scale and np.median(np.abs(n - n_ref)) <= 2e-3 * scale   # differences of two rounded densities / 0.02
 
 
 @pytest.mark.parametrize("gridname", ["init", "blobs", "full"])

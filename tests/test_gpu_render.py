@@ -163,3 +163,104 @@ def test_render_path_of_the_network_uses_the_fused_kernel(dev, oracle):
     assert abs(a[2] - b[2]) <= 1e-4 * abs(b[2]) + 1e-8 and abs(a[3] - b[3]) <= 1e-4 * abs(b[3]) + 1e-8
     assert float((a[4] - b[4]).abs().max()) <= 2e-3 * float(b[4].abs().max())
     assert float((a[5] - b[5]).abs().max()) <= 2e-2 * float(b[5].abs().max())
+
+
+@pytest.mark.parametrize("bg_kind", ["net", "rand"])
+@pytest.mark.parametrize("as_latent", [True, False])
+def test_image_head_matches_the_torch_expressions(dev, bg_kind, as_latent):
+    """csrc/head.hip against the expressions it replaces, evaluated by PyTorch with the model's own modules: background =
+    sigmoid(bg_net(FreqEncoder(rays_d))) in float32 (nerf/network_grid.py:132-153), image + (1 - weights_sum) bg
+    (nerf/renderer.py:797-806), the [1, C, H, W] prediction (nerf/utils.py:533-541) and lambda_opacity mean(ws^2) +
+    lambda_entropy entropy / n + lambda_orient orient / n — values and every gradient (image, weights_sum, ray sums, the four
+    background-network tensors)."""
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf import network_grid as ng
+    from sdfx_nerf.fused_shade import image_head
+    from sdfx_nerf.options import default_opt
+    torch.manual_seed(7)
+    model = ng.NeRFNetwork(default_opt()).to(dev)
+    H = W = 64
+    N = H * W
+    o, d = synth.s_rays(2)
+    rays_d = torch.from_numpy(d).to(dev)
+    g = torch.Generator().manual_seed(3)
+    mk = lambda *s: torch.rand(*s, generator=g).to(dev)
+    lam_ent, n_valid = torch.tensor(7e-4, device=dev), torch.tensor(431234.0, device=dev)
+    lam_op, lam_ori, C = 0.02, 1e-2, 4 if as_latent else 3
+    bg_color = mk(3) if bg_kind == "rand" else None
+    g_pred, g_reg = torch.randn(1, C, H, W, generator=g).to(dev), torch.tensor(37.0, device=dev)
+    image_raw0, ws0, sums0 = mk(N, 3), mk(N) * 0.98, mk(N, 2) * torch.tensor([300.0, 2.0], device=dev)
+
+    def run(fused):
+        image_raw, ws, sums = image_raw0.clone().requires_grad_(), ws0.clone().requires_grad_(), sums0.clone().requires_grad_()
+        model.zero_grad()
+        if fused:
+            pred, reg = image_head(image_raw, ws, sums, rays_d, model.bg_net if bg_kind == "net" else None, bg_color, lam_ent, n_valid,
+                                   lam_op, lam_ori, C, H, W)
+        else:
+            bg = model.background(rays_d) if bg_kind == "net" else bg_color
+            image = image_raw + (1 - ws).unsqueeze(-1) * bg
+            p = torch.cat([image, ws.unsqueeze(-1)], -1) if as_latent else image
+            pred = p.reshape(1, H, W, C).permute(0, 3, 1, 2).contiguous()
+            reg = lam_op * (ws ** 2).mean() + lam_ent * sums[:, 0].sum() / n_valid + lam_ori * sums[:, 1].sum() / n_valid
+        ((pred * g_pred).sum() + reg * g_reg).backward()
+        grads = [p.grad.clone() if p.grad is not None else None for p in model.bg_net.parameters()]
+        return pred.detach(), reg.detach(), image_raw.grad, ws.grad, sums.grad, grads
+
+    a = run(True)
+    b = run(False)
+    assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-6)
+    assert abs(float(a[1]) - float(b[1])) <= 1e-5 * abs(float(b[1]))
+    assert torch.allclose(a[2], b[2], rtol=1e-6, atol=1e-7) and torch.allclose(a[3], b[3], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(a[4], b[4], rtol=1e-5, atol=1e-9)
+    for ga, gb in zip(a[5], b[5]):
+        if bg_kind == "net":
+            assert float((ga - gb).abs().max()) <= 2e-4 * float(gb.abs().max()) + 1e-7
+        else:
+            assert ga is None and gb is None
+
+
+def test_trainer_iteration_with_and_without_the_fused_head(dev):
+    """TrainStep.train_step through csrc/head.hip vs the torch composition (SDFX_FUSED_HEAD), RGB-phase kinds included: same
+    loss, same gradients (fp16 field on both sides; the background network is float32 on both sides)."""
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf import trainer as TR
+    from sdfx_nerf.guidance import synthetic_prior
+    from sdfx_nerf.network_grid import NeRFNetwork
+    from sdfx_nerf.options import default_opt
+    o, d = synth.s_rays(1, 32, 32)
+    ro, rd = torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev)
+    res = {}
+    for flag in (1, 0):
+        TR._FUSED_HEAD = flag
+        torch.manual_seed(0)
+        opt = default_opt(w=32, h=32)
+        opt.lambda_opacity = 1e-3
+        model = NeRFNetwork(opt).to(dev)
+        step = TR.TrainStep(opt, model, synthetic_prior(dev, opt.fp16), dev, seed=0, mode="reference")
+        step.rays_o, step.rays_d = ro, rd
+        model.train()
+        with torch.autocast("cuda", dtype=torch.float16):
+            model.update_extra_state()
+        out = []
+        for kinds in (("normal", True, "net"), ("lambertian", False, "rand"), ("textureless", False, "net")):
+            step.global_step = 2500
+            step._schedule(20.0)
+            step.sc.copy_(step.sc_host)
+            step.sc[1:4] = torch.tensor([0.2, 0.5, 0.9], device=dev)        # the random background colour
+            step.sc[8] = float({"lambertian": 1, "textureless": 2, "normal": 3}[kinds[0]])
+            model.zero_grad()
+            torch.manual_seed(11)
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss = step.train_step(None, *kinds)
+            loss.backward()
+            out.append((float(loss), model.bg_net.net[0].weight.grad.clone() if model.bg_net.net[0].weight.grad is not None else None,
+                        model.sigma_net.net[2].weight.grad.clone()))
+        res[flag] = out
+    TR._FUSED_HEAD = 1
+    for (la, ba, sa), (lb, bb, sb) in zip(res[1], res[0]):
+        assert abs(la - lb) <= 1e-4 * abs(lb)
+        assert (ba is None) == (bb is None)
+        if ba is not None:
+            assert float((ba - bb).abs().max()) <= 1e-3 * float(bb.abs().max()) + 1e-8
+        assert float((sa - sb).abs().max()) <= 5e-3 * float(sb.abs().max()) + 1e-8

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Ordered kernel list of ONE replayed iteration (latent phase, synthetic prior): what is still launched per step, how long each
+# takes and the gaps between them.  Usage: bash tools/gpu_iter_trace.sh <tag> [phase]
+TAG=${1:-it}; PHASE=${2:-latent}
+OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$PWD
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 12 --warmup 3 --phase $PHASE --guidance synthetic --no-cpu-baseline --no-kernel-bench --no-reference-flow > $OUT/prof.log 2>&1
+echo "rocprof exit $?"
+python3 - <<PY > $OUT/iteration_trace.txt
+import csv, glob
+f = glob.glob("$OUT/prof/**/bench_kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+name = lambda r: r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "")
+idx = [i for i, r in enumerate(rows) if "k_adan_update" in r["Kernel_Name"]]
+print("kernels", len(rows), "optimiser steps", len(idx))
+# the iteration between the 8th and the 9th optimiser update of the timed region's tail
+a, b = idx[-6] + 1, idx[-5] + 1
+t0 = int(rows[a]["Start_Timestamp"])
+busy = 0
+prev_end = t0
+for r in rows[a:b]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    busy += e - s
+    print("%9.1f us  +%6.1f gap  %7.1f us  q%s  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), name(r)[:110]))
+    prev_end = max(prev_end, e)
+print("launches %d  span %.1f us  busy %.1f us" % (b - a, (int(rows[b - 1]["End_Timestamp"]) - t0) / 1e3, busy / 1e3))
+PY
+tail -3 $OUT/iteration_trace.txt
+find $OUT/prof -type f -size +1M -delete 2>/dev/null
