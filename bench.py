@@ -598,6 +598,7 @@ def main():
     job.sync()
     applied_before = job.applied()
     stats_before = dict(getattr(getattr(job, "step_obj", None), "stats", {}))
+    host_before = dict(getattr(getattr(job, "step_obj", None), "host_s", {}))
 
     # ---- the timed region: EXACTLY args.steps steps between two barrier + synchronize pairs ----
     if dist is not None:
@@ -624,6 +625,9 @@ def main():
     stage("timed region done")
     applied_in_timed = job.applied() - applied_before
     stats_timed = {k: v - stats_before.get(k, 0) for k, v in getattr(getattr(job, "step_obj", None), "stats", {}).items()}
+    host_now = dict(getattr(getattr(job, "step_obj", None), "host_s", {}))
+    host_steps = max(host_now.get("steps", 0) - host_before.get("steps", 0), 1)
+    host_us = {k: round((v - host_before.get(k, 0.0)) / host_steps * 1e6, 1) for k, v in host_now.items() if k != "steps"}
     elapsed = job_elapsed(elapsed_local, dist, dev)
     phases, prev = {}, t0
     for name, k, t in marks:
@@ -652,6 +656,9 @@ def main():
     result["grad_scale"] = step.get_scale()
     result["graph_stats"] = dict(step.stats)
     result["graph_stats_timed_region"] = stats_timed
+    # host microseconds per step inside the timed region: waiting for the sample count, submitting the march graph (+ the next
+    # iteration's counting pass) and submitting the training graph
+    result["host_us_per_step"] = host_us
     roofline_pass = "timed region"
     if step.mode == "graph":
         # Launches inside a replayed HIP graph do not pass through Python, so the per-kernel HIP events are taken in a

@@ -88,6 +88,19 @@ int sdfx_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
                           float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
                           const float* fars, float* xyzs, float* dirs, float* ts, int32_t* rays, int32_t* counter,
                           const float* noises, float* scratch, sdfx_stream_t stream);
+
+/*
+ * Extension — pass 2 of march_rays_train for an iteration with a fixed sample capacity (HIP-graph replay): writes the samples
+ * recorded in `scratch` by pass 1 into xyzs/dirs/ts [capacity, .] (NOT pre-zeroed: rows from counter[0] to capacity are zeroed
+ * here, as the pre-zeroed buffers of raymarching/raymarching.py:243-245 would leave them), and copies rays_o, rays_d [N,3],
+ * rays [N,2], counter[0] (as int32 and as float32) into the out_* buffers, so that pass 1 of the next iteration may overwrite
+ * its inputs while this iteration trains. One launch.
+ */
+int sdfx_march_rays_train_stage_write(const float* rays_o, const float* rays_d, float bound, int contract, float dt_gamma,
+                                      uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const int32_t* rays,
+                                      const int32_t* counter, const float* scratch, uint32_t capacity, float* xyzs, float* dirs,
+                                      float* ts, float* out_rays_o, float* out_rays_d, int32_t* out_rays, int32_t* out_total,
+                                      float* out_n_valid, sdfx_stream_t stream);
 uint64_t sdfx_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps);
 
 /* raymarching.cu:582-590 composite_rays_train_forward (weights [M] pre-zeroed) */
@@ -285,6 +298,11 @@ uint32_t sdfx_field_packed_words(void);
 /* testing aid: 0 = matrix-core kernels (default), 1 = per-thread v_dot2 kernels, -1 = follow env SDFX_FIELD_IMPL */
 void sdfx_field_set_impl(int impl);
 uint64_t sdfx_field_backward_scratch_bytes(uint32_t B);
+/* Extension — the 7-point finite-difference stencil batch of network_grid.py:81-96 from the M sample positions: points [7, M, 3]
+ * = (x, x + eps e_x, x - eps e_x, ... e_z), the six offset points clamped to [-bound, bound] (network_grid.py:84-89), and
+ * unit [7, M, 3] = (points + bound) / two_bound, the encoder's input (gridencoder/grid.py:157). two_bound = float32(2 * bound). */
+int sdfx_field_stencil_points(const float* xyzs, uint32_t M, float epsilon, float bound, float two_bound, float* points, float* unit,
+                              sdfx_stream_t stream);
 int sdfx_field_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                     uint32_t* packed, sdfx_stream_t stream);
 int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const uint32_t* packed, uint32_t B,
@@ -375,7 +393,7 @@ int sdfx_head_backward(const float* image_raw, const float* weights_sum, const f
  * noise has the dtype of the latents (torch.randn_like), t is int64 [B], alphas_cumprod float32 [1000].
  * sdfx_sds_loss: noise_pred float16 [2B, per_item] = (unconditional, text) halves; classifier-free guidance, w(t) = 1 - abar[t],
  * grad = nan_to_num(grad_scale w (eps - noise)), loss[0] = 0.5 sum (latents - (latents - grad))^2 / B (sd_utils.py:111-159) and
- * grad_latents (dtype of the latents) = out_scale * dloss/dlatents (out_scale = 2 folds the latent phase's x * 2 - 1).
+ * grad_latents (float32) = out_scale * dloss/dlatents (out_scale = 2 folds the latent phase's x * 2 - 1).
  * sdfx_sds_text_mix: out [2, n] float16 = (uncond, w_front front + w_side side + w_back back), the interpolated text
  * embedding of nerf/utils.py:448-470 stacked under the unconditional one; the weights are device float32 scalars.
  * Float16 intermediates are rounded where PyTorch's tensor expressions round them.
@@ -384,7 +402,7 @@ int sdfx_sds_add_noise(const void* x, int is_half, int affine, const void* noise
                        uint32_t B, uint32_t per_item, float* latents_out, void* model_input, int64_t* tt, sdfx_stream_t stream);
 int sdfx_sds_loss(const void* noise_pred, const void* noise, const void* latents, int is_half, const int64_t* t,
                   const float* alphas_cumprod, float guidance_scale, float grad_scale, float out_scale, uint32_t B, uint32_t per_item,
-                  float* loss, void* grad_latents, sdfx_stream_t stream);
+                  float* loss, float* grad_latents, sdfx_stream_t stream);
 /* Bilinear resampling [planes, H, W] -> [planes, OH, OW] with PyTorch's align_corners=False arithmetic (sd_utils.py:93), optionally
  * followed by encode_imgs' 2 x - 1 (sd_utils.py:285; affine) and the cast to float16 (out_half); the backward is the exact
  * adjoint as a gather (no atomics: deterministic), grad_out float16 (grad_half) or float32, times 2 when affine. */

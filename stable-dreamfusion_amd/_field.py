@@ -12,6 +12,16 @@ def packed_words() -> int:
     return int(S.lib().sdfx_field_packed_words())
 
 
+def stencil_points(xyzs, epsilon, bound, points, unit):
+    """points / unit [7, M, 3] from xyzs [M, 3] (include/sdfx.h sdfx_field_stencil_points)."""
+    M = xyzs.shape[0]
+    for t, n in ((xyzs, "xyzs"), (points, "points"), (unit, "unit")):
+        S.check_tensor(t, n, _F32)
+    if points.numel() != 21 * M or unit.numel() != 21 * M:
+        raise RuntimeError("field_stencil_points: points / unit must hold 7 * M * 3 floats")
+    S.call("sdfx_field_stencil_points", S.ptr(xyzs), M, float(epsilon), float(bound), float(2 * bound), S.ptr(points), S.ptr(unit), S.stream())
+
+
 def pack(w1, b1, w2, b2, w3, b3, packed):
     for t, n, shape in ((w1, "w1", (64, 32)), (b1, "b1", (64,)), (w2, "w2", (64, 64)), (b2, "b2", (64,)), (w3, "w3", (4, 64)),
                         (b3, "b3", (4,))):

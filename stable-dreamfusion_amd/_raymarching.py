@@ -79,6 +79,17 @@ def march_rays_train(rays_o, rays_d, grid, bound, contract, dt_gamma, max_steps,
            S.ptr(_f(noises, "noises")), S.ptr(scratch), S.stream())
 
 
+def march_rays_train_stage_write(rays_o, rays_d, bound, contract, dt_gamma, max_steps, N, C, H, rays, counter, scratch, capacity,
+                                 xyzs, dirs, ts, out_rays_o, out_rays_d, out_rays, out_total, out_n_valid):
+    """Pass 2 into fixed-capacity buffers + the staging copies of the iteration, one launch (include/sdfx.h)."""
+    i32 = lambda t, n: S.ptr(S.check_tensor(t, n, _I32))
+    S.call("sdfx_march_rays_train_stage_write", S.ptr(_f(rays_o, "rays_o")), S.ptr(_f(rays_d, "rays_d")), float(bound),
+           int(bool(contract)), float(dt_gamma), max_steps, N, C, H, i32(rays, "rays"), i32(counter, "counter"),
+           S.ptr(_f(scratch, "scratch")), capacity, S.ptr(_f(xyzs, "xyzs")), S.ptr(_f(dirs, "dirs")), S.ptr(_f(ts, "ts")),
+           S.ptr(_f(out_rays_o, "out_rays_o")), S.ptr(_f(out_rays_d, "out_rays_d")), i32(out_rays, "out_rays"),
+           i32(out_total, "out_total"), S.ptr(_f(out_n_valid, "out_n_valid")), S.stream())
+
+
 def composite_rays_train_forward(sigmas, rgbs, ts, rays, M, N, T_thresh, binarize, weights, weights_sum, depth, image):
     S.call("sdfx_composite_rays_train_forward", S.ptr(_f(sigmas, "sigmas")), S.ptr(_f(rgbs, "rgbs")), S.ptr(_f(ts, "ts")),
            S.ptr(S.check_tensor(rays, "rays", _I32)), M, N, float(T_thresh), int(bool(binarize)),

@@ -26,6 +26,8 @@ _SIGNATURES = {
     "sdfx_flatten_rays": [_ptr, _u32, _u32, _ptr, _ptr],
     "sdfx_march_rays_train": [_ptr, _ptr, _ptr, _f32, _int, _f32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr,
                               _ptr, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_march_rays_train_stage_write": [_ptr, _ptr, _f32, _int, _f32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _u32, _ptr, _ptr,
+                                          _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_march_rays_train_scratch_bytes": [_u32, _u32],
     "sdfx_composite_rays_train_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _f32, _int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_composite_rays_train_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32,
@@ -54,6 +56,7 @@ _SIGNATURES = {
     "sdfx_field_packed_words": [],
     "sdfx_field_set_impl": [_int],
     "sdfx_field_backward_scratch_bytes": [_u32],
+    "sdfx_field_stencil_points": [_ptr, _u32, _f32, _f32, _f32, _ptr, _ptr, _ptr],
     "sdfx_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_field_forward": [_ptr, _int, _ptr, _ptr, _u32, _f32, _f32, _ptr, _ptr, _ptr],
     "sdfx_field_backward": [_ptr, _int, _ptr, _ptr, _u32, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,

@@ -604,6 +604,34 @@ uint32_t backward_blocks(uint32_t B) {
     return tiles < kMaxBlocks ? tiles : kMaxBlocks;
 }
 
+// The finite-difference stencil of network_grid.py:81-96 as one batch [7, M, 3]: the sample itself, then x +- eps along each
+// axis clamped to the box, in world coordinates (`points`, for the density blob) and mapped to the encoder's unit cube
+// (`unit` = (p + bound) / (2 bound), gridencoder/grid.py:157; PyTorch divides a tensor by a scalar as a multiplication with
+// the float32 reciprocal). One launch instead of add, clamp, cat, add, mul over the 7 M-point batch.
+__global__ __launch_bounds__(256) void k_stencil_points(const float* __restrict__ xyzs, uint32_t M, float eps, float bound, float two_bound,
+                                                         float* __restrict__ points, float* __restrict__ unit) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const float inv = 1.0f / two_bound;
+    const float x[3] = {xyzs[(size_t)i * 3], xyzs[(size_t)i * 3 + 1], xyzs[(size_t)i * 3 + 2]};
+#pragma unroll
+    for (uint32_t k = 0; k < 7; k++) {
+        float p[3] = {x[0], x[1], x[2]};
+        if (k > 0) {
+            const uint32_t axis = (k - 1) >> 1;
+            p[axis] = x[axis] + ((k & 1) ? eps : -eps);
+#pragma unroll
+            for (uint32_t c = 0; c < 3; c++) p[c] = fminf(fmaxf(p[c], -bound), bound);   // the whole offset point is clamped
+        }
+        const size_t o = ((size_t)k * M + i) * 3;
+#pragma unroll
+        for (uint32_t c = 0; c < 3; c++) {
+            points[o + c] = p[c];
+            unit[o + c] = (p[c] + bound) * inv;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -614,6 +642,15 @@ uint32_t sdfx_field_packed_words(void) { return kPackedWords; }
 void sdfx_field_set_impl(int impl) { g_field_impl = impl; }
 
 uint64_t sdfx_field_backward_scratch_bytes(uint32_t B) { return (uint64_t)backward_blocks(B ? B : 1) * kGradWords * sizeof(float); }
+
+int sdfx_field_stencil_points(const float* xyzs, uint32_t M, float epsilon, float bound, float two_bound, float* points, float* unit,
+                              sdfx_stream_t stream) {
+    SDFX_REQUIRE(xyzs && points && unit, "field_stencil_points: null pointer");
+    SDFX_REQUIRE(bound > 0 && two_bound > 0, "field_stencil_points: bound must be positive");
+    if (M == 0) return SDFX_OK;
+    hipLaunchKernelGGL(k_stencil_points, dim3(div_up(M, 256)), dim3(256), 0, as_stream(stream), xyzs, M, epsilon, bound, two_bound, points, unit);
+    return check_launch("field_stencil_points");
+}
 
 int sdfx_field_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                     uint32_t* packed, sdfx_stream_t stream) {

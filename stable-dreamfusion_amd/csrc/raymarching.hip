@@ -274,6 +274,62 @@ __global__ void k_march_write_tbuf(const float* __restrict__ rays_o, const float
     }
 }
 
+// Pass 2 for a fixed-capacity iteration (HIP-graph replay): the write of k_march_write_tbuf, plus what PyTorch did around it
+// in eight more launches — the rows between the sample total and the capacity are zeroed here instead of pre-zeroing all
+// three buffers, and the staging copies of the rays (origins, directions, (offset, count), the total as int and as float) that
+// free the staging buffers for the next iteration's counting pass are made by the wave that owns the ray.
+__global__ __launch_bounds__(256) void k_march_stage_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                            MarchParams p, uint32_t max_steps, uint32_t N,
+                                                            const int32_t* __restrict__ rays, const int32_t* __restrict__ counter,
+                                                            const float* __restrict__ tbuf, uint32_t capacity, uint32_t ray_blocks,
+                                                            float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ ts,
+                                                            float* __restrict__ out_rays_o, float* __restrict__ out_rays_d,
+                                                            int32_t* __restrict__ out_rays, int32_t* __restrict__ out_total,
+                                                            float* __restrict__ out_n_valid) {
+    if (blockIdx.x >= ray_blocks) {   // padding rows [total, capacity): 8 floats each
+        const uint32_t total = (uint32_t)counter[0];
+        const uint32_t first = total < capacity ? total : capacity;
+        const uint64_t words = (uint64_t)(capacity - first);
+        const uint64_t stride = (uint64_t)(gridDim.x - ray_blocks) * 256;
+        for (uint64_t i = (uint64_t)(blockIdx.x - ray_blocks) * 256 + threadIdx.x; i < words * 3; i += stride) {
+            xyzs[(size_t)first * 3 + i] = 0.f;
+            dirs[(size_t)first * 3 + i] = 0.f;
+            if (i < words * 2) ts[(size_t)first * 2 + i] = 0.f;
+        }
+        return;
+    }
+    const uint32_t n = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out_total[0] = counter[0];
+        out_n_valid[0] = (float)counter[0];
+    }
+    if (n >= N) return;
+    const int lane = lane_id();
+    if (lane < 3) {
+        out_rays_o[(size_t)n * 3 + lane] = rays_o[(size_t)n * 3 + lane];
+        out_rays_d[(size_t)n * 3 + lane] = rays_d[(size_t)n * 3 + lane];
+    } else if (lane < 5) {
+        out_rays[(size_t)n * 2 + (lane - 3)] = rays[(size_t)n * 2 + (lane - 3)];
+    }
+    const uint32_t offset = (uint32_t)rays[n * 2];
+    const uint32_t count = (uint32_t)rays[n * 2 + 1];
+    if (count == 0) return;
+    const MarchRay r = make_march_ray(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3);
+    const float* trow = tbuf + (size_t)n * max_steps;
+    for (uint32_t i = (uint32_t)lane; i < count; i += kWave) {
+        const float t = trow[i];
+        float cx, cy, cz;
+        march_position(r, p, t, cx, cy, cz);
+        const float dt = march_dt(p, t);
+        const size_t s = (size_t)offset + i;
+        if (s >= capacity) break;      // (a capacity below the total is a caller error; never write past the buffers)
+        xyzs[s * 3 + 0] = cx; xyzs[s * 3 + 1] = cy; xyzs[s * 3 + 2] = cz;
+        dirs[s * 3 + 0] = r.dx; dirs[s * 3 + 1] = r.dy; dirs[s * 3 + 2] = r.dz;
+        ts[s * 2 + 0] = t + dt;
+        ts[s * 2 + 1] = dt;
+    }
+}
+
 // Pass 2 (no scratch): replay the march per ray and write as it goes (raymarching.cu:432-447).
 __global__ __launch_bounds__(64) void k_march_write_replay(const float* __restrict__ rays_o,
                                                             const float* __restrict__ rays_d,
@@ -697,6 +753,25 @@ int sdfx_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
                            fars, noises, rays, xyzs, dirs, ts);
     }
     return check_launch("march_rays_train(write)");
+}
+
+int sdfx_march_rays_train_stage_write(const float* rays_o, const float* rays_d, float bound, int contract, float dt_gamma,
+                                      uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const int32_t* rays,
+                                      const int32_t* counter, const float* scratch, uint32_t capacity, float* xyzs, float* dirs,
+                                      float* ts, float* out_rays_o, float* out_rays_d, int32_t* out_rays, int32_t* out_total,
+                                      float* out_n_valid, sdfx_stream_t stream) {
+    SDFX_REQUIRE(rays_o && rays_d && rays && counter && scratch && out_rays_o && out_rays_d && out_rays && out_total && out_n_valid,
+                 "march_rays_train_stage_write: null pointer");
+    SDFX_REQUIRE(capacity == 0 || (xyzs && dirs && ts), "march_rays_train_stage_write: null sample buffer");
+    SDFX_REQUIRE(max_steps > 0 && H > 0 && C > 0, "march_rays_train_stage_write: max_steps, C and H must be positive");
+    if (N == 0) return SDFX_OK;
+    const MarchParams p = make_march_params(bound, contract, dt_gamma, max_steps, C, H);
+    const uint32_t ray_blocks = div_up((uint64_t)N * kWave, 256);
+    const uint32_t pad_blocks = capacity ? 64 : 0;
+    hipLaunchKernelGGL(k_march_stage_write, dim3(ray_blocks + pad_blocks), dim3(256), 0, as_stream(stream), rays_o, rays_d, p,
+                       max_steps, N, rays, counter, scratch, capacity, ray_blocks, xyzs, dirs, ts, out_rays_o, out_rays_d, out_rays,
+                       out_total, out_n_valid);
+    return check_launch("march_rays_train_stage_write");
 }
 
 int sdfx_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* ts, const int32_t* rays,

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kLossThreads) void k_sds_loss(const __half* __restr
                                                            const void* __restrict__ latents, const int64_t* __restrict__ t,
                                                            const float* __restrict__ alphas, float guidance_scale, float grad_scale,
                                                            float out_scale, uint32_t B, uint32_t per, float* __restrict__ loss,
-                                                           void* __restrict__ grad_latents) {
+                                                           float* __restrict__ grad_latents) {
     __shared__ double part[kLossThreads / kWave];
     const uint32_t n = B * per;
     double acc = 0.0;
@@ -93,9 +93,7 @@ __global__ __launch_bounds__(kLossThreads) void k_sds_loss(const __half* __restr
         const float target = l - g;
         const float d = l - target;                                            // what mse_loss sees (not g: l - g is rounded)
         acc += (double)d * (double)d;
-        const float dl = d / (float)B * out_scale;
-        if (HALF) static_cast<__half*>(grad_latents)[i] = __float2half_rn(dl);
-        else static_cast<float*>(grad_latents)[i] = dl;
+        grad_latents[i] = d / (float)B * out_scale;   // float32 also for float16 latents: the caller rounds once, after its factor
     }
     acc = wave_sum(acc);
     if (lane_id() == 0) part[threadIdx.x / kWave] = acc;
@@ -238,7 +236,7 @@ int sdfx_sds_add_noise(const void* x, int is_half, int affine, const void* noise
 
 int sdfx_sds_loss(const void* noise_pred, const void* noise, const void* latents, int is_half, const int64_t* t,
                   const float* alphas_cumprod, float guidance_scale, float grad_scale, float out_scale, uint32_t B, uint32_t per_item,
-                  float* loss, void* grad_latents, sdfx_stream_t stream) {
+                  float* loss, float* grad_latents, sdfx_stream_t stream) {
     SDFX_REQUIRE(noise_pred && noise && latents && t && alphas_cumprod && loss && grad_latents, "sds_loss: null pointer");
     SDFX_REQUIRE(B > 0 && per_item > 0 && (uint64_t)B * per_item < (1ull << 31), "sds_loss: bad sizes B=%u per_item=%u", B, per_item);
     if (is_half)

@@ -15,7 +15,7 @@ import _raymarching as _backend
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "flatten_rays",
            "march_rays_train", "composite_rays_train", "march_rays", "composite_rays", "compact_rays",
-           "march_rays_train_count", "march_rays_train_write"]
+           "march_rays_train_count", "march_rays_train_write", "march_rays_train_stage_write"]
 
 
 def _cuda(t):
@@ -220,6 +220,20 @@ def march_rays_train_write(state, capacity):
                                   C, H, state["nears"], state["fars"], xyzs, dirs, ts, state["rays"], state["counter"],
                                   state["noises"], state["scratch"])
     return xyzs, dirs, ts, state["rays"]
+
+
+def march_rays_train_stage_write(state, capacity, out_rays_o, out_rays_d, out_rays, out_total, out_n_valid):
+    """march_rays_train_write for a replayed iteration: the same xyzs / dirs / ts (padding rows zero) from ONE launch that also
+    copies the counting pass's rays, origins, directions and total into the iteration's own buffers (out_*), freeing the
+    staging buffers. Needs the scratch the counting pass recorded the sample times in."""
+    device = state["rays"].device
+    f = dict(dtype=torch.float32, device=device)
+    xyzs, dirs, ts = torch.empty(capacity, 3, **f), torch.empty(capacity, 3, **f), torch.empty(capacity, 2, **f)
+    bound, contract, dt_gamma, max_steps, N, C, H = state["args"]
+    _backend.march_rays_train_stage_write(state["rays_o"], state["rays_d"], bound, contract, dt_gamma, max_steps, N, C, H,
+                                          state["rays"], state["counter"], state["scratch"], capacity, xyzs, dirs, ts,
+                                          out_rays_o, out_rays_d, out_rays, out_total, out_n_valid)
+    return xyzs, dirs, ts, out_rays
 
 
 class _composite_rays_train(Function):

@@ -22,13 +22,19 @@ class _fused_field(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, x, embeddings, offsets, w1, b1, w2, b2, w3, b3, bound, per_level_scale, base_resolution, gridtype,
-                align_corners, interp, blob_density, blob_radius, slabs, step):
+                align_corners, interp, blob_density, blob_radius, slabs, step, stencil_eps=0.0):
         x = x.float().contiguous()
-        B = x.shape[0]
+        B = x.shape[0] * (7 if stencil_eps > 0 else 1)
         if B == 0:   # a view that hits no occupied cell: nothing to evaluate, nothing to differentiate
             ctx.meta = None
             return x.new_zeros(0), x.new_zeros(0, 3)
-        inputs = ((x + bound) / (2 * bound)).contiguous()       # GridEncoder.forward's map to [0, 1] (grid.py:157)
+        if stencil_eps > 0:      # x: the M samples; the [7, M, 3] stencil batch and its unit-cube image from one kernel
+            pts = torch.empty(B, 3, dtype=torch.float32, device=x.device)
+            inputs = torch.empty(B, 3, dtype=torch.float32, device=x.device)
+            _field.stencil_points(x, stencil_eps, bound, pts, inputs)
+            x = pts
+        else:
+            inputs = ((x + bound) / (2 * bound)).contiguous()       # GridEncoder.forward's map to [0, 1] (grid.py:157)
         L = offsets.shape[0] - 1
         C = embeddings.shape[1]
         S = np.log2(per_level_scale)
@@ -50,7 +56,7 @@ class _fused_field(Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, dsigma, dalbedo):
         if ctx.meta is None:
-            return (None,) * 19
+            return (None,) * 20
         x, inputs, offsets, enc, packed = ctx.saved_tensors
         B, C, L, S, H, gridtype, align_corners, interp, blob_density, blob_radius, emb_shape = ctx.meta
         dev = x.device
@@ -65,7 +71,7 @@ class _fused_field(Function):
         grad_emb = torch.zeros(emb_shape, dtype=torch.half, device=dev)
         _gridencoder.grid_encode_backward(denc, inputs, grad_emb, offsets, grad_emb, B, 3, C, L, L, S, H, None, None, gridtype,
                                           align_corners, interp, 0)
-        return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 10
+        return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 11
 
 
 def supported(encoder, sigma_net, x, density_activation, max_level) -> bool:
@@ -75,11 +81,12 @@ def supported(encoder, sigma_net, x, density_activation, max_level) -> bool:
             and sigma_net.net[0].bias is not None)
 
 
-def fused_field(x, encoder, sigma_net, bound, blob_density, blob_radius, slabs=1, step=0.0):
+def fused_field(x, encoder, sigma_net, bound, blob_density, blob_radius, slabs=1, step=0.0, stencil_eps=0.0):
     """`slabs`, `step`: locality hints for the encoder (include/sdfx.h, sdfx_grid_encode_forward_hint): slabs = 7 when x is the
-    [7, N, 3] batch of a finite-difference stencil, step = distance between consecutive ray samples in the unit cube."""
+    [7, N, 3] batch of a finite-difference stencil, step = distance between consecutive ray samples in the unit cube.
+    `stencil_eps` > 0: x is [N, 3] and the field is evaluated on its 7-point stencil batch (outputs [7 N], [7 N, 3])."""
     n = sigma_net.net
     return _fused_field.apply(x, encoder.embeddings, encoder.offsets, n[0].weight, n[0].bias, n[1].weight, n[1].bias,
                               n[2].weight, n[2].bias, bound, encoder.per_level_scale, encoder.base_resolution,
                               encoder.gridtype_id, encoder.align_corners, encoder.interp_id, blob_density, blob_radius,
-                              int(slabs), float(step))
+                              int(slabs), float(step), float(stencil_eps))

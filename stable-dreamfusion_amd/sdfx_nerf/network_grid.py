@@ -23,6 +23,7 @@ _FUSED = int(os.environ.get("SDFX_FUSED_FIELD", "1"))
 # evaluate the sample and its six finite-difference neighbours in ONE field call (the field is point-wise, so the
 # values are those of the reference's seven separate common_forward calls, network_grid.py:81-96, 108-115)
 _BATCH_STENCIL = int(os.environ.get("SDFX_BATCH_STENCIL", "1"))
+_STENCIL_KERNEL = int(os.environ.get("SDFX_STENCIL_KERNEL", "1"))   # the [7, M, 3] stencil batch from one kernel (csrc/field.hip)
 # normal / shading / orientation glue between the field and the compositor in one HIP kernel each way
 _FUSED_SHADE = int(os.environ.get("SDFX_FUSED_SHADE", "1"))
 # ... and the compositor and the entropy / orientation sums in the same kernel (csrc/render.hip)
@@ -165,9 +166,14 @@ class NeRFNetwork(NeRFRenderer):
         """Field at the 7 stencil points -> ONE kernel for normal, shading, compositing and the two regulariser sums
         (csrc/render.hip). `shading`: a name, or a 0-dim device tensor holding 1 / 2 / 3 (lambertian / textureless / normal).
         Returns weights (detached), weights_sum, depth, image, ray_sums [N, 2] = per-ray (entropy sum, orientation sum)."""
-        neigh = (x.unsqueeze(0) + self._fd_offsets.unsqueeze(1)).clamp(-self.bound, self.bound)
-        pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
-        sigma_all, albedo_all = self.common_forward(pts, slabs=7, ray_ordered=True)
+        if _FUSED and _STENCIL_KERNEL and _ff.supported(self.encoder, self.sigma_net, x, self.opt.density_activation, self.max_level):
+            step = (3.0 ** 0.5) / (self.opt.max_steps * self.bound)
+            sigma_all, albedo_all = _ff.fused_field(x.reshape(-1, 3), self.encoder, self.sigma_net, self.bound, self.opt.blob_density,
+                                                    self.opt.blob_radius, 7, step, stencil_eps=1e-2)
+        else:
+            neigh = (x.unsqueeze(0) + self._fd_offsets.unsqueeze(1)).clamp(-self.bound, self.bound)
+            pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
+            sigma_all, albedo_all = self.common_forward(pts, slabs=7, ray_ordered=True)
         return _fs.fused_render(sigma_all, albedo_all[:x.shape[0]], dirs, ts, rays, rays_o, light_offset, ratio, shading, total, T_thresh)
 
     def infer_fused_available(self, shading, light_d=None):

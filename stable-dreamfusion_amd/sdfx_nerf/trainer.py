@@ -22,8 +22,10 @@ Three ways of driving the same arithmetic (`mode`, default from SDFX_TRAIN_MODE,
 """
 from __future__ import annotations
 
+import collections
 import os
 import random
+import time
 import warnings
 
 import torch
@@ -37,6 +39,8 @@ from .optim import Adan, DeviceAdan
 
 _FUSED_ENTROPY = int(os.environ.get("SDFX_FUSED_ENTROPY", "1"))
 # background network + background mix + [1, C, H, W] layout + the three regulariser terms in one kernel each way (csrc/head.hip)
+_COUNT_WAIT = os.environ.get("SDFX_COUNT_WAIT", "event")   # how the host waits for the sample total: event | query | poll
+_FUSED_STAGE = int(os.environ.get("SDFX_FUSED_STAGE", "1"))
 _FUSED_HEAD = int(os.environ.get("SDFX_FUSED_HEAD", "1"))
 _PREFETCH = int(os.environ.get("SDFX_PREFETCH", "1"))      # counting pass of the next iteration on a second stream
 _STEP_SYNC = int(os.environ.get("SDFX_STEP_SYNC", "0"))    # debugging aid: device-wide synchronisation after every step
@@ -86,6 +90,7 @@ class TrainStep:
             self.side_stream = torch.cuda.Stream(device=device)
             self.staging_free, self.count_done = torch.cuda.Event(), torch.cuda.Event()
             self.count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.count_np = self.count_host.numpy()      # the same pinned word, for the host's spin in _count
         self.n_valid = torch.ones((), dtype=torch.float32, device=device)
         self._num_samples = 0
         self.hw = (opt.h, opt.w)
@@ -99,6 +104,8 @@ class TrainStep:
         self.lr_changes = 0
         self.graph_uses = {}
         self.stats = {"replays": 0, "captures": 0, "eager": 0, "prefetched": 0}
+        self.debug_events = None
+        self.host_s = collections.defaultdict(float)   # host seconds spent waiting for the count / submitting the two graphs
 
     # ------------------------------------------------------------------------------ schedule (host)
     def _schedule(self, azimuth):
@@ -154,7 +161,10 @@ class TrainStep:
         return bool(ng._BG_FP32 and net is not None and net.num_layers == 2 and net.dim_in == 39 and net.dim_hidden == 32
                     and net.dim_out == 3 and net.net[0].bias is not None)
 
-    def train_step(self, marched, shading, as_latent, bg_kind):
+    def train_step(self, marched, shading, as_latent, bg_kind, split=False):
+        """nerf/utils.py:448-582. `split`: return the loss as its separately differentiable terms (a tuple of 0-dim tensors) when
+        the fused head is in use, so that the caller can seed their backward with the loss scale directly instead of building
+        `(a + b) * scale` on the device (add, mul, ones_like, two more muls: five launches on scalars)."""
         opt, sc = self.opt, self.sc
         B = 1
         H, W = self.hw
@@ -175,7 +185,7 @@ class TrainStep:
                                             max(opt.lambda_opacity, 0.0), max(opt.lambda_orient, 0.0), 4 if as_latent else 3, H, W)
             loss = self.guidance.train_step(self.text_z(), pred_rgb, as_latent=as_latent, guidance_scale=opt.guidance_scale,
                                             grad_scale=opt.lambda_guidance)
-            return loss + loss_reg
+            return (loss, loss_reg) if split else loss + loss_reg
         if as_latent:
             pred_rgb = torch.cat([outputs["image"], outputs["weights_sum"].unsqueeze(-1)], dim=-1).reshape(B, H, W, 4)
         else:
@@ -212,6 +222,10 @@ class TrainStep:
     #   _stage_train   everything else (field, compositing, loss, backward, optimiser); reads only the iteration's buffers
     def _stage_march(self, capacity):
         st = self.march_state
+        if _FUSED_STAGE and capacity > 0 and st.get("scratch") is not None and hasattr(raymarching, "march_rays_train_stage_write"):
+            # the five copies, the three zero fills and the writing pass as one launch (csrc/raymarching.hip k_march_stage_write)
+            return raymarching.march_rays_train_stage_write(st, capacity, self.rays_o, self.rays_d, self.cur_rays, self.cur_total,
+                                                            self.n_valid)[:3]
         self.cur_rays.copy_(st["rays"])
         self.cur_total.copy_(st["counter"])
         self.n_valid.copy_(st["counter"][0])                     # int32 -> float32, on the device
@@ -225,10 +239,20 @@ class TrainStep:
         xyzs, dirs, ts = marched
         self.optimizer.zero_grad()
         with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
-            loss = self.train_step((xyzs, dirs, ts, self.cur_rays, self.n_valid, self.cur_total), shading, as_latent, bg_kind)
-        (loss * self.optimizer.scale).backward()
+            loss = self.train_step((xyzs, dirs, ts, self.cur_rays, self.n_valid, self.cur_total), shading, as_latent, bg_kind,
+                                   split=True)
+        if isinstance(loss, tuple):
+            scale = self.optimizer.scale         # 0-dim view of the optimiser's control block, read at execution time
+            torch.autograd.backward(list(loss), [scale.to(t.dtype) if t.dtype != scale.dtype else scale for t in loss])
+            with torch.no_grad():
+                total = loss[0].float()
+                for t in loss[1:]:
+                    total = total + t.float()
+        else:
+            (loss * self.optimizer.scale).backward()
+            total = loss.detach()
         self.optimizer.step()
-        return loss.detach()
+        return total
 
     def _body(self, capacity, *kinds):
         """Everything after the sample total is known, eagerly; no host reads."""
@@ -251,8 +275,18 @@ class TrainStep:
         self.march_state = raymarching.march_rays_train_count(self.in_rays_o, self.in_rays_d, m.bound, m.density_bitfield,
                                                               m.cascade, m.grid_size, nears, fars, True, self.opt.dt_gamma,
                                                               self.opt.max_steps, state=self.march_state)
+        if _COUNT_WAIT == "poll":
+            self.count_np[0] = -1     # (the previous total has been read: _count is the only reader and runs before any launch)
         self.count_host.copy_(self.march_state["counter"], non_blocking=True)
         self.count_done.record()
+        self._mark("count_done")
+
+    def _mark(self, name):
+        """tools/step_timeline.py: a timing event on the current stream (debug_events is None in normal operation)."""
+        if self.debug_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.debug_events.append((name, ev))
 
     def _count(self, rays_o, rays_d):
         """The sample total of this iteration: already on its way if the previous step() prefetched it, else counted now.
@@ -265,7 +299,18 @@ class TrainStep:
             if pending is not None:
                 self.count_done.synchronize()                            # a stale prefetch still owns the staging buffers
             self._launch_count(rays_o, rays_d)
-        self.count_done.synchronize()
+        if _COUNT_WAIT == "poll":
+            # spin on the pinned word the device-to-host copy overwrites (a total is >= 0)
+            np_word, t_end = self.count_np, time.perf_counter() + 30.0
+            while np_word[0] < 0:
+                if time.perf_counter() > t_end:
+                    raise RuntimeError("the counting pass did not deliver its total within 30 s")
+            return int(np_word[0])
+        if _COUNT_WAIT == "query":
+            while not self.count_done.query():
+                pass
+        else:
+            self.count_done.synchronize()
         return int(self.count_host[0])
 
     def _prefetch(self, rays_o, rays_d):
@@ -345,7 +390,12 @@ class TrainStep:
         if self.mode == "reference":
             return self._step_reference(rays_o, rays_d, kinds)
 
+        t0 = time.perf_counter()
         M = self._count(rays_o, rays_d)
+        self.host_s["count_wait"] += time.perf_counter() - t0
+        self.host_s["steps"] += 1
+        # the next iteration refreshes the occupancy grid first if its index is a multiple of the interval: no prefetch then
+        prefetch_ok = bool(next_rays is not None and self.global_step % opt.update_extra_interval != 0 and _PREFETCH)
         if kinds[0] in _SHADE_MODES and getattr(self.model, "fused_render_available", lambda s: False)(kinds[0]):
             kinds = ("fd",) + kinds[1:]      # one graph for the three finite-difference shadings (mode read on the device)
         if self.mode == "device":
@@ -381,16 +431,29 @@ class TrainStep:
                 if self.mode == "graph":
                     g1, g2, loss = self.graphs[key][:3]
                     self.last_key = key
+                    t1 = time.perf_counter()
                     g1.replay()
                     self.staging_free.record()
+                    self._mark("march_done")
+                    # The counting pass of the NEXT iteration goes to the side stream before the training graph is submitted:
+                    # submitting ~65 kernel nodes takes the host about as long as the GPU needs to run them, and the next
+                    # graph cannot be chosen before that count has come back — enqueued after g2.replay() it serialised
+                    # (host submit) -> (count pass) -> (host read) and left the GPU idle for ~1.4 ms of a 3.7 ms iteration.
+                    if prefetch_ok:
+                        self._prefetch(*next_rays)
+                        prefetch_ok = False
+                    t2 = time.perf_counter()
                     g2.replay()
+                    self._mark("train_done")
+                    t3 = time.perf_counter()
+                    self.host_s["march_graph+prefetch"] += t2 - t1
+                    self.host_s["train_graph"] += t3 - t2
                     self.graph_uses[key] += 1
                     self.stats["replays"] += 1
                 else:
                     loss = self._body(M, *kinds)
                     self.stats["eager"] += 1
-        # the next iteration refreshes the occupancy grid first if its index is a multiple of the interval: no prefetch then
-        if next_rays is not None and self.global_step % opt.update_extra_interval != 0 and _PREFETCH:
+        if prefetch_ok:
             self._prefetch(*next_rays)
         if _STEP_SYNC:
             torch.cuda.synchronize()

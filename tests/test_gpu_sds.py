@@ -46,7 +46,7 @@ def test_sds_step_matches_the_tensor_expressions(dev, as_latent, hw):
         assert (ga - gb).abs().max().item() <= 4e-7 * scale
     else:
         # the gradient passes through the VAE stand-in's float16 convolution (RGB) or the bilinear resampling (48 -> 64)
-        assert (ga - gb).abs().max().item() <= 4e-3 * scale
+        assert (ga - gb).abs().max().item() <= 1e-2 * scale and (ga - gb).abs().mean().item() <= 1e-3 * scale
 
 
 def test_sds_nan_and_inf_predictions_follow_nan_to_num(dev):

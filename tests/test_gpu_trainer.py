@@ -110,6 +110,32 @@ def test_padded_capacity_equals_exact_capacity(dev):
     assert (w0 - w1).abs().max().item() <= 1e-3 * w0.abs().max().item() + 1e-12
 
 
+def test_staged_write_equals_copies_fills_and_write(dev):
+    """k_march_stage_write (one launch) against the five copies + three zero fills + writing pass it replaces: bit-identical
+    sample buffers (padding rows included) and iteration-side copies of the rays."""
+    rm = __import__("raymarching")
+    step, model = _make(dev, "device")
+    ro, rd = _rays(dev, 1)
+    step.model.train()
+    with torch.autocast("cuda", dtype=torch.float16):
+        model.update_extra_state()
+    step._schedule(30.0)
+    M = step._count(ro, rd)
+    st = step.march_state
+    assert M > 1000 and st["scratch"] is not None
+    for cap in (M, M + 5000):
+        want = rm.march_rays_train_write(st, cap)
+        N = st["rays"].shape[0]
+        f = dict(dtype=torch.float32, device=dev)
+        o_ro, o_rd = torch.full((N, 3), -7.0, **f), torch.full((N, 3), -7.0, **f)
+        o_rays, o_tot, o_nv = torch.full((N, 2), -7, dtype=torch.int32, device=dev), torch.full((1,), -7, dtype=torch.int32, device=dev), torch.full((), -7.0, **f)
+        got = rm.march_rays_train_stage_write(st, cap, o_ro, o_rd, o_rays, o_tot, o_nv)
+        for a, b in zip(got[:3], want[:3]):
+            assert a.shape == b.shape and torch.equal(a, b)
+        assert torch.equal(o_ro, st["rays_o"]) and torch.equal(o_rd, st["rays_d"]) and torch.equal(o_rays, st["rays"])
+        assert int(o_tot[0]) == M and float(o_nv) == float(M)
+
+
 @pytest.mark.parametrize("mode", ["reference", "device", "graph"])
 def test_train_modes_run_and_update(dev, mode):
     step, model = _make(dev, mode)

@@ -27,6 +27,11 @@ for r in rows[a:b]:
     print("%9.1f us  +%6.1f gap  %7.1f us  q%s  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), name(r)[:110]))
     prev_end = max(prev_end, e)
 print("launches %d  span %.1f us  busy %.1f us" % (b - a, (int(rows[b - 1]["End_Timestamp"]) - t0) / 1e3, busy / 1e3))
+ends = [int(rows[i]["End_Timestamp"]) for i in idx]
+periods = [(ends[k + 1] - ends[k]) / 1e3 for k in range(len(ends) - 12, len(ends) - 1)]
+idle = [(int(rows[idx[k] + 1]["Start_Timestamp"]) - ends[k]) / 1e3 for k in range(len(ends) - 12, len(ends) - 1)]
+print("iteration period (optimiser update to optimiser update), last 11: median %.1f us; idle before the first kernel of an iteration: median %.1f us"
+      % (sorted(periods)[len(periods) // 2], sorted(idle)[len(idle) // 2]))
 PY
-tail -3 $OUT/iteration_trace.txt
+tail -4 $OUT/iteration_trace.txt
 find $OUT/prof -type f -size +1M -delete 2>/dev/null
