@@ -492,7 +492,7 @@ class GpuJob:
     def build(self, mode=None):
         from sdfx_nerf.trainer import TrainStep
         self.step_obj = TrainStep(self.opt, self.model, self.prior, self.dev, seed=self.seed, mode=mode)
-        self.step_obj.graph_prime_span = 1.25   # several (phase, background) kinds: prime fewer neighbours per miss
+        self.step_obj.graph_prime_span = 1.5    # every ladder step within this factor of a missed capacity is captured with it
         if self.args.grid == "trained-proxy":    # start from a trained-scene-like occupancy instead of the empty grid
             import synth
             dens = np.unpackbits(synth.s_grid_blobs(), bitorder="little").astype(np.float32) * 20.0

@@ -300,8 +300,9 @@ void sdfx_field_set_impl(int impl);
 uint64_t sdfx_field_backward_scratch_bytes(uint32_t B);
 /* Extension — the 7-point finite-difference stencil batch of network_grid.py:81-96 from the M sample positions: points [7, M, 3]
  * = (x, x + eps e_x, x - eps e_x, ... e_z), the six offset points clamped to [-bound, bound] (network_grid.py:84-89), and
- * unit [7, M, 3] = (points + bound) / two_bound, the encoder's input (gridencoder/grid.py:157). two_bound = float32(2 * bound). */
-int sdfx_field_stencil_points(const float* xyzs, uint32_t M, float epsilon, float bound, float two_bound, float* points, float* unit,
+ * unit [7, M, 3] = (points + bound) * float32(1 / two_bound), the encoder's input (gridencoder/grid.py:157) as PyTorch evaluates
+ * tensor / scalar; two_bound = 2 * bound in double precision. */
+int sdfx_field_stencil_points(const float* xyzs, uint32_t M, float epsilon, float bound, double two_bound, float* points, float* unit,
                               sdfx_stream_t stream);
 int sdfx_field_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                     uint32_t* packed, sdfx_stream_t stream);
@@ -391,7 +392,9 @@ int sdfx_head_backward(const float* image_raw, const float* weights_sum, const f
  * float16 when is_half: the VAE's output); model_input [2B, per_item] float16 = [noisy, noisy] with
  * noisy = sqrt(abar[t]) latents + sqrt(1 - abar[t]) noise (sd_utils.py:104-106), tt [2B] = [t, t] (sd_utils.py:107).
  * noise has the dtype of the latents (torch.randn_like), t is int64 [B], alphas_cumprod float32 [1000].
- * sdfx_sds_loss: noise_pred float16 [2B, per_item] = (unconditional, text) halves; classifier-free guidance, w(t) = 1 - abar[t],
+ * sdfx_sds_loss: noise_pred float16 [2B, pred_per_item] = (unconditional, text) halves, the noise in the first per_item
+ * elements of every item (pred_per_item = per_item for Stable Diffusion, 2 per_item for DeepFloyd IF's learned-variance UNet,
+ * guidance/if_utils.py:90-93); classifier-free guidance, w(t) = 1 - abar[t],
  * grad = nan_to_num(grad_scale w (eps - noise)), loss[0] = 0.5 sum (latents - (latents - grad))^2 / B (sd_utils.py:111-159) and
  * grad_latents (float32) = out_scale * dloss/dlatents (out_scale = 2 folds the latent phase's x * 2 - 1).
  * sdfx_sds_text_mix: out [2, n] float16 = (uncond, w_front front + w_side side + w_back back), the interpolated text
@@ -402,7 +405,7 @@ int sdfx_sds_add_noise(const void* x, int is_half, int affine, const void* noise
                        uint32_t B, uint32_t per_item, float* latents_out, void* model_input, int64_t* tt, sdfx_stream_t stream);
 int sdfx_sds_loss(const void* noise_pred, const void* noise, const void* latents, int is_half, const int64_t* t,
                   const float* alphas_cumprod, float guidance_scale, float grad_scale, float out_scale, uint32_t B, uint32_t per_item,
-                  float* loss, float* grad_latents, sdfx_stream_t stream);
+                  uint32_t pred_per_item, float* loss, float* grad_latents, sdfx_stream_t stream);
 /* Bilinear resampling [planes, H, W] -> [planes, OH, OW] with PyTorch's align_corners=False arithmetic (sd_utils.py:93), optionally
  * followed by encode_imgs' 2 x - 1 (sd_utils.py:285; affine) and the cast to float16 (out_half); the backward is the exact
  * adjoint as a gather (no atomics: deterministic), grad_out float16 (grad_half) or float32, times 2 when affine. */

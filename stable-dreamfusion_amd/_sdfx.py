@@ -56,7 +56,7 @@ _SIGNATURES = {
     "sdfx_field_packed_words": [],
     "sdfx_field_set_impl": [_int],
     "sdfx_field_backward_scratch_bytes": [_u32],
-    "sdfx_field_stencil_points": [_ptr, _u32, _f32, _f32, _f32, _ptr, _ptr, _ptr],
+    "sdfx_field_stencil_points": [_ptr, _u32, _f32, _f32, C.c_double, _ptr, _ptr, _ptr],
     "sdfx_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_field_forward": [_ptr, _int, _ptr, _ptr, _u32, _f32, _f32, _ptr, _ptr, _ptr],
     "sdfx_field_backward": [_ptr, _int, _ptr, _ptr, _u32, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
@@ -68,7 +68,7 @@ _SIGNATURES = {
     "sdfx_head_forward": [_ptr] * 11 + [_f32, _f32, _u32, _u32, _ptr, _ptr, _ptr, _ptr],
     "sdfx_head_backward": [_ptr] * 11 + [_f32, _f32, _u32, _u32] + [_ptr] * 11,
     "sdfx_sds_add_noise": [_ptr, _int, _int, _ptr, _ptr, _ptr, _u32, _u32, _ptr, _ptr, _ptr, _ptr],
-    "sdfx_sds_loss": [_ptr, _ptr, _ptr, _int, _ptr, _ptr, _f32, _f32, _f32, _u32, _u32, _ptr, _ptr, _ptr],
+    "sdfx_sds_loss": [_ptr, _ptr, _ptr, _int, _ptr, _ptr, _f32, _f32, _f32, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "sdfx_sds_upsample_forward": [_ptr, _u32, _u32, _u32, _u32, _u32, _int, _int, _ptr, _ptr],
     "sdfx_sds_upsample_backward": [_ptr, _int, _u32, _u32, _u32, _u32, _u32, _int, _ptr, _ptr],
     "sdfx_sds_text_mix": [_ptr] * 7 + [_u32, _ptr, _ptr],

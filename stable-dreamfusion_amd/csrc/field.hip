@@ -368,8 +368,8 @@ struct ActsW {  // activations of this lane's sample as packed words (2 features
     float h3[kOut];
 };
 
-__device__ __forceinline__ void mma_forward(const uint32_t* __restrict__ P, int lane, ActsW& a) {
-    const uint4* F = reinterpret_cast<const uint4*>(P + kFragBase);
+// F: the packed weight fragments (P + kFragBase in global memory, or a workgroup's copy of them in LDS)
+__device__ __forceinline__ void mma_forward(const uint32_t* __restrict__ P, const uint4* F, int lane, ActsW& a) {
     const float* bias = reinterpret_cast<const float*>(P);
     {
         float e[2][32];
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_mma(const uint32_t* 
     const int lane = (int)(threadIdx.x & 63);
     ActsW a;
     load_enc_words(enc, enc_layout, B, b, valid, a.enc);
-    mma_forward(P, lane, a);
+    mma_forward(P, reinterpret_cast<const uint4*>(P + kFragBase), lane, a);
     if (!valid) return;
     const float z = a.h3[0] + density_blob(x, b, blob_density, inv_2r2);
     sigma[b] = expf(z);
@@ -448,6 +448,10 @@ __device__ __forceinline__ uint32_t masked_pack(uint32_t act, float g0, float g1
 
 // (Register allocation: 256 VGPRs + 242 AGPRs = one wave per SIMD, one workgroup per CU. Capping it at 256 registers with
 // __launch_bounds__(256, 2) — two workgroups per CU — spills 189 dwords to scratch and is SLOWER: 714 -> 989 us at B = 3 M.)
+// LDSF: the 30 KB of weight fragments are copied to LDS once per workgroup and every layer reads its A operands from there.
+// The kernel runs one wave per SIMD (see below), so nothing hides the latency of the per-tile fragment loads: six layers x an
+// L1/L2 round trip per 256-row tile when they come from global memory.
+template <bool LDSF>
 __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t* __restrict__ enc, int enc_layout,
                                                                   const float* __restrict__ x,
                                                                   const uint32_t* __restrict__ P, uint32_t B,
@@ -457,8 +461,14 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
                                                                   uint32_t* __restrict__ denc,
                                                                   float* __restrict__ partials) {
     __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * kRowHalves];
-    const uint4* F = reinterpret_cast<const uint4*>(P + kFragBase);
+    __shared__ uint4 sfrag[LDSF ? kFrags * 64 : 1];
     const uint32_t t = threadIdx.x;
+    const uint4* F = reinterpret_cast<const uint4*>(P + kFragBase);
+    if (LDSF) {
+        for (uint32_t i = t; i < kFrags * 64; i += kThreads) sfrag[i] = F[i];
+        __syncthreads();
+        F = sfrag;
+    }
     const int lane = (int)(t & 63);
     const uint32_t wave = t >> 6;
     f32x16 acc2, accx;
@@ -467,24 +477,40 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
     float gb = 0.f;
 
     const uint32_t ntiles = (B + kThreads - 1) / kThreads;
+    ActsW a;
+    if (LDSF && blockIdx.x < ntiles) load_enc_words(enc, enc_layout, B, blockIdx.x * kThreads + t, blockIdx.x * kThreads + t < B, a.enc);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t b = tile * kThreads + t;
         const bool valid = b < B;
-        ActsW a;
-        load_enc_words(enc, enc_layout, B, b, valid, a.enc);
-        mma_forward(P, lane, a);
+        // One wave per SIMD: nobody else covers a load's latency. The per-row gradients and the NEXT tile's features are
+        // requested before this tile's arithmetic starts (the smaller register footprint of the LDS variant leaves room).
+        float in_ds = 0.f, in_da[3] = {0.f, 0.f, 0.f}, in_blob = 0.f;
+        uint32_t nxt[kIn / 2];
+        if (LDSF) {
+            if (valid) {
+                in_ds = dsigma[b];
+#pragma unroll
+                for (int c = 0; c < 3; c++) in_da[c] = dalbedo[(size_t)b * 3 + c];
+                in_blob = density_blob(x, b, blob_density, inv_2r2);
+            }
+            const uint32_t bn = (tile + gridDim.x) * kThreads + t;
+            load_enc_words(enc, enc_layout, B, bn, tile + gridDim.x < ntiles && bn < B, nxt);
+        } else {
+            load_enc_words(enc, enc_layout, B, b, valid, a.enc);
+        }
+        mma_forward(P, F, lane, a);
 
         // output activations: d sigma / d z = exp(min(z, 15)) (activation.py:13-16); d sigmoid = s (1 - s)
         uint32_t dh3[8];
         {
             float g0 = 0.f, g[3] = {0.f, 0.f, 0.f};
             if (valid) {
-                const float z = a.h3[0] + density_blob(x, b, blob_density, inv_2r2);
-                g0 = dsigma[b] * expf(fminf(z, 15.0f));
+                const float z = a.h3[0] + (LDSF ? in_blob : density_blob(x, b, blob_density, inv_2r2));
+                g0 = (LDSF ? in_ds : dsigma[b]) * expf(fminf(z, 15.0f));
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const float sg = sigmoidf_(a.h3[1 + c]);
-                    g[c] = dalbedo[(size_t)b * 3 + c] * sg * (1.0f - sg);
+                    g[c] = (LDSF ? in_da[c] : dalbedo[(size_t)b * 3 + c]) * sg * (1.0f - sg);
                 }
             }
             dh3[0] = as_u32(pack(g0, g[0]));
@@ -552,6 +578,10 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
                 }
             }
         }
+        if (LDSF) {
+#pragma unroll
+            for (uint32_t i = 0; i < kIn / 2; i++) a.enc[i] = nxt[i];
+        }
     }
 
     float* out = partials + (size_t)blockIdx.x * kGradWords;
@@ -608,11 +638,10 @@ uint32_t backward_blocks(uint32_t B) {
 // axis clamped to the box, in world coordinates (`points`, for the density blob) and mapped to the encoder's unit cube
 // (`unit` = (p + bound) / (2 bound), gridencoder/grid.py:157; PyTorch divides a tensor by a scalar as a multiplication with
 // the float32 reciprocal). One launch instead of add, clamp, cat, add, mul over the 7 M-point batch.
-__global__ __launch_bounds__(256) void k_stencil_points(const float* __restrict__ xyzs, uint32_t M, float eps, float bound, float two_bound,
+__global__ __launch_bounds__(256) void k_stencil_points(const float* __restrict__ xyzs, uint32_t M, float eps, float bound, float inv,
                                                          float* __restrict__ points, float* __restrict__ unit) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
-    const float inv = 1.0f / two_bound;
     const float x[3] = {xyzs[(size_t)i * 3], xyzs[(size_t)i * 3 + 1], xyzs[(size_t)i * 3 + 2]};
 #pragma unroll
     for (uint32_t k = 0; k < 7; k++) {
@@ -643,12 +672,15 @@ void sdfx_field_set_impl(int impl) { g_field_impl = impl; }
 
 uint64_t sdfx_field_backward_scratch_bytes(uint32_t B) { return (uint64_t)backward_blocks(B ? B : 1) * kGradWords * sizeof(float); }
 
-int sdfx_field_stencil_points(const float* xyzs, uint32_t M, float epsilon, float bound, float two_bound, float* points, float* unit,
+int sdfx_field_stencil_points(const float* xyzs, uint32_t M, float epsilon, float bound, double two_bound, float* points, float* unit,
                               sdfx_stream_t stream) {
     SDFX_REQUIRE(xyzs && points && unit, "field_stencil_points: null pointer");
     SDFX_REQUIRE(bound > 0 && two_bound > 0, "field_stencil_points: bound must be positive");
     if (M == 0) return SDFX_OK;
-    hipLaunchKernelGGL(k_stencil_points, dim3(div_up(M, 256)), dim3(256), 0, as_stream(stream), xyzs, M, epsilon, bound, two_bound, points, unit);
+    // PyTorch divides a tensor by a Python scalar as a multiplication with the reciprocal formed in DOUBLE precision from the
+    // double scalar and then rounded to float32 (measured: float(1 / 3.4) = 0.29411766, not 1.0f / 3.4f = 0.29411763)
+    const float inv = (float)(1.0 / two_bound);
+    hipLaunchKernelGGL(k_stencil_points, dim3(div_up(M, 256)), dim3(256), 0, as_stream(stream), xyzs, M, epsilon, bound, inv, points, unit);
     return check_launch("field_stencil_points");
 }
 
@@ -695,9 +727,15 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
                                enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
                                static_cast<uint32_t*>(denc), scratch);
         } else {
-            hipLaunchKernelGGL(k_field_backward_mma, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
-                               enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
-                               static_cast<uint32_t*>(denc), scratch);
+            static const bool lds_frags = [] { const char* e = getenv("SDFX_FIELD_BWD_LDSFRAG"); return !(e && e[0] == '0'); }();
+            if (lds_frags)
+                hipLaunchKernelGGL(k_field_backward_mma<true>, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
+                                   enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
+                                   static_cast<uint32_t*>(denc), scratch);
+            else
+                hipLaunchKernelGGL(k_field_backward_mma<false>, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
+                                   enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
+                                   static_cast<uint32_t*>(denc), scratch);
         }
     }
     hipLaunchKernelGGL(k_field_wgrad_reduce, dim3(div_up(kGradWords, 64)), dim3(64), 0, st, scratch, nblocks, dw1, db1,

@@ -74,14 +74,17 @@ template <bool HALF>
 __global__ __launch_bounds__(kLossThreads) void k_sds_loss(const __half* __restrict__ eps2, const void* __restrict__ noise,
                                                            const void* __restrict__ latents, const int64_t* __restrict__ t,
                                                            const float* __restrict__ alphas, float guidance_scale, float grad_scale,
-                                                           float out_scale, uint32_t B, uint32_t per, float* __restrict__ loss,
-                                                           float* __restrict__ grad_latents) {
+                                                           float out_scale, uint32_t B, uint32_t per, uint32_t pred_per,
+                                                           float* __restrict__ loss, float* __restrict__ grad_latents) {
     __shared__ double part[kLossThreads / kWave];
     const uint32_t n = B * per;
     double acc = 0.0;
     for (uint32_t i = threadIdx.x; i < n; i += kLossThreads) {
         const uint32_t b = i / per;
-        const float u = h2f(eps2[i]), p = h2f(eps2[(size_t)n + i]);
+        // pred_per >= per elements per item in the prediction: a pixel-space UNet with learned variance returns 2 C channels
+        // of which the first C are the noise (if_utils.py:92-93 split)
+        const size_t j = (size_t)b * pred_per + (i - b * per);
+        const float u = h2f(eps2[j]), p = h2f(eps2[(size_t)B * pred_per + j]);
         const float eps = rh(u + rh(guidance_scale * rh(p - u)));            // three float16 tensor ops
         const float gw = grad_scale * (1.0f - alphas[t[b]]);                   // grad_scale * w[:, None, None, None]
         const float l = load_lat<HALF>(latents, i);
@@ -236,15 +239,17 @@ int sdfx_sds_add_noise(const void* x, int is_half, int affine, const void* noise
 
 int sdfx_sds_loss(const void* noise_pred, const void* noise, const void* latents, int is_half, const int64_t* t,
                   const float* alphas_cumprod, float guidance_scale, float grad_scale, float out_scale, uint32_t B, uint32_t per_item,
-                  float* loss, float* grad_latents, sdfx_stream_t stream) {
+                  uint32_t pred_per_item, float* loss, float* grad_latents, sdfx_stream_t stream) {
     SDFX_REQUIRE(noise_pred && noise && latents && t && alphas_cumprod && loss && grad_latents, "sds_loss: null pointer");
     SDFX_REQUIRE(B > 0 && per_item > 0 && (uint64_t)B * per_item < (1ull << 31), "sds_loss: bad sizes B=%u per_item=%u", B, per_item);
+    SDFX_REQUIRE(pred_per_item >= per_item && (uint64_t)2 * B * pred_per_item < (1ull << 31),
+                 "sds_loss: pred_per_item=%u must be at least per_item=%u", pred_per_item, per_item);
     if (is_half)
         hipLaunchKernelGGL(k_sds_loss<true>, dim3(1), dim3(kLossThreads), 0, as_stream(stream), static_cast<const __half*>(noise_pred),
-                           noise, latents, t, alphas_cumprod, guidance_scale, grad_scale, out_scale, B, per_item, loss, grad_latents);
+                           noise, latents, t, alphas_cumprod, guidance_scale, grad_scale, out_scale, B, per_item, pred_per_item, loss, grad_latents);
     else
         hipLaunchKernelGGL(k_sds_loss<false>, dim3(1), dim3(kLossThreads), 0, as_stream(stream), static_cast<const __half*>(noise_pred),
-                           noise, latents, t, alphas_cumprod, guidance_scale, grad_scale, out_scale, B, per_item, loss, grad_latents);
+                           noise, latents, t, alphas_cumprod, guidance_scale, grad_scale, out_scale, B, per_item, pred_per_item, loss, grad_latents);
     return check_launch("sds_loss");
 }
 

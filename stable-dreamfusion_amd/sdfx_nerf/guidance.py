@@ -209,12 +209,15 @@ class _FusedSDS(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):     # see train_step: the frozen network runs outside the trainer's autocast
             noise_pred = g.unet(model_input, tt, encoder_hidden_states=text_embeddings.to(torch.float16))
         noise_pred = S.check_tensor(noise_pred.contiguous(), "noise_pred", torch.float16)
-        if tuple(noise_pred.shape) != tuple(model_input.shape):
+        C = x.shape[1]
+        # (a learned-variance UNet returns 2 C channels, the noise first: if_utils.py:90-93)
+        if noise_pred.shape[0] != 2 * B or noise_pred.shape[1] not in (C, 2 * C) or noise_pred.shape[2:] != x.shape[2:]:
             raise ValueError(f"noise predictor returned {tuple(noise_pred.shape)} for an input of {tuple(model_input.shape)}")
+        pred_per = noise_pred[0].numel()
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         S.call("sdfx_sds_loss", S.ptr(noise_pred), S.ptr(noise), S.ptr(latents), int(half), S.ptr(t), S.ptr(alphas), guidance_scale,
-               grad_scale, 2.0 if affine else 1.0, B, per, S.ptr(loss), S.ptr(dx), S.stream())
+               grad_scale, 2.0 if affine else 1.0, B, per, pred_per, S.ptr(loss), S.ptr(dx), S.stream())
         ctx.save_for_backward(dx)
         ctx.half = bool(half)
         return loss
@@ -240,6 +243,91 @@ def text_mix(uncond, front, side, back, w_front, w_side, w_back):
 
 def fused_text_mix_available(e):
     return bool(_FUSED_SDS and e.is_cuda and e.dtype == torch.float16 and e.shape[0] == 1)
+
+
+def ddpm_cosine_alphas_cumprod(num_train_timesteps=1000, max_beta=0.999):
+    """alphas_cumprod of a DDPM scheduler with the "squaredcos_cap_v2" betas (Nichol & Dhariwal; diffusers'
+    betas_for_alpha_bar): beta_i = min(1 - abar((i + 1) / T) / abar(i / T), max_beta), abar(u) = cos((u + 0.008) / 1.008 pi / 2)^2.
+    DeepFloyd IF-I's scheduler config is not in the image; this is the schedule its model card names."""
+    import math
+    bar = lambda u: math.cos((u + 0.008) / 1.008 * math.pi / 2) ** 2
+    betas = torch.tensor([min(1 - bar((i + 1) / num_train_timesteps) / bar(i / num_train_timesteps), max_beta)
+                          for i in range(num_train_timesteps)], dtype=torch.float32)
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+class SyntheticPixelUNet(nn.Module):
+    """Stand-in for a pixel-space noise predictor with learned variance (DeepFloyd IF-I: 3 + 3 output channels): the consistent
+    denoiser of SyntheticUNet towards a fixed RGB image in the first three channels, a constant in the variance channels."""
+
+    def __init__(self, alphas):
+        super().__init__()
+        yy, xx = torch.meshgrid(torch.linspace(-1, 1, 64), torch.linspace(-1, 1, 64), indexing="ij")
+        blob = torch.exp(-(xx ** 2 + yy ** 2) / (2 * 0.35 ** 2))
+        target = torch.stack([blob * (0.5 + 0.5 * xx), blob * (0.5 - 0.5 * yy), blob * 0.6], dim=0) * 2 - 1
+        self.register_buffer("target", target[None])
+        a, b = alphas.sqrt(), (1 - alphas).sqrt()
+        self.register_buffer("coef", torch.stack([1 / b, -a / b], dim=1))
+
+    def forward(self, x, t, encoder_hidden_states):
+        c = self.coef[t].to(x.dtype)
+        shift = torch.tanh(encoder_hidden_states[:, 0, :3].to(x.dtype))[:, :, None, None]
+        tgt = torch.add(self.target.to(x.dtype), shift, alpha=1e-3)
+        eps = torch.addcmul(x * c[:, 0, None, None, None], tgt, c[:, 1, None, None, None])
+        return torch.cat([eps, torch.full_like(eps, 0.25)], dim=1)
+
+
+class IFGuidance(nn.Module):
+    """The pixel-space score-distillation step of guidance/if_utils.py:73-110 (`--IF`, BASELINE configs[3]): bilinear 64 x 64,
+    `* 2 - 1`, add_noise, classifier-free guidance on the first three of the UNet's six output channels, w(t) = 1 - abar_t,
+    nan_to_num, the 0.5 mse surrogate. Same kernels as the latent branch of SDSGuidance (csrc/sds.hip) with C = 3 and a
+    6-channel prediction. The frozen network (DeepFloyd IF-I-XL UNet + T5 text encoder) is third-party and absent: a stand-in
+    is plugged in; the wrapper arithmetic is pinned by tests/golden/if_ref.npz from the reference's own train_step."""
+
+    def __init__(self, unet, device, fp16=True, t_range=(0.02, 0.98), alphas=None, ctx_dim=4096, ctx_len=77):
+        super().__init__()
+        self.device = device
+        self.precision_t = torch.float16 if fp16 else torch.float32
+        self.unet = unet.to(device=device, dtype=self.precision_t).eval().requires_grad_(False)
+        self.num_train_timesteps = 1000
+        self.min_step = int(self.num_train_timesteps * t_range[0])
+        self.max_step = int(self.num_train_timesteps * t_range[1])
+        self.alphas = (ddpm_cosine_alphas_cumprod() if alphas is None else alphas).to(device)
+        self.ctx_dim, self.ctx_len = ctx_dim, ctx_len
+
+    get_text_embeds = SDSGuidance.get_text_embeds
+    add_noise = SDSGuidance.add_noise
+    _fused_ok = SDSGuidance._fused_ok
+
+    def train_step(self, text_embeddings, pred_rgb, guidance_scale=100, grad_scale=1, as_latent=False):
+        if self._fused_ok(pred_rgb) and pred_rgb.dtype == torch.float32:
+            x = pred_rgb if tuple(pred_rgb.shape[-2:]) == (64, 64) else F.interpolate(pred_rgb, (64, 64), mode="bilinear",
+                                                                                      align_corners=False)
+            return _FusedSDS.apply(x.contiguous(), self, text_embeddings, float(guidance_scale), float(grad_scale), True)
+        images = F.interpolate(pred_rgb, (64, 64), mode="bilinear", align_corners=False) * 2 - 1
+        t = torch.randint(self.min_step, self.max_step + 1, (images.shape[0],), dtype=torch.long, device=self.device)
+        with torch.no_grad():
+            noise = torch.randn_like(images)
+            images_noisy = self.add_noise(images, noise, t)
+            model_input = torch.cat([images_noisy] * 2)          # DDPMScheduler.scale_model_input is the identity
+            tt = torch.cat([t] * 2)
+            with torch.autocast(images.device.type if images.device.type in ("cuda", "cpu") else "cuda", enabled=False):
+                noise_pred = self.unet(model_input.to(self.precision_t), tt,
+                                       encoder_hidden_states=text_embeddings.to(self.precision_t))
+            noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
+            noise_pred_uncond, _ = noise_pred_uncond.split(model_input.shape[1], dim=1)
+            noise_pred_text, _ = noise_pred_text.split(model_input.shape[1], dim=1)
+            noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
+        w = 1 - self.alphas[t]
+        grad = grad_scale * w[:, None, None, None] * (noise_pred - noise)
+        grad = torch.nan_to_num(grad)
+        targets = (images - grad).detach()
+        return 0.5 * F.mse_loss(images.float(), targets, reduction="sum") / images.shape[0]
+
+
+def synthetic_if_prior(device, fp16=True):
+    alphas = ddpm_cosine_alphas_cumprod()
+    return IFGuidance(SyntheticPixelUNet(alphas), device, fp16, alphas=alphas)
 
 
 def synthetic_prior(device, fp16=True):

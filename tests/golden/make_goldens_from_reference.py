@@ -18,6 +18,9 @@ Runs only in the build container (needs /root/reference; the GPU box does not ha
   adan_ref.npz   optimizer.py Adan (the optimiser `-O` constructs, main.py:365-368) stepped six times on prescribed
                  gradients, two parameter groups, global-norm clipping active on some steps -> pins sdfx_nerf.optim.Adan
                  (and through it csrc/optim.hip's DeviceAdan).
+  if_ref.npz     guidance/if_utils.py IF.train_step called UNBOUND on a stub around this repository's stand-in pixel UNet
+                 (6 output channels) -> pins sdfx_nerf.guidance.IFGuidance: resampling to 64 x 64, the learned-variance split,
+                 classifier-free guidance, w(t), the surrogate loss and its gradient.
   sds_ref.npz    guidance/sd_utils.py StableDiffusion.train_step called UNBOUND on a stub (diffusers / transformers are
                  not installed: the frozen networks are this repository's synthetic stand-ins, scheduler.add_noise and
                  encode_imgs are restated) -> pins the SDS arithmetic of sdfx_nerf/guidance.py: timestep and noise draws,
@@ -295,6 +298,46 @@ def make_sds():
                     f"{name}_grad": pred.grad.numpy()})
     np.savez_compressed(os.path.join(OUT, "sds_ref.npz"), **out)
     print("sds_ref.npz", {k: float(v) for k, v in out.items() if k.endswith("loss")})
+
+
+def make_if():
+    """if_ref.npz: guidance/if_utils.py IF.train_step called UNBOUND on a stub around this repository's stand-in pixel UNet."""
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return self
+        def __getattr__(self, k): return _Any()
+    stub("transformers", CLIPTextModel=_Any, CLIPTokenizer=_Any, logging=_Any())
+    stub("diffusers", AutoencoderKL=_Any, UNet2DConditionModel=_Any, PNDMScheduler=_Any, DDIMScheduler=_Any,
+         StableDiffusionPipeline=_Any, IFPipeline=_Any, DDPMScheduler=_Any)
+    stub("diffusers.utils")
+    stub("diffusers.utils.import_utils", is_xformers_available=lambda: False)
+    from guidance.if_utils import IF
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))            # repo root
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf import guidance as G
+    alphas = G.ddpm_cosine_alphas_cumprod()
+    unet = G.SyntheticPixelUNet(alphas)
+
+    def add_noise(x, noise, t):                                           # DDPMScheduler.add_noise (diffusers, absent)
+        a = alphas[t].to(x.dtype)
+        return a.sqrt()[:, None, None, None] * x + (1 - a).sqrt()[:, None, None, None] * noise
+
+    fake = types.SimpleNamespace(
+        device="cpu", min_step=20, max_step=980, alphas=alphas,
+        scheduler=types.SimpleNamespace(add_noise=add_noise, scale_model_input=lambda x, t: x),
+        unet=lambda x, t, encoder_hidden_states: types.SimpleNamespace(sample=unet(x, t, encoder_hidden_states)))
+    g = torch.Generator().manual_seed(9)
+    emb = torch.randn(2, 77, 64, generator=g)
+    out = dict(text_embeddings=emb.numpy())
+    for name, hw in (("s64", 64), ("s96", 96)):
+        pred = torch.rand(1, 3, hw, hw, generator=g).requires_grad_()
+        torch.manual_seed(78)
+        loss = IF.train_step(fake, emb, pred, guidance_scale=100, grad_scale=1)
+        loss.backward()
+        out.update({f"{name}_pred": pred.detach().numpy(), f"{name}_loss": np.float64(loss.item()), f"{name}_grad": pred.grad.numpy()})
+    np.savez_compressed(os.path.join(OUT, "if_ref.npz"), **out)
+    print("if_ref.npz", {k: float(v) for k, v in out.items() if k.endswith("loss")})
 
 
 def make_trainstep():
@@ -709,6 +752,9 @@ if __name__ == "__main__":
     if "--only-sds" in sys.argv:
         make_sds()
         sys.exit(0)
+    if "--only-if" in sys.argv:
+        make_if()
+        sys.exit(0)
     if "--only-trainstep" in sys.argv:
         make_trainstep()
         sys.exit(0)
@@ -734,6 +780,7 @@ if __name__ == "__main__":
     make_shade()
     make_adan()
     make_sds()
+    make_if()
     make_trainstep()
     make_gridmodule()
     make_network()

@@ -281,4 +281,7 @@ def test_stencil_points_kernel_is_bit_exact(dev, bound):
     unit = (pts + bound) / (2 * bound)
     got_p, got_u = torch.empty_like(pts), torch.empty_like(unit)
     F_.stencil_points(x, e, bound, got_p, got_u)
-    assert torch.equal(got_p, pts) and torch.equal(got_u, unit)
+    bad_p, bad_u = (got_p != pts), (got_u != unit)
+    assert not bool(bad_p.any()), (int(bad_p.sum()), float((got_p - pts).abs().max()))
+    assert not bool(bad_u.any()), (int(bad_u.sum()), float((got_u - unit).abs().max()), got_u[bad_u][:4].tolist(), unit[bad_u][:4].tolist(),
+                                   pts[bad_u][:4].tolist())

@@ -257,6 +257,23 @@ def test_sds_arithmetic_reproduces_the_reference_train_step(mods, phase):
     assert np.allclose(pred.grad.numpy(), g[f"{phase}_grad"], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("case", ["s64", "s96"])
+def test_if_arithmetic_reproduces_the_reference_train_step(mods, case):
+    """tests/golden/if_ref.npz: loss and d loss / d pred_rgb of the reference's own IF.train_step (guidance/if_utils.py:73-110)
+    around this repository's stand-in pixel UNet, same seed; 96 x 96 exercises the bilinear resampling to 64 x 64."""
+    import os
+    from conftest import ROOT
+    from sdfx_nerf import guidance as G
+    g = np.load(os.path.join(ROOT, "tests", "golden", "if_ref.npz"))
+    guide = G.synthetic_if_prior(torch.device("cpu"), fp16=False)
+    pred = torch.from_numpy(g[f"{case}_pred"].copy()).requires_grad_()
+    torch.manual_seed(78)
+    loss = guide.train_step(torch.from_numpy(g["text_embeddings"]), pred, guidance_scale=100, grad_scale=1)
+    loss.backward()
+    assert abs(float(loss) - float(g[f"{case}_loss"])) <= 1e-6 * abs(float(g[f"{case}_loss"]))
+    assert np.allclose(pred.grad.numpy(), g[f"{case}_grad"], rtol=1e-5, atol=1e-7)
+
+
 def test_train_step_schedule_and_loss_reproduce_the_reference_trainer(mods):
     """tests/golden/trainstep_ref.npz: the reference's own Trainer.train_step (nerf/utils.py:439-722) run on a stub
     trainer at eight (global_step, azimuth, seed) points. Same stubs behind TrainStep.train_step: the shading mode,

@@ -18,7 +18,7 @@ x = (torch.rand(B, 3, generator=g) * 2 - 1).to(dev)
 packed = torch.empty(_field.packed_words(), dtype=torch.int32, device=dev)
 _field.pack(*w, packed)
 sigma = torch.empty(B, device=dev); albedo = torch.empty(B, 3, device=dev)
-ds = torch.randn(B, device=dev) * 0.1; da = torch.randn(B, 3, device=dev) * 0.1
+ds = (torch.randn(B, generator=g) * 0.1).to(dev); da = (torch.randn(B, 3, generator=g) * 0.1).to(dev)
 denc = torch.empty_like(enc)
 grads = [torch.empty_like(t) for t in w]
 grads = [grads[0], grads[1], grads[2], grads[3], grads[4], grads[5]]
@@ -31,4 +31,6 @@ m.record()
 for i in range(n):
     _field.backward(enc, 0, x, packed, B, 5.0, 0.2, ds, da, denc, *grads)
 e.record(); torch.cuda.synchronize()
-print(f"field fwd {s.elapsed_time(m)/n*1e3:.1f} us, bwd {m.elapsed_time(e)/n*1e3:.1f} us  (B={B})")
+print(f"field fwd {s.elapsed_time(m)/n*1e3:.1f} us, bwd {m.elapsed_time(e)/n*1e3:.1f} us  (B={B})  "
+      f"checksums denc {denc.float().abs().double().sum().item():.6e} dw1 {grads[0].double().abs().sum().item():.9e} "
+      f"dw2 {grads[2].double().abs().sum().item():.9e} db3 {grads[5].double().abs().sum().item():.9e}")

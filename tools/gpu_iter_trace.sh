@@ -27,11 +27,23 @@ for r in rows[a:b]:
     print("%9.1f us  +%6.1f gap  %7.1f us  q%s  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), name(r)[:110]))
     prev_end = max(prev_end, e)
 print("launches %d  span %.1f us  busy %.1f us" % (b - a, (int(rows[b - 1]["End_Timestamp"]) - t0) / 1e3, busy / 1e3))
+occ = [i for i, r in enumerate(rows) if "k_occ_points" in r["Kernel_Name"]]
+if occ:
+    import collections
+    o = occ[-1]
+    a2 = max(i for i in idx if i < o) + 1
+    b2 = min(i for i in idx if i > o) + 1
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows[a2:b2]:
+        k = agg[name(r)[:70]]; k[0] += 1; k[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    print("iteration with an occupancy refresh: launches %d  span %.1f us; top kernels:" % (b2 - a2, (int(rows[b2 - 1]["End_Timestamp"]) - int(rows[a2]["Start_Timestamp"])) / 1e3))
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+        print("   %8.1f us  x%-3d %s" % (t, n, k))
 ends = [int(rows[i]["End_Timestamp"]) for i in idx]
 periods = [(ends[k + 1] - ends[k]) / 1e3 for k in range(len(ends) - 12, len(ends) - 1)]
 idle = [(int(rows[idx[k] + 1]["Start_Timestamp"]) - ends[k]) / 1e3 for k in range(len(ends) - 12, len(ends) - 1)]
 print("iteration period (optimiser update to optimiser update), last 11: median %.1f us; idle before the first kernel of an iteration: median %.1f us"
       % (sorted(periods)[len(periods) // 2], sorted(idle)[len(idle) // 2]))
 PY
-tail -4 $OUT/iteration_trace.txt
+tail -22 $OUT/iteration_trace.txt
 find $OUT/prof -type f -size +1M -delete 2>/dev/null
