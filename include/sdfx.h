@@ -44,6 +44,16 @@ enum {
 };
 
 const char* sdfx_last_error(void);
+
+/*
+ * Extension — padding rows of fixed-capacity sample buffers. An iteration replayed from a HIP graph marches into buffers of a
+ * fixed capacity >= the sample total (which only the device knows at replay time); rows past the total are padding. With a limit
+ * set (calling thread only; total = NULL clears it), the D = 3, C = 2 hinted encoder forward, the field forward / backward and
+ * the binned table-gradient scatter treat row r of a [k, period, ...] batch as padding when (r % period) >= total[0] (period 0:
+ * r >= total[0]): they neither read nor write such rows and skip tiles that hold nothing else. total is a DEVICE pointer read
+ * when the kernel runs. Set it around calls whose buffers share one sample axis, clear it afterwards.
+ */
+void sdfx_set_row_limit(const int32_t* total, uint32_t period);
 /* version / build info string (arch, git-less) */
 const char* sdfx_build_info(void);
 

@@ -83,6 +83,7 @@ _SIGNATURES = {
                                    _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_entropy_forward": [_ptr, _u32, _ptr, _ptr, _ptr],
     "sdfx_entropy_backward": [_ptr, _u32, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_set_row_limit": [_ptr, _u32],
     "sdfx_march_set_impl": [_int],
     "sdfx_grid_set_impl": [_int, _int],
     "sdfx_grid_forward_plan": [_ptr, _u32, _f32, _u32, _int, _u32, _u32, _f32, _ptr, _u32, _ptr],
@@ -126,6 +127,26 @@ def lib() -> C.CDLL:
             fn.restype = _RESTYPES.get(name, _int)
         _LIB = handle
     return _LIB
+
+
+class row_limit:
+    """`with row_limit(total, period): ...` — sdfx_set_row_limit around the calls inside (include/sdfx.h): rows whose index modulo
+    `period` is >= total[0] (an int32 device tensor) are padding for the hinted encoder forward, the field kernels and the binned
+    table-gradient scatter. `total` None: no-op."""
+
+    def __init__(self, total, period):
+        self.total, self.period = total, int(period)
+
+    def __enter__(self):
+        if self.total is not None:
+            check_tensor(self.total, "row limit", torch.int32)
+            lib().sdfx_set_row_limit(ptr(self.total), self.period)
+        return self
+
+    def __exit__(self, *exc):
+        if self.total is not None:
+            lib().sdfx_set_row_limit(None, 0)
+        return False
 
 
 def exported_symbols():

@@ -114,9 +114,9 @@ __global__ __launch_bounds__(kThreads) void k_field_forward(const uint32_t* __re
                                                              const float* __restrict__ x,
                                                              const uint32_t* __restrict__ P, uint32_t B,
                                                              float blob_density, float inv_2r2,
-                                                             float* __restrict__ sigma, float* __restrict__ albedo) {
+                                                             float* __restrict__ sigma, float* __restrict__ albedo, RowLimit rl) {
     const uint32_t b = blockIdx.x * kThreads + threadIdx.x;
-    if (b >= B) return;
+    if (b >= B || !row_live(rl, b)) return;
     Acts a;
     load_enc(enc, enc_layout, B, b, a.enc);
     mlp_forward(P, a);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
                                                               const float* __restrict__ dsigma,
                                                               const float* __restrict__ dalbedo,
                                                               uint32_t* __restrict__ denc,
-                                                              float* __restrict__ partials) {
+                                                              float* __restrict__ partials, RowLimit rl) {
     __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * kRowHalves];
     const uint32_t t = threadIdx.x;
     const int lane = (int)(t & 63);
@@ -195,8 +195,9 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
 
     const uint32_t ntiles = (B + kThreads - 1) / kThreads;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (rows_dead(rl, tile * kThreads, kThreads)) continue;   // a tile of padding rows (workgroup-uniform)
         const uint32_t b = tile * kThreads + t;
-        const bool valid = b < B;
+        const bool valid = b < B && row_live(rl, b);
         Acts a;
         h2 dh1[kHid / 2], dh2[kHid / 2], dh3[kOut / 2];
         if (valid) {
@@ -421,9 +422,10 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_mma(const uint32_t* 
                                                                  const float* __restrict__ x,
                                                                  const uint32_t* __restrict__ P, uint32_t B,
                                                                  float blob_density, float inv_2r2,
-                                                                 float* __restrict__ sigma, float* __restrict__ albedo) {
+                                                                 float* __restrict__ sigma, float* __restrict__ albedo, RowLimit rl) {
+    if (rows_dead(rl, blockIdx.x * kThreads, kThreads)) return;   // a tile of padding rows
     const uint32_t b = blockIdx.x * kThreads + threadIdx.x;
-    const bool valid = b < B;  // every lane takes part in the swaps and the MFMAs; out-of-range lanes compute on zeros
+    const bool valid = b < B && row_live(rl, b);  // every lane takes part in the swaps and the MFMAs; the others compute on zeros
     const int lane = (int)(threadIdx.x & 63);
     ActsW a;
     load_enc_words(enc, enc_layout, B, b, valid, a.enc);
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
                                                                   const float* __restrict__ dsigma,
                                                                   const float* __restrict__ dalbedo,
                                                                   uint32_t* __restrict__ denc,
-                                                                  float* __restrict__ partials) {
+                                                                  float* __restrict__ partials, RowLimit rl) {
     __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * kRowHalves];
     __shared__ uint4 sfrag[LDSF ? kFrags * 64 : 1];
     const uint32_t t = threadIdx.x;
@@ -478,10 +480,18 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
 
     const uint32_t ntiles = (B + kThreads - 1) / kThreads;
     ActsW a;
-    if (LDSF && blockIdx.x < ntiles) load_enc_words(enc, enc_layout, B, blockIdx.x * kThreads + t, blockIdx.x * kThreads + t < B, a.enc);
+    auto live = [&](uint32_t r) { return r < B && row_live(rl, r); };
+    if (LDSF && blockIdx.x < ntiles) load_enc_words(enc, enc_layout, B, blockIdx.x * kThreads + t, live(blockIdx.x * kThreads + t), a.enc);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t b = tile * kThreads + t;
-        const bool valid = b < B;
+        const bool valid = live(b);
+        if (rows_dead(rl, tile * kThreads, kThreads)) {   // a tile of padding rows (workgroup-uniform): only keep the prefetch chain going
+            if (LDSF) {
+                const uint32_t bn = (tile + gridDim.x) * kThreads + t;
+                load_enc_words(enc, enc_layout, B, bn, tile + gridDim.x < ntiles && live(bn), a.enc);
+            }
+            continue;
+        }
         // One wave per SIMD: nobody else covers a load's latency. The per-row gradients and the NEXT tile's features are
         // requested before this tile's arithmetic starts (the smaller register footprint of the LDS variant leaves room).
         float in_ds = 0.f, in_da[3] = {0.f, 0.f, 0.f}, in_blob = 0.f;
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
                 in_blob = density_blob(x, b, blob_density, inv_2r2);
             }
             const uint32_t bn = (tile + gridDim.x) * kThreads + t;
-            load_enc_words(enc, enc_layout, B, bn, tile + gridDim.x < ntiles && bn < B, nxt);
+            load_enc_words(enc, enc_layout, B, bn, tile + gridDim.x < ntiles && live(bn), nxt);
         } else {
             load_enc_words(enc, enc_layout, B, b, valid, a.enc);
         }
@@ -597,23 +607,31 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
     else if (t < 132) out[gB3 + (t - 128)] = gb;
 }
 
-// sum the per-workgroup partials into the six parameter gradients
-__global__ __launch_bounds__(64) void k_field_wgrad_reduce(const float* __restrict__ partials, uint32_t nblocks,
-                                                             float* __restrict__ dw1, float* __restrict__ db1,
-                                                             float* __restrict__ dw2, float* __restrict__ db2,
-                                                             float* __restrict__ dw3, float* __restrict__ db3) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= kGradWords) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent load/add chains
-    uint32_t k = 0;
-    for (; k + 4 <= nblocks; k += 4) {
-        s0 += partials[(size_t)(k + 0) * kGradWords + i];
-        s1 += partials[(size_t)(k + 1) * kGradWords + i];
-        s2 += partials[(size_t)(k + 2) * kGradWords + i];
-        s3 += partials[(size_t)(k + 3) * kGradWords + i];
+// sum the per-workgroup partials into the six parameter gradients: 64 entries per workgroup, the (up to 512) partials of an
+// entry split over 16 threads whose sums are joined in a fixed order (deterministic). One thread per entry walking all
+// partials was a chain of 128 dependent loads: 43 us for 13 MB.
+constexpr uint32_t kReduceSplit = 16;
+__global__ __launch_bounds__(64 * kReduceSplit) void k_field_wgrad_reduce(const float* __restrict__ partials, uint32_t nblocks,
+                                                                           float* __restrict__ dw1, float* __restrict__ db1,
+                                                                           float* __restrict__ dw2, float* __restrict__ db2,
+                                                                           float* __restrict__ dw3, float* __restrict__ db3) {
+    __shared__ float part[kReduceSplit][64];
+    const uint32_t e = threadIdx.x & 63, q = threadIdx.x >> 6, i = blockIdx.x * 64 + e;
+    float s0 = 0.f, s1 = 0.f;  // two independent load/add chains
+    if (i < kGradWords) {
+        uint32_t k = q;
+        for (; k + kReduceSplit < nblocks; k += 2 * kReduceSplit) {
+            s0 += partials[(size_t)k * kGradWords + i];
+            s1 += partials[(size_t)(k + kReduceSplit) * kGradWords + i];
+        }
+        if (k < nblocks) s0 += partials[(size_t)k * kGradWords + i];
     }
-    for (; k < nblocks; k++) s0 += partials[(size_t)k * kGradWords + i];
-    const float s = (s0 + s1) + (s2 + s3);
+    part[q][e] = s0 + s1;
+    __syncthreads();
+    if (q != 0 || i >= kGradWords) return;
+    float s = 0.f;
+#pragma unroll
+    for (uint32_t r = 0; r < kReduceSplit; r++) s += part[r][e];
     if (i < gB1) dw1[i - gW1] = s;
     else if (i < gW2) db1[i - gB1] = s;
     else if (i < gB2) dw2[i - gW2] = s;
@@ -701,11 +719,11 @@ int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const ui
     if (use_dot2()) {
         hipLaunchKernelGGL(k_field_forward, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
-                           1.0f / (2 * blob_radius * blob_radius), sigma, albedo);
+                           1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit());
     } else {
         hipLaunchKernelGGL(k_field_forward_mma, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
-                           1.0f / (2 * blob_radius * blob_radius), sigma, albedo);
+                           1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit());
     }
     return check_launch("field_forward");
 }
@@ -725,20 +743,20 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
         if (use_dot2()) {
             hipLaunchKernelGGL(k_field_backward, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
                                enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
-                               static_cast<uint32_t*>(denc), scratch);
+                               static_cast<uint32_t*>(denc), scratch, row_limit());
         } else {
             static const bool lds_frags = [] { const char* e = getenv("SDFX_FIELD_BWD_LDSFRAG"); return !(e && e[0] == '0'); }();
             if (lds_frags)
                 hipLaunchKernelGGL(k_field_backward_mma<true>, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
                                    enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
-                                   static_cast<uint32_t*>(denc), scratch);
+                                   static_cast<uint32_t*>(denc), scratch, row_limit());
             else
                 hipLaunchKernelGGL(k_field_backward_mma<false>, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
                                    enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
-                                   static_cast<uint32_t*>(denc), scratch);
+                                   static_cast<uint32_t*>(denc), scratch, row_limit());
         }
     }
-    hipLaunchKernelGGL(k_field_wgrad_reduce, dim3(div_up(kGradWords, 64)), dim3(64), 0, st, scratch, nblocks, dw1, db1,
+    hipLaunchKernelGGL(k_field_wgrad_reduce, dim3(div_up(kGradWords, 64)), dim3(64 * kReduceSplit), 0, st, scratch, nblocks, dw1, db1,
                        dw2, db2, dw3, db3);
     return check_launch("field_backward");
 }

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
                                                                GridPlan plan, BinPlan bin, uint32_t gridtype,
                                                                int align_corners, uint32_t interp, int grad_layout,
                                                                uint32_t* __restrict__ cursors,
-                                                               Item<HALF>* __restrict__ items) {
+                                                               Item<HALF>* __restrict__ items, RowLimit rl) {
     using T = typename Elem<HALF>::type;
     using E = Elem<HALF>;
     constexpr uint32_t D = 3, C = 2, NCORN = 8, NITEM = NCORN * kPointsPerThread;
@@ -161,6 +161,8 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
     uint32_t level, tile;
     const bool has_item = plan_item(plan, level, tile);  // wave-uniform (depends on blockIdx only)
     if (!has_item) return;
+    // a tile of padding rows (sdfx_set_row_limit) has nothing to scatter
+    if (rows_dead(rl, b0 + tile * (kBinThreads * kPointsPerThread), kBinThreads * kPointsPerThread)) return;
     const int lane = lane_id();
     const uint32_t nb = bin.bucket_first[level + 1] - bin.bucket_first[level];
     for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) hist[i] = 0;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
 #pragma unroll
     for (uint32_t k = 0; k < kPointsPerThread; k++) {
         const uint32_t b = b0 + tile * (kBinThreads * kPointsPerThread) + k * kBinThreads + threadIdx.x;
-        bool valid = b < b1;
+        bool valid = b < b1 && row_live(rl, b);
         float in[D] = {0.f, 0.f, 0.f};
         if (valid) {
 #pragma unroll
@@ -659,7 +661,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         if (is_half) {
             hipLaunchKernelGGL(k_grid_bwd_bin<true>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const __half*>(grad),
                                inputs, static_cast<__half*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
-                               interp, grad_layout, cursors, static_cast<Item<true>*>(items));
+                               interp, grad_layout, cursors, static_cast<Item<true>*>(items), row_limit());
             hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(nsplits), dim3(kReduceThreadsFixed), 0, st,
                                static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items),
                                shared_acc);
@@ -669,7 +671,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         } else {
             hipLaunchKernelGGL(k_grid_bwd_bin<false>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const float*>(grad),
                                inputs, static_cast<float*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
-                               interp, grad_layout, cursors, static_cast<Item<false>*>(items));
+                               interp, grad_layout, cursors, static_cast<Item<false>*>(items), row_limit());
             hipLaunchKernelGGL(k_grid_bwd_reduce_ticket, dim3(nsplits), dim3(kReduceThreads), kReduceLdsBytes, st,
                                static_cast<float*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<false>*>(items));
         }

@@ -71,14 +71,24 @@ template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
 __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ inputs,
                                                      const typename Elem<HALF>::type* __restrict__ table,
                                                      typename Elem<HALF>::type* __restrict__ outputs, uint32_t B, uint32_t L,
-                                                     FwdPlan plan, int out_layout) {
+                                                     FwdPlan plan, int out_layout, const int32_t* __restrict__ row_total) {
     using T = typename Elem<HALF>::type;
     constexpr uint32_t C = 2;
     constexpr uint32_t RB = HALF ? 4u : 2u;   // rows per 16-byte block
     using RowT = typename std::conditional<HALF, uint32_t, uint2>::type;
     constexpr uint32_t P = 1;   // points per thread (the loops below are written for any P; 2 and 4 were measured slower)
+    constexpr uint32_t P_TILE = P * kTile;
     uint32_t level, tile;
     if (!fwd_item(plan, level, tile)) return;
+    // padding rows of a fixed-capacity batch (sdfx_set_row_limit): samples >= row_total[0] are neither read nor written, and a
+    // tile of nothing else ends here. (Stencil batches: the sample is the row within the slab; otherwise the row itself.)
+    const uint32_t n_rows = plan.slabs == kGroup ? plan.slab_points : B;
+    const uint32_t n_live = row_total ? min(n_rows, (uint32_t)row_total[0]) : n_rows;
+    {
+        const uint32_t first_slot = tile * P_TILE;
+        const uint32_t first = plan.slabs == kGroup ? (first_slot >> 6) * kGroupsPerWave : first_slot;
+        if (first >= n_live) return;
+    }
 
     const LevelConst lc = plan.lv[level];
     const bool hashed = HASHGRID && (lc.flags & 1u);
@@ -94,10 +104,10 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
         if (plan.slabs == kGroup) {   // lane = 7 * (sample within the wave) + stencil point; lane 63 idles
             const uint32_t lane = slot & 63u, g = lane / kGroup;
             const uint32_t sample = (slot >> 6) * kGroupsPerWave + g;
-            live[j] = lane < kGroup * kGroupsPerWave && sample < plan.slab_points;
+            live[j] = lane < kGroup * kGroupsPerWave && sample < n_live;
             pt[j] = (lane - g * kGroup) * plan.slab_points + sample;
         } else {
-            live[j] = slot < B;
+            live[j] = slot < n_live;
             pt[j] = slot;
         }
         if (!live[j]) pt[j] = 0;   // a valid address to load from; nothing is stored
@@ -318,9 +328,13 @@ void launch(const float* inputs, const void* table, void* outputs, uint32_t B, u
             int align_corners, uint32_t interp, int out_layout, hipStream_t st) {
     using T = typename Elem<HALF>::type;
     const uint32_t grid = fwd_grid_size(plan);
+    // sdfx_set_row_limit: honoured when its period is this batch's sample axis (computing padding rows anyway is harmless)
+    const RowLimit rl = row_limit();
+    const uint32_t axis = plan.slabs == kGroup ? plan.slab_points : B;
+    const int32_t* row_total = (rl.total && (rl.period == axis || (rl.period == 0 && plan.slabs != kGroup))) ? rl.total : nullptr;
 #define SDFX_FWD(INTERP_, ALIGN_, HASH_)                                                                               \
     hipLaunchKernelGGL((k_grid_fwd<HALF, INTERP_, ALIGN_, HASH_>), dim3(grid), dim3(kTile), 0, st, inputs,            \
-                       static_cast<const T*>(table), static_cast<T*>(outputs), B, L, plan, out_layout)
+                       static_cast<const T*>(table), static_cast<T*>(outputs), B, L, plan, out_layout, row_total)
     const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
     switch (sel) {
         case 0: SDFX_FWD(0u, false, false); break;

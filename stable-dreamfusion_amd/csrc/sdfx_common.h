@@ -27,6 +27,15 @@ int check_launch(const char* what);
     } while (0)
 
 static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// Padding rows of fixed-capacity sample buffers (sdfx_set_row_limit): row r of a [k, period, ...] buffer is padding when
+// (r % period) >= total[0] (period 0: r >= total[0]); total == nullptr: no limit. Kernels that honour it neither read nor
+// write padding rows, so every producer / consumer pair of such a buffer must honour the same limit.
+struct RowLimit {
+    const int32_t* total;
+    uint32_t period;
+};
+RowLimit row_limit();   // the calling thread's current setting
 static inline hipStream_t as_stream(sdfx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Zero `bytes` (a multiple of 4) of device memory with a KERNEL. hipMemsetAsync is avoided on purpose: captured into
@@ -42,6 +51,20 @@ static inline void zero_device(void* p, uint64_t bytes, hipStream_t st) {
     const uint64_t blocks = (words + 1023) / 1024;
     hipLaunchKernelGGL(k_zero_words, dim3((uint32_t)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st,
                        static_cast<uint32_t*>(p), words);
+}
+#endif
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool row_live(const RowLimit& rl, uint32_t r) {
+    if (!rl.total) return true;
+    const uint32_t j = rl.period ? r % rl.period : r;
+    return j < (uint32_t)rl.total[0];
+}
+// are the n <= period rows from r0 on all padding?
+__device__ __forceinline__ bool rows_dead(const RowLimit& rl, uint32_t r0, uint32_t n) {
+    if (!rl.total) return false;
+    const uint32_t j0 = rl.period ? r0 % rl.period : r0;
+    return j0 >= (uint32_t)rl.total[0] && (rl.period == 0 || j0 + n <= rl.period);
 }
 #endif
 

@@ -23,11 +23,16 @@ int check_launch(const char* what) {
     return SDFX_OK;
 }
 
+static thread_local RowLimit g_row_limit = {nullptr, 0};
+RowLimit row_limit() { return g_row_limit; }
+
 }  // namespace sdfx
 
 extern "C" {
 
 const char* sdfx_last_error(void) { return sdfx::g_err; }
+
+void sdfx_set_row_limit(const int32_t* total, uint32_t period) { sdfx::g_row_limit = {total, period}; }
 
 const char* sdfx_build_info(void) { return "libsdfx_hip gfx950 (CDNA4) wave64 -ffp-contract=off " __DATE__ " " __TIME__; }
 

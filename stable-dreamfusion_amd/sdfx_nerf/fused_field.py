@@ -16,14 +16,18 @@ from torch.amp import custom_bwd, custom_fwd
 
 import _field
 import _gridencoder
+import _sdfx
 
 
 class _fused_field(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, x, embeddings, offsets, w1, b1, w2, b2, w3, b3, bound, per_level_scale, base_resolution, gridtype,
-                align_corners, interp, blob_density, blob_radius, slabs, step, stencil_eps=0.0):
+                align_corners, interp, blob_density, blob_radius, slabs, step, stencil_eps=0.0, row_total=None):
         x = x.float().contiguous()
+        # row_total (int32 [1], device): the live rows of a fixed-capacity sample buffer; the kernels below skip the padding
+        # behind it (include/sdfx.h, sdfx_set_row_limit) instead of evaluating the field on zeros
+        limit = (row_total, x.shape[0] if stencil_eps > 0 else 0)
         B = x.shape[0] * (7 if stencil_eps > 0 else 1)
         if B == 0:   # a view that hits no occupied cell: nothing to evaluate, nothing to differentiate
             ctx.meta = None
@@ -40,14 +44,16 @@ class _fused_field(Function):
         S = np.log2(per_level_scale)
         emb = embeddings.to(torch.half).contiguous()             # autocast: fp16 table (grid.py:46-47)
         enc = torch.empty(L, B, C, device=x.device, dtype=torch.half)
-        _gridencoder.grid_encode_forward(inputs, emb, offsets, enc, B, 3, C, L, L, S, base_resolution, None, gridtype,
-                                         align_corners, interp, 0, slabs, step)
         packed = torch.empty(_field.packed_words(), dtype=torch.int32, device=x.device)
         _field.pack(w1.detach().float().contiguous(), b1.detach().float().contiguous(), w2.detach().float().contiguous(),
                     b2.detach().float().contiguous(), w3.detach().float().contiguous(), b3.detach().float().contiguous(), packed)
         sigma = torch.empty(B, dtype=torch.float32, device=x.device)
         albedo = torch.empty(B, 3, dtype=torch.float32, device=x.device)
-        _field.forward(enc, 0, x, packed, B, blob_density, blob_radius, sigma, albedo)
+        with _sdfx.row_limit(*limit):
+            _gridencoder.grid_encode_forward(inputs, emb, offsets, enc, B, 3, C, L, L, S, base_resolution, None, gridtype,
+                                             align_corners, interp, 0, slabs, step)
+            _field.forward(enc, 0, x, packed, B, blob_density, blob_radius, sigma, albedo)
+        ctx.limit = limit
         ctx.save_for_backward(x, inputs, offsets, enc, packed)
         ctx.meta = (B, C, L, S, base_resolution, gridtype, align_corners, interp, blob_density, blob_radius, tuple(emb.shape))
         return sigma, albedo
@@ -56,7 +62,7 @@ class _fused_field(Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, dsigma, dalbedo):
         if ctx.meta is None:
-            return (None,) * 20
+            return (None,) * 21
         x, inputs, offsets, enc, packed = ctx.saved_tensors
         B, C, L, S, H, gridtype, align_corners, interp, blob_density, blob_radius, emb_shape = ctx.meta
         dev = x.device
@@ -67,11 +73,12 @@ class _fused_field(Function):
         dw1, db1 = torch.empty(64, 32, **f32), torch.empty(64, **f32)
         dw2, db2 = torch.empty(64, 64, **f32), torch.empty(64, **f32)
         dw3, db3 = torch.empty(4, 64, **f32), torch.empty(4, **f32)
-        _field.backward(enc, 0, x, packed, B, blob_density, blob_radius, dsigma, dalbedo, denc, dw1, db1, dw2, db2, dw3, db3)
         grad_emb = torch.zeros(emb_shape, dtype=torch.half, device=dev)
-        _gridencoder.grid_encode_backward(denc, inputs, grad_emb, offsets, grad_emb, B, 3, C, L, L, S, H, None, None, gridtype,
-                                          align_corners, interp, 0)
-        return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 11
+        with _sdfx.row_limit(*ctx.limit):
+            _field.backward(enc, 0, x, packed, B, blob_density, blob_radius, dsigma, dalbedo, denc, dw1, db1, dw2, db2, dw3, db3)
+            _gridencoder.grid_encode_backward(denc, inputs, grad_emb, offsets, grad_emb, B, 3, C, L, L, S, H, None, None, gridtype,
+                                              align_corners, interp, 0)
+        return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 12
 
 
 def supported(encoder, sigma_net, x, density_activation, max_level) -> bool:
@@ -81,12 +88,14 @@ def supported(encoder, sigma_net, x, density_activation, max_level) -> bool:
             and sigma_net.net[0].bias is not None)
 
 
-def fused_field(x, encoder, sigma_net, bound, blob_density, blob_radius, slabs=1, step=0.0, stencil_eps=0.0):
+def fused_field(x, encoder, sigma_net, bound, blob_density, blob_radius, slabs=1, step=0.0, stencil_eps=0.0, row_total=None):
     """`slabs`, `step`: locality hints for the encoder (include/sdfx.h, sdfx_grid_encode_forward_hint): slabs = 7 when x is the
     [7, N, 3] batch of a finite-difference stencil, step = distance between consecutive ray samples in the unit cube.
-    `stencil_eps` > 0: x is [N, 3] and the field is evaluated on its 7-point stencil batch (outputs [7 N], [7 N, 3])."""
+    `stencil_eps` > 0: x is [N, 3] and the field is evaluated on its 7-point stencil batch (outputs [7 N], [7 N, 3]).
+    `row_total`: int32 device tensor [1] — only the first row_total[0] samples are live (fixed-capacity buffers); the outputs and
+    gradients of the rows behind them are left unwritten."""
     n = sigma_net.net
     return _fused_field.apply(x, encoder.embeddings, encoder.offsets, n[0].weight, n[0].bias, n[1].weight, n[1].bias,
                               n[2].weight, n[2].bias, bound, encoder.per_level_scale, encoder.base_resolution,
                               encoder.gridtype_id, encoder.align_corners, encoder.interp_id, blob_density, blob_radius,
-                              int(slabs), float(step), float(stencil_eps))
+                              int(slabs), float(step), float(stencil_eps), row_total)

@@ -23,6 +23,7 @@ _FUSED = int(os.environ.get("SDFX_FUSED_FIELD", "1"))
 # evaluate the sample and its six finite-difference neighbours in ONE field call (the field is point-wise, so the
 # values are those of the reference's seven separate common_forward calls, network_grid.py:81-96, 108-115)
 _BATCH_STENCIL = int(os.environ.get("SDFX_BATCH_STENCIL", "1"))
+_ROW_LIMIT = int(os.environ.get("SDFX_ROW_LIMIT", "1"))   # skip the padding rows of fixed-capacity buffers in the field kernels
 _STENCIL_KERNEL = int(os.environ.get("SDFX_STENCIL_KERNEL", "1"))   # the [7, M, 3] stencil batch from one kernel (csrc/field.hip)
 # normal / shading / orientation glue between the field and the compositor in one HIP kernel each way
 _FUSED_SHADE = int(os.environ.get("SDFX_FUSED_SHADE", "1"))
@@ -168,8 +169,9 @@ class NeRFNetwork(NeRFRenderer):
         Returns weights (detached), weights_sum, depth, image, ray_sums [N, 2] = per-ray (entropy sum, orientation sum)."""
         if _FUSED and _STENCIL_KERNEL and _ff.supported(self.encoder, self.sigma_net, x, self.opt.density_activation, self.max_level):
             step = (3.0 ** 0.5) / (self.opt.max_steps * self.bound)
+            live = total if (_ROW_LIMIT and torch.is_tensor(total) and total.dtype == torch.int32 and total.is_cuda) else None
             sigma_all, albedo_all = _ff.fused_field(x.reshape(-1, 3), self.encoder, self.sigma_net, self.bound, self.opt.blob_density,
-                                                    self.opt.blob_radius, 7, step, stencil_eps=1e-2)
+                                                    self.opt.blob_radius, 7, step, stencil_eps=1e-2, row_total=live)
         else:
             neigh = (x.unsqueeze(0) + self._fd_offsets.unsqueeze(1)).clamp(-self.bound, self.bound)
             pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
