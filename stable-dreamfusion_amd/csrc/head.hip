@@ -8,7 +8,7 @@
 //
 // In PyTorch these are ~25 launches forward and ~35 backward on 4096-element tensors (frequency encode, two GEMMs, ReLU, sigmoid,
 // the mix, cat / permute / contiguous, three scalar losses and their sums); inside the replayed HIP graph each of them costs
-// 2-5 us of execution plus a 5-15 us dependency gap — together ~0.5 ms of a 3.8 ms iteration (profiles/r02_iteration_trace.txt).
+// 2-5 us of execution plus a 5-15 us dependency gap — together ~0.5 ms of a 3.8 ms iteration (profiles/r02_iteration_trace_152_launches.txt).
 //
 // 4096 rays are 64 waves: a thread-per-ray kernel leaves three quarters of the chip idle and runs the 39 -> 32 -> 3 background
 // MLP (1379 parameters, float32 as sdfx_nerf evaluates it) serially in every lane (65 us forward, 95 us backward when it was
