@@ -669,3 +669,67 @@ def test_binned_table_gradient_is_bit_reproducible(oracle, dev):
         B.grid_encode_backward(grad, x, table, offsets, gt, n, 3, 2, 16, 16, S, 16, None, None, 0, False, 1, 0)
         outs.append(gt)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_row_limit_skips_padding_rows_and_nothing_else(oracle, dev):
+    """sdfx_set_row_limit (fixed-capacity sample buffers of a replayed iteration): with `total` live samples per stencil slab of
+    `cap` rows, the hinted encoder forward, the field forward / backward and the binned scatter must produce, on the live rows,
+    exactly what they produce on the compact [7, total] batch — and must not touch the padding rows (sentinels stay) nor read
+    them (the padding rows of every input hold NaN)."""
+    import _field
+    import _gridencoder as B
+    import _sdfx as S
+    offsets, pls, table = _grid_setup(oracle, dtype=np.float16, desired_resolution=2048)
+    bf = synth.s_grid_init()[2]
+    o, d = synth.s_rays(1)
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    xyzs = oracle.march_rays_train(o, d, 1.0, bf, 1, 128, nears, fars, synth.s_noises(4096))[0]
+    total, cap = 20011, 20011 + 4097                      # neither a multiple of the 256 / 512-row tiles
+    xyzs = xyzs[:total]
+    e = np.float32(1e-2)
+    offs = np.array([[0, 0, 0], [e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]], np.float32)
+    pts = np.clip(xyzs[None] + offs[:, None], -1, 1)                                   # [7, total, 3]
+    unit = ((pts + np.float32(1)) / np.float32(2)).astype(np.float32)
+    L, C, Sc, step = 16, 2, float(np.log2(pls)), 1.0 / 591.0
+    g = torch.Generator().manual_seed(3)
+    w = [torch.randn(64, 32, generator=g) * 0.2, torch.randn(64, generator=g) * 0.1, torch.randn(64, 64, generator=g) * 0.15,
+         torch.randn(64, generator=g) * 0.1, torch.randn(4, 64, generator=g) * 0.15, torch.randn(4, generator=g) * 0.1]
+    w = [t.to(dev) for t in w]
+    packed = torch.empty(_field.packed_words(), dtype=torch.int32, device=dev)
+    _field.pack(*w, packed)
+    ds_c = (torch.randn(7, total, generator=g) * 0.1).to(dev)
+    da_c = (torch.randn(7, total, 3, generator=g) * 0.1).to(dev)
+    tab, off_t = T(table, dev), T(offsets, dev)
+    nan = float("nan")
+
+    def pad(t, fill):                                     # [7, total, ...] -> [7, cap, ...] with `fill` in the padding rows
+        out = torch.full((7, cap) + tuple(t.shape[2:]), fill, dtype=t.dtype, device=dev)
+        out[:, :total] = t
+        return out
+
+    def run(unit_t, pts_t, ds, da, n, limit):
+        Bn = 7 * n
+        enc = torch.full((L, Bn, C), 7.0, dtype=torch.float16, device=dev)
+        sigma, albedo = torch.full((Bn,), 7.0, device=dev), torch.full((Bn, 3), 7.0, device=dev)
+        denc = torch.full((L, Bn, C), 7.0, dtype=torch.float16, device=dev)
+        grads = [torch.empty_like(t) for t in w]
+        gt = torch.zeros_like(tab)
+        with S.row_limit(limit, n):
+            B.grid_encode_forward(unit_t.reshape(-1, 3), tab, off_t, enc, Bn, 3, C, L, L, Sc, 16, None, 0, False, 1, 0, 7, step)
+            _field.forward(enc, 0, pts_t.reshape(-1, 3), packed, Bn, 5.0, 0.2, sigma, albedo)
+            _field.backward(enc, 0, pts_t.reshape(-1, 3), packed, Bn, 5.0, 0.2, ds.reshape(-1), da.reshape(-1, 3), denc, *grads)
+            B.grid_encode_backward(denc, unit_t.reshape(-1, 3), tab, off_t, gt, Bn, 3, C, L, L, Sc, 16, None, None, 0, False, 1, 0)
+        torch.cuda.synchronize()
+        return enc.view(L, 7, n, C), sigma.view(7, n), albedo.view(7, n, 3), denc.view(L, 7, n, C), grads, gt
+
+    ref = run(T(unit, dev), T(pts.astype(np.float32), dev), ds_c, da_c, total, None)
+    lim = torch.tensor([total], dtype=torch.int32, device=dev)
+    got = run(pad(T(unit, dev), nan), pad(T(pts.astype(np.float32), dev), nan), pad(ds_c, nan), pad(da_c, nan), cap, lim)
+    for k in (0, 3):                                      # level-major features and their gradients
+        assert torch.equal(got[k][:, :, :total], ref[k]) and bool((got[k][:, :, total:] == 7.0).all())
+    for k in (1, 2):
+        assert torch.equal(got[k][:, :total], ref[k]) and bool((got[k][:, total:] == 7.0).all())
+    for a, b in zip(got[4], ref[4]):                      # weight gradients: the same rows in differently aligned tiles
+        assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7
+    assert bool(torch.isfinite(got[5].float()).all())
+    assert float((got[5].float() - ref[5].float()).abs().max()) <= 2e-3 * float(ref[5].float().abs().max())
