@@ -95,6 +95,25 @@ __global__ __launch_bounds__(256) void k_field_pack(const float* __restrict__ w1
         }
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) packed[kFragBase + i * 4 + q] = as_u32(pack(v8[2 * q], v8[2 * q + 1]));
+        // the native-layout set: same (layer, mb, st), K column of slot (hi, j) = the feature that lane half holds there
+        const uint32_t hi = l >> 5, lm = l & 31;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t fe = 2 * (8 * hi + 4 * st + (j >> 1)) + (j & 1);                               // encoder features (st < 2)
+            const uint32_t fh = 32 * (st >> 1) + 4 * hi + 8 * (2 * (st & 1) + (j >> 2)) + (j & 3);        // hidden features
+            float v = 0.f;
+            switch (layer) {
+                case 0: v = w1[m * kIn + fe]; break;
+                case 1: v = w2[m * kHid + fh]; break;
+                case 2: v = lm < kOut ? w3[lm * kHid + fh] : 0.f; break;
+                case 3: v = (8 * hi + j) < kOut ? w3[(8 * hi + j) * kHid + m] : 0.f; break;
+                case 4: v = w2[fh * kHid + m]; break;
+                default: v = w1[fh * kIn + lm]; break;
+            }
+            v8[j] = v;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) packed[kFragBaseN + i * 4 + q] = as_u32(pack(v8[2 * q], v8[2 * q + 1]));
     }
 }
 
@@ -607,6 +626,276 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
     else if (t < 132) out[gB3 + (t - 128)] = gb;
 }
 
+// =========================================================================================
+// Backward in the matrix cores' own layout (default). The kernel above keeps "one lane = one sample" and converts every layer's
+// operands and results with v_permlane32_swap (223 swaps, 64 fp32 temporaries and ~570 AGPR <-> VGPR moves per 256-row tile).
+// Here a wave's 64 samples are two column blocks of 32, and lane (n, hi) holds HALF the features of sample n of each block —
+// exactly the rows of the MFMA result it receives: D element r of lane (n, hi) is feature (r & 3) + 8 (r >> 2) + 4 hi of the
+// 32-row block. Packed pairwise they ARE the B operand of the next layer if that layer's weight fragments have their K columns
+// in the same order (the second fragment set k_field_pack writes): no swaps, no temporaries, results consumed where they land.
+// The per-sample scalars (activations' derivatives of the 4 outputs) live in the hi = 0 lanes. The weight-gradient contractions
+// use the same [feature][sample] LDS staging, accumulators and output layout as above.
+// =========================================================================================
+constexpr uint32_t kBiasPad = 2 * kHid + 32;   // b1 | b2 | b3 padded to a 32-row block (rows >= 4 are zero)
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.f;
+    return z;
+}
+__device__ __forceinline__ h8 words_h8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return __builtin_bit_cast(h8, make_uint4(a, b, c, d)); }
+
+// the staging helpers of the kernel above for a tile of TS samples (row pitch RH = TS + 8 halves)
+template <uint32_t RH>
+__device__ __forceinline__ h8 frag_n(const _Float16* stage, uint32_t row, uint32_t step, int lane) {
+    return *reinterpret_cast<const h8*>(stage + (size_t)(row + (lane & 31)) * RH + step * 16 + 8 * (lane >> 5));
+}
+template <uint32_t RH, uint32_t TS>
+__device__ __forceinline__ f32x16 contract_n(const _Float16* stage, uint32_t a_row0, uint32_t b_row0, f32x16 acc, int lane, bool a_valid = true) {
+#pragma unroll 4
+    for (uint32_t step = 0; step < TS / 16; step++) {
+        h8 a = frag_n<RH>(stage, a_row0, step, lane);
+        if (!a_valid) a = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, frag_n<RH>(stage, b_row0, step, lane), acc, 0, 0, 0);
+    }
+    return acc;
+}
+template <uint32_t RH, uint32_t TS>
+__device__ __forceinline__ float row_sum_n(const _Float16* stage, uint32_t row) {
+    const h8* r = reinterpret_cast<const h8*>(stage + (size_t)row * RH);
+    float s = 0.f;
+#pragma unroll 4
+    for (uint32_t i = 0; i < TS / 8; i++) {
+        const h8 v = r[i];
+        s += ((float)v[0] + (float)v[1]) + ((float)v[2] + (float)v[3]) + (((float)v[4] + (float)v[5]) + ((float)v[6] + (float)v[7]));
+    }
+    return s;
+}
+
+// relu(acc + bias) packed pairwise: words 8 mb .. 8 mb + 7 of a hidden vector
+__device__ __forceinline__ void nat_relu_pack(const f32x16& a, const float* bias32, int hi, uint32_t* out8) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int r = 2 * q, row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        out8[q] = as_u32(pack(fmaxf(a[r] + bias32[row], 0.f), fmaxf(a[r + 1] + bias32[row + 1], 0.f)));
+    }
+}
+__device__ __forceinline__ void nat_mask_pack(const f32x16& a, const uint32_t* act8, uint32_t* out8) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) out8[q] = masked_pack(act8[q], a[2 * q], a[2 * q + 1]);
+}
+
+// hidden vector (16 words of this lane) -> stage rows row0 + feature, column col
+template <uint32_t RH>
+__device__ __forceinline__ void nat_stage_hidden(_Float16* stage, uint32_t row0, uint32_t col, int hi, const uint32_t* w16) {
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        const uint32_t f = 32 * (p >> 3) + 4 * hi + 8 * ((p & 7) >> 1) + 2 * (p & 1);
+        const h2 v = as_h2(w16[p]);
+        stage[(size_t)(row0 + f) * RH + col] = v.x;
+        stage[(size_t)(row0 + f + 1) * RH + col] = v.y;
+    }
+}
+
+// NB column blocks of 32 samples per wave: the tile of a workgroup is TS = 128 NB samples. NB = 1 halves the registers a
+// lane needs for activations (two workgroups, or more, per CU); NB = 2 reuses every weight fragment for two MFMAs.
+template <bool LDSF, int NB>
+__global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_nat(const uint32_t* __restrict__ enc, const float* __restrict__ x,
+                                                                                   const uint32_t* __restrict__ P, uint32_t B,
+                                                                                   float blob_density, float inv_2r2,
+                                                                                   const float* __restrict__ dsigma,
+                                                                                   const float* __restrict__ dalbedo,
+                                                                                   uint32_t* __restrict__ denc, float* __restrict__ partials,
+                                                                                   RowLimit rl) {
+    constexpr uint32_t TS = 128 * NB, RH = TS + 8;
+    __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * RH];
+    __shared__ uint4 sfrag[LDSF ? kFrags * 64 : 1];
+    __shared__ float sbias[kBiasPad];
+    const uint32_t t = threadIdx.x;
+    const uint4* F = reinterpret_cast<const uint4*>(P + kFragBaseN);
+    if (LDSF) {
+        for (uint32_t i = t; i < kFrags * 64; i += kThreads) sfrag[i] = F[i];
+        F = sfrag;
+    }
+    if (t < kBiasPad) sbias[t] = t < 2 * kHid + kOut ? __builtin_bit_cast(float, P[kB1 + t]) : 0.f;
+    __syncthreads();
+    const int lane = (int)(t & 63), hi = lane >> 5;
+    const uint32_t n = (uint32_t)lane & 31u, wave = t >> 6;
+    f32x16 acc2 = zero16(), accx = zero16();
+    float gb = 0.f;
+
+    // one 32-row block of a layer for the wave's column blocks: a[c] = sum_t A[frag0 + t] . X_c[4t .. 4t + 3]
+    auto block = [&](uint32_t frag0, int ks, uint32_t (*xw)[16], f32x16* a) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) a[c] = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (s < ks) {
+                const h8 A = __builtin_bit_cast(h8, F[(size_t)(frag0 + s) * 64 + lane]);
+#pragma unroll
+                for (int c = 0; c < NB; c++)
+                    a[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, words_h8(xw[c][4 * s], xw[c][4 * s + 1], xw[c][4 * s + 2], xw[c][4 * s + 3]),
+                                                                  a[c], 0, 0, 0);
+            }
+        }
+    };
+
+    const uint32_t ntiles = (B + TS - 1) / TS;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (rows_dead(rl, tile * TS, TS)) continue;   // a tile of padding rows (workgroup-uniform)
+        uint32_t col[NB], row[NB];
+        bool live[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            col[c] = 32 * NB * wave + 32 * c + n;     // this lane's sample of column block c within the tile
+            row[c] = tile * TS + col[c];
+            live[c] = row[c] < B && row_live(rl, row[c]);
+        }
+        // features: lane half hi holds levels 8 hi .. 8 hi + 7 (words 0..7; the array is 16 wide for the common operand type)
+        uint32_t e[NB][16];
+        float ds[NB], da[NB][3], bl[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) e[c][p] = live[c] ? enc[(size_t)(8 * hi + p) * B + row[c]] : 0u;
+            ds[c] = 0.f; da[c][0] = da[c][1] = da[c][2] = 0.f; bl[c] = 0.f;
+            if (hi == 0 && live[c]) {   // the hi = 0 lanes own the 4 outputs of a sample
+                ds[c] = dsigma[row[c]];
+                da[c][0] = dalbedo[(size_t)row[c] * 3]; da[c][1] = dalbedo[(size_t)row[c] * 3 + 1]; da[c][2] = dalbedo[(size_t)row[c] * 3 + 2];
+                bl[c] = density_blob(x, row[c], blob_density, inv_2r2);
+            }
+        }
+
+        // ---- forward recompute ----
+        uint32_t h1[NB][16], h2w[NB][16];
+        f32x16 a[NB];
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++) {
+            block(fW1 + 2 * mb, 2, e, a);
+#pragma unroll
+            for (int c = 0; c < NB; c++) nat_relu_pack(a[c], sbias + 32 * mb, hi, h1[c] + 8 * mb);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++) {
+            block(fW2 + 4 * mb, 4, h1, a);
+#pragma unroll
+            for (int c = 0; c < NB; c++) nat_relu_pack(a[c], sbias + kHid + 32 * mb, hi, h2w[c] + 8 * mb);
+        }
+        block(fW3, 4, h2w, a);
+        // output activations' derivatives: d sigma / d z = exp(min(z, 15)) (activation.py:13-16); d sigmoid = s (1 - s)
+        uint32_t d3[NB][16];
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            d3[c][0] = d3[c][1] = d3[c][2] = d3[c][3] = 0u;
+            if (hi == 0 && live[c]) {
+                const float* b3 = sbias + 2 * kHid;
+                float h3[kOut];
+#pragma unroll
+                for (int o = 0; o < (int)kOut; o++) h3[o] = (float)(_Float16)(a[c][o] + b3[o]);
+                const float g0 = ds[c] * expf(fminf(h3[0] + bl[c], 15.0f));
+                float g[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float sg = sigmoidf_(h3[1 + k]);
+                    g[k] = da[c][k] * sg * (1.0f - sg);
+                }
+                d3[c][0] = as_u32(pack(g0, g[0]));
+                d3[c][1] = as_u32(pack(g[1], g[2]));
+            }
+        }
+
+        // ---- dW3 += dh3 . h2^T ; db3 : rows [0,64) = h2, [64,68) = dh3 ----
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            nat_stage_hidden<RH>(stage, 0, col[c], hi, h2w[c]);
+            if (hi == 0) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const h2 u = as_h2(d3[c][p]);
+                    stage[(size_t)(kHid + 2 * p) * RH + col[c]] = u.x;
+                    stage[(size_t)(kHid + 2 * p + 1) * RH + col[c]] = u.y;
+                }
+            }
+        }
+        __syncthreads();
+        if (wave >= 2) accx = contract_n<RH, TS>(stage, kHid, 32 * (wave - 2), accx, lane, (lane & 31) < (int)kOut);
+        if (t >= 128 && t < 128 + kOut) gb += row_sum_n<RH, TS>(stage, kHid + (t - 128));
+
+        // d h2 = relu'(h2) * W3^T d h3 (one K step: slots 0..3 of the hi = 0 lanes)
+        uint32_t g2[NB][16];
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++) {
+            block(fW3T + mb, 1, d3, a);
+#pragma unroll
+            for (int c = 0; c < NB; c++) nat_mask_pack(a[c], h2w[c] + 8 * mb, g2[c] + 8 * mb);
+        }
+
+        // ---- dW2 += dh2 . h1^T ; db2 : rows [0,64) = h1, [64,128) = dh2 ----
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            nat_stage_hidden<RH>(stage, 0, col[c], hi, h1[c]);
+            nat_stage_hidden<RH>(stage, kHid, col[c], hi, g2[c]);
+        }
+        __syncthreads();
+        acc2 = contract_n<RH, TS>(stage, kHid + 32 * (wave >> 1), 32 * (wave & 1), acc2, lane);
+        if (t < kHid) gb += row_sum_n<RH, TS>(stage, kHid + t);
+
+        // d h1 = relu'(h1) * W2^T d h2
+        uint32_t g1[NB][16];
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++) {
+            block(fW2T + 4 * mb, 4, g2, a);
+#pragma unroll
+            for (int c = 0; c < NB; c++) nat_mask_pack(a[c], h1[c] + 8 * mb, g1[c] + 8 * mb);
+        }
+
+        // ---- dW1 += dh1 . enc^T ; db1 : rows [0,32) = enc, [32,96) = dh1 ----
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) {   // level 8 hi + p = features 2 (8 hi + p), + 1
+                const uint32_t f = 2 * (8 * hi + p);
+                const h2 u = as_h2(e[c][p]);
+                stage[(size_t)f * RH + col[c]] = u.x;
+                stage[(size_t)(f + 1) * RH + col[c]] = u.y;
+            }
+            nat_stage_hidden<RH>(stage, kIn, col[c], hi, g1[c]);
+        }
+        __syncthreads();
+        if (wave < 2) accx = contract_n<RH, TS>(stage, kIn + 32 * wave, 0, accx, lane);
+        if (t >= 64 && t < 64 + kHid) gb += row_sum_n<RH, TS>(stage, kIn + (t - 64));
+
+        // d features = W1^T d h1: word q of lane half hi is level (q & 1) + 4 (q >> 1) + 2 hi
+        block(fW1T, 4, g1, a);
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            if (live[c]) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t level = (q & 1) + 4 * (q >> 1) + 2 * hi;
+                    denc[(size_t)level * B + row[c]] = as_u32(pack(a[c][2 * q], a[c][2 * q + 1]));
+                }
+            }
+        }
+    }
+
+    float* out = partials + (size_t)blockIdx.x * kGradWords;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t orow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ocol = lane & 31;
+        out[gW2 + (32 * (wave >> 1) + orow) * kHid + 32 * (wave & 1) + ocol] = acc2[r];
+        if (wave < 2) out[gW1 + (32 * wave + orow) * kIn + ocol] = accx[r];
+        else if (orow < kOut) out[gW3 + orow * kHid + 32 * (wave - 2) + ocol] = accx[r];
+    }
+    if (t < 64) out[gB2 + t] = gb;
+    else if (t < 128) out[gB1 + (t - 64)] = gb;
+    else if (t < 132) out[gB3 + (t - 128)] = gb;
+}
+
 // sum the per-workgroup partials into the six parameter gradients: 64 entries per workgroup, the (up to 512) partials of an
 // entry split over 16 threads whose sums are joined in a fixed order (deterministic). One thread per entry walking all
 // partials was a chain of 128 dependent loads: 43 us for 13 MB.
@@ -746,7 +1035,20 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
                                static_cast<uint32_t*>(denc), scratch, row_limit());
         } else {
             static const bool lds_frags = [] { const char* e = getenv("SDFX_FIELD_BWD_LDSFRAG"); return !(e && e[0] == '0'); }();
-            if (lds_frags)
+            static const bool native = [] { const char* e = getenv("SDFX_FIELD_BWD_NAT"); return !(e && e[0] == '0'); }();
+            if (native && enc_layout == 0) {
+                static const int nb = [] { const char* e = getenv("SDFX_FIELD_BWD_NB"); return (e && e[0] == '2') ? 2 : 1; }();
+                const float i2 = 1.0f / (2 * blob_radius * blob_radius);
+                const uint32_t* ep = static_cast<const uint32_t*>(enc);
+                uint32_t* dp = static_cast<uint32_t*>(denc);
+                const RowLimit rlim = row_limit();
+#define SDFX_NAT(LDSF_, NB_)                                                                                                       \
+    hipLaunchKernelGGL((k_field_backward_nat<LDSF_, NB_>), dim3(nblocks), dim3(kThreads), 0, st, ep, x, packed, B, blob_density, i2, \
+                       dsigma, dalbedo, dp, scratch, rlim)
+                if (nb == 2) { if (lds_frags) SDFX_NAT(true, 2); else SDFX_NAT(false, 2); }
+                else { if (lds_frags) SDFX_NAT(true, 1); else SDFX_NAT(false, 1); }
+#undef SDFX_NAT
+            } else if (lds_frags)
                 hipLaunchKernelGGL(k_field_backward_mma<true>, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
                                    enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
                                    static_cast<uint32_t*>(denc), scratch, row_limit());

@@ -25,7 +25,10 @@ constexpr uint32_t kDotWords = kB3 + kOut;           // 6532: the v_dot2 layouts
 // MFMA A-operand fragments (v_mfma_f32_32x32x16_f16): fragment f, lane l = 8 halves A[32 mb + (l & 31)][16 s + 8 (l >> 5) + j]
 constexpr uint32_t fW1 = 0, fW2 = 4, fW3 = 12, fW3T = 16, fW2T = 18, fW1T = 26, kFrags = 30;
 constexpr uint32_t kFragBase = (kDotWords + 3) & ~3u;  // 16-byte aligned start of the fragment section
-constexpr uint32_t kPackedWords = kFragBase + kFrags * 64 * 4;  // 14212
+// a second set of the same 30 fragments with their K columns (and W1^T's rows) in the order the "native layout" backward kernel
+// holds activations in (k_field_backward_nat, csrc/field.hip): K-step t, lane half hi, slot j <-> feature phi(t, hi, j)
+constexpr uint32_t kFragBaseN = kFragBase + kFrags * 64 * 4;
+constexpr uint32_t kPackedWords = kFragBaseN + kFrags * 64 * 4;  // 21892
 
 // gradient block (floats), same order as the torch parameters
 constexpr uint32_t gW1 = 0, gB1 = gW1 + kHid * kIn, gW2 = gB1 + kHid, gB2 = gW2 + kHid * kHid, gW3 = gB2 + kHid,
