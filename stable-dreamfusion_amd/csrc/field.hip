@@ -681,9 +681,19 @@ __device__ __forceinline__ void nat_relu_pack(const f32x16& a, const float* bias
         out8[q] = as_u32(pack(fmaxf(a[r] + bias32[row], 0.f), fmaxf(a[r + 1] + bias32[row + 1], 0.f)));
     }
 }
+// masked_pack on the bits: the activations are ReLU outputs (>= +0 as halves), so "act > 0" is "magnitude bits != 0"; the mask is
+// formed for both halves at once (v_pk_min_u16, v_pk_sub_u16) and ANDed onto the packed gradient pair: 5 instructions per word
+// where compare + select + convert per element took 7.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t masked_pack_bits(uint32_t act, float g0, float g1) {
+    us2 m = __builtin_bit_cast(us2, act & 0x7FFF7FFFu);
+    m = __builtin_elementwise_min(m, us2{1, 1});
+    m = us2{0, 0} - m;   // 0 or 0xFFFF per half
+    return as_u32(pack(g0, g1)) & __builtin_bit_cast(uint32_t, m);
+}
 __device__ __forceinline__ void nat_mask_pack(const f32x16& a, const uint32_t* act8, uint32_t* out8) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) out8[q] = masked_pack(act8[q], a[2 * q], a[2 * q + 1]);
+    for (int q = 0; q < 8; q++) out8[q] = masked_pack_bits(act8[q], a[2 * q], a[2 * q + 1]);
 }
 
 // hidden vector (16 words of this lane) -> stage rows row0 + feature, column col
@@ -896,6 +906,83 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
     else if (t < 132) out[gB3 + (t - 128)] = gb;
 }
 
+// Forward in the same layout (persistent workgroups, the 16 forward fragments in LDS): no lane swaps, the layer results are packed
+// where the MFMA leaves them, the 4 outputs of a sample come out in its hi = 0 lane.
+template <int NB>
+__global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* __restrict__ enc, const float* __restrict__ x,
+                                                                 const uint32_t* __restrict__ P, uint32_t B, float blob_density,
+                                                                 float inv_2r2, float* __restrict__ sigma, float* __restrict__ albedo,
+                                                                 RowLimit rl) {
+    constexpr uint32_t TS = 128 * NB, kFwdFrags = fW3T;   // fragments of W1, W2, W3
+    __shared__ uint4 sfrag[kFwdFrags * 64];
+    __shared__ float sbias[kBiasPad];
+    const uint32_t t = threadIdx.x;
+    {
+        const uint4* F = reinterpret_cast<const uint4*>(P + kFragBaseN);
+        for (uint32_t i = t; i < kFwdFrags * 64; i += kThreads) sfrag[i] = F[i];
+        if (t < kBiasPad) sbias[t] = t < 2 * kHid + kOut ? __builtin_bit_cast(float, P[kB1 + t]) : 0.f;
+    }
+    __syncthreads();
+    const int lane = (int)(t & 63), hi = lane >> 5;
+    const uint32_t n = (uint32_t)lane & 31u, wave = t >> 6;
+    auto block = [&](uint32_t frag0, int ks, uint32_t (*xw)[16], f32x16* a) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) a[c] = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (s < ks) {
+                const h8 A = __builtin_bit_cast(h8, sfrag[(size_t)(frag0 + s) * 64 + lane]);
+#pragma unroll
+                for (int c = 0; c < NB; c++)
+                    a[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, words_h8(xw[c][4 * s], xw[c][4 * s + 1], xw[c][4 * s + 2], xw[c][4 * s + 3]),
+                                                                  a[c], 0, 0, 0);
+            }
+        }
+    };
+    const uint32_t ntiles = (B + TS - 1) / TS;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (rows_dead(rl, tile * TS, TS)) continue;
+        uint32_t row[NB];
+        bool live[NB];
+        uint32_t e[NB][16];
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            row[c] = tile * TS + 32 * NB * wave + 32 * c + n;
+            live[c] = row[c] < B && row_live(rl, row[c]);
+#pragma unroll
+            for (int p = 0; p < 8; p++) e[c][p] = live[c] ? enc[(size_t)(8 * hi + p) * B + row[c]] : 0u;
+        }
+        uint32_t h1[NB][16], h2w[NB][16];
+        f32x16 a[NB];
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++) {
+            block(fW1 + 2 * mb, 2, e, a);
+#pragma unroll
+            for (int c = 0; c < NB; c++) nat_relu_pack(a[c], sbias + 32 * mb, hi, h1[c] + 8 * mb);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++) {
+            block(fW2 + 4 * mb, 4, h1, a);
+#pragma unroll
+            for (int c = 0; c < NB; c++) nat_relu_pack(a[c], sbias + kHid + 32 * mb, hi, h2w[c] + 8 * mb);
+        }
+        block(fW3, 4, h2w, a);
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            if (hi == 0 && live[c]) {
+                const float* b3 = sbias + 2 * kHid;
+                float h3[kOut];
+#pragma unroll
+                for (int o = 0; o < (int)kOut; o++) h3[o] = (float)(_Float16)(a[c][o] + b3[o]);
+                sigma[row[c]] = expf(h3[0] + density_blob(x, row[c], blob_density, inv_2r2));  // trunc_exp forward (activation.py:9-11)
+                albedo[(size_t)row[c] * 3 + 0] = sigmoidf_(h3[1]);
+                albedo[(size_t)row[c] * 3 + 1] = sigmoidf_(h3[2]);
+                albedo[(size_t)row[c] * 3 + 2] = sigmoidf_(h3[3]);
+            }
+        }
+    }
+}
+
 // sum the per-workgroup partials into the six parameter gradients: 64 entries per workgroup, the (up to 512) partials of an
 // entry split over 16 threads whose sums are joined in a fixed order (deterministic). One thread per entry walking all
 // partials was a chain of 128 dependent loads: 43 us for 13 MB.
@@ -934,6 +1021,12 @@ bool use_dot2() {
     if (g_field_impl >= 0) return g_field_impl == 1;
     static const int v = [] { const char* e = getenv("SDFX_FIELD_IMPL"); return (e && e[0] == 'd') ? 1 : 0; }();
     return v != 0;
+}
+
+// SDFX_FIELD_FWD_NAT: 0 = the lane-per-sample forward, 1 / 2 = native layout with that many column blocks per wave (default 2)
+int native_forward() {
+    static const int v = [] { const char* e = getenv("SDFX_FIELD_FWD_NAT"); return e ? atoi(e) : 2; }();
+    return v;
 }
 
 uint32_t backward_blocks(uint32_t B) {
@@ -1009,6 +1102,15 @@ int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const ui
         hipLaunchKernelGGL(k_field_forward, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
                            1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit());
+    } else if (enc_layout == 0 && native_forward() > 0) {
+        const int nb = native_forward();
+        const uint32_t tiles = div_up(B, 128u * nb), blocks = tiles < 2048u ? tiles : 2048u;
+        if (nb == 2)
+            hipLaunchKernelGGL(k_field_forward_nat<2>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), static_cast<const uint32_t*>(enc), x,
+                               packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit());
+        else
+            hipLaunchKernelGGL(k_field_forward_nat<1>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), static_cast<const uint32_t*>(enc), x,
+                               packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit());
     } else {
         hipLaunchKernelGGL(k_field_forward_mma, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
