@@ -661,16 +661,22 @@ __device__ __forceinline__ f32x16 contract_n(const _Float16* stage, uint32_t a_r
     }
     return acc;
 }
+// sum of one staged row over the tile's samples (bias gradient): v_dot2_f32_f16 against (1, 1) adds two halves into a float
+// accumulator exactly, one instruction per pair instead of two conversions and two additions
 template <uint32_t RH, uint32_t TS>
 __device__ __forceinline__ float row_sum_n(const _Float16* stage, uint32_t row) {
-    const h8* r = reinterpret_cast<const h8*>(stage + (size_t)row * RH);
-    float s = 0.f;
+    const uint4* r = reinterpret_cast<const uint4*>(stage + (size_t)row * RH);
+    const h2 one = h2{(_Float16)1.0f, (_Float16)1.0f};
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll 4
     for (uint32_t i = 0; i < TS / 8; i++) {
-        const h8 v = r[i];
-        s += ((float)v[0] + (float)v[1]) + ((float)v[2] + (float)v[3]) + (((float)v[4] + (float)v[5]) + ((float)v[6] + (float)v[7]));
+        const uint4 v = r[i];
+        s0 = __builtin_amdgcn_fdot2(as_h2(v.x), one, s0, false);
+        s1 = __builtin_amdgcn_fdot2(as_h2(v.y), one, s1, false);
+        s0 = __builtin_amdgcn_fdot2(as_h2(v.z), one, s0, false);
+        s1 = __builtin_amdgcn_fdot2(as_h2(v.w), one, s1, false);
     }
-    return s;
+    return s0 + s1;
 }
 
 // relu(acc + bias) packed pairwise: words 8 mb .. 8 mb + 7 of a hidden vector
