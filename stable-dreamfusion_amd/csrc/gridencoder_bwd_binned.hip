@@ -650,8 +650,14 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         const uint32_t b1 = b0 + chunk < B ? b0 + chunk : B;
         const uint32_t n = b1 - b0;
         // one plan tile = one K1 workgroup = kBinThreads * kPointsPerThread samples
-        const GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, eb,
-                                        (uint64_t)div_up(n, kBinThreads * kPointsPerThread) * kTile);
+        GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, eb,
+                                  (uint64_t)div_up(n, kBinThreads * kPointsPerThread) * kTile);
+        // The per-XCD level ranges are unbalanced for K1 (levels 15 + 0 on one XCD cost ~4x levels 8 + 7 on another; average
+        // occupancy 1.8 waves per SIMD by PMC), but giving every XCD the same mix of levels (SDFX_GRIDBWD_FLAT=1: workgroup i takes
+        // item i) is SLOWER, 784 -> 1091 us at B = 1.81 M: the slices of a bucket's item list reserved by workgroups of different
+        // XCDs share cache lines, and the XCDs' L2s are not coherent with each other, so those lines go to memory as partial writes.
+        static const int flat = [] { const char* e = getenv("SDFX_GRIDBWD_FLAT"); return (e && e[0] == '1') ? 1 : 0; }();
+        plan.flat = (uint32_t)flat;
         uint64_t items_1024;
         uint32_t nbuckets, nsplits, acc_rows, coarse_buckets;
         const BinPlan bin = make_bin_plan(plan, max_level, chunk, &items_1024, &nbuckets, &nsplits, &acc_rows, &coarse_buckets);
