@@ -201,6 +201,13 @@ void sdfx_grid_set_impl(int fwd_impl, int balance);
 int sdfx_grid_forward_plan(const int32_t* offsets_host, uint32_t max_level, float S, uint32_t H, int is_half, uint32_t B,
                            uint32_t slabs, float step, int32_t* segments, uint32_t max_segments, uint32_t* tiles_per_level);
 
+/* Host-only (no GPU work): the per-XCD item ranges the binned backward's first kernel would use for a batch of B points:
+ * ranges[2k], ranges[2k + 1] = [start, end) of XCD k over the (virtual level, tile) items in virtual-level-major order,
+ * *tiles = tiles per level. balance 0: equal counts (default), 1: cut by the per-level cost table (env SDFX_GRIDBWD_BALANCE=1
+ * selects it for the kernel; SDFX_GRIDBWD_LEVEL_COST overrides the table). Returns the number of levels, < 0 on error. */
+int sdfx_grid_backward_plan(const int32_t* offsets_host, uint32_t max_level, float S, uint32_t H, uint32_t B, int balance,
+                            int32_t* ranges, uint32_t* tiles);
+
 /*
  * gridencoder.cu:467-490 grid_encode_forward.
  *   inputs [B,D] f32 in [0,1]; embeddings [sum, C] f32|f16; offsets [L+1] i32 (device);

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "sdfx_set_row_limit": [_ptr, _u32],
     "sdfx_march_set_impl": [_int],
     "sdfx_grid_set_impl": [_int, _int],
+    "sdfx_grid_backward_plan": [_ptr, _u32, _f32, _u32, _u32, _int, _ptr, _ptr],
     "sdfx_grid_forward_plan": [_ptr, _u32, _f32, _u32, _int, _u32, _u32, _f32, _ptr, _u32, _ptr],
     "sdfx_adan_ctl_words": [],
     "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],

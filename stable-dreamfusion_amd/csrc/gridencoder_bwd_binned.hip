@@ -590,9 +590,78 @@ uint64_t scratch_bytes_for(const GridPlan& plan, uint32_t levels, uint32_t chunk
     return header_bytes(acc_rows) + items * 1024u * (half ? sizeof(Item<true>) : sizeof(Item<false>));
 }
 
+// K1's per-XCD ranges cut by COST instead of count. The ranges stay contiguous in (virtual level, tile) order — the slices of a
+// bucket's item list that share cache lines stay on one XCD's L2 (see the flat-mapping measurement below) — but every XCD gets the
+// same share of the estimated work. cost[l] = relative cost of one tile of level l.
+void balance_plan(GridPlan& p, uint32_t levels, const float* cost) {
+    double cum[kMaxLevels + 1];
+    cum[0] = 0.0;
+    double mean = 0.0;
+    for (uint32_t l = 0; l < levels; l++) mean += cost[l] > 0 ? cost[l] : 0;
+    mean = mean > 0 ? mean / levels : 1.0;
+    auto c_of = [&](uint32_t v) { const double c = cost[p.order[v]]; return c > 1e-3 * mean ? c : 1e-3 * mean; };
+    for (uint32_t v = 0; v < levels; v++) cum[v + 1] = cum[v] + (double)p.tiles * c_of(v);
+    const double total = cum[levels];
+    uint32_t cut[kXcds + 1];
+    cut[0] = 0;
+    cut[kXcds] = levels * p.tiles;
+    for (uint32_t k = 1; k < kXcds; k++) {
+        const double target = total * k / kXcds;
+        uint32_t v = 0;
+        while (v + 1 < levels && cum[v + 1] <= target) v++;
+        uint64_t off = (uint64_t)((target - cum[v]) / c_of(v));
+        if (off > p.tiles) off = p.tiles;
+        cut[k] = v * p.tiles + (uint32_t)off;
+        if (cut[k] < cut[k - 1]) cut[k] = cut[k - 1];
+        if (cut[k] > cut[kXcds]) cut[k] = cut[kXcds];
+    }
+    for (uint32_t k = 0; k < kXcds; k++) { p.start[k] = cut[k]; p.end[k] = cut[k + 1]; }
+}
+
+// relative cost of one K1 tile per level for the -O configuration (16 levels, base 16, 2048 finest), from the kernel-trace
+// durations per max_level in profiles/r02_gridbwd_balance.txt; SDFX_GRIDBWD_LEVEL_COST="c0,c1,..." overrides
+const float* k1_level_cost(uint32_t levels) {
+    static float table[kMaxLevels];
+    static const bool init = [] {
+        const float measured[16] = {51, 41, 52, 19, 5, 5, 29, 26, 27, 29, 32, 36, 25, 30, 34, 59};
+        for (uint32_t l = 0; l < kMaxLevels; l++) table[l] = l < 16 ? measured[l] : 30.f;
+        if (const char* e = getenv("SDFX_GRIDBWD_LEVEL_COST")) {
+            uint32_t l = 0;
+            while (*e && l < kMaxLevels) {
+                char* end = nullptr;
+                const float v = strtof(e, &end);
+                if (end == e) break;
+                table[l++] = v;
+                e = (*end == ',') ? end + 1 : end;
+            }
+        }
+        return true;
+    }();
+    (void)init; (void)levels;
+    return table;
+}
+
+// SDFX_GRIDBWD_BALANCE=1: cost-balanced ranges (measured next round; default: equal tile counts)
+bool k1_balance_enabled() {
+    static const int v = [] { const char* e = getenv("SDFX_GRIDBWD_BALANCE"); return (e && e[0] == '1') ? 1 : 0; }();
+    return v != 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+// host-only: the per-XCD item ranges K1 would use (ranges[2k], ranges[2k+1] = [start, end) of XCD k in virtual-level-major
+// (level order[v], tile) items), tiles per level in *tiles; balance: 0 equal counts, 1 cost-balanced. Returns the level count.
+int sdfx_grid_backward_plan(const int32_t* offsets_host, uint32_t max_level, float S, uint32_t H, uint32_t B, int balance,
+                            int32_t* ranges, uint32_t* tiles) {
+    if (!offsets_host || !ranges || max_level < 1 || max_level > kMaxLevels) return SDFX_E_INVALID;
+    GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, 2, (uint64_t)div_up(B, kBinThreads * kPointsPerThread) * kTile);
+    if (balance) balance_plan(plan, max_level, k1_level_cost(max_level));
+    for (uint32_t k = 0; k < kXcds; k++) { ranges[2 * k] = (int32_t)plan.start[k]; ranges[2 * k + 1] = (int32_t)plan.end[k]; }
+    if (tiles) *tiles = plan.tiles;
+    return (int)max_level;
+}
 
 // bytes of scratch that let `chunk_points` samples be processed per pass (more samples are chunked)
 uint64_t sdfx_grid_encode_backward_binned_scratch_bytes(const int32_t* offsets_host, uint32_t L, uint32_t max_level, float S,
@@ -658,6 +727,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         // XCDs share cache lines, and the XCDs' L2s are not coherent with each other, so those lines go to memory as partial writes.
         static const int flat = [] { const char* e = getenv("SDFX_GRIDBWD_FLAT"); return (e && e[0] == '1') ? 1 : 0; }();
         plan.flat = (uint32_t)flat;
+        if (!flat && k1_balance_enabled()) balance_plan(plan, max_level, k1_level_cost(max_level));
         uint64_t items_1024;
         uint32_t nbuckets, nsplits, acc_rows, coarse_buckets;
         const BinPlan bin = make_bin_plan(plan, max_level, chunk, &items_1024, &nbuckets, &nsplits, &acc_rows, &coarse_buckets);

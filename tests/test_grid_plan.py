@@ -50,3 +50,37 @@ def test_step_hint_balances_the_modelled_cost(oracle):
     even, _ = _plan(offsets, pls, 16, 1, 1810900, 7, 0.0)
     load_even = [sum(cost[l] * c for x, l, f, c in even if x == k) for k in range(8)]
     assert max(load_even) > 1.5 * min(load_even)
+
+
+@pytest.mark.parametrize("B", [1, 511, 4096 * 7, 1810900, 3150000])
+@pytest.mark.parametrize("L", [16, 9, 1])
+@pytest.mark.parametrize("balance", [0, 1])
+def test_backward_ranges_partition_the_items(oracle, B, L, balance):
+    """sdfx_grid_backward_plan: the eight per-XCD ranges of the binned scatter's first kernel are contiguous, ordered and cover every
+    (level, tile) item exactly once, with equal counts (default) or cut by the per-level cost table (SDFX_GRIDBWD_BALANCE=1); with the
+    table, the modelled cost of the ranges is even."""
+    offsets, pls = oracle.grid_offsets(desired_resolution=2048)
+    off = (C.c_int32 * len(offsets))(*[int(v) for v in offsets])
+    ranges = (C.c_int32 * 16)()
+    tiles = C.c_uint32()
+    n = S.lib().sdfx_grid_backward_plan(off, L, float(np.log2(pls)), 16, B, balance, ranges, C.byref(tiles))
+    assert n == L
+    T = int(tiles.value)
+    assert T == -(-B // 512)
+    r = np.array(ranges[:]).reshape(8, 2)
+    assert r[0, 0] == 0 and r[-1, 1] == L * T
+    assert (r[:, 0] <= r[:, 1]).all() and (r[1:, 0] == r[:-1, 1]).all()
+    if not balance:
+        assert (r[:, 1] - r[:, 0]).max() - (r[:, 1] - r[:, 0]).min() <= 1
+    elif L == 16 and B >= 4096 * 7:
+        cost = np.array([51, 41, 52, 19, 5, 5, 29, 26, 27, 29, 32, 36, 25, 30, 34, 59], float)
+        order = []
+        lo, hi = 0, L
+        for v in range(L):
+            if v & 1:
+                order.append(lo); lo += 1
+            else:
+                hi -= 1; order.append(hi)
+        item_cost = np.repeat(cost[order], T)
+        per = np.array([item_cost[a:b].sum() for a, b in r])
+        assert per.max() <= 1.02 * per.mean() + cost.max()
