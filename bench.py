@@ -52,11 +52,16 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--guidance", default=os.environ.get("SDFX_BENCH_GUIDANCE", "auto"),
                     choices=["auto", "synthetic", "sd15_random"])
+    ap.add_argument("--prior", default=os.environ.get("SDFX_BENCH_PRIOR", "sd"), choices=["sd", "if"],
+                    help="sd (default): BASELINE configs[1], latent-space SDS (guidance/sd_utils.py); if: configs[3], the `--IF` preset "
+                         "(main.py:181-185: pixel-space SDS at 64 x 64, guidance/if_utils.py, no latent phase)")
+    ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)   # child mode of cpu_baseline's thread probe
     ap.add_argument("--grid", default="init", choices=["trained-proxy", "init"],
                     help="occupancy the model starts from (the iteration refreshes it every 16 steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
-    ap.add_argument("--no-nerf-only", action="store_true", help="skip the second timed pass without the SD-1.5 UNet")
+    ap.add_argument("--no-nerf-only", action="store_true", help="skip the secondary timed passes (without the frozen UNet; with the "
+                                                                "synthetic prior = this repository's kernels only)")
     ap.add_argument("--phase", default="mix", choices=["mix", "latent", "rgb"],
                     help="mix (default): 20 %% of the timed steps in the latent phase, 80 %% in the RGB phase, as in a default run; "
                          "latent / rgb: that phase only")
@@ -300,16 +305,11 @@ def _reference_o2_model():
     return NeRFNetwork(opt).train()
 
 
-def cpu_baseline(budget_s=30.0):
-    """BASELINE.md §3 / SURVEY.md §8(d): the `-O2` vanilla-NeRF path (4096 rays x (64 + 32) samples, render + backward with a
-    dummy SDS gradient, fp32, perturb=True) on the host cores. The thread count is PROBED (32, 64, 128, all cores: one
-    iteration each while it keeps getting faster) and the fastest is used and reported as `cores` — handing all 256 hardware
-    threads of the GPU box's EPYC to PyTorch's intra-op pools made an iteration 40x slower than 32 threads (70 s vs < 2 s:
-    the tensors of this path are a few MB, the pools spin). Then 1 warm-up + up to 5 timed iterations per shading within the
-    budget. kind = "reference" when the reference's own code ran, "port" for oracle/o2_path.py."""
+def _o2_setup():
+    """(model, kind, iteration(shading)) of the `-O2` CPU path: the reference's own code when /root/reference is mounted
+    (kind "reference"), else oracle/o2_path.py (kind "port", pinned to it by tests/golden/o2_ref.npz)."""
     import synth
     from oracle import o2_path
-    ncpu = os.cpu_count() or 1
     o, d = synth.s_rays(0)
     ro, rd = torch.from_numpy(o), torch.from_numpy(d)
     model, kind = None, "port"
@@ -336,21 +336,63 @@ def cpu_baseline(budget_s=30.0):
             loss = loss + 1e-2 * out["loss_orient"]
         loss.backward()
 
-    t_begin = time.perf_counter()
-    probe, best = {}, None
-    for n in sorted({min(c, ncpu) for c in (32, 64, 128, ncpu)}):
-        torch.set_num_threads(n)
+    return model, kind, iteration
+
+
+def cpu_probe_child(n_threads):
+    """`bench.py --cpu-probe N` (a child of cpu_baseline): 'albedo' iterations of the -O2 path with N torch threads, one line per
+    finished iteration, so that the parent can bound an unreasonable thread count by a timeout and still read what finished."""
+    torch.set_num_threads(n_threads)
+    _, _, iteration = _o2_setup()
+    for it in range(3):
         t0 = time.perf_counter()
         iteration("albedo")
-        probe[n] = time.perf_counter() - t0
-        if best is not None and probe[n] > 1.15 * probe[best]:
-            break                                  # more threads made it slower: stop climbing
-        if best is None or probe[n] < probe[best]:
-            best = n
-        if time.perf_counter() - t_begin > 0.3 * budget_s:
-            break
+        print(f"PROBE {it} {time.perf_counter() - t0:.4f}", flush=True)
+
+
+def _probe_threads(n, timeout_s):
+    """Seconds per 'albedo' iteration with n torch threads, measured in a child process (killed at timeout_s)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-probe", str(n)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(n), MKL_NUM_THREADS=str(n))
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, env=env).stdout
+        timed_out = False
+    except subprocess.TimeoutExpired as exc:
+        out, timed_out = exc.stdout or b"", True
+    times = [float(l.split()[2]) for l in out.decode("utf-8", "replace").splitlines() if l.startswith("PROBE ")]
+    if not times:
+        return None, f">{timeout_s:.0f} (no iteration finished in {time.perf_counter() - t0:.0f} s)"
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return best, f"{best:.2f}" + (" (first iteration only: killed at the time limit)" if timed_out and len(times) == 1 else "")
+
+
+def cpu_baseline(budget_s=30.0, probe_timeout_s=25.0):
+    """BASELINE.md §3 / SURVEY.md §8(d): the `-O2` vanilla-NeRF path (4096 rays x (64 + 32) samples, render + backward with a
+    dummy SDS gradient, fp32, perturb=True) on the host cores. The thread count is PROBED at 32, 64, 128 and all hardware
+    threads — every point measured, each in a child process bounded by a timeout, because handing all 256 hardware threads of the
+    GPU box's EPYC to PyTorch's intra-op pools made an iteration 40x slower than 32 threads (70 s vs < 2 s: the tensors of this
+    path are a few MB, the pools spin) — and the fastest is used for the timed iterations and reported as `cores`. Then 1 warm-up +
+    up to 5 timed iterations per shading within the budget. kind = "reference" when the reference's own code ran, "port" for
+    oracle/o2_path.py."""
+    ncpu = os.cpu_count() or 1
+    t_begin = time.perf_counter()
+    probe, probe_txt, best = {}, {}, None
+    for n in sorted({min(c, ncpu) for c in (32, 64, 128, ncpu)}):
+        sec, txt = _probe_threads(n, probe_timeout_s)
+        probe_txt[str(n)] = txt
+        if sec is not None:
+            probe[n] = sec
+            if best is None or sec < probe[best]:
+                best = n
+    t_probe = time.perf_counter() - t_begin
+    if best is None:
+        best = min(32, ncpu)
+    _, kind, iteration = _o2_setup()
     torch.set_num_threads(best)
     cores = ncpu
+    t_begin2 = time.perf_counter()
     res = {}
     for shading, share in (("albedo", 0.6), ("lambertian", 1.0)):
         times = []
@@ -359,7 +401,7 @@ def cpu_baseline(budget_s=30.0):
             iteration(shading)
             if it >= 1:
                 times.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_begin > budget_s * share and times:
+            if time.perf_counter() - t_begin2 > budget_s * share and times:
                 break
         res[shading] = {"s_per_iter_median": float(np.median(times)), "s_per_iter_min": float(min(times)), "iters": len(times),
                         "rays_per_s": 4096.0 / float(np.median(times))}
@@ -370,7 +412,8 @@ def cpu_baseline(budget_s=30.0):
     except OSError:
         pass
     return {"kind": kind, "cores": int(torch.get_num_threads()), "os_cpu_count": cores, "cpu_model": cpu_model, "shadings": res,
-            "thread_probe_s_per_albedo_iter": {str(k): round(v, 2) for k, v in probe.items()}, "seconds": time.perf_counter() - t_begin}
+            "thread_probe_s_per_albedo_iter": probe_txt, "probe_seconds": t_probe,
+            "seconds": time.perf_counter() - t_begin}
 
 
 # ---- multi-GPU control path (independent prompts, one process per GPU) ------------------------------
@@ -407,8 +450,11 @@ def agree(ok: bool, dist, device) -> bool:
     return bool(int(t.item()))
 
 
-def phase_plan(phase: str, steps: int):
-    """[(phase name, steps)] of the timed region: the 20 / 80 mix of a default run, or one phase."""
+def phase_plan(phase: str, steps: int, prior: str = "sd"):
+    """[(phase name, steps)] of the timed region: the 20 / 80 mix of a default run, or one phase. `--IF` has no latent phase
+    (main.py:185: latent_iter_ratio = 0): every step is an RGB-phase step."""
+    if prior == "if":
+        return [("rgb", steps)]
     if phase != "mix":
         return [(phase, steps)]
     k_lat = min(max(1, round(0.2 * steps)), steps)
@@ -449,30 +495,46 @@ class GpuJob:
         torch.manual_seed(seed)
         np.random.seed(seed)
         self.seed, self.opt = seed, default_opt()
+        if args.prior == "if":
+            from sdfx_nerf.options import if_preset
+            if_preset(self.opt)                      # main.py:181-185: latent_iter_ratio = 0
         self.model = NeRFNetwork(self.opt).to(dev)
         self.prior, self.guidance_kind, self.prior_ok = None, args.guidance, True
+        big = "if_random" if args.prior == "if" else "sd15_random"
         if args.guidance in ("auto", "sd15_random"):
             try:
-                from sdfx_nerf.sd15_arch import sd15_random_prior
-                self.prior = sd15_random_prior(dev, self.opt.fp16)
+                t_build = time.perf_counter()
                 # one call of the SDS glue through the big network before anything depends on it (MIOpen's solver search for its
-                # convolution shapes happens here, per rank, a few seconds — outside every timed region); both phases, so the
-                # VAE encoder's shapes are searched too. Any failure falls back to the synthetic prior on ALL ranks.
-                with torch.autocast("cuda", dtype=torch.float16, enabled=self.opt.fp16):
-                    z = torch.cat([self.prior.get_text_embeds(["uncond"]), self.prior.get_text_embeds(["front"])])
-                    probe = self.prior.train_step(z, torch.rand(1, 4, 64, 64, device=dev), as_latent=True)
-                    x = torch.rand(1, 3, 64, 64, device=dev, requires_grad=True)
-                    probe2 = self.prior.train_step(z, x, as_latent=False)
-                    probe2.backward()
+                # convolution shapes happens here — outside every timed region); both phases, so the VAE encoder's shapes are
+                # searched too. Any failure falls back to the synthetic prior on ALL ranks.
+                if args.prior == "if":
+                    from sdfx_nerf.sd15_arch import if_random_prior
+                    self.prior = if_random_prior(dev, self.opt.fp16)
+                    with torch.autocast("cuda", dtype=torch.float16, enabled=self.opt.fp16):
+                        z = torch.cat([self.prior.get_text_embeds(["uncond"]), self.prior.get_text_embeds(["front"])])
+                        x = torch.rand(1, 3, 64, 64, device=dev, requires_grad=True)
+                        probe = probe2 = self.prior.train_step(z, x)
+                        probe2.backward()
+                else:
+                    from sdfx_nerf.sd15_arch import sd15_random_prior
+                    self.prior = sd15_random_prior(dev, self.opt.fp16)
+                    with torch.autocast("cuda", dtype=torch.float16, enabled=self.opt.fp16):
+                        z = torch.cat([self.prior.get_text_embeds(["uncond"]), self.prior.get_text_embeds(["front"])])
+                        probe = self.prior.train_step(z, torch.rand(1, 4, 64, 64, device=dev), as_latent=True)
+                        x = torch.rand(1, 3, 64, 64, device=dev, requires_grad=True)
+                        probe2 = self.prior.train_step(z, x, as_latent=False)
+                        probe2.backward()
                 if not (bool(torch.isfinite(probe)) and bool(torch.isfinite(probe2))):
-                    raise RuntimeError("non-finite SDS loss from the SD-1.5-architecture prior")
-                self.guidance_kind = "sd15_random"
+                    raise RuntimeError("non-finite SDS loss from the random-weight prior")
+                torch.cuda.synchronize()
+                self.guidance_kind = big
+                self.prior_build_s = time.perf_counter() - t_build
             except Exception as exc:  # noqa: BLE001
                 if args.guidance == "sd15_random":
                     raise
                 self.prior, self.prior_ok = None, False
                 if rank == 0:
-                    print(f"[bench] SD-1.5-architecture prior unavailable ({type(exc).__name__}: {exc}); synthetic prior", file=sys.stderr)
+                    print(f"[bench] {big} prior unavailable ({type(exc).__name__}: {exc}); synthetic prior", file=sys.stderr)
         else:
             self.prior_ok = False
         poses, fovy = synth.reference_cameras()
@@ -486,20 +548,22 @@ class GpuJob:
 
     def use_synthetic_prior(self):
         from sdfx_nerf import guidance as G
-        self.prior = G.synthetic_prior(self.dev, self.opt.fp16)
+        self.prior = (G.synthetic_if_prior if self.args.prior == "if" else G.synthetic_prior)(self.dev, self.opt.fp16)
         self.guidance_kind = "synthetic"
 
     def build(self, mode=None):
         from sdfx_nerf.trainer import TrainStep
         self.step_obj = TrainStep(self.opt, self.model, self.prior, self.dev, seed=self.seed, mode=mode)
-        self.step_obj.graph_prime_span = 1.5    # every ladder step within this factor of a missed capacity is captured with it
+        # every ladder step within this factor of a missed capacity is captured with it. Each captured graph keeps a private
+        # memory pool holding the frozen prior's activations (trainer.py _capture), so the span is narrower with the big prior
+        self.step_obj.graph_prime_span = 1.5 if self.guidance_kind == "synthetic" else 1.3
         if self.args.grid == "trained-proxy":    # start from a trained-scene-like occupancy instead of the empty grid
             import synth
             dens = np.unpackbits(synth.s_grid_blobs(), bitorder="little").astype(np.float32) * 20.0
             self.model.density_grid.copy_(torch.from_numpy(dens).view(1, -1).to(self.dev))
         self.phase_step = {"latent": 0, "rgb": int(self.opt.iters * self.opt.latent_iter_ratio) + 1}
         self.phase = None
-        self.set_phase("latent" if self.args.phase != "rgb" else "rgb")
+        self.set_phase("latent" if (self.args.phase != "rgb" and self.args.prior != "if") else "rgb")
 
     @property
     def train_mode(self):
@@ -553,6 +617,8 @@ class GpuJob:
 
 def main():
     args = parse()
+    if args.cpu_probe:
+        return cpu_probe_child(args.cpu_probe)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -567,10 +633,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # generous timeout: before the first collective every rank builds the 0.9 B-parameter prior and runs MIOpen's solver
+        # search (about a minute on one rank, serialised below), far beyond what a data-path collective would ever wait for
+        tmo = datetime.timedelta(minutes=30)
         if dry:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used for barriers + two small reductions only
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)   # RCCL over xGMI; barriers + small reductions only
 
     t_start = time.perf_counter()
 
@@ -579,8 +649,23 @@ def main():
             print(f"[bench +{time.perf_counter() - t_start:6.1f} s] {name}", file=sys.stderr, flush=True)
 
     timer = KernelTimer()
-    job = (DryJob if dry else GpuJob)(args, rank, world, dev)
+    # Building the job runs MIOpen's solver search for every convolution shape of the frozen prior, forward and backward. The
+    # find-db (~/.config/miopen) is shared by the ranks of a node and its writers are serialised by file locks, so N ranks
+    # searching at once contend for it: rank 0 searches first, the others start behind a barrier and hit a warm find-db.
+    Job = DryJob if dry else GpuJob
+    job = None
+    if dist is None or rank == 0:
+        job = Job(args, rank, world, dev)
+    if dist is not None:
+        dist.barrier()
+        if rank != 0:
+            job = Job(args, rank, world, dev)
+    t_built = time.perf_counter() - t_start
     stage("model and prior built")
+    first_barrier_s = [t_built]
+    if dist is not None:      # per-rank seconds to the first barrier after the build (rank 0 searched, the others came after)
+        first_barrier_s = [None] * world
+        dist.all_gather_object(first_barrier_s, round(t_built, 2))
     if not dry:
         install_timers(timer)
     if not agree(job.prior_ok, dist, dev):      # one rank without the big prior: nobody uses it
@@ -588,7 +673,7 @@ def main():
     job.build()
     calib = job.calibrate()
     stage(f"loss scale calibrated ({calib} iterations)")
-    plan = phase_plan(args.phase, args.steps)
+    plan = phase_plan(args.phase, args.steps, args.prior)
     for name, _ in plan:
         job.prime(name)
         stage(f"phase {name} primed")
@@ -645,6 +730,7 @@ def main():
         result["config"] = {"workload": "dry run of the control path (no GPU work)", "parallelism": f"independent-prompts x{world}",
                             "guidance": job.guidance_kind}
         result["dry_run"] = True
+        result["seconds_to_first_barrier_per_rank"] = first_barrier_s
         if rank == 0:
             print(json.dumps(result))
         if dist is not None:
@@ -692,14 +778,15 @@ def main():
             dist.barrier()
         return job_throughput(world, args.steps, job_elapsed(time.perf_counter() - t1, dist, dev))
 
-    # second figure, same run: the iteration without the frozen prior's UNet (the part of it this repository implements)
-    nerf_only = None
-    if job.guidance_kind == "sd15_random" and not args.no_nerf_only:
+    # second figure, same run: the iteration without the frozen prior's UNet (the RGB phase still runs the SD-1.5 VAE encoder)
+    big = job.guidance_kind in ("sd15_random", "if_random")
+    without_unet = None
+    if big and not args.no_nerf_only:
         job.prior.unet.skip_unet = True
         step.graphs.clear(); step.graph_uses.clear(); step._warm.clear()
         for name, _ in plan:
             job.prime(name)
-        nerf_only = timed_pass()
+        without_unet = timed_pass()
         job.prior.unet.skip_unet = False
         step.graphs.clear(); step.graph_uses.clear(); step._warm.clear()
     # third figure: the reference's host flow (torch.amp.GradScaler + foreach Adan, no device-side tail, no graph replay,
@@ -711,9 +798,33 @@ def main():
         job.calibrate()
         ref_flow = timed_pass()
         job.step_obj = graph_step
+    # fourth figure: THIS REPOSITORY's part of the iteration on its own — the same scene, cameras and phase mix with the frozen
+    # networks (UNet and VAE encoder: stock PyTorch / MIOpen kernels, ~85 % of the headline step) replaced by the few-launch
+    # consistent stand-in: march, 7-point hash-grid field, fused render, image head, SDS arithmetic, backward, scatter, Adan
+    nerf_only = nerf_only_ms = nerf_only_samples = None
+    if not args.no_nerf_only:
+        if big:
+            graph_step, big_prior, big_kind = job.step_obj, job.prior, job.guidance_kind
+            job.use_synthetic_prior()
+            job.build()
+            job.calibrate()
+            for name, _ in plan:
+                job.prime(name)
+            nerf_only = timed_pass()
+            nerf_only_samples = job.step_obj.last.get("num_samples")
+            job.step_obj, job.prior, job.guidance_kind = graph_step, big_prior, big_kind
+        else:
+            nerf_only = job_throughput(world, args.steps, elapsed)      # the headline run already used the stand-in
+        nerf_only_ms = 1e3 * world / nerf_only
     stage("secondary passes done")
-    result["iters_per_sec_without_unet"] = nerf_only
+    result["iters_per_sec_without_unet"] = without_unet
     result["iters_per_sec_reference_flow"] = ref_flow
+    result["iters_per_sec_nerf_only"] = nerf_only
+    result["ms_nerf_only"] = nerf_only_ms
+    # the scene this pass runs on is the one the headline pass trained (denser than a fresh scene: the iteration's cost is
+    # proportional to the samples the march emits), so the sample count of its last iteration is printed beside it
+    result["samples_last_iter_nerf_only"] = nerf_only_samples
+    result["seconds_to_first_barrier_per_rank"] = first_barrier_s
 
     if rank != 0:
         if dist is not None:
@@ -722,32 +833,79 @@ def main():
         return
 
     ksum = timer.summary()
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the number comes from the
-    # committed summary of `tools/gpu_profile_round.sh` over this same command, taken this round (FETCH_SIZE doubled: on
-    # gfx950 it tallies 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM"); null when the file is absent.
-    traffic, traffic_file = None, "profiles/r02_pmc_traffic.json"
-    try:
-        with open(os.path.join(ROOT, traffic_file)) as f:
-            pm = json.load(f)["k_grid_fwd"]
-        traffic = (2.0 * pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM traffic: rocprofv3 PMC passes cannot run inside this process, so the numbers come from the committed summary of
+    # `tools/gpu_profile_round.sh` over this same command, taken this round (FETCH_SIZE doubled: on gfx950 it tallies 128-byte
+    # requests at 64 B, MI355X_MICROARCH.md "HBM"). The file stores, per kernel, the counters AND the work of the launches they
+    # were averaged over (`points_per_launch`); traffic is scaled per point to the launch size this run reports, so that
+    # `traffic`, `algorithmic_bytes_per_launch` and `avg_launch_us` describe the same launch. null when the file is absent.
+    traffic_file = next((f for f in ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
+                         if os.path.exists(os.path.join(ROOT, f))), None)
+    pmc = {}
+    if traffic_file:
+        try:
+            with open(os.path.join(ROOT, traffic_file)) as f:
+                pmc = json.load(f)
+        except (OSError, ValueError):
+            pmc = {}
+
+    def scaled_traffic(kernel, units_this_run, unit_bytes_written):
+        """(traffic bytes per launch at this run's size, units per launch of the PMC pass); the PMC pass's own work per launch is
+        its `points_per_launch` when recorded, else WRITE_SIZE / bytes written per unit."""
+        pm = pmc.get(kernel)
+        if not pm or "FETCH_SIZE_KB_avg" not in pm or "WRITE_SIZE_KB_avg" not in pm or not units_this_run:
+            return None, None
+        total = (2.0 * pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]) * 1024.0
+        units = pm.get("points_per_launch") or (pm["WRITE_SIZE_KB_avg"] * 1024.0 / unit_bytes_written)
+        return total / units * units_this_run, units
+
     enc = ksum.get("grid_encode_forward", {"GBps": 0.0, "avg_us": 0.0, "launches": 0, "bytes": 0})
+    enc_points = (enc["bytes"] / enc["launches"] / 588.0) if enc.get("launches") else 0.0
+    traffic, pmc_points = scaled_traffic("k_grid_fwd", enc_points, 64.0)        # 16 levels x 2 halves written per point
+    prior_txt = {
+        "sd15_random": " (SD-1.5 UNet + VAE-encoder architecture, 860 M + 34 M parameters, random weights, evaluated in full; its damped "
+                       "output is added to the consistent stand-in; diffusers/hub weights absent)",
+        "if_random": " (pixel-space UNet for `--IF`: this repository's SD-1.5-topology UNet with 3 -> 6 channels and a 4096-wide text "
+                     "context, ~0.9 B parameters = the size of IF-I-L, random weights, evaluated in full at 64 x 64; DeepFloyd IF-I-XL "
+                     "(4.3 B) and T5 absent)",
+    }.get(job.guidance_kind, " (consistent-denoiser stand-in for the frozen prior; diffusers/hub weights absent)")
+    cfg_name = "BASELINE configs[3] (`--IF`: pixel-space SDS at 64 x 64, no latent phase)" if args.prior == "if" else "BASELINE configs[1]"
     result["config"] = {
-        "workload": "BASELINE configs[1]: Instant-NGP -O iteration, 4096 rays (64x64), 128^3 occupancy grid, <=1024 steps/ray, "
+        "workload": cfg_name + ": Instant-NGP -O iteration, 4096 rays (64x64), 128^3 occupancy grid, <=1024 steps/ray, "
                     "16-level hash grid (2^19 x 2 fp16), 7 field evals/sample, SDS loss, AMP backward, Adan step, grid refresh "
                     "every 16 iters; timed steps = " + " + ".join(f"{k} {n}" for n, k in plan),
-        "guidance": job.guidance_kind + (" (SD-1.5 UNet + VAE-encoder architecture, 860 M + 34 M parameters, random weights, evaluated in full; "
-                                         "its damped output is added to the consistent stand-in; diffusers/hub weights absent)"
-                                         if job.guidance_kind == "sd15_random" else
-                                         " (consistent-denoiser stand-in for the frozen prior; diffusers/hub weights absent)"),
+        "guidance": job.guidance_kind + prior_txt, "prior": args.prior,
         "rays_per_iter": 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid, "phase": args.phase}
+    sec = enc["avg_us"] * 1e-6
     result["roofline"] = {
         "bound": "hbm", "kernel": "k_grid_fwd<half> (7-point stencil batches of the iteration)", "achieved": enc["GBps"],
         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": enc["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
-        "traffic_unit": f"bytes per launch ({traffic_file})",
+        "traffic_unit": f"bytes per launch, rocprofv3 2*FETCH_SIZE + WRITE_SIZE of {traffic_file} (measured at {pmc_points and round(pmc_points)} "
+                        f"points per launch) scaled per point to this run's launch size",
+        "hbm_frac": (traffic / sec / 1e9 / HBM_PEAK_GBPS) if (traffic and sec > 0) else None,
+        "points_per_launch": enc_points,
         "algorithmic_bytes_per_launch": (enc["bytes"] / enc["launches"]) if enc.get("launches") else None,
         "avg_launch_us": enc["avg_us"], "launches": enc["launches"], "measured_in": roofline_pass, "algorithmic_bytes_per_point": 588}
+    # north_star's second kernel: the compositor. On the training path it is fused with normal + shading + regulariser sums
+    # (csrc/render.hip), so two byte counts are given: SURVEY.md §8(d)'s compositor bytes (what the reference's kernel alone
+    # would move: 28 / 44 B per sample + 28 / 48 B per ray) and the fused kernel's own compulsory bytes (64 / 100 B per sample
+    # + 48 / 96 B per ray: 7 densities, albedo, direction, (t, dt) in; weight out; the gradients of all of those backward).
+    comp = {}
+    for tag, key, k_pmc, survey, fused_b, wr in (("forward", "render_train_forward", "k_render_train_fwd", COMPOSITE_FWD_BYTES, RENDER_FWD_BYTES, 4.0),
+                                                 ("backward", "render_train_backward", "k_render_train_bwd", COMPOSITE_BWD_BYTES, RENDER_BWD_BYTES, 40.0)):
+        r = ksum.get(key)
+        if not r or not r["launches"]:
+            continue
+        M = (r["bytes"] / r["launches"] - 4096 * fused_b[1]) / fused_b[0]        # samples per launch (the timer counted fused bytes)
+        t = r["avg_us"] * 1e-6
+        b_survey, b_fused = M * survey[0] + 4096 * survey[1], M * fused_b[0] + 4096 * fused_b[1]
+        tr, _ = scaled_traffic(k_pmc, M, wr)
+        comp[tag] = {"kernel": k_pmc, "avg_launch_us": r["avg_us"], "samples_per_launch": M, "rays": 4096,
+                     "achieved_survey_bytes": b_survey / t / 1e9, "frac_survey_bytes": b_survey / t / 1e9 / HBM_PEAK_GBPS,
+                     "achieved_fused_bytes": b_fused / t / 1e9, "frac_fused_bytes": b_fused / t / 1e9 / HBM_PEAK_GBPS,
+                     "traffic": tr, "hbm_frac": (tr / t / 1e9 / HBM_PEAK_GBPS) if tr else None, "Mrays_per_s": 4096 / t / 1e6}
+    result["roofline_composite"] = dict(comp, bound="hbm", peak=HBM_PEAK_GBPS, unit="GB/s", measured_in=roofline_pass,
+                                        bytes_survey_per_sample_fwd_bwd=[COMPOSITE_FWD_BYTES[0], COMPOSITE_BWD_BYTES[0]],
+                                        bytes_fused_per_sample_fwd_bwd=[RENDER_FWD_BYTES[0], RENDER_BWD_BYTES[0]])
     result["kernels_in_step"] = {k: {"GBps": round(v["GBps"], 1), "avg_us": round(v["avg_us"], 1), "launches": v["launches"]}
                                  for k, v in ksum.items()}
     if not args.no_kernel_bench:
@@ -768,6 +926,7 @@ def main():
                 "sample": f"the reference's -O2 vanilla-NeRF path ({'its own code, /root/reference' if cb['kind'] == 'reference' else 'oracle/o2_path.py, pinned to it by tests/golden/o2_ref.npz'}): "
                           f"4096 rays x (64 + 32) samples, render + backward with a dummy SDS gradient, fp32, "
                           f"torch threads = {cb['cores']} = the fastest of the probe {cb['thread_probe_s_per_albedo_iter']} s per 'albedo' iteration "
+                          f"(every thread count measured in its own child process, {cb['probe_seconds']:.0f} s in total) "
                           f"(os.cpu_count() = {cb['os_cpu_count']}, {cb['cpu_model']}); value = 'lambertian' "
                           f"shading (autograd normals, as 80 % of a run): median of {lam['iters']} iterations {lam['s_per_iter_median']:.2f} s; "
                           f"'albedo': {cb['shadings']['albedo']['s_per_iter_median']:.2f} s; {cb['seconds']:.0f} s of CPU work in total",

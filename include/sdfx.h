@@ -54,6 +54,17 @@ const char* sdfx_last_error(void);
  * when the kernel runs. Set it around calls whose buffers share one sample axis, clear it afterwards.
  */
 void sdfx_set_row_limit(const int32_t* total, uint32_t period);
+/*
+ * Extension — finite-difference stencil batches formed inside the kernels. The -O iteration evaluates the field at each sample
+ * and at x +- epsilon along each axis (nerf/network_grid.py:81-96): a [7, M, 3] batch that is a pure function of the M samples.
+ * With a source set (calling thread only; xyzs = NULL clears it), the grid-encoder forward / backward (all four kernels), the
+ * binned scatter and the field forward / backward take row r of a B = 7 M row batch from xyzs[r % M] and slab r / M — slab 0 the
+ * sample, slabs 1..6 = +x, -x, +y, -y, +z, -z with the whole offset point clamped to [-bound, bound] — instead of reading their
+ * `inputs` / `x` arguments, which may then be NULL: world coordinates for the density blob, (p + bound) * float(1 / two_bound)
+ * for the encoder (gridencoder/grid.py:157 as PyTorch evaluates it). Bit-identical to passing the tensors
+ * sdfx_field_stencil_points writes. xyzs is a DEVICE pointer [M, 3] float32 read when the kernel runs; B must equal 7 M.
+ */
+void sdfx_set_stencil_source(const float* xyzs, uint32_t M, float epsilon, float bound, double two_bound);
 /* version / build info string (arch, git-less) */
 const char* sdfx_build_info(void);
 

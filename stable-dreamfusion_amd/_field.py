@@ -43,7 +43,8 @@ def _check_enc(enc, layout, B):
 
 def forward(enc, layout, x, packed, B, blob_density, blob_radius, sigma, albedo):
     _check_enc(enc, layout, B)
-    S.check_tensor(x, "x", _F32)
+    if x is not None:           # None inside `_sdfx.stencil_source`
+        S.check_tensor(x, "x", _F32)
     S.check_tensor(packed, "packed", torch.int32)
     S.call("sdfx_field_forward", S.ptr(enc), layout, S.ptr(x), S.ptr(packed), B, float(blob_density), float(blob_radius),
            S.ptr(S.check_tensor(sigma, "sigma", _F32)), S.ptr(S.check_tensor(albedo, "albedo", _F32)), S.stream())
@@ -52,7 +53,9 @@ def forward(enc, layout, x, packed, B, blob_density, blob_radius, sigma, albedo)
 def backward(enc, layout, x, packed, B, blob_density, blob_radius, dsigma, dalbedo, denc, dw1, db1, dw2, db2, dw3, db3):
     _check_enc(enc, layout, B)
     _check_enc(denc, layout, B)
-    for t, n in ((x, "x"), (dsigma, "dsigma"), (dalbedo, "dalbedo"), (dw1, "dw1"), (db1, "db1"), (dw2, "dw2"), (db2, "db2"),
+    if x is not None:
+        S.check_tensor(x, "x", _F32)
+    for t, n in ((dsigma, "dsigma"), (dalbedo, "dalbedo"), (dw1, "dw1"), (db1, "db1"), (dw2, "dw2"), (db2, "db2"),
                  (dw3, "dw3"), (db3, "db3")):
         S.check_tensor(t, n, _F32)
     nbytes = int(S.lib().sdfx_field_backward_scratch_bytes(B))

@@ -38,8 +38,10 @@ def _same(a, b, na, nb):
 
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C_, L, max_level, S_, H, dy_dx, gridtype,
                         align_corners, interp, out_layout=0, slabs=1, step=0.0):
-    """`slabs`, `step` (extensions): locality hints of sdfx_grid_encode_forward_hint; outputs do not depend on them."""
-    S.check_tensor(inputs, "inputs", torch.float32)
+    """`slabs`, `step` (extensions): locality hints of sdfx_grid_encode_forward_hint; outputs do not depend on them.
+    `inputs` may be None inside `_sdfx.stencil_source` (the kernels form the stencil batch themselves)."""
+    if inputs is not None:
+        S.check_tensor(inputs, "inputs", torch.float32)
     _table(embeddings, "embeddings")
     S.check_tensor(offsets, "offsets", torch.int32)
     _table(outputs, "outputs")
@@ -80,7 +82,8 @@ def _binned_scratch(device, offsets, L, max_level, S_, H, is_half):
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C_, L, max_level, S_, H, dy_dx,
                          grad_inputs, gridtype, align_corners, interp, grad_layout=0):
     _table(grad, "grad")
-    S.check_tensor(inputs, "inputs", torch.float32)
+    if inputs is not None:      # None inside `_sdfx.stencil_source`
+        S.check_tensor(inputs, "inputs", torch.float32)
     _table(embeddings, "embeddings")
     S.check_tensor(offsets, "offsets", torch.int32)
     _table(grad_embeddings, "grad_embeddings")

@@ -38,7 +38,8 @@ _HEAD_SCRATCH = {}
 
 
 def _head_scratch(device, N):
-    key = (device.index, N)
+    # one buffer per (device, stream, N): the kernels of one stream are ordered, two trainers on different streams must not share it
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, N)
     buf = _HEAD_SCRATCH.get(key)
     if buf is None:
         buf = _HEAD_SCRATCH[key] = torch.empty(int(S.lib().sdfx_head_scratch_bytes(N)), dtype=torch.uint8, device=device)

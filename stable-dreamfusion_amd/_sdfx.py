@@ -84,6 +84,7 @@ _SIGNATURES = {
     "sdfx_entropy_forward": [_ptr, _u32, _ptr, _ptr, _ptr],
     "sdfx_entropy_backward": [_ptr, _u32, _ptr, _ptr, _ptr, _ptr],
     "sdfx_set_row_limit": [_ptr, _u32],
+    "sdfx_set_stencil_source": [_ptr, _u32, _f32, _f32, C.c_double],
     "sdfx_march_set_impl": [_int],
     "sdfx_grid_set_impl": [_int, _int],
     "sdfx_grid_backward_plan": [_ptr, _u32, _f32, _u32, _u32, _int, _ptr, _ptr],
@@ -147,6 +148,26 @@ class row_limit:
     def __exit__(self, *exc):
         if self.total is not None:
             lib().sdfx_set_row_limit(None, 0)
+        return False
+
+
+class stencil_source:
+    """`with stencil_source(xyzs, epsilon, bound): ...` — sdfx_set_stencil_source around the calls inside (include/sdfx.h): the
+    grid-encoder and field kernels form row r of the [7, M, 3] finite-difference stencil batch of `xyzs` [M, 3] themselves and
+    ignore their `inputs` / `x` arguments (pass None). `xyzs` None: no-op."""
+
+    def __init__(self, xyzs, epsilon, bound):
+        self.xyzs, self.epsilon, self.bound = xyzs, float(epsilon), float(bound)
+
+    def __enter__(self):
+        if self.xyzs is not None:
+            check_tensor(self.xyzs, "stencil source", torch.float32)
+            lib().sdfx_set_stencil_source(ptr(self.xyzs), self.xyzs.shape[0], self.epsilon, self.bound, 2.0 * self.bound)
+        return self
+
+    def __exit__(self, *exc):
+        if self.xyzs is not None:
+            lib().sdfx_set_stencil_source(None, 0, 0.0, 0.0, 0.0)
         return False
 
 

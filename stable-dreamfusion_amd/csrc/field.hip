@@ -118,8 +118,16 @@ __global__ __launch_bounds__(256) void k_field_pack(const float* __restrict__ w1
 }
 
 // density blob of nerf/renderer.py:345: blob_density * exp(-|x|^2 / (2 r^2))
-__device__ __forceinline__ float density_blob(const float* __restrict__ x, uint32_t b, float blob_density, float inv_2r2) {
-    const float px = x[(size_t)b * 3], py = x[(size_t)b * 3 + 1], pz = x[(size_t)b * 3 + 2];
+// (with a stencil source, sdfx_set_stencil_source, row b of the [7, M, 3] batch is formed from the base samples instead of read)
+__device__ __forceinline__ float density_blob(const StencilSrc& src, const float* __restrict__ x, uint32_t b, float blob_density,
+                                              float inv_2r2) {
+    float p[3];
+    if (src.xyzs) {
+        stencil_world_row(src, b, p);
+    } else {
+        p[0] = x[(size_t)b * 3]; p[1] = x[(size_t)b * 3 + 1]; p[2] = x[(size_t)b * 3 + 2];
+    }
+    const float px = p[0], py = p[1], pz = p[2];
     const float d = px * px + py * py + pz * pz;
     return blob_density * expf(-d * inv_2r2);
 }
@@ -133,13 +141,13 @@ __global__ __launch_bounds__(kThreads) void k_field_forward(const uint32_t* __re
                                                              const float* __restrict__ x,
                                                              const uint32_t* __restrict__ P, uint32_t B,
                                                              float blob_density, float inv_2r2,
-                                                             float* __restrict__ sigma, float* __restrict__ albedo, RowLimit rl) {
+                                                             float* __restrict__ sigma, float* __restrict__ albedo, RowLimit rl, StencilSrc src) {
     const uint32_t b = blockIdx.x * kThreads + threadIdx.x;
     if (b >= B || !row_live(rl, b)) return;
     Acts a;
     load_enc(enc, enc_layout, B, b, a.enc);
     mlp_forward(P, a);
-    const float z = a.h3[0] + density_blob(x, b, blob_density, inv_2r2);
+    const float z = a.h3[0] + density_blob(src, x, b, blob_density, inv_2r2);
     sigma[b] = expf(z);  // trunc_exp forward (activation.py:9-11)
     albedo[(size_t)b * 3 + 0] = sigmoidf_(a.h3[1]);
     albedo[(size_t)b * 3 + 1] = sigmoidf_(a.h3[2]);
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
                                                               const float* __restrict__ dsigma,
                                                               const float* __restrict__ dalbedo,
                                                               uint32_t* __restrict__ denc,
-                                                              float* __restrict__ partials, RowLimit rl) {
+                                                              float* __restrict__ partials, RowLimit rl, StencilSrc src) {
     __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * kRowHalves];
     const uint32_t t = threadIdx.x;
     const int lane = (int)(t & 63);
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward(const uint32_t* __r
             load_enc(enc, enc_layout, B, b, a.enc);
             mlp_forward(P, a);
             // output activations: d sigma / d z = exp(min(z, 15)) (activation.py:13-16); d sigmoid = a (1 - a)
-            const float z = a.h3[0] + density_blob(x, b, blob_density, inv_2r2);
+            const float z = a.h3[0] + density_blob(src, x, b, blob_density, inv_2r2);
             const float g0 = dsigma[b] * expf(fminf(z, 15.0f));
             float g[3];
 #pragma unroll
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_mma(const uint32_t* 
                                                                  const float* __restrict__ x,
                                                                  const uint32_t* __restrict__ P, uint32_t B,
                                                                  float blob_density, float inv_2r2,
-                                                                 float* __restrict__ sigma, float* __restrict__ albedo, RowLimit rl) {
+                                                                 float* __restrict__ sigma, float* __restrict__ albedo, RowLimit rl, StencilSrc src) {
     if (rows_dead(rl, blockIdx.x * kThreads, kThreads)) return;   // a tile of padding rows
     const uint32_t b = blockIdx.x * kThreads + threadIdx.x;
     const bool valid = b < B && row_live(rl, b);  // every lane takes part in the swaps and the MFMAs; the others compute on zeros
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_mma(const uint32_t* 
     load_enc_words(enc, enc_layout, B, b, valid, a.enc);
     mma_forward(P, reinterpret_cast<const uint4*>(P + kFragBase), lane, a);
     if (!valid) return;
-    const float z = a.h3[0] + density_blob(x, b, blob_density, inv_2r2);
+    const float z = a.h3[0] + density_blob(src, x, b, blob_density, inv_2r2);
     sigma[b] = expf(z);
     albedo[(size_t)b * 3 + 0] = sigmoidf_(a.h3[1]);
     albedo[(size_t)b * 3 + 1] = sigmoidf_(a.h3[2]);
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
                                                                   const float* __restrict__ dsigma,
                                                                   const float* __restrict__ dalbedo,
                                                                   uint32_t* __restrict__ denc,
-                                                                  float* __restrict__ partials, RowLimit rl) {
+                                                                  float* __restrict__ partials, RowLimit rl, StencilSrc src) {
     __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * kRowHalves];
     __shared__ uint4 sfrag[LDSF ? kFrags * 64 : 1];
     const uint32_t t = threadIdx.x;
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
                 in_ds = dsigma[b];
 #pragma unroll
                 for (int c = 0; c < 3; c++) in_da[c] = dalbedo[(size_t)b * 3 + c];
-                in_blob = density_blob(x, b, blob_density, inv_2r2);
+                in_blob = density_blob(src, x, b, blob_density, inv_2r2);
             }
             const uint32_t bn = (tile + gridDim.x) * kThreads + t;
             load_enc_words(enc, enc_layout, B, bn, tile + gridDim.x < ntiles && live(bn), nxt);
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
         {
             float g0 = 0.f, g[3] = {0.f, 0.f, 0.f};
             if (valid) {
-                const float z = a.h3[0] + (LDSF ? in_blob : density_blob(x, b, blob_density, inv_2r2));
+                const float z = a.h3[0] + (LDSF ? in_blob : density_blob(src, x, b, blob_density, inv_2r2));
                 g0 = (LDSF ? in_ds : dsigma[b]) * expf(fminf(z, 15.0f));
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
                                                                                    const float* __restrict__ dsigma,
                                                                                    const float* __restrict__ dalbedo,
                                                                                    uint32_t* __restrict__ denc, float* __restrict__ partials,
-                                                                                   RowLimit rl) {
+                                                                                   RowLimit rl, StencilSrc src) {
     constexpr uint32_t TS = 128 * NB, RH = TS + 8;
     __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * RH];
     __shared__ uint4 sfrag[LDSF ? kFrags * 64 : 1];
@@ -779,7 +787,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
             if (hi == 0 && live[c]) {   // the hi = 0 lanes own the 4 outputs of a sample
                 ds[c] = dsigma[row[c]];
                 da[c][0] = dalbedo[(size_t)row[c] * 3]; da[c][1] = dalbedo[(size_t)row[c] * 3 + 1]; da[c][2] = dalbedo[(size_t)row[c] * 3 + 2];
-                bl[c] = density_blob(x, row[c], blob_density, inv_2r2);
+                bl[c] = density_blob(src, x, row[c], blob_density, inv_2r2);
             }
         }
 
@@ -918,7 +926,7 @@ template <int NB>
 __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* __restrict__ enc, const float* __restrict__ x,
                                                                  const uint32_t* __restrict__ P, uint32_t B, float blob_density,
                                                                  float inv_2r2, float* __restrict__ sigma, float* __restrict__ albedo,
-                                                                 RowLimit rl) {
+                                                                 RowLimit rl, StencilSrc src) {
     constexpr uint32_t TS = 128 * NB, kFwdFrags = fW3T;   // fragments of W1, W2, W3
     __shared__ uint4 sfrag[kFwdFrags * 64];
     __shared__ float sbias[kBiasPad];
@@ -980,7 +988,7 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* 
                 float h3[kOut];
 #pragma unroll
                 for (int o = 0; o < (int)kOut; o++) h3[o] = (float)(_Float16)(a[c][o] + b3[o]);
-                sigma[row[c]] = expf(h3[0] + density_blob(x, row[c], blob_density, inv_2r2));  // trunc_exp forward (activation.py:9-11)
+                sigma[row[c]] = expf(h3[0] + density_blob(src, x, row[c], blob_density, inv_2r2));  // trunc_exp forward (activation.py:9-11)
                 albedo[(size_t)row[c] * 3 + 0] = sigmoidf_(h3[1]);
                 albedo[(size_t)row[c] * 3 + 1] = sigmoidf_(h3[2]);
                 albedo[(size_t)row[c] * 3 + 2] = sigmoidf_(h3[3]);
@@ -1099,7 +1107,9 @@ int sdfx_field_pack(const float* w1, const float* b1, const float* w2, const flo
 
 int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const uint32_t* packed, uint32_t B,
                        float blob_density, float blob_radius, float* sigma, float* albedo, sdfx_stream_t stream) {
-    SDFX_REQUIRE(enc && x && packed && sigma && albedo, "field_forward: null pointer");
+    SDFX_REQUIRE(enc && packed && sigma && albedo, "field_forward: null pointer");
+    SDFX_REQUIRE(stencil_src().xyzs ? (uint64_t)stencil_src().M * 7u == B : x != nullptr,
+                 "field_forward: null x, or a stencil source whose 7 M differs from B = %u", B);
     SDFX_REQUIRE(enc_layout == 0 || enc_layout == 1, "field_forward: enc_layout must be 0 ([L,B,2]) or 1 ([B,32])");
     SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_forward: features misaligned");
     SDFX_REQUIRE(blob_radius > 0, "field_forward: blob_radius must be positive");
@@ -1107,20 +1117,20 @@ int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const ui
     if (use_dot2()) {
         hipLaunchKernelGGL(k_field_forward, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
-                           1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit());
+                           1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src());
     } else if (enc_layout == 0 && native_forward() > 0) {
         const int nb = native_forward();
         const uint32_t tiles = div_up(B, 128u * nb), blocks = tiles < 2048u ? tiles : 2048u;
         if (nb == 2)
             hipLaunchKernelGGL(k_field_forward_nat<2>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), static_cast<const uint32_t*>(enc), x,
-                               packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit());
+                               packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src());
         else
             hipLaunchKernelGGL(k_field_forward_nat<1>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), static_cast<const uint32_t*>(enc), x,
-                               packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit());
+                               packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src());
     } else {
         hipLaunchKernelGGL(k_field_forward_mma, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
-                           1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit());
+                           1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src());
     }
     return check_launch("field_forward");
 }
@@ -1129,8 +1139,10 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
                         float blob_density, float blob_radius, const float* dsigma, const float* dalbedo, void* denc,
                         float* scratch, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
                         sdfx_stream_t stream) {
-    SDFX_REQUIRE(enc && x && packed && dsigma && dalbedo && denc && scratch && dw1 && db1 && dw2 && db2 && dw3 && db3,
+    SDFX_REQUIRE(enc && packed && dsigma && dalbedo && denc && scratch && dw1 && db1 && dw2 && db2 && dw3 && db3,
                  "field_backward: null pointer");
+    SDFX_REQUIRE(stencil_src().xyzs ? (uint64_t)stencil_src().M * 7u == B : x != nullptr,
+                 "field_backward: null x, or a stencil source whose 7 M differs from B = %u", B);
     SDFX_REQUIRE(enc_layout == 0 || enc_layout == 1, "field_backward: enc_layout must be 0 ([L,B,2]) or 1 ([B,32])");
     SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_backward: features misaligned");
     SDFX_REQUIRE(blob_radius > 0, "field_backward: blob_radius must be positive");
@@ -1140,7 +1152,7 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
         if (use_dot2()) {
             hipLaunchKernelGGL(k_field_backward, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
                                enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
-                               static_cast<uint32_t*>(denc), scratch, row_limit());
+                               static_cast<uint32_t*>(denc), scratch, row_limit(), stencil_src());
         } else {
             static const bool lds_frags = [] { const char* e = getenv("SDFX_FIELD_BWD_LDSFRAG"); return !(e && e[0] == '0'); }();
             static const bool native = [] { const char* e = getenv("SDFX_FIELD_BWD_NAT"); return !(e && e[0] == '0'); }();
@@ -1152,18 +1164,18 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
                 const RowLimit rlim = row_limit();
 #define SDFX_NAT(LDSF_, NB_)                                                                                                       \
     hipLaunchKernelGGL((k_field_backward_nat<LDSF_, NB_>), dim3(nblocks), dim3(kThreads), 0, st, ep, x, packed, B, blob_density, i2, \
-                       dsigma, dalbedo, dp, scratch, rlim)
+                       dsigma, dalbedo, dp, scratch, rlim, stencil_src())
                 if (nb == 2) { if (lds_frags) SDFX_NAT(true, 2); else SDFX_NAT(false, 2); }
                 else { if (lds_frags) SDFX_NAT(true, 1); else SDFX_NAT(false, 1); }
 #undef SDFX_NAT
             } else if (lds_frags)
                 hipLaunchKernelGGL(k_field_backward_mma<true>, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
                                    enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
-                                   static_cast<uint32_t*>(denc), scratch, row_limit());
+                                   static_cast<uint32_t*>(denc), scratch, row_limit(), stencil_src());
             else
                 hipLaunchKernelGGL(k_field_backward_mma<false>, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
                                    enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
-                                   static_cast<uint32_t*>(denc), scratch, row_limit());
+                                   static_cast<uint32_t*>(denc), scratch, row_limit(), stencil_src());
         }
     }
     hipLaunchKernelGGL(k_field_wgrad_reduce, dim3(div_up(kGradWords, 64)), dim3(64 * kReduceSplit), 0, st, scratch, nblocks, dw1, db1,

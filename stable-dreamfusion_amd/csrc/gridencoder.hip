@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kTile) void k_grid_forward(const float* __restrict_
                                                          uint32_t L, GridPlan plan,
                                                          typename Elem<HALF>::type* __restrict__ dy_dx,
                                                          uint32_t gridtype, int align_corners, uint32_t interp,
-                                                         int out_layout) {
+                                                         int out_layout, StencilSrc src) {
     using T = typename Elem<HALF>::type;
     using E = Elem<HALF>;
     uint32_t level, tile;
@@ -46,9 +46,12 @@ __global__ __launch_bounds__(kTile) void k_grid_forward(const float* __restrict_
 
     float in[D];
     bool oob = false;
+    if constexpr (D == 3) {
+        if (src.xyzs) stencil_unit_row(src, b, in);   // sdfx_set_stencil_source: the [7, M, 3] batch formed here
+    }
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
-        in[d] = inputs[(size_t)b * D + d];
+        if (!(D == 3 && src.xyzs)) in[d] = inputs[(size_t)b * D + d];
         if (in[d] < 0 || in[d] > 1) oob = true;
     }
     if (oob) {  // gridencoder.cu:105-130
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(kTile) void k_grid_backward(const typename Elem<HAL
                                                           const float* __restrict__ inputs,
                                                           typename Elem<HALF>::type* __restrict__ grad_table,
                                                           uint32_t B, uint32_t L, GridPlan plan, uint32_t gridtype,
-                                                          int align_corners, uint32_t interp, int grad_layout) {
+                                                          int align_corners, uint32_t interp, int grad_layout, RowLimit rl,
+                                                          StencilSrc src) {
     using T = typename Elem<HALF>::type;
     using E = Elem<HALF>;
     constexpr uint32_t N_C = C < 2 ? C : 2;
@@ -205,12 +209,18 @@ __global__ __launch_bounds__(kTile) void k_grid_backward(const typename Elem<HAL
     const uint32_t gid = tile * kTile + threadIdx.x;
     const uint32_t b = gid * N_C / C;
     if (b >= B) return;
+    // padding rows of a fixed-capacity batch (sdfx_set_row_limit): their gradient rows were never written by the producer
+    // (the field backward honours the same limit), so they must not be read here either
+    if (!row_live(rl, b)) return;
     const uint32_t ch = gid * N_C - b * C;
 
     float in[D];
+    if constexpr (D == 3) {
+        if (src.xyzs) stencil_unit_row(src, b, in);
+    }
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
-        in[d] = inputs[(size_t)b * D + d];
+        if (!(D == 3 && src.xyzs)) in[d] = inputs[(size_t)b * D + d];
         if (in[d] < 0 || in[d] > 1) return;  // gridencoder.cu:279-284
     }
 
@@ -387,7 +397,21 @@ void launch_forward(const FwdArgs& a) {
     using T = typename Elem<HALF>::type;
     hipLaunchKernelGGL((k_grid_forward<D, C, HALF>), dim3(a.grid), dim3(kTile), 0, a.st, a.inputs,
                        static_cast<const T*>(a.table), static_cast<T*>(a.outputs), a.B, a.L, a.plan,
-                       static_cast<T*>(a.dy_dx), a.gridtype, a.align_corners, a.interp, a.out_layout);
+                       static_cast<T*>(a.dy_dx), a.gridtype, a.align_corners, a.interp, a.out_layout, stencil_src());
+}
+
+// sdfx_set_stencil_source: `inputs` may be NULL, the batch must be the [7, M, 3] stencil batch of the M source samples
+static inline bool stencil_ok(const float* inputs, uint32_t B, uint32_t D, const char* what) {
+    const StencilSrc src = stencil_src();
+    if (!src.xyzs) {
+        if (!inputs) set_error("%s: null inputs", what);
+        return inputs != nullptr;
+    }
+    if (D != 3 || (uint64_t)src.M * 7u != B) {
+        set_error("%s: a stencil source of M = %u samples needs D = 3 and B = 7 M (got D = %u, B = %u)", what, src.M, D, B);
+        return false;
+    }
+    return true;
 }
 
 struct BwdArgs {
@@ -403,7 +427,7 @@ void launch_backward(const BwdArgs& a) {
     } else {
         hipLaunchKernelGGL((k_grid_backward<D, C, HALF>), dim3(a.grid), dim3(kTile), 0, a.st,
                            static_cast<const T*>(a.grad), a.inputs, static_cast<T*>(a.grad_table), a.B, a.L, a.plan,
-                           a.gridtype, a.align_corners, a.interp, a.grad_layout);
+                           a.gridtype, a.align_corners, a.interp, a.grad_layout, row_limit(), stencil_src());
         if (a.dy_dx && a.grad_inputs) {
             hipLaunchKernelGGL((k_grid_input_backward<D, C, HALF>), dim3(div_up((uint64_t)a.B * D, 256)), dim3(256), 0,
                                a.st, static_cast<const T*>(a.grad), static_cast<const T*>(a.dy_dx),
@@ -448,7 +472,8 @@ int sdfx_grid_encode_forward_hint(const float* inputs, const void* embeddings, c
                                   sdfx_stream_t stream) {
     (void)offsets;
     if (B == 0) return SDFX_OK;   // an empty batch (a view that hits no occupied cell) is a no-op, whatever the pointers
-    SDFX_REQUIRE(inputs && embeddings && offsets_host && outputs, "grid_encode_forward: null pointer");
+    SDFX_REQUIRE(embeddings && offsets_host && outputs, "grid_encode_forward: null pointer");
+    if (!stencil_ok(inputs, B, D, "grid_encode_forward")) return SDFX_E_INVALID;
     if (!supported_dc(D, C)) {  // gridencoder.cu:392,409 throw std::runtime_error here
         set_error("GridEncoding: D must be 2, 3, 4 or 5 and C must be 1, 2, 4, 8, 16 or 32 (got D=%u C=%u)", D, C);
         return SDFX_E_UNSUPPORTED;
@@ -492,7 +517,8 @@ int sdfx_grid_encode_backward(const void* grad, const float* inputs, const void*
                               uint32_t gridtype, int align_corners, uint32_t interp, int is_half, int grad_layout,
                               sdfx_stream_t stream) {
     (void)offsets; (void)embeddings;
-    SDFX_REQUIRE(grad && inputs && offsets_host && grad_embeddings, "grid_encode_backward: null pointer");
+    SDFX_REQUIRE(grad && offsets_host && grad_embeddings, "grid_encode_backward: null pointer");
+    if (B && !stencil_ok(inputs, B, D, "grid_encode_backward")) return SDFX_E_INVALID;
     if (!supported_dc(D, C)) {
         set_error("GridEncoding: D must be 2, 3, 4 or 5 and C must be 1, 2, 4, 8, 16 or 32 (got D=%u C=%u)", D, C);
         return SDFX_E_UNSUPPORTED;

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
                                                                GridPlan plan, BinPlan bin, uint32_t gridtype,
                                                                int align_corners, uint32_t interp, int grad_layout,
                                                                uint32_t* __restrict__ cursors,
-                                                               Item<HALF>* __restrict__ items, RowLimit rl) {
+                                                               Item<HALF>* __restrict__ items, RowLimit rl, StencilSrc src) {
     using T = typename Elem<HALF>::type;
     using E = Elem<HALF>;
     constexpr uint32_t D = 3, C = 2, NCORN = 8, NITEM = NCORN * kPointsPerThread;
@@ -184,9 +184,10 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
         bool valid = b < b1 && row_live(rl, b);
         float in[D] = {0.f, 0.f, 0.f};
         if (valid) {
+            if (src.xyzs) stencil_unit_row(src, b, in);   // sdfx_set_stencil_source: the [7, M, 3] batch formed here
 #pragma unroll
             for (uint32_t d = 0; d < D; d++) {
-                in[d] = inputs[(size_t)b * D + d];
+                if (!src.xyzs) in[d] = inputs[(size_t)b * D + d];
                 if (in[d] < 0 || in[d] > 1) valid = false;  // gridencoder.cu:279-284
             }
         }
@@ -678,7 +679,12 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
                                      uint32_t max_level, float S, uint32_t H, uint32_t gridtype, int align_corners,
                                      uint32_t interp, int is_half, int grad_layout, void* scratch, uint64_t scratch_bytes,
                                      sdfx_stream_t stream) {
-    SDFX_REQUIRE(grad && inputs && offsets_host && grad_embeddings && scratch, "grid_encode_backward_binned: null pointer");
+    SDFX_REQUIRE(grad && offsets_host && grad_embeddings && scratch, "grid_encode_backward_binned: null pointer");
+    {
+        const StencilSrc src = stencil_src();   // sdfx_set_stencil_source: inputs may be NULL, B must be 7 M
+        SDFX_REQUIRE(src.xyzs ? (B == 0 || (uint64_t)src.M * 7u == B) : inputs != nullptr,
+                     "grid_encode_backward_binned: null inputs, or a stencil source whose 7 M differs from B = %u", B);
+    }
     if (!binned_supported(D, C, L, offsets_host)) {
         set_error("grid_encode_backward_binned: only D=3, C=2, levels of at most %u rows", kMaxBucketsPerLevel * kBucketRows);
         return SDFX_E_UNSUPPORTED;
@@ -737,7 +743,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         if (is_half) {
             hipLaunchKernelGGL(k_grid_bwd_bin<true>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const __half*>(grad),
                                inputs, static_cast<__half*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
-                               interp, grad_layout, cursors, static_cast<Item<true>*>(items), row_limit());
+                               interp, grad_layout, cursors, static_cast<Item<true>*>(items), row_limit(), stencil_src());
             hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(nsplits), dim3(kReduceThreadsFixed), 0, st,
                                static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items),
                                shared_acc);
@@ -747,7 +753,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         } else {
             hipLaunchKernelGGL(k_grid_bwd_bin<false>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const float*>(grad),
                                inputs, static_cast<float*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
-                               interp, grad_layout, cursors, static_cast<Item<false>*>(items), row_limit());
+                               interp, grad_layout, cursors, static_cast<Item<false>*>(items), row_limit(), stencil_src());
             hipLaunchKernelGGL(k_grid_bwd_reduce_ticket, dim3(nsplits), dim3(kReduceThreads), kReduceLdsBytes, st,
                                static_cast<float*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<false>*>(items));
         }

@@ -71,7 +71,8 @@ template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
 __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ inputs,
                                                      const typename Elem<HALF>::type* __restrict__ table,
                                                      typename Elem<HALF>::type* __restrict__ outputs, uint32_t B, uint32_t L,
-                                                     FwdPlan plan, int out_layout, const int32_t* __restrict__ row_total) {
+                                                     FwdPlan plan, int out_layout, const int32_t* __restrict__ row_total,
+                                                     StencilSrc src) {
     using T = typename Elem<HALF>::type;
     constexpr uint32_t C = 2;
     constexpr uint32_t RB = HALF ? 4u : 2u;   // rows per 16-byte block
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
     const T* tab = table + (size_t)lc.row0 * C;
 
     // ---- slots of this thread -> points ----
-    uint32_t pt[P];
+    uint32_t pt[P], sk[P], sm[P];   // row of the batch; stencil point and base sample of that row (stencil batches)
     bool live[P];
 #pragma unroll
     for (uint32_t j = 0; j < P; j++) {
@@ -105,19 +106,33 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
             const uint32_t lane = slot & 63u, g = lane / kGroup;
             const uint32_t sample = (slot >> 6) * kGroupsPerWave + g;
             live[j] = lane < kGroup * kGroupsPerWave && sample < n_live;
-            pt[j] = (lane - g * kGroup) * plan.slab_points + sample;
+            sk[j] = lane - g * kGroup;
+            sm[j] = sample;
+            pt[j] = sk[j] * plan.slab_points + sample;
         } else {
             live[j] = slot < n_live;
             pt[j] = slot;
+            sk[j] = 0; sm[j] = 0;
+            if (src.xyzs) { sk[j] = stencil_slab(slot < B ? slot : 0u, src.M); sm[j] = (slot < B ? slot : 0u) - sk[j] * src.M; }
         }
-        if (!live[j]) pt[j] = 0;   // a valid address to load from; nothing is stored
+        if (!live[j]) { pt[j] = 0; sk[j] = 0; sm[j] = 0; }   // a valid address to load from; nothing is stored
     }
 
     float xin[P][3];
 #pragma unroll
     for (uint32_t j = 0; j < P; j++) {
+        if (src.xyzs) {
+            // stencil batch formed here (sdfx_set_stencil_source): the seven lanes of a sample read the same 12 bytes — one or two
+            // 128-byte lines per wave and coordinate instead of one or two per SLAB
+            const float x[3] = {src.xyzs[(size_t)sm[j] * 3], src.xyzs[(size_t)sm[j] * 3 + 1], src.xyzs[(size_t)sm[j] * 3 + 2]};
+            float p[3];
+            stencil_world(src, sk[j], x, p);
 #pragma unroll
-        for (int d = 0; d < 3; d++) xin[j][d] = inputs[(size_t)pt[j] * 3 + d];
+            for (int d = 0; d < 3; d++) xin[j][d] = (p[d] + src.bound) * src.inv;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; d++) xin[j][d] = inputs[(size_t)pt[j] * 3 + d];
+        }
     }
 
     auto wrap = [&](uint32_t idx) -> uint32_t {   // index % hashmap_size (gridencoder.cu:78)
@@ -332,9 +347,10 @@ void launch(const float* inputs, const void* table, void* outputs, uint32_t B, u
     const RowLimit rl = row_limit();
     const uint32_t axis = plan.slabs == kGroup ? plan.slab_points : B;
     const int32_t* row_total = (rl.total && (rl.period == axis || (rl.period == 0 && plan.slabs != kGroup))) ? rl.total : nullptr;
+    const StencilSrc src = stencil_src();   // validated by the caller: src.M * 7 == B when set
 #define SDFX_FWD(INTERP_, ALIGN_, HASH_)                                                                               \
     hipLaunchKernelGGL((k_grid_fwd<HALF, INTERP_, ALIGN_, HASH_>), dim3(grid), dim3(kTile), 0, st, inputs,            \
-                       static_cast<const T*>(table), static_cast<T*>(outputs), B, L, plan, out_layout, row_total)
+                       static_cast<const T*>(table), static_cast<T*>(outputs), B, L, plan, out_layout, row_total, src)
     const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
     switch (sel) {
         case 0: SDFX_FWD(0u, false, false); break;

@@ -98,6 +98,11 @@ __global__ __launch_bounds__(kThreads, WAVES) void k_render_infer(InferArgs a, c
         bool have = false;
         float dt = 0.f, px = 0.f, py = 0.f, pz = 0.f;
         if (active) {
+            // Step cap: exactly max_steps samples per ray. The reference's host loop (renderer.py:768-794) counts ROUNDS of
+            // n_step = clamp(N / n_alive, 1, 8) samples and stops once the sum of the rounds' n_step reaches max_steps, so a ray
+            // that is still alive then has taken between max_steps and max_steps + 7 samples, depending on how many OTHER rays
+            // were alive in each round — a frame-global quantity a per-ray kernel cannot (and should not) reproduce. Rays that
+            // terminate by T < T_thresh or by leaving the box (all rays of a converged scene) are unaffected.
             while (t < far && steps < a.max_steps) {
                 if (march_probe(r, a.mp, a.bitfield, t, dt, px, py, pz)) { have = true; break; }
             }

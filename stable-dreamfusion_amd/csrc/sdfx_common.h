@@ -38,6 +38,18 @@ struct RowLimit {
 RowLimit row_limit();   // the calling thread's current setting
 static inline hipStream_t as_stream(sdfx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Finite-difference stencil batches formed in the kernels (sdfx_set_stencil_source): row r of the [7, M, 3] batch of
+// network_grid.py:81-96 — slab k = r / M: the sample itself (k = 0), then x +- eps along each axis with the WHOLE offset point
+// clamped to the box — is computed from the M base samples instead of being read. xyzs == nullptr: inactive. The arithmetic is
+// k_stencil_points' (csrc/field.hip), which is bit-identical to the tensor expressions: `unit` = (p + bound) * inv with inv the
+// float32 rounding of the double-precision reciprocal of 2 * bound (what PyTorch's `tensor / scalar` multiplies by).
+struct StencilSrc {
+    const float* xyzs;
+    uint32_t M;
+    float eps, bound, inv;
+};
+StencilSrc stencil_src();   // the calling thread's current setting
+
 // Zero `bytes` (a multiple of 4) of device memory with a KERNEL. hipMemsetAsync is avoided on purpose: captured into
 // a HIP graph it becomes a memset node, and the 5 MB one of the binned scatter did not clear its whole range on
 // replay (ROCm 7.2): accumulators kept sums from earlier iterations until the table gradient overflowed.
@@ -65,6 +77,42 @@ __device__ __forceinline__ bool rows_dead(const RowLimit& rl, uint32_t r0, uint3
     if (!rl.total) return false;
     const uint32_t j0 = rl.period ? r0 % rl.period : r0;
     return j0 >= (uint32_t)rl.total[0] && (rl.period == 0 || j0 + n <= rl.period);
+}
+#endif
+
+#if defined(__HIPCC__)
+// slab of row r in a [7, M, ...] batch without an integer division (r < 7 M)
+__device__ __forceinline__ uint32_t stencil_slab(uint32_t r, uint32_t M) {
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < 7; i++) k += (r >= i * M) ? 1u : 0u;
+    return k;
+}
+// world coordinates of stencil point k of the sample at `x` (k_stencil_points' arithmetic)
+__device__ __forceinline__ void stencil_world(const StencilSrc& s, uint32_t k, const float x[3], float p[3]) {
+    p[0] = x[0]; p[1] = x[1]; p[2] = x[2];
+    if (k > 0) {
+        const uint32_t axis = (k - 1) >> 1;
+        const float off = (k & 1) ? s.eps : -s.eps;
+#pragma unroll
+        for (uint32_t c = 0; c < 3; c++) {
+            const float v = c == axis ? x[c] + off : x[c];
+            p[c] = fminf(fmaxf(v, -s.bound), s.bound);
+        }
+    }
+}
+// row r -> world coordinates (loads the base sample)
+__device__ __forceinline__ void stencil_world_row(const StencilSrc& s, uint32_t r, float p[3]) {
+    const uint32_t k = stencil_slab(r, s.M), m = r - k * s.M;
+    const float x[3] = {s.xyzs[(size_t)m * 3], s.xyzs[(size_t)m * 3 + 1], s.xyzs[(size_t)m * 3 + 2]};
+    stencil_world(s, k, x, p);
+}
+// row r -> the encoder's unit-cube coordinates (gridencoder/grid.py:157)
+__device__ __forceinline__ void stencil_unit_row(const StencilSrc& s, uint32_t r, float u[3]) {
+    float p[3];
+    stencil_world_row(s, r, p);
+#pragma unroll
+    for (uint32_t c = 0; c < 3; c++) u[c] = (p[c] + s.bound) * s.inv;
 }
 #endif
 

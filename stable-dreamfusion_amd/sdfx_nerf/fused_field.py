@@ -14,9 +14,14 @@ import torch
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
+import os
+
 import _field
 import _gridencoder
 import _sdfx
+
+# the [7, M, 3] finite-difference stencil batch formed inside the kernels (sdfx_set_stencil_source) instead of by k_stencil_points
+_STENCIL_SOURCE = int(os.environ.get("SDFX_STENCIL_SOURCE", "1"))
 
 
 class _fused_field(Function):
@@ -32,7 +37,12 @@ class _fused_field(Function):
         if B == 0:   # a view that hits no occupied cell: nothing to evaluate, nothing to differentiate
             ctx.meta = None
             return x.new_zeros(0), x.new_zeros(0, 3)
-        if stencil_eps > 0:      # x: the M samples; the [7, M, 3] stencil batch and its unit-cube image from one kernel
+        src = None
+        if stencil_eps > 0 and _STENCIL_SOURCE:
+            # x: the M samples. The kernels form the [7, M, 3] stencil batch and its unit-cube image themselves
+            # (sdfx_set_stencil_source): no [7, M, 3] tensors, no stencil launch, one or two coordinate lines per wave
+            src, inputs = (x, stencil_eps, bound), None
+        elif stencil_eps > 0:    # the [7, M, 3] stencil batch and its unit-cube image from one kernel
             pts = torch.empty(B, 3, dtype=torch.float32, device=x.device)
             inputs = torch.empty(B, 3, dtype=torch.float32, device=x.device)
             _field.stencil_points(x, stencil_eps, bound, pts, inputs)
@@ -49,10 +59,13 @@ class _fused_field(Function):
                     b2.detach().float().contiguous(), w3.detach().float().contiguous(), b3.detach().float().contiguous(), packed)
         sigma = torch.empty(B, dtype=torch.float32, device=x.device)
         albedo = torch.empty(B, 3, dtype=torch.float32, device=x.device)
-        with _sdfx.row_limit(*limit):
+        with _sdfx.row_limit(*limit), _sdfx.stencil_source(*(src or (None, 0.0, 0.0))):
             _gridencoder.grid_encode_forward(inputs, emb, offsets, enc, B, 3, C, L, L, S, base_resolution, None, gridtype,
                                              align_corners, interp, 0, slabs, step)
-            _field.forward(enc, 0, x, packed, B, blob_density, blob_radius, sigma, albedo)
+            _field.forward(enc, 0, None if src else x, packed, B, blob_density, blob_radius, sigma, albedo)
+        ctx.src = None if src is None else src[1:]
+        if src is not None:
+            inputs = x.new_empty(0)      # placeholders: the backward forms the batch from x as well
         ctx.limit = limit
         ctx.save_for_backward(x, inputs, offsets, enc, packed)
         ctx.meta = (B, C, L, S, base_resolution, gridtype, align_corners, interp, blob_density, blob_radius, tuple(emb.shape))
@@ -74,10 +87,12 @@ class _fused_field(Function):
         dw2, db2 = torch.empty(64, 64, **f32), torch.empty(64, **f32)
         dw3, db3 = torch.empty(4, 64, **f32), torch.empty(4, **f32)
         grad_emb = torch.zeros(emb_shape, dtype=torch.half, device=dev)
-        with _sdfx.row_limit(*ctx.limit):
-            _field.backward(enc, 0, x, packed, B, blob_density, blob_radius, dsigma, dalbedo, denc, dw1, db1, dw2, db2, dw3, db3)
-            _gridencoder.grid_encode_backward(denc, inputs, grad_emb, offsets, grad_emb, B, 3, C, L, L, S, H, None, None, gridtype,
-                                              align_corners, interp, 0)
+        src = (None, 0.0, 0.0) if ctx.src is None else (x,) + ctx.src
+        with _sdfx.row_limit(*ctx.limit), _sdfx.stencil_source(*src):
+            _field.backward(enc, 0, None if ctx.src else x, packed, B, blob_density, blob_radius, dsigma, dalbedo, denc, dw1, db1, dw2,
+                            db2, dw3, db3)
+            _gridencoder.grid_encode_backward(denc, None if ctx.src else inputs, grad_emb, offsets, grad_emb, B, 3, C, L, L, S, H, None,
+                                              None, gridtype, align_corners, interp, 0)
         return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 12
 
 

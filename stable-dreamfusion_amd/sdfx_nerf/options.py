@@ -19,3 +19,11 @@ def default_opt(**overrides) -> argparse.Namespace:
     for k, v in overrides.items():
         setattr(opt, k, v)
     return opt
+
+
+def if_preset(opt: argparse.Namespace) -> argparse.Namespace:
+    """`--IF` (main.py:181-185): DeepFloyd-IF guidance in pixel space; "must not do as_latent" — with latent_iter_ratio = 0 the
+    schedule of Trainer.train_step never takes its latent branch (global_step >= 1 when it is evaluated)."""
+    opt.latent_iter_ratio = 0
+    opt.IF = True
+    return opt

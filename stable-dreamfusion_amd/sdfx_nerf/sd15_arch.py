@@ -207,3 +207,39 @@ def sd15_random_prior(device, fp16=True, seed=1234):
         torch.random.set_rng_state(gen_state)
     unet.unet.to(memory_format=torch.channels_last)
     return G.SDSGuidance(unet, vae, device, fp16)
+
+
+class IfPriorUNet(nn.Module):
+    """Pixel-space counterpart of Sd15PriorUNet for the `--IF` configuration (BASELINE configs[3]): eps_hat (6 channels: noise +
+    learned variance, guidance/if_utils.py:90-93) = consistent stand-in (guidance.SyntheticPixelUNet) + damp * UNet(x_t, t, ctx).
+
+    DeepFloyd IF-I-XL (4.3 B parameters, T5-XXL text encoder; guidance/if_utils.py:40-58 pulls both from the hub) is absent like
+    every other hub model. What stands in for its COST here is the UNet topology of this file evaluated in pixel space —
+    3 -> 6 channels at 64 x 64 with a 4096-wide (T5) text context, ~0.9 B parameters, i.e. the size of IF-I-L, not of IF-I-XL;
+    bench.py's `config.guidance` says so."""
+
+    def __init__(self, alphas, damp=1e-3, **unet_kwargs):
+        super().__init__()
+        self.unet = UNetSD15(in_ch=3, out_ch=6, ctx_dim=4096, **unet_kwargs)
+        self.standin = G.SyntheticPixelUNet(alphas)
+        self.damp = damp
+        self.skip_unet = False
+
+    def forward(self, x, t, encoder_hidden_states):
+        out = self.standin(x, t, encoder_hidden_states)
+        if self.skip_unet:
+            return out
+        y = self.unet(x.contiguous(memory_format=torch.channels_last), t, encoder_hidden_states)
+        return out + self.damp * torch.nan_to_num(y)
+
+
+def if_random_prior(device, fp16=True, seed=4321):
+    alphas = G.ddpm_cosine_alphas_cumprod()
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        unet = IfPriorUNet(alphas)
+    finally:
+        torch.random.set_rng_state(gen_state)
+    unet.unet.to(memory_format=torch.channels_last)
+    return G.IFGuidance(unet, device, fp16, alphas=alphas)

@@ -335,7 +335,9 @@ class TrainStep:
         nothing, so it needs no valid sample data — only that the lazy initialisations behind the body (MIOpen
         find, hipBLASLt heuristics, scratch allocations) have happened in an earlier eager iteration."""
         if len(self.graphs) >= self.max_graphs:   # evict the least used graph — never one captured by the _prime call in progress
-            old = [k for k in self.graphs if k not in self._priming] or list(self.graphs)
+            old = [k for k in self.graphs if k not in self._priming]
+            if not old:          # the cache holds nothing but this prime's own captures (max_graphs smaller than a prime set):
+                return False     # the neighbouring ladder step is simply not captured now
             victim = min(old, key=lambda k: self.graph_uses.get(k, 0))
             del self.graphs[victim]
             self.graph_uses.pop(victim, None)
@@ -354,6 +356,7 @@ class TrainStep:
         self.graph_uses[key] = 0
         self._priming.add(key)
         self.stats["captures"] += 1
+        return True
 
     def _prime(self, key):
         """Capture `key` and the ladder steps around it (the sample total drifts as the scene trains)."""
@@ -366,12 +369,16 @@ class TrainStep:
             other = (kinds[0], kinds[1], "rand" if kinds[2] == "net" else "net") + kinds[3:]
             if other in self._warm:      # only a kind that has run eagerly once (lazy library initialisations cannot be captured)
                 variants.append(other)
+        # the requested key first: whatever max_graphs is, it is in the cache when this returns (an eviction never touches
+        # the keys of the prime in progress, and a cache full of them stops the priming of neighbours)
+        if key not in self.graphs:
+            self._capture(key)
         lo, hi = cap / self.graph_prime_span, cap * self.graph_prime_span
         c = self._ladder(max(int(lo), 1))
         while c <= hi:
             for kv in variants:
-                if (c,) + kv not in self.graphs:
-                    self._capture((c,) + kv)
+                if (c,) + kv not in self.graphs and not self._capture((c,) + kv):
+                    return
             c = self._ladder(c + 1)
 
     def step(self, rays_o, rays_d, azimuth=0.0, H=64, W=64, next_rays=None):
@@ -386,6 +393,7 @@ class TrainStep:
                 self.model.update_extra_state()
         self.global_step += 1                 # before the schedule, as in train_one_epoch (nerf/utils.py:1039-1049)
         kinds = self._schedule(azimuth)
+        self._scheduled_shading = kinds[0]
         self.sc.copy_(self.sc_host, non_blocking=True)
         if self.mode == "reference":
             return self._step_reference(rays_o, rays_d, kinds)
@@ -398,10 +406,8 @@ class TrainStep:
         prefetch_ok = bool(next_rays is not None and self.global_step % opt.update_extra_interval != 0 and _PREFETCH)
         if kinds[0] in _SHADE_MODES and getattr(self.model, "fused_render_available", lambda s: False)(kinds[0]):
             kinds = ("fd",) + kinds[1:]      # one graph for the three finite-difference shadings (mode read on the device)
-        if self.mode == "device":
-            loss = self._body(M, *kinds)
-            self.stats["eager"] += 1
-        else:
+        shading_name, graph_class = self._scheduled_shading, kinds[0]
+        if self.mode == "graph":
             # learning rates are kernel arguments of the captured optimiser step: part of the key. The -O schedule is
             # constant (main.py: LambdaLR(lambda iter: 1)); a scheduler that moves them every step falls back to 'device'.
             lr_sig = tuple(g["lr"] for g in self.optimizer.param_groups)
@@ -409,9 +415,13 @@ class TrainStep:
                 self.lr_changes += 1
                 if self.lr_changes > 8:
                     warnings.warn("learning rates change every few steps: HIP-graph replay disabled (mode='device')")
-                    self.mode = "device"
+                    self.mode = "device"       # this very step already runs eagerly: nothing is captured for the new key
                     self.graphs.clear(); self.graph_uses.clear()
             self._lr_sig = lr_sig
+        if self.mode == "device":
+            loss = self._body(M, *kinds)
+            self.stats["eager"] += 1
+        else:
             kinds = kinds + (H, W, lr_sig)
             key = (self._ladder(M),) + kinds
             first = kinds not in self._warm
@@ -457,7 +467,9 @@ class TrainStep:
             self._prefetch(*next_rays)
         if _STEP_SYNC:
             torch.cuda.synchronize()
-        self.last = {"num_samples": M, "shading": kinds[0]}
+        # `shading`: what the schedule drew ('lambertian' / 'textureless' / 'normal' / 'albedo'), in every mode;
+        # `graph_class`: the class the iteration ran as ('fd' = one kernel / one graph for the three finite-difference shadings)
+        self.last = {"num_samples": M, "shading": shading_name, "graph_class": graph_class}
         return loss
 
     def _step_reference(self, rays_o, rays_d, kinds):
@@ -477,7 +489,7 @@ class TrainStep:
             self.model.encoder.grad_weight_decay(opt.lambda_wd)
         self.scaler.step(self.optimizer)
         self.scaler.update()
-        self.last = {"num_samples": int(self._num_samples), "shading": kinds[0]}
+        self.last = {"num_samples": int(self._num_samples), "shading": kinds[0], "graph_class": kinds[0]}
         return loss
 
     # ------------------------------------------------------------------------------ reporting (these synchronise)

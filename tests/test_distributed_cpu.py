@@ -90,6 +90,18 @@ def test_bench_main_control_path_two_ranks():
     assert r["config"]["parallelism"] == "independent-prompts x2"
 
 
+def test_bench_main_control_path_eight_ranks():
+    """The launch the driver uses on an 8-GPU node, minus the GPUs: 8 ranks under gloo through bench.main() — rank 0 builds its
+    job first, the others behind a barrier (the serialised solver search), one time-to-first-barrier per rank, IF preset plan."""
+    r = _run_bench_dry(8, args=("--steps", "6", "--warmup", "1", "--prior", "if"))
+    assert r["n_gpus"] == 8 and r["config"]["parallelism"] == "independent-prompts x8"
+    assert list(r["phases"]) == ["rgb"] and r["phases"]["rgb"]["steps"] == 6          # --IF: no latent phase
+    assert r["value"] == pytest.approx(8 * 6 / (r["ms_per_step"] * 6 / 1e3), rel=1e-6)
+    t = r["seconds_to_first_barrier_per_rank"]
+    assert len(t) == 8 and all(x is not None and x >= 0 for x in t)
+    assert min(t[1:]) >= t[0] - 0.05                   # nobody passed the barrier before rank 0 had built its job
+
+
 def test_bench_ranks_agree_on_the_prior():
     """One rank failing to build the big prior must move EVERY rank to the synthetic one (same configuration, same barriers)."""
     r = _run_bench_dry(2, {"SDFX_DRY_PRIOR_FAIL_RANK": "1"})
@@ -107,3 +119,4 @@ def test_phase_plan():
     assert bench.phase_plan("mix", 40) == [("latent", 8), ("rgb", 32)]
     assert bench.phase_plan("mix", 1) == [("latent", 1)]
     assert bench.phase_plan("latent", 7) == [("latent", 7)] and bench.phase_plan("rgb", 7) == [("rgb", 7)]
+    assert bench.phase_plan("mix", 40, "if") == [("rgb", 40)] and bench.phase_plan("latent", 5, "if") == [("rgb", 5)]
