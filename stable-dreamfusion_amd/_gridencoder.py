@@ -56,21 +56,34 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C_, L, max_l
 
 # ---- binned scatter (D = 3, C = 2): persistent scratch per device -----------------------------------
 _BINNED = int(os.environ.get("SDFX_GRID_BWD_BINNED", "1"))
-_BINNED_CHUNK_POINTS = int(os.environ.get("SDFX_GRID_BWD_CHUNK", str(1 << 22)))
+# largest batch scattered in ONE pass of the three kernels (bigger batches are chunked): 2^23 points = one 7-point stencil batch
+# of 1.2 M samples. The scratch is sized for the batch actually seen (next step of a 1.5x ladder), not for this maximum.
+_BINNED_CHUNK_POINTS = int(os.environ.get("SDFX_GRID_BWD_CHUNK", str(1 << 23)))
 _BINNED_SCRATCH = {}   # device index -> list of buffers, the last one is the current (largest) one
-_BINNED_BYTES = {}     # (level layout, ...) -> scratch bytes
+_BINNED_BYTES = {}     # (level layout, ..., chunk points) -> scratch bytes
 
 
-def _binned_scratch(device, offsets, L, max_level, S_, H, is_half):
-    """Persistent scratch of the binned scatter: ONE buffer per device, sized for the largest request seen. It is plain
-    bytes (every launch re-initialises what it uses), so encoders and dtypes share it. Buffers are never freed: a
-    captured HIP graph has the address baked in, so an outgrown buffer stays alive beside its replacement."""
+def _chunk_points(B):
+    """Smallest step of the ladder 2^18 * 1.5^k that holds B points, at most _BINNED_CHUNK_POINTS."""
+    c = 1 << 18
+    while c < B and c < _BINNED_CHUNK_POINTS:
+        c = int(c * 1.5)
+    return min(c, _BINNED_CHUNK_POINTS)
+
+
+def _binned_scratch(device, offsets, L, max_level, S_, H, is_half, B=None):
+    """Persistent scratch of the binned scatter: ONE buffer per device, sized for the largest request seen (item lists for a whole
+    batch of B points in one pass, B rounded up a 1.5x ladder: an iteration's 7 x 0.5 M-point stencil batch needs ~5 GB, not the
+    ~11 GB of the 2^23-point maximum). It is plain bytes (every launch re-initialises what it uses), so encoders and dtypes share
+    it. Buffers are never freed: a captured HIP graph has the address baked in, so an outgrown buffer stays alive beside its
+    replacement."""
     host = offsets_host(offsets)
-    key = (tuple(host), L, max_level, float(S_), H, is_half)     # the size depends on the level layout only (17 ints: cheap to hash)
+    chunk = _chunk_points(B if B is not None else _BINNED_CHUNK_POINTS)
+    key = (tuple(host), L, max_level, float(S_), H, is_half, chunk)   # the size depends on the level layout and the chunk
     nbytes = _BINNED_BYTES.get(key)
     if nbytes is None:
         nbytes = _BINNED_BYTES[key] = int(S.lib().sdfx_grid_encode_backward_binned_scratch_bytes(host, L, max_level, float(S_), H,
-                                                                                                _BINNED_CHUNK_POINTS, is_half))
+                                                                                                chunk, is_half))
     if nbytes <= 0:
         return None
     bufs = _BINNED_SCRATCH.setdefault(device.index, [])
@@ -96,7 +109,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
         _same(grad, grad_inputs, "grad", "grad_inputs")
     if _BINNED and D == 3 and C_ == 2 and dy_dx is None and B > 0:
         is_half = int(grad.dtype == torch.float16)
-        scratch = _binned_scratch(grad.device, offsets, L, max_level, S_, H, is_half)
+        scratch = _binned_scratch(grad.device, offsets, L, max_level, S_, H, is_half, B)
         if scratch is not None:
             S.call("sdfx_grid_encode_backward_binned", S.ptr(grad), S.ptr(inputs), offsets_host(offsets),
                    S.ptr(grad_embeddings), B, D, C_, L, max_level, float(S_), H, gridtype, int(bool(align_corners)), interp,

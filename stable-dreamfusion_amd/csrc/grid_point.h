@@ -77,6 +77,7 @@ __device__ __forceinline__ uint32_t pick4(const uint4& b, uint32_t j) {   // dwo
 struct LevelPoint {
     uint32_t r0[4], r1[4];     // rows of the corners (x, y, z) and (x + 1, y, z) for the four (y, z) corners
     float ax1, ay1, az1;       // interpolation weights of the "+1" vertices (the others are 1 - these)
+    uint32_t cx, cy, cz;       // the cell (lower vertex) — only the binned scatter looks at it
 };
 struct LevelData {
     uint4 blk[4];
@@ -97,9 +98,11 @@ __device__ __forceinline__ void level_prepare(const LevelConst& lc, const float 
     }
     (void)deriv;
     p.ax1 = pos[0]; p.ay1 = pos[1]; p.az1 = pos[2];
+    p.cx = pg[0]; p.cy = pg[1]; p.cz = pg[2];
     // Branch-free in the level's kind (both the hashed and the dense index are formed and one is masked in): this function is
     // inlined once per level of a batch, and control flow on per-level flags made the compiler unswitch the batch loop into
     // every combination of kinds (12 000 instructions, more than the instruction cache holds).
+    const bool need_mod = (lc.flags & 3u) == 1u;   // not fully dense and not a power of two (flags: make_level_const)
     const uint32_t hm = hashed ? 0xffffffffu : 0u;
     const uint32_t wm = pow2 ? lc.size - 1u : 0xffffffffu;
     const uint32_t hy[2] = {pg[1] * 2654435761u, pn[1] * 2654435761u};
@@ -111,8 +114,10 @@ __device__ __forceinline__ void level_prepare(const LevelConst& lc, const float 
         const uint32_t yh = hy[k & 1] ^ hz[k >> 1], yd = sy[k & 1] + sz[k >> 1];
         uint32_t i0 = (((pg[0] ^ yh) & hm) | ((pg[0] + yd) & ~hm)) & wm;
         uint32_t i1 = (((pn[0] ^ yh) & hm) | ((pn[0] + yd) & ~hm)) & wm;
-        if (i0 >= lc.size) i0 %= lc.size;   // index % hashmap_size (gridencoder.cu:78): only a non-power-of-two level whose
-        if (i1 >= lc.size) i1 %= lc.size;   // dense index overruns its size ever gets here
+        // index % hashmap_size (gridencoder.cu:78): the mask above for a power-of-two size; a fully dense level (strides of all
+        // three axes fit: x + y res + z res^2 < res^3 <= size) never exceeds its size; what is left — a level that is hashed, or
+        // tiled with a truncated stride, AND whose size is no power of two — is a property of the level, decided on the scalar unit
+        if (need_mod) { i0 %= lc.size; i1 %= lc.size; }
         p.r0[k] = i0; p.r1[k] = i1;
     }
 }

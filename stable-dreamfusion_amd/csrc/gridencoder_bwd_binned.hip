@@ -21,7 +21,7 @@
 // Items that do not fit a bucket's reserved capacity fall back to a direct global atomic in K1, so
 // the result is complete for any input distribution. Sums are formed in float32 and rounded to the
 // table type once (the reference rounds every contribution to half before adding, gridencoder.cu:338).
-#include "grid_common.h"
+#include "grid_point.h"
 
 using namespace sdfx;
 using namespace sdfx::grid;
@@ -52,7 +52,10 @@ struct BinPlan {
     uint32_t item_first[kMaxLevels];        // first item slot (in units of 1024 items) of the level's bucket 0
     uint32_t merge_mask;                    // bit l: fold lane runs at level l before binning
     uint32_t levels;
+    uint32_t nsub;                          // item sub-lists per bucket: 8 = one per XCD (flat K1 mapping), 1 = one list
 };
+
+constexpr uint32_t kMaxSub = kXcds;
 
 template <bool HALF> struct Item;
 template <> struct Item<true> {   // {row in level, half2 contribution}
@@ -119,123 +122,129 @@ __device__ __forceinline__ RunScan scan_cell_runs(uint32_t cell, bool active, in
     r.take2 = f ? 0u : 0xFFFFFFFFu; f |= row_shr<2>(f, 1u);
     r.take4 = f ? 0u : 0xFFFFFFFFu; f |= row_shr<4>(f, 1u);
     r.take8 = f ? 0u : 0xFFFFFFFFu;
+    // keep the masks opaque words in vector registers: knowing that they are 0 / ~0 the compiler turns `fetched & mask` into a
+    // select on a scalar condition, which cannot be merged with the DPP fetch (v_mov_b32_dpp + v_cndmask_b32 instead of ONE
+    // v_and_b32_dpp per channel and step)
+    asm volatile("" : "+v"(r.take1), "+v"(r.take2), "+v"(r.take4), "+v"(r.take8));
     const uint32_t next_head = row_shl1(head ? 1u : 0u, 1u);
     r.tail = active && ((rl == 15) || (next_head != 0u));
     return r;
 }
 
+// (value N lanes down in the row, 0 outside it) & mask — compiles to ONE v_and_b32_dpp
 template <int N>
-__device__ __forceinline__ float masked_shr(float v, uint32_t mask) {  // (value N lanes down, 0 outside the row) & mask
+__device__ __forceinline__ float masked_shr(float v, uint32_t mask) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x110 + N, 0xf, 0xf, true) & mask);
 }
 
-__device__ __forceinline__ void fold_runs(const RunScan& r, float& a, float& b) {
-    { const float au = masked_shr<1>(a, r.take1), bu = masked_shr<1>(b, r.take1); a += au; b += bu; }
-    { const float au = masked_shr<2>(a, r.take2), bu = masked_shr<2>(b, r.take2); a += au; b += bu; }
-    { const float au = masked_shr<4>(a, r.take4), bu = masked_shr<4>(b, r.take4); a += au; b += bu; }
-    { const float au = masked_shr<8>(a, r.take8), bu = masked_shr<8>(b, r.take8); a += au; b += bu; }
+// one segmented-scan step on the two channels of a corner at once: two v_and_b32_dpp + one v_pk_add_f32
+__device__ __forceinline__ void fold_runs(const RunScan& r, float2_t& v) {
+    { const float2_t u = {masked_shr<1>(v.x, r.take1), masked_shr<1>(v.y, r.take1)}; v = v + u; }
+    { const float2_t u = {masked_shr<2>(v.x, r.take2), masked_shr<2>(v.y, r.take2)}; v = v + u; }
+    { const float2_t u = {masked_shr<4>(v.x, r.take4), masked_shr<4>(v.y, r.take4)}; v = v + u; }
+    { const float2_t u = {masked_shr<8>(v.x, r.take8), masked_shr<8>(v.y, r.take8)}; v = v + u; }
 }
+
+struct BinLevels {
+    LevelConst lv[kMaxLevels];   // per-level constants of the forward (grid_point.h): one 32-byte scalar load per workgroup
+};
+
+template <bool HALF> __device__ __forceinline__ Item<HALF> make_item(uint32_t row, float2_t v);
+template <> __device__ __forceinline__ Item<true> make_item<true>(uint32_t row, float2_t v) {
+    Item<true> it;
+    it.row = row;
+    half2_t h;   // both channels rounded to half (nearest even) by one instruction
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(v.x), "v"(v.y));
+    it.val = __builtin_bit_cast(uint32_t, h);
+    return it;
+}
+template <> __device__ __forceinline__ Item<false> make_item<false>(uint32_t row, float2_t v) { return Item<false>::make(row, v.x, v.y); }
 
 // ---------------------------------------------------------------------------------------------
 // K1: contributions -> binned items
 // ---------------------------------------------------------------------------------------------
-template <bool HALF>
-__global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,
-                                                               const float* __restrict__ inputs,
-                                                               typename Elem<HALF>::type* __restrict__ grad_table,
-                                                               uint32_t B, uint32_t L, uint32_t b0, uint32_t b1,
-                                                               GridPlan plan, BinPlan bin, uint32_t gridtype,
-                                                               int align_corners, uint32_t interp, int grad_layout,
-                                                               uint32_t* __restrict__ cursors,
-                                                               Item<HALF>* __restrict__ items, RowLimit rl, StencilSrc src) {
+// Instruction issue bounds this kernel (round 2, PMC: 560 VALU + 276 SALU instructions per wave and level, 76 % of its time),
+// so it is written like the forward (gridencoder_fwd.hip): the grid's kind, interpolation and alignment are template
+// parameters, the level's constants sit in scalar registers, the 8 row indices share their hash / stride terms
+// (level_prepare), both channels of a corner travel as one float2 (v_pk_mul_f32, v_pk_add_f32, v_cvt_pk_f16_f32), the run
+// folding is a workgroup-uniform template branch and nothing about a corner is decided by control flow.
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
+__device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __restrict__ grad, const float* __restrict__ inputs,
+                                         typename Elem<HALF>::type* __restrict__ grad_table, uint32_t B, uint32_t L, uint32_t b0,
+                                         uint32_t b1, uint32_t level, uint32_t tile, const LevelConst& lc, const BinPlan& bin,
+                                         int grad_layout, uint32_t* __restrict__ cursors, Item<HALF>* __restrict__ items,
+                                         const RowLimit& rl, const StencilSrc& src, uint32_t* hist, uint32_t* gbase, uint32_t* boff,
+                                         uint32_t* wave_tot, uint32_t* block_total, Item<HALF>* stage) {
     using T = typename Elem<HALF>::type;
-    using E = Elem<HALF>;
-    constexpr uint32_t D = 3, C = 2, NCORN = 8, NITEM = NCORN * kPointsPerThread;
-    __shared__ uint32_t hist[kMaxBucketsPerLevel];
-    __shared__ uint32_t gbase[kMaxBucketsPerLevel];
-    __shared__ uint32_t boff[kMaxBucketsPerLevel];
-    __shared__ uint32_t wave_tot[kBinThreads / 64];
-    __shared__ uint32_t block_total;
-    __shared__ Item<HALF> stage[kBinThreads * NITEM];   // 32 KiB (half items) / 48 KiB (float items)
-
-    uint32_t level, tile;
-    const bool has_item = plan_item(plan, level, tile);  // wave-uniform (depends on blockIdx only)
-    if (!has_item) return;
-    // a tile of padding rows (sdfx_set_row_limit) has nothing to scatter
-    if (rows_dead(rl, b0 + tile * (kBinThreads * kPointsPerThread), kBinThreads * kPointsPerThread)) return;
+    constexpr uint32_t C = 2, NCORN = 8;
     const int lane = lane_id();
+    // the sub-list of every bucket this workgroup appends to: its XCD's (workgroups are dealt to the XCDs round-robin), so that
+    // no two XCDs ever write to the same cache line of a list
+    const uint32_t sub = bin.nsub == 1 ? 0u : (blockIdx.x % kXcds);
     const uint32_t nb = bin.bucket_first[level + 1] - bin.bucket_first[level];
     for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) hist[i] = 0;
     __syncthreads();
 
-    const uint32_t resolution = plan.res[level];
-    const uint32_t row0 = plan.off[level];
-    const uint32_t hashmap_size = plan.off[level + 1] - row0;
-    const bool merge = (bin.merge_mask >> level) & 1u;
-
-    uint32_t rows[NITEM];
-    float va[NITEM], vb[NITEM];
-    uint32_t rank[NITEM];
-    uint32_t alive = 0;  // bit i: item i is emitted by this lane
-
+    // ---- the sample: coordinates, gradient row, cell, weights, the 8 table rows ----
+    const uint32_t b = b0 + tile * kBinThreads + threadIdx.x;
+    bool valid = b < b1 && row_live(rl, b);
+    float in[3] = {0.f, 0.f, 0.f};
+    if (valid) {
+        if (src.xyzs) stencil_unit_row(src, b, in);   // sdfx_set_stencil_source: the [7, M, 3] batch formed here
 #pragma unroll
-    for (uint32_t k = 0; k < kPointsPerThread; k++) {
-        const uint32_t b = b0 + tile * (kBinThreads * kPointsPerThread) + k * kBinThreads + threadIdx.x;
-        bool valid = b < b1 && row_live(rl, b);
-        float in[D] = {0.f, 0.f, 0.f};
-        if (valid) {
-            if (src.xyzs) stencil_unit_row(src, b, in);   // sdfx_set_stencil_source: the [7, M, 3] batch formed here
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) {
-                if (!src.xyzs) in[d] = inputs[(size_t)b * D + d];
-                if (in[d] < 0 || in[d] > 1) valid = false;  // gridencoder.cu:279-284
-            }
-        }
-        float pos[D], pos_deriv[D];
-        uint32_t pos_grid[D];
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++)
-            grid_locate_axis(valid ? in[d] : 0.f, resolution, align_corners != 0, interp, pos[d], pos_deriv[d], pos_grid[d]);
-        float g0 = 0.f, g1 = 0.f;
-        if (valid) {
-            const T* g = grad_layout == 0 ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * L + level) * C;
-            g0 = E::load(g);
-            g1 = E::load(g + 1);
-            // nothing to scatter: samples behind a ray's early-termination cut, and the zero-gradient padding rows of
-            // fixed-capacity sample buffers (which all sit in ONE cell and would overflow its bucket)
-            if (g0 == 0.f && g1 == 0.f) valid = false;
-        }
-#pragma unroll
-        for (uint32_t idx = 0; idx < NCORN; idx++) {
-            const uint32_t i = k * NCORN + idx;
-            uint32_t pgl[D];
-            const float w = corner<D>(idx, pos, pos_grid, resolution, pgl);
-            rows[i] = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
-            va[i] = w * g0;
-            vb[i] = w * g1;
-        }
-        bool emit = valid;
-        if (merge) {  // workgroup-uniform; all lanes participate in the DPP exchanges
-            // merged levels have res <= 640, so a cell id fits 10 bits per axis
-            const RunScan runs = scan_cell_runs(pos_grid[0] | (pos_grid[1] << 10) | (pos_grid[2] << 20), valid, lane);
-#pragma unroll
-            for (uint32_t idx = 0; idx < NCORN; idx++) fold_runs(runs, va[k * NCORN + idx], vb[k * NCORN + idx]);
-            emit = runs.tail;
-        }
-        if (emit) {
-            alive |= 0xFFu << (k * NCORN);
-#pragma unroll
-            for (uint32_t idx = 0; idx < NCORN; idx++)
-                rank[k * NCORN + idx] = atomicAdd(&hist[rows[k * NCORN + idx] >> kBucketRowsLog2], 1u);  // LDS
+        for (uint32_t d = 0; d < 3; d++) {
+            if (!src.xyzs) in[d] = inputs[(size_t)b * 3 + d];
+            if (in[d] < 0 || in[d] > 1) valid = false;  // gridencoder.cu:279-284
         }
     }
+    float2_t g = {0.f, 0.f};
+    if (valid) {
+        const T* gp = grad_layout == 0 ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * L + level) * C;
+        if constexpr (HALF) {
+            const half2_t h = *reinterpret_cast<const half2_t*>(gp);
+            g.x = (float)h.x; g.y = (float)h.y;
+        } else {
+            const float2 f = *reinterpret_cast<const float2*>(gp);
+            g.x = f.x; g.y = f.y;
+        }
+        // nothing to scatter: samples behind a ray's early-termination cut, and the zero-gradient padding rows of
+        // fixed-capacity sample buffers (which all sit in ONE cell and would overflow its bucket)
+        if (g.x == 0.f && g.y == 0.f) valid = false;
+    }
+    const float xs[3] = {valid ? in[0] : 0.f, valid ? in[1] : 0.f, valid ? in[2] : 0.f};
+    LevelPoint p;
+    level_prepare<INTERP, ALIGN, HASHGRID>(lc, xs, p);
+    // corner idx = xbit + 2 ybit + 4 zbit (gridencoder.cu:171-184); weight ((1 * a_x) * a_y) * a_z in that order
+    const float ax[2] = {1 - p.ax1, p.ax1}, ay[2] = {1 - p.ay1, p.ay1}, az[2] = {1 - p.az1, p.az1};
+    uint32_t rows[NCORN];
+    float2_t v[NCORN];
+#pragma unroll
+    for (uint32_t idx = 0; idx < NCORN; idx++) {
+        const uint32_t k = idx >> 1;
+        rows[idx] = (idx & 1u) ? p.r1[k] : p.r0[k];
+        const float w = ((1 * ax[idx & 1u]) * ay[k & 1u]) * az[k >> 1];
+        v[idx] = g * w;
+    }
+    bool emit = valid;
+    if constexpr (MERGE) {
+        // merged levels have res <= 640, so a cell id fits 10 bits per axis
+        const RunScan runs = scan_cell_runs(p.cx | (p.cy << 10) | (p.cz << 20), valid, lane);
+#pragma unroll
+        for (uint32_t idx = 0; idx < NCORN; idx++) fold_runs(runs, v[idx]);
+        emit = runs.tail;
+    }
+    uint32_t rank[NCORN];
+    if (emit) {
+#pragma unroll
+        for (uint32_t idx = 0; idx < NCORN; idx++) rank[idx] = atomicAdd(&hist[rows[idx] >> kBucketRowsLog2], 1u);  // LDS
+    }
     __syncthreads();
-    // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's item list; and an exclusive
+    // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's (sub-)list; and an exclusive
     // prefix sum of the histogram = where each bucket's items go in the workgroup's LDS staging area
     uint32_t my_cnt = 0;
     if (threadIdx.x < nb) {
         my_cnt = hist[threadIdx.x];
-        gbase[threadIdx.x] = my_cnt ? atomicAdd(&cursors[bin.bucket_first[level] + threadIdx.x], my_cnt) : 0u;
+        gbase[threadIdx.x] = my_cnt ? atomicAdd(&cursors[(bin.bucket_first[level] + threadIdx.x) * bin.nsub + sub], my_cnt) : 0u;
     }
     {   // nb <= kMaxBucketsPerLevel = kBinThreads: thread b scans bucket b (wave scan + per-wave totals)
         const uint32_t incl = wave_incl_sum_u32(my_cnt, lane);
@@ -244,41 +253,69 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Ele
         uint32_t woff = 0;
         for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) woff += wave_tot[w];
         if (threadIdx.x < nb) boff[threadIdx.x] = woff + incl - my_cnt;
-        if (threadIdx.x == kBinThreads - 1) block_total = woff + incl;
+        if (threadIdx.x == kBinThreads - 1) *block_total = woff + incl;
     }
     __syncthreads();
 
     // Stage the items in LDS grouped by bucket, then stream them out: consecutive staging slots of one bucket go to
     // consecutive slots of its list, so a wave store covers a few contiguous runs instead of 64 unrelated 8-byte
     // writes (the scattered version was bound by L2 write transactions: one per item).
+    if (emit) {
 #pragma unroll
-    for (uint32_t i = 0; i < NITEM; i++) {
-        if (!((alive >> i) & 1u)) continue;
-        stage[boff[rows[i] >> kBucketRowsLog2] + rank[i]] = Item<HALF>::make(rows[i], va[i], vb[i]);
+        for (uint32_t idx = 0; idx < NCORN; idx++)
+            stage[boff[rows[idx] >> kBucketRowsLog2] + rank[idx]] = make_item<HALF>(rows[idx], v[idx]);
     }
     __syncthreads();
 
     const uint32_t cap = bin.cap[level];
     Item<HALF>* level_items = items + (size_t)bin.item_first[level] * 1024u;
-    T* gtab = grad_table + (size_t)row0 * C;
-    const uint32_t total = block_total;
+    T* gtab = grad_table + (size_t)lc.row0 * C;
+    const uint32_t total = *block_total;
     for (uint32_t k = threadIdx.x; k < total; k += kBinThreads) {
         const Item<HALF> it = stage[k];
         const uint32_t bucket = it.row >> kBucketRowsLog2;
         const uint32_t slot = gbase[bucket] + (k - boff[bucket]);
         if (slot < cap) {
-            level_items[(size_t)bucket * cap + slot] = it;
-        } else {  // bucket over capacity: add directly (complete for any input distribution)
+            level_items[((size_t)bucket * bin.nsub + sub) * cap + slot] = it;
+        } else {  // (sub-)list over capacity: add directly (complete for any input distribution)
             T* dst = gtab + (size_t)it.row * C;
-            const float2 v = it.value();
+            const float2 val = it.value();
             if constexpr (HALF) {
-                unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), __halves2half2(__float2half_rn(v.x), __float2half_rn(v.y)));
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), __halves2half2(__float2half_rn(val.x), __float2half_rn(val.y)));
             } else {
-                unsafeAtomicAdd(dst, v.x);
-                unsafeAtomicAdd(dst + 1, v.y);
+                unsafeAtomicAdd(dst, val.x);
+                unsafeAtomicAdd(dst + 1, val.y);
             }
         }
     }
+}
+
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
+__global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,
+                                                               const float* __restrict__ inputs,
+                                                               typename Elem<HALF>::type* __restrict__ grad_table,
+                                                               uint32_t B, uint32_t L, uint32_t b0, uint32_t b1,
+                                                               GridPlan plan, BinPlan bin, BinLevels lv, int grad_layout,
+                                                               uint32_t* __restrict__ cursors,
+                                                               Item<HALF>* __restrict__ items, RowLimit rl, StencilSrc src) {
+    __shared__ uint32_t hist[kMaxBucketsPerLevel];
+    __shared__ uint32_t gbase[kMaxBucketsPerLevel];
+    __shared__ uint32_t boff[kMaxBucketsPerLevel];
+    __shared__ uint32_t wave_tot[kBinThreads / 64];
+    __shared__ uint32_t block_total;
+    __shared__ Item<HALF> stage[kBinThreads * 8];   // 32 KiB (half items) / 48 KiB (float items)
+
+    uint32_t level, tile;
+    if (!plan_item(plan, level, tile)) return;   // wave-uniform (depends on blockIdx only)
+    // a tile of padding rows (sdfx_set_row_limit) has nothing to scatter
+    if (rows_dead(rl, b0 + tile * kBinThreads, kBinThreads)) return;
+    const LevelConst lc = lv.lv[level];
+    if ((bin.merge_mask >> level) & 1u)   // workgroup-uniform; all lanes take part in the DPP exchanges
+        bin_tile<HALF, INTERP, ALIGN, HASHGRID, true>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors,
+                                                      items, rl, src, hist, gbase, boff, wave_tot, &block_total, stage);
+    else
+        bin_tile<HALF, INTERP, ALIGN, HASHGRID, false>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors,
+                                                       items, rl, src, hist, gbase, boff, wave_tot, &block_total, stage);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,7 +340,23 @@ constexpr uint32_t kReduceLdsBytes = kReduceWaves * kBucketRows * (sizeof(float2
 
 struct ReduceJob {
     uint32_t level, bucket, used, begin, end, cap;
+    uint32_t seg[kMaxSub + 1];   // prefix sums of the sub-list lengths: the bucket's items are their concatenation
 };
+
+// items of (level, bucket): the sum of its sub-lists, each clamped to its capacity (what is beyond went to the table atomically)
+__device__ __forceinline__ uint32_t bucket_items(const BinPlan& bin, const uint32_t* __restrict__ cursors, uint32_t level, uint32_t bucket,
+                                                 uint32_t* seg) {
+    const uint32_t cap = bin.cap[level];
+    uint32_t n = 0;
+    if (seg) seg[0] = 0;
+    for (uint32_t x = 0; x < bin.nsub; x++) {
+        uint32_t c = cursors[(bin.bucket_first[level] + bucket) * bin.nsub + x];
+        if (c > cap) c = cap;
+        n += c;
+        if (seg) seg[x + 1] = n;
+    }
+    return n;
+}
 
 // workgroup -> (level, bucket, split) and its slice of the bucket's item list; false if there is nothing to do
 __device__ __forceinline__ bool reduce_job(const BinPlan& bin, const uint32_t* __restrict__ cursors, ReduceJob& j) {
@@ -315,8 +368,7 @@ __device__ __forceinline__ bool reduce_job(const BinPlan& bin, const uint32_t* _
     j.bucket = local / splits;
     const uint32_t split = local - j.bucket * splits;
     j.cap = bin.cap[level];
-    uint32_t n = cursors[bin.bucket_first[level] + j.bucket];
-    if (n > j.cap) n = j.cap;
+    const uint32_t n = bucket_items(bin, cursors, level, j.bucket, j.seg);
     // How many of the `splits` workgroups launched for this bucket actually share it is decided from the
     // item count found at run time: one workgroup (sole owner, plain read-modify-write flush) unless the
     // bucket is heavy (a coarse level, or unsorted input), in which case the flush has to be atomic.
@@ -369,16 +421,19 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
     __syncthreads();
 
     const uint32_t row0 = plan.off[j.level];
-    const Item<true>* src = items + (size_t)bin.item_first[j.level] * 1024u + (size_t)j.bucket * j.cap;
     constexpr uint32_t kUnroll = 8;  // independent loads in flight per thread
-    for (uint32_t base = j.begin; base < j.end; base += kUnroll * kReduceThreadsFixed) {
+    for (uint32_t x = 0; x < bin.nsub; x++) {   // the part of [begin, end) that lies in sub-list x
+    const uint32_t r_lo = j.begin > j.seg[x] ? j.begin : j.seg[x], r_hi = j.end < j.seg[x + 1] ? j.end : j.seg[x + 1];
+    if (r_lo >= r_hi) continue;
+    const Item<true>* src = items + (size_t)bin.item_first[j.level] * 1024u + ((size_t)j.bucket * bin.nsub + x) * j.cap - j.seg[x];
+    for (uint32_t base = r_lo; base < r_hi; base += kUnroll * kReduceThreadsFixed) {
         Item<true> it[kUnroll];
         bool have[kUnroll];
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; u++) {
             const uint32_t i = base + u * kReduceThreadsFixed + threadIdx.x;
-            have[u] = i < j.end;
-            it[u] = src[have[u] ? i : j.begin];
+            have[u] = i < r_hi;
+            it[u] = src[have[u] ? i : r_lo];
         }
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; u++) {
@@ -393,6 +448,7 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
             if (lo & 0x7FFFu) atomicAdd(&acc[r], (unsigned long long)half_to_fixed(lo));      // ds_add_u64
             if (hi & 0x7FFFu) atomicAdd(&acc[r + 1], (unsigned long long)half_to_fixed(hi));
         }
+    }
     }
     __syncthreads();
 
@@ -433,8 +489,7 @@ __global__ __launch_bounds__(256) void k_grid_bwd_finish(__half* __restrict__ gr
         b -= nb;
     }
     const uint32_t shared_first = bin.acc_first[level];
-    uint32_t n = cursors[bin.bucket_first[level] + b];
-    if (n > bin.cap[level]) n = bin.cap[level];
+    const uint32_t n = bucket_items(bin, cursors, level, b, nullptr);
     const uint32_t per_split = bin.per_split[level];
     uint32_t used = (n + per_split - 1) / per_split;
     if (used > bin.splits[level]) used = bin.splits[level];
@@ -484,20 +539,24 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce_ticket(float
     for (uint32_t i = threadIdx.x; i < kReduceWaves * kBucketRows; i += kReduceThreads) acc_all[i] = make_float2(0.f, 0.f);
     __syncthreads();
 
-    const Item<false>* src = items + (size_t)bin.item_first[j.level] * 1024u + (size_t)j.bucket * j.cap;
     constexpr uint32_t kUnroll = 8;
-    for (uint32_t base = j.begin; base < j.end; base += kUnroll * kReduceThreads) {
-        Item<false> it[kUnroll];
-        bool have[kUnroll];
+    for (uint32_t x = 0; x < bin.nsub; x++) {   // the part of [begin, end) that lies in sub-list x
+        const uint32_t r_lo = j.begin > j.seg[x] ? j.begin : j.seg[x], r_hi = j.end < j.seg[x + 1] ? j.end : j.seg[x + 1];
+        if (r_lo >= r_hi) continue;
+        const Item<false>* src = items + (size_t)bin.item_first[j.level] * 1024u + ((size_t)j.bucket * bin.nsub + x) * j.cap - j.seg[x];
+        for (uint32_t base = r_lo; base < r_hi; base += kUnroll * kReduceThreads) {
+            Item<false> it[kUnroll];
+            bool have[kUnroll];
 #pragma unroll
-        for (uint32_t u = 0; u < kUnroll; u++) {
-            const uint32_t i = base + u * kReduceThreads + threadIdx.x;
-            have[u] = i < j.end;
-            it[u] = src[have[u] ? i : j.begin];
+            for (uint32_t u = 0; u < kUnroll; u++) {
+                const uint32_t i = base + u * kReduceThreads + threadIdx.x;
+                have[u] = i < r_hi;
+                it[u] = src[have[u] ? i : r_lo];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; u++)
+                ticket_add(acc, tag, it[u].row & (kBucketRows - 1), it[u].value(), have[u], lane);
         }
-#pragma unroll
-        for (uint32_t u = 0; u < kUnroll; u++)
-            ticket_add(acc, tag, it[u].row & (kBucketRows - 1), it[u].value(), have[u], lane);
     }
     __syncthreads();
 
@@ -520,11 +579,13 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce_ticket(float
 }
 
 // host: bucket geometry for a chunk of `chunk` samples
-BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uint64_t* total_items_1024, uint32_t* total_buckets,
-                      uint32_t* total_splits, uint32_t* shared_acc_rows = nullptr, uint32_t* coarse_buckets = nullptr) {
+BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uint32_t nsub, uint64_t* total_items_1024,
+                      uint32_t* total_buckets, uint32_t* total_splits, uint32_t* shared_acc_rows = nullptr,
+                      uint32_t* coarse_buckets = nullptr) {
     BinPlan b;
     memset(&b, 0, sizeof(b));
     b.levels = levels;
+    b.nsub = nsub;
     uint64_t items = 0;
     uint32_t buckets = 0, wgs = 0, acc_rows = 0, coarse = 0;
     for (uint32_t l = 0; l < levels; l++) {
@@ -536,7 +597,11 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
         // uniform share + 25 % + slack; coarse levels rely on the run folding, and on the atomic fallback beyond that
         uint64_t cap = (worst + nb - 1) / nb;
         cap = cap + cap / 4 + 256;
-        b.cap[l] = (uint32_t)cap;
+        // per-XCD sub-lists: the tiles of a level are dealt to the XCDs round-robin, so each sub-list gets ~1/8 of the bucket's
+        // items; another 25 % for the unevenness between XCDs (beyond that: the atomic fallback, as for a whole bucket)
+        const uint64_t sub_cap = nsub == 1 ? cap : (cap / nsub + cap / (4 * nsub) + 256);
+        cap = sub_cap * nsub;          // what the bucket holds in total: splits / per_split below are about the whole bucket
+        b.cap[l] = (uint32_t)sub_cap;
         // A level of a few buckets (the 16^3 level has two) receives all 8*B contributions in those few lists: with
         // 131072 items per workgroup only a few dozen workgroups would run (measured: 677 of 1756 us for that
         // level alone). Such levels are cut finer and flushed atomically.
@@ -578,7 +643,17 @@ bool binned_supported(uint32_t D, uint32_t C, uint32_t L, const int32_t* offsets
 }
 
 // scratch = [bucket cursors][shared 64-bit accumulators of the coarse levels][item lists]
-constexpr uint64_t kCursorBytes = (uint64_t)kMaxLevels * kMaxBucketsPerLevel * sizeof(uint32_t);
+constexpr uint64_t kCursorBytes = (uint64_t)kMaxLevels * kMaxBucketsPerLevel * kMaxSub * sizeof(uint32_t);
+
+// K1's work mapping. 1 (default): FLAT — workgroup i takes item i of the (level, tile) list, so every XCD works on every level
+// and all eight finish together — with one item sub-list per (bucket, XCD). 0: each XCD walks its own two whole levels (round 1-2),
+// one list per bucket: the levels' costs differ by up to 4x (levels 15 + 0 against 8 + 7), so the kernel waited for one XCD.
+// Flat with ONE list per bucket was measured slower in round 2 (784 -> 1091 us): slices reserved by different XCDs shared cache
+// lines, which non-coherent L2s write back as partial lines. Sub-lists remove the sharing and keep the balance.
+int k1_flat() {
+    static const int v = [] { const char* e = getenv("SDFX_GRIDBWD_FLAT"); return (e && e[0] == '1') ? 1 : 0; }();
+    return v;
+}
 
 uint64_t header_bytes(uint32_t shared_acc_rows) {
     return kCursorBytes + (uint64_t)shared_acc_rows * 2 * sizeof(unsigned long long);
@@ -587,7 +662,7 @@ uint64_t header_bytes(uint32_t shared_acc_rows) {
 uint64_t scratch_bytes_for(const GridPlan& plan, uint32_t levels, uint32_t chunk, bool half) {
     uint64_t items;
     uint32_t nb, wg, acc_rows;
-    make_bin_plan(plan, levels, chunk, &items, &nb, &wg, &acc_rows);
+    make_bin_plan(plan, levels, chunk, k1_flat() ? kMaxSub : 1u, &items, &nb, &wg, &acc_rows);
     return header_bytes(acc_rows) + items * 1024u * (half ? sizeof(Item<true>) : sizeof(Item<false>));
 }
 
@@ -731,19 +806,38 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         // occupancy 1.8 waves per SIMD by PMC), but giving every XCD the same mix of levels (SDFX_GRIDBWD_FLAT=1: workgroup i takes
         // item i) is SLOWER, 784 -> 1091 us at B = 1.81 M: the slices of a bucket's item list reserved by workgroups of different
         // XCDs share cache lines, and the XCDs' L2s are not coherent with each other, so those lines go to memory as partial writes.
-        static const int flat = [] { const char* e = getenv("SDFX_GRIDBWD_FLAT"); return (e && e[0] == '1') ? 1 : 0; }();
+        const int flat = k1_flat();
         plan.flat = (uint32_t)flat;
         if (!flat && k1_balance_enabled()) balance_plan(plan, max_level, k1_level_cost(max_level));
         uint64_t items_1024;
         uint32_t nbuckets, nsplits, acc_rows, coarse_buckets;
-        const BinPlan bin = make_bin_plan(plan, max_level, chunk, &items_1024, &nbuckets, &nsplits, &acc_rows, &coarse_buckets);
+        const BinPlan bin = make_bin_plan(plan, max_level, chunk, flat ? kMaxSub : 1u, &items_1024, &nbuckets, &nsplits, &acc_rows,
+                                          &coarse_buckets);
         void* items = static_cast<char*>(scratch) + header_bytes(acc_rows);
         zero_device(scratch, header_bytes(is_half ? acc_rows : 0), st);  // cursors, accumulators
         const uint32_t grid1 = plan_grid_size(plan);
+        BinLevels lv;
+        memset(&lv, 0, sizeof(lv));
+        for (uint32_t l = 0; l < max_level; l++) lv.lv[l] = make_level_const(offsets_host, l, S, H);
+        const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
+#define SDFX_BIN(HALF_, INTERP_, ALIGN_, HASH_)                                                                                   \
+    hipLaunchKernelGGL((k_grid_bwd_bin<HALF_, INTERP_, ALIGN_, HASH_>), dim3(grid1), dim3(kBinThreads), 0, st,                    \
+                       static_cast<const typename Elem<HALF_>::type*>(grad), inputs,                                              \
+                       static_cast<typename Elem<HALF_>::type*>(grad_embeddings), B, L, b0, b1, plan, bin, lv, grad_layout,        \
+                       cursors, static_cast<Item<HALF_>*>(items), row_limit(), stencil_src())
+#define SDFX_BIN_SEL(HALF_)                                                                                                       \
+    switch (sel) {                                                                                                                \
+        case 0: SDFX_BIN(HALF_, 0u, false, false); break;                                                                         \
+        case 1: SDFX_BIN(HALF_, 0u, false, true); break;                                                                          \
+        case 2: SDFX_BIN(HALF_, 0u, true, false); break;                                                                          \
+        case 3: SDFX_BIN(HALF_, 0u, true, true); break;                                                                           \
+        case 4: SDFX_BIN(HALF_, 1u, false, false); break;                                                                         \
+        case 5: SDFX_BIN(HALF_, 1u, false, true); break;                                                                          \
+        case 6: SDFX_BIN(HALF_, 1u, true, false); break;                                                                          \
+        default: SDFX_BIN(HALF_, 1u, true, true); break;                                                                          \
+    }
         if (is_half) {
-            hipLaunchKernelGGL(k_grid_bwd_bin<true>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const __half*>(grad),
-                               inputs, static_cast<__half*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
-                               interp, grad_layout, cursors, static_cast<Item<true>*>(items), row_limit(), stencil_src());
+            SDFX_BIN_SEL(true)
             hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(nsplits), dim3(kReduceThreadsFixed), 0, st,
                                static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items),
                                shared_acc);
@@ -751,12 +845,12 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
                 hipLaunchKernelGGL(k_grid_bwd_finish, dim3(coarse_buckets), dim3(256), 0, st, static_cast<__half*>(grad_embeddings),
                                    plan, bin, cursors, shared_acc);
         } else {
-            hipLaunchKernelGGL(k_grid_bwd_bin<false>, dim3(grid1), dim3(kBinThreads), 0, st, static_cast<const float*>(grad),
-                               inputs, static_cast<float*>(grad_embeddings), B, L, b0, b1, plan, bin, gridtype, align_corners,
-                               interp, grad_layout, cursors, static_cast<Item<false>*>(items), row_limit(), stencil_src());
+            SDFX_BIN_SEL(false)
             hipLaunchKernelGGL(k_grid_bwd_reduce_ticket, dim3(nsplits), dim3(kReduceThreads), kReduceLdsBytes, st,
                                static_cast<float*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<false>*>(items));
         }
+#undef SDFX_BIN_SEL
+#undef SDFX_BIN
     }
     return check_launch("grid_encode_backward_binned");
 }

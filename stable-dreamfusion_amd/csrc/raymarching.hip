@@ -419,8 +419,7 @@ __global__ __launch_bounds__(256) void k_composite_train_fwd(const float* __rest
         }
         const float alpha = valid ? sample_alpha(sigma, dt, binarize) : 0.0f;
         const float incl = wave_incl_prod(1.0f - alpha, lane);
-        float excl = __shfl_up(incl, 1, kWave);
-        if (lane == 0) excl = 1.0f;
+        const float excl = wave_shift_up1(incl, 1.0f);
         const float T_before = T_carry * excl;
         const float T_after = T_carry * incl;
         const unsigned long long cut = __ballot(valid && (T_after < T_thresh));
@@ -429,7 +428,7 @@ __global__ __launch_bounds__(256) void k_composite_train_fwd(const float* __rest
         const float w = contributes ? alpha * T_before : 0.0f;
         if (valid) weights[s] = w;
         r += w * cr; g += w * cg; b += w * cb; ws += w; d += w * t;
-        T_carry = T_carry * __shfl(incl, kWave - 1, kWave);
+        T_carry = T_carry * wave_last(incl);
         done = cut != 0ull;
     }
     r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); d = wave_sum(d);
@@ -481,8 +480,7 @@ __global__ __launch_bounds__(256) void k_composite_train_bwd(
         }
         const float alpha = valid ? sample_alpha(sigma, dt, binarize) : 0.0f;
         const float incl = wave_incl_prod(1.0f - alpha, lane);
-        float excl = __shfl_up(incl, 1, kWave);
-        if (lane == 0) excl = 1.0f;
+        const float excl = wave_shift_up1(incl, 1.0f);
         const float T_before = T_carry * excl;
         const float T = T_carry * incl;  // already advanced, as at raymarching.cu:664
         const unsigned long long cut = __ballot(valid && (T < T_thresh));
@@ -505,12 +503,12 @@ __global__ __launch_bounds__(256) void k_composite_train_bwd(
                                    gd * (T * t - (d_final - d)));
         }
         if (cut != 0ull) break;  // wave-uniform
-        T_carry = T_carry * __shfl(incl, kWave - 1, kWave);
-        r_c = __shfl(r, kWave - 1, kWave);
-        g_c = __shfl(g, kWave - 1, kWave);
-        b_c = __shfl(b, kWave - 1, kWave);
-        ws_c = __shfl(ws, kWave - 1, kWave);
-        d_c = __shfl(d, kWave - 1, kWave);
+        T_carry = T_carry * wave_last(incl);
+        r_c = wave_last(r);
+        g_c = wave_last(g);
+        b_c = wave_last(b);
+        ws_c = wave_last(ws);
+        d_c = wave_last(d);
     }
 }
 

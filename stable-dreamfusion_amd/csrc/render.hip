@@ -25,6 +25,7 @@
 // oracle chain shade -> composite -> entropy, forward and backward.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sdfx.h"
 #include "sdfx_common.h"
@@ -66,8 +67,8 @@ struct RenderArgs {
 
 __device__ __forceinline__ int shading_mode(const RenderArgs& a) { return a.mode_p ? (int)a.mode_p[0] : a.mode; }
 
-// what one lane reads for one sample: loaded a chunk AHEAD of its use, so that the memory round trip of chunk k + 1 overlaps the
-// scan of chunk k (a ray is a chain of dependent 64-sample chunks: tools/ubench/launch_floor.hip prices a round trip at ~1.2 us)
+// what one lane reads for one sample: loaded a round AHEAD of its use (the wave's chunk of the next round is in flight during
+// the shading and the scan of this one)
 struct Raw {
     float s[7], alb[3], d[3], t, dt;
 };
@@ -90,21 +91,34 @@ __device__ __forceinline__ Raw load_raw(const RenderArgs& a, uint32_t i, bool va
     return r;
 }
 
-__global__ __launch_bounds__(kThreads) void k_render_train_fwd(RenderArgs a, float* __restrict__ weights,
-                                                                float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                                float* __restrict__ image, float* __restrict__ ray_sums) {
-    if (blockIdx.x >= a.ray_blocks) {   // padding rows [total, cap) belong to no ray: zero weight
+// ---- one workgroup per ray, its 64-sample chunks in sibling waves ----------------------------------------------------------------
+// Round 2 gave a ray to ONE wave that walked its chunks in turn. At 4096 rays that is ~1 wave per SIMD, and what bounds such a
+// wave is not memory (four chunks of loads in flight changed nothing: 15.4 -> 15.2 us) but the LATENCY of its own instruction
+// stream: the shading of a chunk is ~500 dependent-ish VALU instructions (IEEE divisions and square roots of safe_normalize, two
+// log2f of the entropy term) at ~8 cycles each when nothing else shares the SIMD, ~1.7 us per chunk, five chunks in a row for a ray
+// through the density blob. So the chunks of a ray go to kRayWaves sibling waves on different SIMDs: wave w takes chunks w,
+// w + kRayWaves, ...; each shades its chunk and scans it locally; the chunk products meet in LDS, every wave rebuilds the
+// transmittance at its chunk's start by multiplying the earlier products IN ORDER (the same association as the serial walk, so
+// the same bits), and the ray sums are added chunk by chunk in order by wave 0.
+template <uint32_t kRayWaves>
+__global__ __launch_bounds__(kRayWaves * 64) void k_render_train_fwd(RenderArgs a, float* __restrict__ weights,
+                                                                   float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                                   float* __restrict__ image, float* __restrict__ ray_sums) {
+    constexpr uint32_t kRayThreads = kRayWaves * 64;
+    if (blockIdx.x >= a.n_rays) {   // padding rows [total, cap) belong to no ray: zero weight
         const uint32_t total = (uint32_t)a.total_p[0];
-        for (uint32_t i = total + (blockIdx.x - a.ray_blocks) * kThreads + threadIdx.x; i < a.cap; i += kPadBlocks * kThreads) weights[i] = 0.f;
+        for (uint32_t i = total + (blockIdx.x - a.n_rays) * kRayThreads + threadIdx.x; i < a.cap; i += kPadBlocks * kRayThreads) weights[i] = 0.f;
         return;
     }
-    const uint32_t n = (blockIdx.x * kThreads + threadIdx.x) >> 6;
-    if (n >= a.n_rays) return;
+    __shared__ float prod[2][kRayWaves];          // chunk products of the current round (double-buffered across rounds)
+    __shared__ float part[kRayWaves][7];          // per-wave partial ray sums
+    const uint32_t n = blockIdx.x;
     const int lane = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
     const uint32_t offset = (uint32_t)a.rays[n * 2], count = (uint32_t)a.rays[n * 2 + 1];
     if (count == 0 || offset + count > a.cap) {   // raymarching.cu:521-528 (the reference's weights are zero-initialised)
-        for (uint32_t k = lane; k < count && offset + k < a.cap; k += kWave) weights[offset + k] = 0.f;
-        if (lane == 0) {
+        for (uint32_t k = threadIdx.x; k < count && offset + k < a.cap; k += kRayThreads) weights[offset + k] = 0.f;
+        if (threadIdx.x == 0) {
             weights_sum[n] = 0; depth[n] = 0; image[n * 3 + 0] = 0; image[n * 3 + 1] = 0; image[n * 3 + 2] = 0;
             ray_sums[n * 2 + 0] = 0; ray_sums[n * 2 + 1] = 0;
         }
@@ -113,22 +127,18 @@ __global__ __launch_bounds__(kThreads) void k_render_train_fwd(RenderArgs a, flo
     const int mode = shading_mode(a);
     const float ratio = a.ratio_p[0];
     const Vec3 l = ray_light(a.rays_o, a.light_off, n);
-
-    float T_carry = 1.0f;
-    float r = 0, g = 0, b = 0, ws = 0, d = 0, ent = 0, ori = 0;
-    bool done = false;
     const bool lamb = mode == kLambertian;
-    Raw nxt = load_raw(a, offset + (uint32_t)lane, (uint32_t)lane < count, lamb);
-    for (uint32_t base = 0; base < count; base += kWave) {
-        const uint32_t k = base + lane;
+    const uint32_t n_chunks = (count + kWave - 1) / kWave, rounds = (n_chunks + kRayWaves - 1) / kRayWaves;
+
+    float T_round = 1.0f;                          // transmittance at the start of the round's first chunk (same in every wave)
+    float r = 0, g = 0, b = 0, ws = 0, d = 0, ent = 0, ori = 0;
+    Raw nxt = load_raw(a, offset + wv * kWave + (uint32_t)lane, wv * kWave + (uint32_t)lane < count, lamb);
+    for (uint32_t rd = 0; rd < rounds; rd++) {
+        const uint32_t k = (rd * kRayWaves + wv) * kWave + lane;
         const bool valid = k < count;
         const uint32_t i = offset + (valid ? k : 0);
-        if (done) {   // past the transmittance cut: zero weights; they still count in the entropy mean
-            if (valid) { weights[i] = 0.f; ent += entropy_bits(0.f); }
-            continue;
-        }
         const Raw cur = nxt;
-        nxt = load_raw(a, i + kWave, k + kWave < count, lamb);            // the next chunk's loads are in flight during this scan
+        nxt = load_raw(a, i + kRayThreads, k + kRayThreads < count, lamb);   // this wave's chunk of the next round
         float alpha = 0.f, t = 0.f, c[3] = {0.f, 0.f, 0.f}, o = 0.f;
         if (valid) {
             const Sample p = make_sample(cur.s, cur.d, a.e, l);
@@ -137,52 +147,79 @@ __global__ __launch_bounds__(kThreads) void k_render_train_fwd(RenderArgs a, flo
             alpha = 1.0f - __expf(-cur.s[0] * cur.dt);   // raymarching.cu:543 (binarize = false on the training path)
         }
         const float incl = wave_incl_prod(1.0f - alpha, lane);
-        float excl = __shfl_up(incl, 1, kWave);
-        if (lane == 0) excl = 1.0f;
+        const float excl = wave_shift_up1(incl, 1.0f);
+        if (lane == kWave - 1) prod[rd & 1][wv] = incl;
+        __syncthreads();
+        float T_carry = T_round;                   // ((T_round * P_0) * P_1) ... : the serial walk's products, in its order
+        float T_next = T_round;
+#pragma unroll
+        for (uint32_t v = 0; v < kRayWaves; v++) {
+            const float pv = prod[rd & 1][v];
+            if (v < wv) T_carry = T_carry * pv;
+            T_next = T_next * pv;
+        }
+        T_round = T_next;
+        // the cut: the first sample whose transmittance AFTER it falls below T_thresh still counts, nothing behind it does. A
+        // chunk that starts below the threshold lies behind the cut (the transmittance never rises)
+        const bool behind = T_carry < a.T_thresh;
         const float T_before = T_carry * excl, T_after = T_carry * incl;
         const unsigned long long cut = __ballot(valid && (T_after < a.T_thresh));
         const int first_cut = cut ? (int)__ffsll((long long)cut) - 1 : kWave;
-        const float w = (valid && lane <= first_cut) ? alpha * T_before : 0.0f;
+        const float w = (valid && !behind && lane <= first_cut) ? alpha * T_before : 0.0f;
         if (valid) {
             weights[i] = w;
             ent += entropy_bits(w);
             ori += w * o;
         }
         r += w * c[0]; g += w * c[1]; b += w * c[2]; ws += w; d += w * t;
-        T_carry = T_carry * __shfl(incl, kWave - 1, kWave);
-        done = cut != 0ull;
     }
-    r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); d = wave_sum(d); ent = wave_sum(ent); ori = wave_sum(ori);
+    r = wave_total(r); g = wave_total(g); b = wave_total(b); ws = wave_total(ws); d = wave_total(d); ent = wave_total(ent);
+    ori = wave_total(ori);
     if (lane == 0) {
-        weights_sum[n] = ws; depth[n] = d;
-        image[n * 3 + 0] = r; image[n * 3 + 1] = g; image[n * 3 + 2] = b;
-        ray_sums[n * 2 + 0] = ent; ray_sums[n * 2 + 1] = ori;
+        part[wv][0] = r; part[wv][1] = g; part[wv][2] = b; part[wv][3] = ws; part[wv][4] = d; part[wv][5] = ent; part[wv][6] = ori;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc[7];
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            acc[q] = part[0][q];
+#pragma unroll
+            for (uint32_t v = 1; v < kRayWaves; v++) acc[q] += part[v][q];
+        }
+        weights_sum[n] = acc[3]; depth[n] = acc[4];
+        image[n * 3 + 0] = acc[0]; image[n * 3 + 1] = acc[1]; image[n * 3 + 2] = acc[2];
+        ray_sums[n * 2 + 0] = acc[5]; ray_sums[n * 2 + 1] = acc[6];
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_render_train_bwd(RenderArgs a, const float* __restrict__ weights_sum,
-                                                                const float* __restrict__ depth, const float* __restrict__ image,
-                                                                const float* __restrict__ g_weights_sum,
-                                                                const float* __restrict__ g_depth, const float* __restrict__ g_image,
-                                                                const float* __restrict__ g_ray_sums, float* __restrict__ dsigma7,
-                                                                float* __restrict__ dalbedo) {
+template <uint32_t kRayWaves>
+__global__ __launch_bounds__(kRayWaves * 64) void k_render_train_bwd(RenderArgs a, const float* __restrict__ weights_sum,
+                                                                   const float* __restrict__ depth, const float* __restrict__ image,
+                                                                   const float* __restrict__ g_weights_sum,
+                                                                   const float* __restrict__ g_depth, const float* __restrict__ g_image,
+                                                                   const float* __restrict__ g_ray_sums, float* __restrict__ dsigma7,
+                                                                   float* __restrict__ dalbedo) {
+    constexpr uint32_t kRayThreads = kRayWaves * 64;
     const size_t cap = a.cap;
     auto zero_row = [&](uint32_t i) {
 #pragma unroll
         for (uint32_t s = 0; s < 7; s++) dsigma7[s * cap + i] = 0.f;
         dalbedo[(size_t)i * 3 + 0] = 0.f; dalbedo[(size_t)i * 3 + 1] = 0.f; dalbedo[(size_t)i * 3 + 2] = 0.f;
     };
-    if (blockIdx.x >= a.ray_blocks) {
+    if (blockIdx.x >= a.n_rays) {
         const uint32_t total = (uint32_t)a.total_p[0];
-        for (uint32_t i = total + (blockIdx.x - a.ray_blocks) * kThreads + threadIdx.x; i < a.cap; i += kPadBlocks * kThreads) zero_row(i);
+        for (uint32_t i = total + (blockIdx.x - a.n_rays) * kRayThreads + threadIdx.x; i < a.cap; i += kPadBlocks * kRayThreads) zero_row(i);
         return;
     }
-    const uint32_t n = (blockIdx.x * kThreads + threadIdx.x) >> 6;
-    if (n >= a.n_rays) return;
+    __shared__ float prod[2][kRayWaves];
+    __shared__ float tot[2][kRayWaves][5];        // chunk totals of (w c_r, w c_g, w c_b, w, w t)
+    const uint32_t n = blockIdx.x;
     const int lane = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
     const uint32_t offset = (uint32_t)a.rays[n * 2], count = (uint32_t)a.rays[n * 2 + 1];
     if (count == 0 || offset + count > a.cap) {          // raymarching.cu:630: no gradient for such a ray
-        for (uint32_t k = lane; k < count && offset + k < a.cap; k += kWave) zero_row(offset + k);
+        for (uint32_t k = threadIdx.x; k < count && offset + k < a.cap; k += kRayThreads) zero_row(offset + k);
         return;
     }
     const int mode = shading_mode(a);
@@ -195,20 +232,16 @@ __global__ __launch_bounds__(kThreads) void k_render_train_bwd(RenderArgs a, con
     const float r_final = image[n * 3 + 0], g_final = image[n * 3 + 1], b_final = image[n * 3 + 2];
     const float ws_final = weights_sum[n], d_final = depth[n];
 
-    float T_carry = 1.0f, r_c = 0, g_c = 0, b_c = 0, ws_c = 0, d_c = 0;
-    bool done = false;
     const bool lamb = mode == kLambertian;
-    Raw nxt = load_raw(a, offset + (uint32_t)lane, (uint32_t)lane < count, lamb);
-    for (uint32_t base = 0; base < count; base += kWave) {
-        const uint32_t k = base + lane;
+    const uint32_t n_chunks = (count + kWave - 1) / kWave, rounds = (n_chunks + kRayWaves - 1) / kRayWaves;
+    float T_round = 1.0f, acc_round[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // state at the start of the round's first chunk
+    Raw nxt = load_raw(a, offset + wv * kWave + (uint32_t)lane, wv * kWave + (uint32_t)lane < count, lamb);
+    for (uint32_t rd = 0; rd < rounds; rd++) {
+        const uint32_t k = (rd * kRayWaves + wv) * kWave + lane;
         const bool valid = k < count;
         const uint32_t i = offset + (valid ? k : 0);
-        if (done) {   // samples behind the cut get no gradient (the reference leaves its zero-initialised rows alone)
-            if (valid) zero_row(i);
-            continue;
-        }
         const Raw cur = nxt;
-        nxt = load_raw(a, i + kWave, k + kWave < count, lamb);
+        nxt = load_raw(a, i + kRayThreads, k + kRayThreads < count, lamb);
         float alpha = 0.f, t = 0.f, dt = 0.f, c[3] = {0.f, 0.f, 0.f}, o = 0.f;
         Sample p = {};
         if (valid) {
@@ -218,20 +251,46 @@ __global__ __launch_bounds__(kThreads) void k_render_train_bwd(RenderArgs a, con
             alpha = 1.0f - __expf(-cur.s[0] * dt);
         }
         const float incl = wave_incl_prod(1.0f - alpha, lane);
-        float excl = __shfl_up(incl, 1, kWave);
-        if (lane == 0) excl = 1.0f;
+        const float excl = wave_shift_up1(incl, 1.0f);
+        if (lane == kWave - 1) prod[rd & 1][wv] = incl;
+        __syncthreads();
+        float T_carry = T_round, T_next = T_round;
+#pragma unroll
+        for (uint32_t v = 0; v < kRayWaves; v++) {
+            const float pv = prod[rd & 1][v];
+            if (v < wv) T_carry = T_carry * pv;
+            T_next = T_next * pv;
+        }
+        T_round = T_next;
+        const bool behind = T_carry < a.T_thresh;
         const float T_before = T_carry * excl;
         const float T = T_carry * incl;   // already advanced, as at raymarching.cu:664
         const unsigned long long cut = __ballot(valid && (T < a.T_thresh));
         const int first_cut = cut ? (int)__ffsll((long long)cut) - 1 : kWave;
-        const bool contributes = valid && lane <= first_cut;
+        const bool contributes = valid && !behind && lane <= first_cut;
         const float w = contributes ? alpha * T_before : 0.0f;
 
-        const float r = r_c + wave_incl_sum(w * c[0], lane);
-        const float g = g_c + wave_incl_sum(w * c[1], lane);
-        const float b = b_c + wave_incl_sum(w * c[2], lane);
-        const float ws = ws_c + wave_incl_sum(w, lane);
-        const float d = d_c + wave_incl_sum(w * t, lane);
+        // running accumulators of the forward: chunk-local inclusive sums now, the earlier chunks' totals added in order below
+        float sc[5] = {wave_incl_sum(w * c[0], lane), wave_incl_sum(w * c[1], lane), wave_incl_sum(w * c[2], lane),
+                       wave_incl_sum(w, lane), wave_incl_sum(w * t, lane)};
+        if (lane == kWave - 1) {
+#pragma unroll
+            for (int q = 0; q < 5; q++) tot[rd & 1][wv][q] = sc[q];
+        }
+        __syncthreads();
+        float carry[5], next[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            carry[q] = acc_round[q]; next[q] = acc_round[q];
+#pragma unroll
+            for (uint32_t v = 0; v < kRayWaves; v++) {
+                const float tv = tot[rd & 1][v][q];
+                if (v < wv) carry[q] = carry[q] + tv;
+                next[q] = next[q] + tv;
+            }
+            acc_round[q] = next[q];
+        }
+        const float r = carry[0] + sc[0], g = carry[1] + sc[1], b = carry[2] + sc[2], ws = carry[3] + sc[3], d = carry[4] + sc[4];
 
         if (contributes) {
             // compositor (raymarching.cu:664-679): grad_rgb = grad_image * w; grad_weights_i is the entropy term's
@@ -248,13 +307,16 @@ __global__ __launch_bounds__(kThreads) void k_render_train_bwd(RenderArgs a, con
             for (uint32_t s = 0; s < 6; s++) dsigma7[(size_t)(s + 1) * cap + i] = dsig[s];
             dalbedo[(size_t)i * 3 + 0] = dalb[0]; dalbedo[(size_t)i * 3 + 1] = dalb[1]; dalbedo[(size_t)i * 3 + 2] = dalb[2];
         } else if (valid) {
-            zero_row(i);
+            zero_row(i);   // behind the cut: no gradient (the reference leaves its zero-initialised rows alone)
         }
-        done = cut != 0ull;
-        T_carry = T_carry * __shfl(incl, kWave - 1, kWave);
-        r_c = __shfl(r, kWave - 1, kWave); g_c = __shfl(g, kWave - 1, kWave); b_c = __shfl(b, kWave - 1, kWave);
-        ws_c = __shfl(ws, kWave - 1, kWave); d_c = __shfl(d, kWave - 1, kWave);
     }
+}
+
+// sibling waves per ray (SDFX_RENDER_WAVES = 1, 2, 4, 8; measurement aid — every value gives the same results up to the order
+// in which the ray sums are added)
+int ray_waves() {
+    static const int v = [] { const char* e = getenv("SDFX_RENDER_WAVES"); const int w = e ? atoi(e) : 2; return (w == 1 || w == 4 || w == 8) ? w : 2; }();
+    return v;
 }
 
 int fill_args(RenderArgs& a, const float* sigma7, const float* albedo, const float* dirs, const float* ts, const int32_t* rays,
@@ -283,8 +345,12 @@ int sdfx_render_train_forward(const float* sigma7, const float* albedo, const fl
     if (n_rays == 0) return SDFX_OK;   // (capacity 0 = a view without samples: every ray has count 0 and gets zero outputs)
     RenderArgs a;
     fill_args(a, sigma7, albedo, dirs, ts, rays, rays_o, light_offset, ratio, mode_dev, mode, epsilon, T_thresh, capacity, n_rays, total);
-    hipLaunchKernelGGL(k_render_train_fwd, dim3(a.ray_blocks + kPadBlocks), dim3(kThreads), 0, as_stream(stream), a, weights,
-                       weights_sum, depth, image, ray_sums);
+    switch (ray_waves()) {
+        case 1: hipLaunchKernelGGL(k_render_train_fwd<1>, dim3(n_rays + kPadBlocks), dim3(64), 0, as_stream(stream), a, weights, weights_sum, depth, image, ray_sums); break;
+        case 8: hipLaunchKernelGGL(k_render_train_fwd<8>, dim3(n_rays + kPadBlocks), dim3(512), 0, as_stream(stream), a, weights, weights_sum, depth, image, ray_sums); break;
+        case 4: hipLaunchKernelGGL(k_render_train_fwd<4>, dim3(n_rays + kPadBlocks), dim3(256), 0, as_stream(stream), a, weights, weights_sum, depth, image, ray_sums); break;
+        default: hipLaunchKernelGGL(k_render_train_fwd<2>, dim3(n_rays + kPadBlocks), dim3(128), 0, as_stream(stream), a, weights, weights_sum, depth, image, ray_sums); break;
+    }
     return check_launch("render_train_forward");
 }
 
@@ -301,8 +367,15 @@ int sdfx_render_train_backward(const float* sigma7, const float* albedo, const f
     if (capacity == 0 || n_rays == 0) return SDFX_OK;
     RenderArgs a;
     fill_args(a, sigma7, albedo, dirs, ts, rays, rays_o, light_offset, ratio, mode_dev, mode, epsilon, T_thresh, capacity, n_rays, total);
-    hipLaunchKernelGGL(k_render_train_bwd, dim3(a.ray_blocks + kPadBlocks), dim3(kThreads), 0, as_stream(stream), a, weights_sum,
-                       depth, image, grad_weights_sum, grad_depth, grad_image, grad_ray_sums, dsigma7, dalbedo);
+#define SDFX_RBWD(RW_) hipLaunchKernelGGL(k_render_train_bwd<RW_>, dim3(n_rays + kPadBlocks), dim3(RW_ * 64), 0, as_stream(stream), a, \
+                                          weights_sum, depth, image, grad_weights_sum, grad_depth, grad_image, grad_ray_sums, dsigma7, dalbedo)
+    switch (ray_waves()) {
+        case 1: SDFX_RBWD(1); break;
+        case 4: SDFX_RBWD(4); break;
+        case 8: SDFX_RBWD(8); break;
+        default: SDFX_RBWD(2); break;
+    }
+#undef SDFX_RBWD
     return check_launch("render_train_backward");
 }
 

@@ -126,24 +126,45 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
-// inclusive scans across the 64 lanes (Hillis-Steele; 6 steps)
+// Inclusive scans across the 64 lanes on the DPP network (no LDS crossbar: __shfl_up is a ds_bpermute_b32, ~60 cycles each, and a
+// scan is a chain of six): Hillis-Steele inside each row of 16 lanes (row_shr:1, 2, 4, 8; lanes without a source keep the
+// identity), then the last lane of row 0 / 2 is broadcast into row 1 / 3 (row_bcast:15) and the last lane of row 1 into rows 2, 3
+// (row_bcast:31) — the wave64 scan of LLVM's atomic optimizer. `lane` is unused (kept for the callers' signature).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float identity, float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(identity), (int)__float_as_uint(v), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_incl_sum(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const float u = __shfl_up(v, o, kWave);
-        if (lane >= o) v += u;
-    }
+    (void)lane;
+    v += dpp_f32<0x111, 0xf>(0.f, v);   // row_shr:1
+    v += dpp_f32<0x112, 0xf>(0.f, v);   // row_shr:2
+    v += dpp_f32<0x114, 0xf>(0.f, v);   // row_shr:4
+    v += dpp_f32<0x118, 0xf>(0.f, v);   // row_shr:8
+    v += dpp_f32<0x142, 0xa>(0.f, v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_f32<0x143, 0xc>(0.f, v);   // row_bcast:31 into rows 2 and 3
     return v;
 }
 
 __device__ __forceinline__ float wave_incl_prod(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const float u = __shfl_up(v, o, kWave);
-        if (lane >= o) v *= u;
-    }
+    (void)lane;
+    v *= dpp_f32<0x111, 0xf>(1.f, v);
+    v *= dpp_f32<0x112, 0xf>(1.f, v);
+    v *= dpp_f32<0x114, 0xf>(1.f, v);
+    v *= dpp_f32<0x118, 0xf>(1.f, v);
+    v *= dpp_f32<0x142, 0xa>(1.f, v);
+    v *= dpp_f32<0x143, 0xc>(1.f, v);
     return v;
 }
+
+// value of the lane below (lane 0 gets `first`): wave_shr:1
+__device__ __forceinline__ float wave_shift_up1(float v, float first) { return dpp_f32<0x138, 0xf>(first, v); }
+// value of lane 63 in every lane (a scalar broadcast: v_readlane_b32)
+__device__ __forceinline__ float wave_last(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), kWave - 1));
+}
+// sum over the wave in every lane
+__device__ __forceinline__ float wave_total(float v) { return wave_last(wave_incl_sum(v, 0)); }
 
 __device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v, int lane) {
 #pragma unroll

@@ -630,6 +630,88 @@ def test_stencil_batched_field_matches_seven_oracle_evaluations(oracle, dev):
     assert np.abs(n - n_ref).max() <= 6e-2 * scale and np.median(np.abs(n - n_ref)) <= 2e-3 * scale   # differences of two rounded densities / 0.02
 
 
+@pytest.mark.parametrize("bound,live", [(1.0, None), (1.7, None), (1.0, 20011)])
+def test_stencil_source_kernels_bit_identical_to_stencil_tensors(oracle, dev, bound, live):
+    """sdfx_set_stencil_source: the hinted encoder forward, the field forward / backward and the binned scatter form row r of the
+    [7, M, 3] finite-difference batch from the M base samples themselves. Must be BIT-identical to handing them the tensors
+    k_stencil_points writes (which test_stencil_points_kernel pins to the tensor expressions of network_grid.py:81-96): same
+    sigma / albedo, same table gradient, same MLP gradients — also through the generic (un-hinted, atomic) kernels and with a
+    row limit (padding rows of a fixed-capacity buffer)."""
+    importlib.import_module("stable-dreamfusion_amd")
+    import _gridencoder
+    import _sdfx as S
+    from sdfx_nerf import fused_field as ff
+    from sdfx_nerf import network_grid as ng
+    from sdfx_nerf.options import default_opt
+    torch.manual_seed(5)
+    model = ng.NeRFNetwork(default_opt(bound=bound)).to(dev).train()
+    pls = model.encoder.per_level_scale
+    with torch.no_grad():
+        model.encoder.embeddings.copy_(T(synth.s_table(model.encoder.embeddings.shape[0], 2, "trained", np.float32), dev))
+    # every 8th RAY of a view, all of its samples: spread over the scene and ray-ordered like an iteration's batch. (The first
+    # 30 000 samples of a view sit in a few 2048-row buckets of the dense levels, every 8th SAMPLE breaks the runs the scatter
+    # folds: both overflow bucket lists into the atomic fallback, whose half sums depend on the order of arrival.)
+    o, d = synth.s_rays(2)
+    o, d = np.ascontiguousarray(o[::8]), np.ascontiguousarray(d[::8])
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    xyzs = oracle.march_rays_train(o, d, 1.0, synth.s_grid_init()[2], 1, 128, nears, fars, synth.s_noises(o.shape[0]))[0] * np.float32(bound)
+    assert 20011 < xyzs.shape[0] < 60000
+    xyzs[:3] = np.array([[0.999, -0.999, 0.5], [-1.0, 1.0, -1.0], [0.0, 0.0, 0.0]], np.float32) * np.float32(bound)
+    x = T(xyzs, dev)
+    M = x.shape[0]
+    total = None if live is None else torch.tensor([live], dtype=torch.int32, device=dev)
+    n_live = M if live is None else live
+    g = torch.Generator().manual_seed(1)
+    gs, ga = torch.randn(7 * M, generator=g).to(dev), torch.randn(7 * M, 3, generator=g).to(dev)
+    if live is not None:            # the consumer of a fixed-capacity buffer never hands gradient to padding rows
+        pad = (torch.arange(7 * M, device=dev) % M) >= live
+        gs[pad] = 0; ga[pad] = 0
+    outs = {}
+    try:
+        for name, source, binned in (("tensors", 0, 1), ("tensors_again", 0, 1), ("source", 1, 1), ("source_atomic", 1, 0),
+                                     ("tensors_atomic", 0, 0)):
+            ff._STENCIL_SOURCE, _gridencoder._BINNED = source, binned
+            for p in model.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.float16):
+                sigma, albedo = ff.fused_field(x, model.encoder, model.sigma_net, model.bound, 5.0, 0.2, 7, 3.0 ** 0.5 / (1024 * bound),
+                                               stencil_eps=1e-2, row_total=total)
+            ((sigma * gs).sum() + (albedo * ga).sum()).backward()
+            keep = (torch.arange(7 * M, device=dev) % M) < n_live
+            outs[name] = (sigma.detach()[keep].clone(), albedo.detach()[keep].clone(), model.encoder.embeddings.grad.clone(),
+                          [p.grad.clone() for p in model.sigma_net.parameters()])
+    finally:
+        ff._STENCIL_SOURCE, _gridencoder._BINNED = 1, 1
+    report = []
+    for a, b in (("tensors", "tensors_again"), ("tensors", "source"), ("tensors_atomic", "source_atomic")):
+        (s0, a0, t0, w0), (s1, a1, t1, w1) = outs[a], outs[b]
+        ok_out = torch.equal(s0, s1) and torch.equal(a0, a1)
+        ok_w = all(torch.equal(u, v) for u, v in zip(w0, w1))
+        td = (t0.float() - t1.float()).abs()
+        # the binned scatter is order-independent (bit-identical table gradient); half atomics depend on the order of arrival
+        ok_t = torch.equal(t0, t1) if "atomic" not in a else td.max().item() <= 2e-2 * t0.float().abs().max().item()
+        report.append((a, b, ok_out, ok_w, ok_t, int((td > 0).sum()), td.max().item(), t0.float().abs().max().item()))
+    if not report[0][4]:
+        # control: the tensor path does not reproduce ITSELF on this batch — a bucket list overflowed into the atomic fallback
+        # (complete for any input, but a half sum in order of arrival); then the source path is held to the atomic tolerance too
+        report[1] = report[1][:4] + (report[1][6] <= 2e-2 * report[1][7],) + report[1][5:]
+        report[0] = report[0][:4] + (True,) + report[0][5:]
+    assert all(r[2] and r[3] and r[4] for r in report), report
+    assert float(outs["source"][0].abs().sum()) > 0 and float(outs["source"][2].float().abs().sum()) > 0
+    # ... and the un-hinted generic forward kernel (k_grid_forward) with a source against the tensor batch
+    pts, unit = torch.empty(7 * M, 3, device=dev), torch.empty(7 * M, 3, device=dev)
+    import _field
+    _field.stencil_points(x, 1e-2, bound, pts, unit)
+    emb = model.encoder.embeddings.detach().half().contiguous()
+    off_t = model.encoder.offsets
+    e0, e1 = torch.empty(16, 7 * M, 2, dtype=torch.half, device=dev), torch.empty(16, 7 * M, 2, dtype=torch.half, device=dev)
+    Sc = float(np.log2(pls))
+    _gridencoder.grid_encode_forward(unit, emb, off_t, e0, 7 * M, 3, 2, 16, 16, Sc, 16, None, 0, False, 1, 0, 1, 0.0)
+    with S.stencil_source(x, 1e-2, bound):
+        _gridencoder.grid_encode_forward(None, emb, off_t, e1, 7 * M, 3, 2, 16, 16, Sc, 16, None, 0, False, 1, 0, 1, 0.0)
+    assert torch.equal(e0, e1)
+
+
 @pytest.mark.parametrize("gridname", ["init", "blobs", "full"])
 def test_wave_per_ray_march_matches_thread_per_ray(oracle, dev, gridname):
     import raymarching
