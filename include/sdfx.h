@@ -484,6 +484,52 @@ int sdfx_adan_update(float* const* params, const float* const* grads, float* con
                      const float* weight_decays, uint32_t tensors, const float* ctl, float eps, float beta1, float beta2,
                      float beta3, int no_prox, sdfx_stream_t stream);
 
+/* ------------------------------------------------------------ DMTet fine-tune stage (extension; BASELINE configs[4]) */
+
+/*
+ * Marching tetrahedra — `class DMTet.__call__` of nerf/renderer.py:94-178 (occupancy masks, torch.unique over the sorted edges of the
+ * valid tetrahedra, index remapping, two gathers through the triangle table: ~25 tensor operations and a sort per iteration) as
+ * three kernels with IDENTICAL outputs: vertex order, face order, indices, float32 vertex positions.
+ *   edges      int32 [E, 2]: the unique edges (a < b) of the WHOLE grid in lexicographic order — static, built once on the host
+ *   tets       int32 [F, 4]; tet_edges int32 [F, 6]: position in `edges` of each tetrahedron's edges (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+ *   count      counts[0..2] = (vertices V, one-triangle tetrahedra F1, two-triangle tetrahedra F2); scratch keeps per-workgroup
+ *              offsets for `emit`, which must be called with the same sdf
+ *   emit       edge_vid [E] (-1: no vertex), verts [>= V, 3], vert_edges [>= V, 2] (the grid edge of each vertex), faces [>= F1 + 2 F2, 3]:
+ *              rows [0, F1) from the one-triangle tetrahedra, then pairs of rows from the two-triangle ones, each in grid order
+ *   backward   grad_pos [N, 3] / grad_sdf [N] += gradients of the interpolation v = p_a (-s_b / (s_a - s_b)) + p_b (s_a / (s_a - s_b))
+ */
+uint64_t sdfx_marching_tets_scratch_bytes(uint32_t E, uint32_t F);
+int sdfx_marching_tets_count(const float* sdf, const int32_t* edges, uint32_t E, const int32_t* tets, uint32_t F, void* scratch,
+                             int32_t* counts, sdfx_stream_t stream);
+int sdfx_marching_tets_emit(const float* pos, const float* sdf, const int32_t* edges, uint32_t E, const int32_t* tets,
+                            const int32_t* tet_edges, uint32_t F, const void* scratch, const int32_t* counts, int32_t* edge_vid,
+                            float* verts, int32_t* vert_edges, uint32_t cap_verts, int32_t* faces, uint32_t cap_faces,
+                            sdfx_stream_t stream);
+int sdfx_marching_tets_backward(const float* grad_verts, uint32_t V, const int32_t* vert_edges, const float* pos, const float* sdf,
+                                float* grad_pos, float* grad_sdf, sdfx_stream_t stream);
+
+/*
+ * Mesh rasterisation — the three nvdiffrast calls of run_dmtet (nerf/renderer.py:900 dr.rasterize, :903-904 dr.interpolate,
+ * :932-933 dr.antialias), B = 1. nvdiffrast is a third-party dependency absent from the reference checkout: these follow its
+ * published contract (csrc/raster.hip). pos_clip [N, 4], tri int32 [F, 3], rast [H, W, 4] = (u, v, z/w, triangle id + 1; 0 =
+ * background), row 0 = NDC y -1. Backward entry points ADD into grad_pos / grad_attr (zero them first) and WRITE grad_rast /
+ * grad_color. adj_opp int32 [F, 3]: vertex opposite to edge k (vertices k, k + 1) in the triangle across that edge, -1: none.
+ */
+uint64_t sdfx_rasterize_scratch_bytes(uint32_t H, uint32_t W);
+int sdfx_rasterize_forward(const float* pos_clip, const int32_t* tri, uint32_t N, uint32_t F, uint32_t H, uint32_t W, void* scratch,
+                           float* rast, sdfx_stream_t stream);
+int sdfx_rasterize_backward(const float* pos_clip, const int32_t* tri, uint32_t N, uint32_t H, uint32_t W, const float* rast,
+                            const float* grad_rast, float* grad_pos, sdfx_stream_t stream);
+int sdfx_interpolate_forward(const float* attr, const int32_t* tri, uint32_t C, uint32_t H, uint32_t W, const float* rast, float* out,
+                             sdfx_stream_t stream);
+int sdfx_interpolate_backward(const float* attr, const int32_t* tri, uint32_t C, uint32_t H, uint32_t W, const float* rast,
+                              const float* grad_out, float* grad_attr, float* grad_rast, sdfx_stream_t stream);
+int sdfx_antialias_forward(const float* color, const float* rast, const float* pos_clip, const int32_t* tri, const int32_t* adj_opp,
+                           uint32_t N, uint32_t C, uint32_t H, uint32_t W, float* out, sdfx_stream_t stream);
+int sdfx_antialias_backward(const float* color, const float* rast, const float* pos_clip, const int32_t* tri, const int32_t* adj_opp,
+                            uint32_t N, uint32_t C, uint32_t H, uint32_t W, const float* grad_out, float* grad_color, float* grad_pos,
+                            sdfx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.realpath(__file__))  # realpath: backends_only/ holds symlinks to these files
-LIB_PATH = os.path.join(_HERE, "csrc", "libsdfx_hip.so")
+# (SDFX_LIB: a differently configured build of the same library, for A/B measurements)
+LIB_PATH = os.environ.get("SDFX_LIB") or os.path.join(_HERE, "csrc", "libsdfx_hip.so")
 
 _u32, _f32, _int, _ptr, _u64 = C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_uint64
 
@@ -89,6 +90,17 @@ _SIGNATURES = {
     "sdfx_grid_set_impl": [_int, _int],
     "sdfx_grid_backward_plan": [_ptr, _u32, _f32, _u32, _u32, _int, _ptr, _ptr],
     "sdfx_grid_forward_plan": [_ptr, _u32, _f32, _u32, _int, _u32, _u32, _f32, _ptr, _u32, _ptr],
+    "sdfx_marching_tets_scratch_bytes": [_u32, _u32],
+    "sdfx_marching_tets_count": [_ptr, _ptr, _u32, _ptr, _u32, _ptr, _ptr, _ptr],
+    "sdfx_marching_tets_emit": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _u32, _ptr],
+    "sdfx_marching_tets_backward": [_ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_rasterize_scratch_bytes": [_u32, _u32],
+    "sdfx_rasterize_forward": [_ptr, _ptr, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr],
+    "sdfx_rasterize_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_interpolate_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
+    "sdfx_interpolate_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_antialias_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _ptr, _ptr],
+    "sdfx_antialias_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr],
     "sdfx_adan_ctl_words": [],
     "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],
     "sdfx_adan_prepare": [_ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _u32, _ptr],
@@ -99,6 +111,8 @@ _RESTYPES = {
     "sdfx_compact_rays_scratch_bytes": _u64,
     "sdfx_head_scratch_bytes": _u64,
     "sdfx_grid_encode_backward_binned_scratch_bytes": _u64,
+    "sdfx_marching_tets_scratch_bytes": _u64,
+    "sdfx_rasterize_scratch_bytes": _u64,
     "sdfx_field_packed_words": _u32,
     "sdfx_field_backward_scratch_bytes": _u64,
     "sdfx_adan_ctl_words": _u32,

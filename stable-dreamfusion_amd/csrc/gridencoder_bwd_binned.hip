@@ -28,7 +28,10 @@ using namespace sdfx::grid;
 
 namespace {
 
-constexpr uint32_t kBucketRowsLog2 = 11;
+#ifndef SDFX_BUCKET_LOG2
+#define SDFX_BUCKET_LOG2 11   // measurement aid: -DSDFX_BUCKET_LOG2=12 builds the 4096-row variant (64 KiB of accumulators in K2)
+#endif
+constexpr uint32_t kBucketRowsLog2 = SDFX_BUCKET_LOG2;
 constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;  // rows per bucket (16 KiB of float2 accumulators)
 constexpr uint32_t kMaxBucketsPerLevel = 512;            // levels up to 2^20 rows
 constexpr uint32_t kBinThreads = 512;
@@ -621,7 +624,9 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
         buckets += nb;
         wgs += nb * splits;
         // fold lane runs where neighbouring samples (~1/600 of the unit cube apart) usually share a cell
-        if (plan.res[l] <= 640) b.merge_mask |= 1u << l;  // (scan_cell_runs packs a cell id into 10 bits per axis: res <= 1024)
+        // (scan_cell_runs packs a cell id into 10 bits per axis: res <= 1023; SDFX_GRIDBWD_MERGE_RES moves the threshold for A/B runs)
+        static const uint32_t merge_res = [] { const char* e = getenv("SDFX_GRIDBWD_MERGE_RES"); const int v = e ? atoi(e) : 640; return (uint32_t)(v < 0 ? 0 : (v > 1023 ? 1023 : v)); }();
+        if (plan.res[l] <= merge_res) b.merge_mask |= 1u << l;
     }
     b.bucket_first[levels] = buckets;
     b.split_first[levels] = wgs;

@@ -51,12 +51,22 @@ struct FwdPlan {
     uint32_t vec16;           // table base 16-byte aligned: paired gathers allowed
     uint32_t slabs;           // 1, or 7 = stencil batch [7, B/7, 3] evaluated with the 7 points of a sample in neighbouring lanes
     uint32_t slab_points;     // B / slabs
+    // measurement aid (SDFX_GRID_PLAN=sample_major): every XCD takes 1/8 of the tiles and evaluates ALL levels of a tile before the
+    // next tile — the table access pattern of a kernel that fuses the encode into the MLP (all 16 levels of a sample in one
+    // place): no XCD's L2 can hold the 23 MB of tables. The A/B against the level-major default prices that fusion.
+    uint32_t sample_major, tiles, levels;
 };
 
 // workgroup -> (level, tile) through the XCD's segment list (walked in order); false when there is nothing to do
 __device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint32_t& tile) {
     const uint32_t xcd = blockIdx.x % kXcds;
     uint32_t local = blockIdx.x / kXcds;
+    if (p.sample_major) {
+        const uint32_t per = (p.tiles + kXcds - 1) / kXcds;
+        tile = xcd * per + local / p.levels;
+        level = p.levels - 1u - local % p.levels;
+        return local < per * p.levels && tile < p.tiles;
+    }
     if (local >= p.ntiles[xcd]) return false;
 #pragma unroll
     for (uint32_t s = 0; s < kMaxSegs; s++) {
@@ -283,6 +293,11 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
     p.slab_points = B / p.slabs;
     const uint64_t slots = p.slabs == kGroup ? (uint64_t)div_up(p.slab_points, kGroupsPerWave) * 64u : B;
     const uint32_t T = div_up(slots, (uint64_t)kTile * P);   // tiles per level
+    p.tiles = T; p.levels = levels;
+    {
+        static const int sm = [] { const char* e = getenv("SDFX_GRID_PLAN"); return (e && !strcmp(e, "sample_major")) ? 1 : 0; }();
+        p.sample_major = (uint32_t)sm;
+    }
 
     // ---- the sequence of levels and what a tile of each costs ----
     Unit units[kMaxLevels];
@@ -323,6 +338,7 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
 }
 
 uint32_t fwd_grid_size(const FwdPlan& p) {
+    if (p.sample_major) return ((p.tiles + kXcds - 1) / kXcds) * p.levels * kXcds;
     uint32_t longest = 0;
     for (uint32_t k = 0; k < kXcds; k++) longest = p.ntiles[k] > longest ? p.ntiles[k] : longest;
     return longest * kXcds;

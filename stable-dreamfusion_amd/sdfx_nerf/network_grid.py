@@ -255,4 +255,7 @@ class NeRFNetwork(NeRFRenderer):
                   {"params": self.sigma_net.parameters(), "lr": lr}]
         if self.opt.bg_radius > 0:
             params.append({"params": self.bg_net.parameters(), "lr": lr})
+        if getattr(self.opt, "dmtet", False) and not getattr(self.opt, "lock_geo", False):   # network_grid.py:168-170
+            params.append({"params": self.sdf, "lr": lr})
+            params.append({"params": self.deform, "lr": lr})
         return params

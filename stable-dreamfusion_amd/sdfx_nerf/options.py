@@ -15,6 +15,7 @@ def default_opt(**overrides) -> argparse.Namespace:
         lambda_entropy=1e-3, lambda_opacity=0.0, lambda_orient=1e-2, lambda_tv=0.0, lambda_wd=0.0, lambda_guidance=1.0,
         lambda_normal=0.0, lambda_2d_normal_smooth=0.0, lambda_3d_normal_smooth=0.0, grad_clip=-1.0,
         guidance_scale=100.0, exp_start_iter=0, exp_end_iter=10000,
+        tet_grid_size=128, lock_geo=False, dmtet_reso_scale=8, lambda_mesh_normal=0.5, lambda_mesh_laplacian=0.5,
     )
     for k, v in overrides.items():
         setattr(opt, k, v)
@@ -26,4 +27,13 @@ def if_preset(opt: argparse.Namespace) -> argparse.Namespace:
     schedule of Trainer.train_step never takes its latent branch (global_step >= 1 when it is evaluated)."""
     opt.latent_iter_ratio = 0
     opt.IF = True
+    return opt
+
+
+def dmtet_preset(opt: argparse.Namespace) -> argparse.Namespace:
+    """`--dmtet` (main.py:253-260): render at h, w x dmtet_reso_scale (64 -> 512), timestep range of the guidance [0.02, 0.50]."""
+    opt.dmtet = True
+    opt.h = int(opt.h * opt.dmtet_reso_scale)
+    opt.w = int(opt.w * opt.dmtet_reso_scale)
+    opt.t_range = [0.02, 0.50]
     return opt

@@ -485,6 +485,90 @@ def make_renderer():
     print("renderer_ref.npz", out["mean_density"], out["lambertian_weights"].shape, float(out["lambertian_loss"]))
 
 
+def make_dmtet():
+    """tests/golden/dmtet_ref.npz — the DMTet fine-tune stage (BASELINE configs[4]) from the reference's own code:
+    (1) `class DMTet.__call__` (nerf/renderer.py:94-178, pure torch) on this repository's Kuhn tetrahedral grid: vertices, faces
+        (order and indices are part of the golden) and the gradients of a linear functional of the vertices into sdf and positions;
+    (2) `NeRFRenderer.run_dmtet` (renderer.py:862-964) at 96 x 96 in three shading modes, with the three nvdiffrast calls served by
+        oracle/raster.py (nvdiffrast is absent: the golden pins everything of run_dmtet AROUND those calls — tanh deform, mesh
+        normals, vertex-normal scatter, clip transform, masking, shading, clamps, background mix, normal-consistency and Laplacian
+        losses — and the gradients into sdf, deform and the field's parameters through all of it)."""
+    import argparse
+    repo = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    import importlib
+    importlib.import_module("stable-dreamfusion_amd")
+    import synth
+    from oracle.raster import Dr
+    from sdfx_nerf.dmtet import kuhn_tet_grid
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import nerf.renderer as RR
+    RR.dr = Dr
+    n = 12
+    grid = kuhn_tet_grid(n)
+    verts0 = -torch.tensor(grid["vertices"], dtype=torch.float32) * 2            # renderer.py:294
+    tets = torch.tensor(grid["indices"], dtype=torch.long)
+    g = torch.Generator().manual_seed(61)
+    r = verts0.norm(dim=-1)
+    sdf0 = (0.55 - r * (1 + 0.25 * torch.sin(5 * verts0[:, 0]) * torch.cos(4 * verts0[:, 1]))) + 0.02 * torch.randn(r.shape, generator=g)
+    deform0 = 0.5 * torch.randn(verts0.shape, generator=g)
+    out = dict(grid_n=np.int32(n), sdf=sdf0.numpy(), deform=deform0.numpy())
+
+    # (1) the class alone
+    sdf = sdf0.clone().requires_grad_()
+    pos = (verts0 + torch.tanh(deform0) / n).clone().requires_grad_()
+    verts, faces = RR.DMTet("cpu")(pos, sdf, tets)
+    gv = torch.randn(verts.shape, generator=g)
+    (verts * gv).sum().backward()
+    out.update(mt_pos=pos.detach().numpy(), mt_verts=verts.detach().numpy(), mt_faces=faces.numpy().astype(np.int32), mt_gv=gv.numpy(),
+               mt_dsdf=sdf.grad.numpy(), mt_dpos=pos.grad.numpy())
+
+    # (2) run_dmtet over the oracle rasteriser
+    theta = torch.tensor([0.3, -0.2, 0.5, 0.7], requires_grad=True)
+    opt = argparse.Namespace(tet_grid_size=n, lock_geo=False, bg_radius=1.4, lambda_2d_normal_smooth=0.0, lambda_normal=0.0,
+                             lambda_mesh_normal=0.5, lambda_mesh_laplacian=0.5)
+
+    class Stub:
+        pass
+    o = Stub()
+    o.opt, o.training, o.glctx = opt, True, None
+    o.verts, o.indices, o.dmtet_model = verts0, tets, RR.DMTet("cpu")
+    o.sdf = torch.nn.Parameter(sdf0.clone())
+    o.deform = torch.nn.Parameter(deform0.clone())
+    o.density = lambda x: {"albedo": torch.sigmoid(theta[:3] + theta[3] * x)}
+    o.background = lambda d: torch.sigmoid(d * theta[:3])
+    H = W = 96
+    poses, fovy = synth.reference_cameras()
+    pose = torch.from_numpy(poses[3]).float()[None]
+    focal = H / (2 * np.tan(np.deg2rad(float(fovy[3])) / 2))
+    near, far = 0.01, 1000.0
+    projection = torch.tensor([[2 * focal / W, 0, 0, 0], [0, -2 * focal / H, 0, 0],
+                               [0, 0, -(far + near) / (far - near), -(2 * far * near) / (far - near)], [0, 0, -1, 0]],
+                              dtype=torch.float32)[None]                           # nerf/provider.py:222-227
+    mvp = projection @ torch.inverse(pose)
+    ro, rd = synth.get_rays(poses[3], float(fovy[3]), H, W)
+    rays_o, rays_d = torch.from_numpy(ro)[None], torch.from_numpy(rd)[None]
+    gi = torch.randn(1, H, W, 3, generator=g)
+    out.update(theta=theta.detach().numpy(), mvp=mvp.numpy(), rays_o=rays_o.numpy(), rays_d=rays_d.numpy(), gi=gi.numpy(), hw=np.int32(H))
+    for shading, ratio, bg in (("lambertian", 0.4, None), ("albedo", 1.0, torch.tensor([0.2, 0.5, 0.9])), ("normal", 1.0, None)):
+        torch.manual_seed(62)
+        for p_ in (o.sdf, o.deform, theta):
+            p_.grad = None
+        res = RR.NeRFRenderer.run_dmtet(o, rays_o, rays_d, mvp, H, W, light_d=None, ambient_ratio=ratio, shading=shading, bg_color=bg)
+        loss = (res["image"] * gi).sum() + res["weights_sum"].sum() + 3.0 * res["normal_loss"] + 2.0 * res["lap_loss"]
+        loss.backward()
+        out.update({f"{shading}_image": res["image"].detach().numpy(), f"{shading}_alpha": res["weights_sum"].detach().numpy(),
+                    f"{shading}_depth": res["depth"].detach().numpy(), f"{shading}_normal_loss": np.float64(res["normal_loss"].item()),
+                    f"{shading}_lap_loss": np.float64(res["lap_loss"].item()), f"{shading}_loss": np.float64(loss.item()),
+                    f"{shading}_dsdf": o.sdf.grad.numpy().copy(), f"{shading}_ddeform": o.deform.grad.numpy().copy(),
+                    f"{shading}_dtheta": theta.grad.numpy().copy()})
+    np.savez_compressed(os.path.join(OUT, "dmtet_ref.npz"), **out)
+    print("dmtet_ref.npz", out["mt_verts"].shape, out["mt_faces"].shape, float(out["lambertian_loss"]),
+          float((out["lambertian_alpha"] > 0).mean()))
+
+
+
 def _sparse(t):
     rows = (t != 0).any(1).nonzero().flatten()
     return rows.numpy().astype(np.int32), t[rows].numpy()
@@ -773,6 +857,9 @@ if __name__ == "__main__":
     if "--only-o2" in sys.argv:
         make_o2()
         sys.exit(0)
+    if "--only-dmtet" in sys.argv:
+        make_dmtet()
+        sys.exit(0)
     if "--only-encmodule" in sys.argv:
         make_encmodule()
         sys.exit(0)
@@ -788,6 +875,7 @@ if __name__ == "__main__":
     make_encmodule()
     make_o2()
     make_renderer()      # last: it monkey-patches torch.Tensor.cuda
+    make_dmtet()
     make_freq()
     make_run_composite()
     make_field()
