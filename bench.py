@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--prior", default=os.environ.get("SDFX_BENCH_PRIOR", "sd"), choices=["sd", "if"],
                     help="sd (default): BASELINE configs[1], latent-space SDS (guidance/sd_utils.py); if: configs[3], the `--IF` preset "
                          "(main.py:181-185: pixel-space SDS at 64 x 64, guidance/if_utils.py, no latent phase)")
+    ap.add_argument("--stage", default="nerf", choices=["nerf", "dmtet"],
+                    help="nerf (default): the volumetric -O iteration; dmtet: BASELINE configs[4], the DMTet fine-tune stage (marching "
+                         "tetrahedra on a 128-size grid, mesh rasterised at 512^2, SDS at 512^2; main.py:253-260)")
     ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)   # child mode of cpu_baseline's thread probe
     ap.add_argument("--grid", default="init", choices=["trained-proxy", "init"],
                     help="occupancy the model starts from (the iteration refreshes it every 16 steps)")
@@ -498,7 +501,17 @@ class GpuJob:
         if args.prior == "if":
             from sdfx_nerf.options import if_preset
             if_preset(self.opt)                      # main.py:181-185: latent_iter_ratio = 0
+        self.dmtet = args.stage == "dmtet"
+        if self.dmtet:
+            from sdfx_nerf.options import dmtet_preset
+            dmtet_preset(self.opt)                   # main.py:253-260: 512 x 512, t_range [0.02, 0.50]
         self.model = NeRFNetwork(self.opt).to(dev)
+        if self.dmtet:
+            # what `--init_with <NeRF checkpoint>` leaves behind (main.py:317-323, nerf/utils.py:1301-1303): an occupancy grid, then
+            # sdf / tet_scale initialised from the density field — here the density blob of a fresh field
+            with torch.autocast("cuda", dtype=torch.float16, enabled=self.opt.fp16):
+                self.model.update_extra_state()
+                self.model.init_tet()
         self.prior, self.guidance_kind, self.prior_ok = None, args.guidance, True
         big = "if_random" if args.prior == "if" else "sd15_random"
         if args.guidance in ("auto", "sd15_random"):
@@ -517,7 +530,7 @@ class GpuJob:
                         probe2.backward()
                 else:
                     from sdfx_nerf.sd15_arch import sd15_random_prior
-                    self.prior = sd15_random_prior(dev, self.opt.fp16)
+                    self.prior = sd15_random_prior(dev, self.opt.fp16, t_range=tuple(getattr(self.opt, "t_range", (0.02, 0.98))))
                     with torch.autocast("cuda", dtype=torch.float16, enabled=self.opt.fp16):
                         z = torch.cat([self.prior.get_text_embeds(["uncond"]), self.prior.get_text_embeds(["front"])])
                         probe = self.prior.train_step(z, torch.rand(1, 4, 64, 64, device=dev), as_latent=True)
@@ -539,16 +552,21 @@ class GpuJob:
             self.prior_ok = False
         poses, fovy = synth.reference_cameras()
         self.views = []
+        hw = (self.opt.h, self.opt.w)
         for v in range(len(poses)):
-            o, d = synth.get_rays(poses[v], float(fovy[v]))
+            o, d = synth.get_rays(poses[v], float(fovy[v]), *hw)
             az = float(np.degrees(np.arctan2(poses[v][0, 3], poses[v][2, 3])))
-            self.views.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), az))
+            mvp = torch.from_numpy(synth.mvp_from_pose(poses[v], float(fovy[v]), *hw))[None].to(dev) if self.dmtet else None
+            self.views.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), az, mvp))
         self.phase_step = {}
         self.phase = None
 
     def use_synthetic_prior(self):
         from sdfx_nerf import guidance as G
-        self.prior = (G.synthetic_if_prior if self.args.prior == "if" else G.synthetic_prior)(self.dev, self.opt.fp16)
+        if self.args.prior == "if":
+            self.prior = G.synthetic_if_prior(self.dev, self.opt.fp16)
+        else:
+            self.prior = G.synthetic_prior(self.dev, self.opt.fp16, t_range=tuple(getattr(self.opt, "t_range", (0.02, 0.98))))
         self.guidance_kind = "synthetic"
 
     def build(self, mode=None):
@@ -578,9 +596,9 @@ class GpuJob:
         st.global_step = self.phase_step[phase]   # (a count prefetched for the other phase's next step no longer matches: recounted)
 
     def step(self, i):
-        ro, rd, az = self.views[rank_view(self.rank, i, len(self.views))]
+        ro, rd, az, mvp = self.views[rank_view(self.rank, i, len(self.views))]
         nxt = self.views[rank_view(self.rank, i + 1, len(self.views))]      # what a data loader knows: the next camera's rays
-        self.step_obj.step(ro, rd, azimuth=az, next_rays=(nxt[0], nxt[1]))
+        self.step_obj.step(ro, rd, azimuth=az, H=self.opt.h, W=self.opt.w, next_rays=(nxt[0], nxt[1]), mvp=mvp)
         return self.step_obj.last["num_samples"]
 
     def sync(self):
@@ -723,7 +741,8 @@ def main():
         "metric": "sds_iters_per_sec", "value": job_throughput(world, args.steps, elapsed), "unit": "iters/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f16 table/features, f32 coordinates+compositing", "data": "synthetic",
-        "phases": phases, "rays_per_s": world * args.steps * 4096 / elapsed, "samples_per_iter": samples / max(args.steps, 1),
+        "phases": phases, "rays_per_s": world * args.steps * (512 * 512 if args.stage == "dmtet" else 4096) / elapsed,
+        "samples_per_iter": samples / max(args.steps, 1),
         "optimizer_steps_applied": applied_in_timed, "scaler_calibration_iters": calib, "train_mode": job.train_mode,
     }
     if dry:
@@ -792,7 +811,7 @@ def main():
     # third figure: the reference's host flow (torch.amp.GradScaler + foreach Adan, no device-side tail, no graph replay,
     # nerf/utils.py:1032-1072) on the same kernels — what an unchanged main.py gets from the drop-in operators
     ref_flow = None
-    if not args.no_reference_flow:
+    if not args.no_reference_flow and args.stage != "dmtet":   # (the DMTet stage runs the reference's host flow as its headline)
         graph_step = job.step_obj
         job.build(mode="reference")
         job.calibrate()
@@ -858,9 +877,13 @@ def main():
         units = pm.get("points_per_launch") or (pm["WRITE_SIZE_KB_avg"] * 1024.0 / unit_bytes_written)
         return total / units * units_this_run, units
 
-    enc = ksum.get("grid_encode_forward", {"GBps": 0.0, "avg_us": 0.0, "launches": 0, "bytes": 0})
+    enc = ksum.get("grid_encode_forward") or {"GBps": 0.0, "avg_us": 0.0, "launches": 0, "bytes": 0}
+    enc_kernel, pmc_key = "k_grid_fwd<half> (7-point stencil batches of the iteration)", "k_grid_fwd"
+    if not enc["launches"] and ksum.get("grid_encode_forward_unhinted"):     # DMTet stage: one un-hinted encode of the visible points
+        enc, enc_kernel = ksum["grid_encode_forward_unhinted"], "k_grid_forward<3, 2, half> (surface points of the rasterised mesh, no hint)"
+        pmc_key = "k_grid_forward"
     enc_points = (enc["bytes"] / enc["launches"] / 588.0) if enc.get("launches") else 0.0
-    traffic, pmc_points = scaled_traffic("k_grid_fwd", enc_points, 64.0)        # 16 levels x 2 halves written per point
+    traffic, pmc_points = scaled_traffic(pmc_key, enc_points, 64.0)        # 16 levels x 2 halves written per point
     prior_txt = {
         "sd15_random": " (SD-1.5 UNet + VAE-encoder architecture, 860 M + 34 M parameters, random weights, evaluated in full; its damped "
                        "output is added to the consistent stand-in; diffusers/hub weights absent)",
@@ -869,15 +892,22 @@ def main():
                      "(4.3 B) and T5 absent)",
     }.get(job.guidance_kind, " (consistent-denoiser stand-in for the frozen prior; diffusers/hub weights absent)")
     cfg_name = "BASELINE configs[3] (`--IF`: pixel-space SDS at 64 x 64, no latent phase)" if args.prior == "if" else "BASELINE configs[1]"
+    workload = (cfg_name + ": Instant-NGP -O iteration, 4096 rays (64x64), 128^3 occupancy grid, <=1024 steps/ray, "
+                "16-level hash grid (2^19 x 2 fp16), 7 field evals/sample, SDS loss, AMP backward, Adan step, grid refresh "
+                "every 16 iters")
+    if args.stage == "dmtet":
+        m = job.model
+        workload = (f"BASELINE configs[4]: DMTet fine-tune iteration — marching tetrahedra on a 128-size grid ({m.verts.shape[0]} vertices, "
+                    f"{m.indices.shape[0]} tetrahedra; Kuhn n = 64, the reference's tets/128_tets.npz is a missing blob), mesh rasterised / "
+                    f"interpolated / antialiased at 512 x 512, albedo from the 16-level hash-grid field at the visible surface points, "
+                    f"SDS at 512^2, normal-consistency + Laplacian regularisers, AMP backward, Adan (sdf, deform, field)")
     result["config"] = {
-        "workload": cfg_name + ": Instant-NGP -O iteration, 4096 rays (64x64), 128^3 occupancy grid, <=1024 steps/ray, "
-                    "16-level hash grid (2^19 x 2 fp16), 7 field evals/sample, SDS loss, AMP backward, Adan step, grid refresh "
-                    "every 16 iters; timed steps = " + " + ".join(f"{k} {n}" for n, k in plan),
+        "workload": workload + "; timed steps = " + " + ".join(f"{k} {n}" for n, k in plan), "stage": args.stage,
         "guidance": job.guidance_kind + prior_txt, "prior": args.prior,
-        "rays_per_iter": 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid, "phase": args.phase}
+        "rays_per_iter": 512 * 512 if args.stage == "dmtet" else 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid, "phase": args.phase}
     sec = enc["avg_us"] * 1e-6
     result["roofline"] = {
-        "bound": "hbm", "kernel": "k_grid_fwd<half> (7-point stencil batches of the iteration)", "achieved": enc["GBps"],
+        "bound": "hbm", "kernel": enc_kernel, "achieved": enc["GBps"],
         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": enc["GBps"] / HBM_PEAK_GBPS, "traffic": traffic,
         "traffic_unit": f"bytes per launch, rocprofv3 2*FETCH_SIZE + WRITE_SIZE of {traffic_file} (measured at {pmc_points and round(pmc_points)} "
                         f"points per launch) scaled per point to this run's launch size",

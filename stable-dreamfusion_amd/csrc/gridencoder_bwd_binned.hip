@@ -293,8 +293,10 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
     }
 }
 
+// (second bound = waves per SIMD: 8, i.e. 4 workgroups per CU, which the 38 KB of LDS allow: the kernel waits on memory and barriers most of the time —
+// PMC: 61 % of its wave cycles — so residency matters more than registers; without the bound the compiler took 72 VGPRs = 3 workgroups)
 template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
-__global__ __launch_bounds__(kBinThreads) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,
+__global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,
                                                                const float* __restrict__ inputs,
                                                                typename Elem<HALF>::type* __restrict__ grad_table,
                                                                uint32_t B, uint32_t L, uint32_t b0, uint32_t b1,

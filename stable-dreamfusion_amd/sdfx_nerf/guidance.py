@@ -330,5 +330,5 @@ def synthetic_if_prior(device, fp16=True):
     return IFGuidance(SyntheticPixelUNet(alphas), device, fp16, alphas=alphas)
 
 
-def synthetic_prior(device, fp16=True):
-    return SDSGuidance(SyntheticUNet(), SyntheticVAE(), device, fp16)
+def synthetic_prior(device, fp16=True, t_range=(0.02, 0.98)):
+    return SDSGuidance(SyntheticUNet(), SyntheticVAE(), device, fp16, t_range=t_range)

@@ -198,7 +198,7 @@ class Sd15PriorUNet(nn.Module):
         return out + self.damp * torch.nan_to_num(y)
 
 
-def sd15_random_prior(device, fp16=True, seed=1234):
+def sd15_random_prior(device, fp16=True, seed=1234, t_range=(0.02, 0.98)):
     gen_state = torch.random.get_rng_state()
     torch.manual_seed(seed)
     try:
@@ -206,7 +206,7 @@ def sd15_random_prior(device, fp16=True, seed=1234):
     finally:
         torch.random.set_rng_state(gen_state)
     unet.unet.to(memory_format=torch.channels_last)
-    return G.SDSGuidance(unet, vae, device, fp16)
+    return G.SDSGuidance(unet, vae, device, fp16, t_range=t_range)
 
 
 class IfPriorUNet(nn.Module):

@@ -58,6 +58,11 @@ class TrainStep:
         self.rng = random.Random(seed)
         if opt.optim != "adan" and self.mode != "reference":
             self.mode = "reference"  # the device-side tail implements Adan only
+        self.mvp = None
+        if getattr(opt, "dmtet", False) and self.mode != "reference":
+            # the DMTet fine-tune stage (mesh extraction with a data-dependent vertex count, rasterisation) runs the reference's
+            # host flow: GradScaler + Adan around model.render -> run_dmtet
+            self.mode = "reference"
         if (opt.grad_clip >= 0 or opt.lambda_tv > 0 or opt.lambda_wd > 0) and self.mode != "reference":
             # these act on UNSCALED gradients between backward and step (nerf/utils.py:1055-1066): only the host flow does that
             warnings.warn("grad_clip / lambda_tv / lambda_wd need the reference host flow: TrainStep(mode='reference')")
@@ -172,7 +177,7 @@ class TrainStep:
         shading_dev = None
         if shading == "fd":   # the class of the three finite-difference shadings: the kernel reads which one from the block
             shading, shading_dev = "lambertian", sc[_SC_MODE]
-        outputs = self.model.render(self.rays_o, self.rays_d, None, H, W, staged=False, perturb=True, bg_color=bg_color,
+        outputs = self.model.render(self.rays_o, self.rays_d, self.mvp, H, W, staged=False, perturb=True, bg_color=bg_color,
                                     ambient_ratio=sc[_SC_AMBIENT], shading=shading, binarize=False, marched=marched,
                                     shading_dev=shading_dev, defer_head=self._head_ok(bg_kind))
         self._num_samples = outputs.get("num_samples", 0)
@@ -194,6 +199,12 @@ class TrainStep:
 
         loss = self.guidance.train_step(self.text_z(), pred_rgb, as_latent=as_latent,
                                         guidance_scale=opt.guidance_scale, grad_scale=opt.lambda_guidance)
+        if getattr(opt, "dmtet", False):     # nerf/utils.py:715-721: the mesh regularisers replace the volumetric ones
+            if opt.lambda_mesh_normal > 0:
+                loss = loss + opt.lambda_mesh_normal * outputs["normal_loss"]
+            if opt.lambda_mesh_laplacian > 0:
+                loss = loss + opt.lambda_mesh_laplacian * outputs["lap_loss"]
+            return loss
         if opt.lambda_opacity > 0:
             loss = loss + opt.lambda_opacity * (outputs["weights_sum"] ** 2).mean()
         if opt.lambda_entropy > 0:
@@ -381,12 +392,13 @@ class TrainStep:
                     return
             c = self._ladder(c + 1)
 
-    def step(self, rays_o, rays_d, azimuth=0.0, H=64, W=64, next_rays=None):
+    def step(self, rays_o, rays_d, azimuth=0.0, H=64, W=64, next_rays=None, mvp=None):
         """update_extra_state (every N steps) -> train_step under autocast -> backward -> optimiser.
         `next_rays` = (rays_o, rays_d) of the following call, if the caller knows them (a data loader does): their
         counting pass then overlaps this iteration instead of leaving the GPU idle around the host read."""
         opt = self.opt
         self.hw = (H, W)
+        self.mvp = mvp                        # [B, 4, 4], the DMTet stage's rasteriser needs it (nerf/utils.py:474)
         self.model.train()
         if self.global_step % opt.update_extra_interval == 0:
             with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):

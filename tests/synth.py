@@ -36,6 +36,14 @@ def get_rays(pose: np.ndarray, fovy_deg: float, H: int = 64, W: int = 64):
     return rays_o, rays_d.astype(np.float32)
 
 
+def mvp_from_pose(pose: np.ndarray, fovy_deg: float, H: int, W: int, near: float = 0.01, far: float = 1000.0) -> np.ndarray:
+    """projection @ inverse(pose) of nerf/provider.py:219-229 (near = opt.min_near, far = 1000), float32 [4, 4]"""
+    focal = H / (2 * np.tan(np.deg2rad(fovy_deg) / 2))
+    proj = np.array([[2 * focal / W, 0, 0, 0], [0, -2 * focal / H, 0, 0],
+                     [0, 0, -(far + near) / (far - near), -(2 * far * near) / (far - near)], [0, 0, -1, 0]], np.float32)
+    return (proj @ np.linalg.inv(pose.astype(np.float32))).astype(np.float32)
+
+
 def orbit_pose(radius: float, theta_deg: float, phi_deg: float) -> np.ndarray:
     """Look-at pose of an orbit camera (nerf/provider.py:110-137 without jitter)."""
     th, ph = np.deg2rad(theta_deg), np.deg2rad(phi_deg)

@@ -153,3 +153,37 @@ def test_run_dmtet_on_hip_reproduces_the_reference(D, dev, shading, ratio, bg):
     l2 = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     assert l2(N_(r.sdf.grad), GOLD[f"{shading}_dsdf"]) < 0.05 and l2(N_(r.deform.grad), GOLD[f"{shading}_ddeform"]) < 0.05
     assert l2(N_(theta.grad), GOLD[f"{shading}_dtheta"]) < 0.02
+
+
+def test_dmtet_stage_iterations_train_sdf_deform_and_field(D, dev):
+    """A few iterations of the DMTet fine-tune stage through TrainStep (reference host flow: GradScaler + Adan around
+    model.render -> run_dmtet -> SDS + mesh regularisers): init_tet from the density field, finite losses, and sdf, deform and the
+    hash table all move."""
+    import synth
+    from sdfx_nerf.guidance import synthetic_prior
+    from sdfx_nerf.network_grid import NeRFNetwork
+    from sdfx_nerf.options import default_opt, dmtet_preset
+    from sdfx_nerf.trainer import TrainStep
+    torch.manual_seed(0)
+    opt = dmtet_preset(default_opt(tet_grid_size=32, dmtet_reso_scale=2))
+    assert (opt.h, opt.w) == (128, 128) and opt.dmtet
+    model = NeRFNetwork(opt).to(dev)
+    with torch.autocast("cuda", dtype=torch.float16):
+        model.update_extra_state()
+        model.init_tet()
+    assert float((model.sdf > 0).float().mean()) > 0.001 and float((model.sdf < 0).float().mean()) > 0.5     # a blob inside the grid
+    step = TrainStep(opt, model, synthetic_prior(dev, opt.fp16, t_range=tuple(opt.t_range)), dev, seed=1)
+    assert step.mode == "reference"
+    step.global_step = int(opt.iters * opt.latent_iter_ratio)          # RGB phase
+    before = [p.detach().clone() for p in (model.sdf, model.deform, model.encoder.embeddings)]
+    poses, fovy = synth.reference_cameras()
+    losses = []
+    for it in range(24):
+        v = it % 4
+        o, d = synth.get_rays(poses[v], float(fovy[v]), 128, 128)
+        mvp = torch.from_numpy(synth.mvp_from_pose(poses[v], float(fovy[v]), 128, 128))[None].to(dev)
+        losses.append(float(step.step(torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), azimuth=15.0 * v, H=128, W=128,
+                                      mvp=mvp)))
+    assert np.isfinite(losses).all() and step.applied_steps() >= 3
+    moved = [float((a.detach() - b).abs().max()) for a, b in zip((model.sdf, model.deform, model.encoder.embeddings), before)]
+    assert all(m > 0 for m in moved), moved

@@ -29,7 +29,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] != C:
                 continue
             n = r["Kernel_Name"]
-            for key in ("k_grid_fwd", "k_grid_forward", "k_grid_bwd_bin", "k_grid_bwd_reduce", "k_field_backward_mma", "k_field_forward_mma",
+            for key in ("k_grid_fwd", "k_grid_forward", "k_grid_bwd_bin", "k_grid_bwd_reduce", "k_field_backward_nat", "k_field_forward_nat",
                         "k_render_train_fwd", "k_render_train_bwd", "k_composite_train_fwd", "k_composite_train_bwd", "k_march_count",
                         "k_adan_update"):
                 if key in n:
@@ -37,6 +37,14 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         for k, v in per.items():
             out.setdefault(k, {})[C + "_KB_avg"] = sum(v) / len(v)
             out[k]["launches"] = len(v)
+# the work of the launches the counters were averaged over, from the bytes each kernel WRITES per unit (bench.py scales the
+# traffic per unit to the launch size it reports): encode forward 16 levels x 2 halves = 64 B per point; fused render forward one
+# float weight per sample (+ 28 B per ray), backward 7 + 3 floats per sample
+units = {"k_grid_fwd": (64.0, 0.0), "k_grid_forward": (64.0, 0.0), "k_render_train_fwd": (4.0, 4096 * 28.0), "k_render_train_bwd": (40.0, 0.0)}
+for k, (per_unit, fixed) in units.items():
+    if k in out and "WRITE_SIZE_KB_avg" in out[k]:
+        out[k]["points_per_launch"] = max((out[k]["WRITE_SIZE_KB_avg"] * 1024.0 - fixed) / per_unit, 0.0)
+        out[k]["points_per_launch_from"] = "WRITE_SIZE / %g B per unit" % per_unit
 json.dump(out, open("$OUT/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
