@@ -55,29 +55,40 @@ struct FwdPlan {
     // next tile — the table access pattern of a kernel that fuses the encode into the MLP (all 16 levels of a sample in one
     // place): no XCD's L2 can hold the 23 MB of tables. The A/B against the level-major default prices that fusion.
     uint32_t sample_major, tiles, levels;
+    // measurement aid (SDFX_GRID_LDS=1): bit l set = level l's whole table (<= 48 KiB: levels 0 and 1 of the -O grid) is copied
+    // into LDS by a workgroup that then walks kLdsTiles tiles of that level, gathering with ds_read instead of through the
+    // texture-address path — north_star's "LDS staging", measured in profiles/r03_encode_lds_levels.txt
+    uint32_t lds_mask, lds_bytes;
 };
+constexpr uint32_t kLdsTiles = 16;
 
 // workgroup -> (level, tile) through the XCD's segment list (walked in order); false when there is nothing to do
-__device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint32_t& tile) {
+__device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint32_t& tile, uint32_t& seg_end) {
     const uint32_t xcd = blockIdx.x % kXcds;
     uint32_t local = blockIdx.x / kXcds;
     if (p.sample_major) {
         const uint32_t per = (p.tiles + kXcds - 1) / kXcds;
         tile = xcd * per + local / p.levels;
         level = p.levels - 1u - local % p.levels;
+        seg_end = tile + 1;
         return local < per * p.levels && tile < p.tiles;
     }
     if (local >= p.ntiles[xcd]) return false;
 #pragma unroll
     for (uint32_t s = 0; s < kMaxSegs; s++) {
         const Seg sg = p.seg[xcd][s];
-        if (local < sg.count) { level = sg.level; tile = sg.first + local; return true; }
+        if (local < sg.count) {
+            level = sg.level; tile = sg.first + local; seg_end = sg.first + sg.count;
+            // an LDS-resident level: one workgroup in kLdsTiles takes that many consecutive tiles, the others have nothing to do
+            if ((p.lds_mask >> sg.level) & 1u) return local % kLdsTiles == 0;
+            return true;
+        }
         local -= sg.count;
     }
     return false;
 }
 
-template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool LDS>
 __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ inputs,
                                                      const typename Elem<HALF>::type* __restrict__ table,
                                                      typename Elem<HALF>::type* __restrict__ outputs, uint32_t B, uint32_t L,
@@ -89,22 +100,36 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
     using RowT = typename std::conditional<HALF, uint32_t, uint2>::type;
     constexpr uint32_t P = 1;   // points per thread (the loops below are written for any P; 2 and 4 were measured slower)
     constexpr uint32_t P_TILE = P * kTile;
-    uint32_t level, tile;
-    if (!fwd_item(plan, level, tile)) return;
+    uint32_t level, tile0, seg_end;
+    if (!fwd_item(plan, level, tile0, seg_end)) return;
     // padding rows of a fixed-capacity batch (sdfx_set_row_limit): samples >= row_total[0] are neither read nor written, and a
     // tile of nothing else ends here. (Stencil batches: the sample is the row within the slab; otherwise the row itself.)
     const uint32_t n_rows = plan.slabs == kGroup ? plan.slab_points : B;
     const uint32_t n_live = row_total ? min(n_rows, (uint32_t)row_total[0]) : n_rows;
-    {
-        const uint32_t first_slot = tile * P_TILE;
-        const uint32_t first = plan.slabs == kGroup ? (first_slot >> 6) * kGroupsPerWave : first_slot;
-        if (first >= n_live) return;
-    }
 
     const LevelConst lc = plan.lv[level];
     const bool hashed = HASHGRID && (lc.flags & 1u);
     const bool pow2 = (lc.flags & 2u) != 0u;
     const T* tab = table + (size_t)lc.row0 * C;
+    // SDFX_GRID_LDS (measurement aid): the level's table in LDS, kLdsTiles tiles per workgroup
+    extern __shared__ uint4 lds_tab[];   // dynamic: kLdsBytes when the plan has an LDS-resident level, nothing otherwise
+    const bool in_lds = LDS && HALF && ((plan.lds_mask >> level) & 1u);   // (LDS = false: the default kernel, none of this is compiled in)
+    uint32_t tile_end = tile0 + 1;
+    if (in_lds) {
+        if constexpr (HALF) {
+            const uint4* src = reinterpret_cast<const uint4*>(tab);
+            const uint32_t n16 = (lc.size * 4u + 15u) / 16u;      // rows are padded to multiples of 8 (grid.py:131): whole blocks
+            for (uint32_t i = threadIdx.x; i < n16; i += kTile) lds_tab[i] = src[i];
+            __syncthreads();
+        }
+        tile_end = min(tile0 + kLdsTiles, seg_end);
+    }
+    for (uint32_t tile = tile0; tile < tile_end; tile++) {
+    {
+        const uint32_t first_slot = tile * P_TILE;
+        const uint32_t first = plan.slabs == kGroup ? (first_slot >> 6) * kGroupsPerWave : first_slot;
+        if (first >= n_live) continue;
+    }
 
     // ---- slots of this thread -> points ----
     uint32_t pt[P], sk[P], sm[P];   // row of the batch; stencil point and base sample of that row (stencil batches)
@@ -199,14 +224,24 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
 #pragma unroll
         for (uint32_t j = 0; j < P; j++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) blk[j][k] = *reinterpret_cast<const uint4*>(tab + (size_t)(r0[j][k] & ~(RB - 1)) * C);
+            for (int k = 0; k < 4; k++) {
+                if (in_lds) blk[j][k] = lds_tab[r0[j][k] >> 2];
+                else blk[j][k] = *reinterpret_cast<const uint4*>(tab + (size_t)(r0[j][k] & ~(RB - 1)) * C);
+            }
         }
         RowT extra[P][4];
 #pragma unroll
         for (uint32_t j = 0; j < P; j++) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if ((r0[j][k] ^ r1[j][k]) >= RB) extra[j][k] = *reinterpret_cast<const RowT*>(tab + (size_t)r1[j][k] * C);
+                if ((r0[j][k] ^ r1[j][k]) >= RB) {
+                    if constexpr (HALF) {
+                        if (in_lds) extra[j][k] = reinterpret_cast<const uint32_t*>(lds_tab)[r1[j][k]];
+                        else extra[j][k] = *reinterpret_cast<const RowT*>(tab + (size_t)r1[j][k] * C);
+                    } else {
+                        extra[j][k] = *reinterpret_cast<const RowT*>(tab + (size_t)r1[j][k] * C);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -249,6 +284,7 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
             acc.store(out, oob[j]);
         }
     }
+    }   // tiles of this workgroup
 }
 
 // ---- host: the plan -------------------------------------------------------------------------------------------------
@@ -288,12 +324,18 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
         const LevelConst& c = p.lv[l];
         lines[l] = lines_per_wave((double)c.res * step, slabs == kGroup);
     }
-    (void)elem_bytes;
     p.slabs = slabs == kGroup && B % kGroup == 0 ? kGroup : 1u;
     p.slab_points = B / p.slabs;
     const uint64_t slots = p.slabs == kGroup ? (uint64_t)div_up(p.slab_points, kGroupsPerWave) * 64u : B;
     const uint32_t T = div_up(slots, (uint64_t)kTile * P);   // tiles per level
     p.tiles = T; p.levels = levels;
+    {
+        // SDFX_GRID_LDS = largest level table (bytes) to keep in LDS: 16384 = level 0 of the -O grid, 49152 = levels 0 and 1
+        static const uint32_t lds = [] { const char* e = getenv("SDFX_GRID_LDS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : (v > 65536 ? 65536 : v)); }();
+        if (lds && elem_bytes == 2)
+            for (uint32_t l = 0; l < levels; l++)
+                if ((uint64_t)p.lv[l].size * 4u <= lds) { p.lds_mask |= 1u << l; if (p.lv[l].size * 4u > p.lds_bytes) p.lds_bytes = (p.lv[l].size * 4u + 15u) & ~15u; }
+    }
     {
         static const int sm = [] { const char* e = getenv("SDFX_GRID_PLAN"); return (e && !strcmp(e, "sample_major")) ? 1 : 0; }();
         p.sample_major = (uint32_t)sm;
@@ -365,8 +407,14 @@ void launch(const float* inputs, const void* table, void* outputs, uint32_t B, u
     const int32_t* row_total = (rl.total && (rl.period == axis || (rl.period == 0 && plan.slabs != kGroup))) ? rl.total : nullptr;
     const StencilSrc src = stencil_src();   // validated by the caller: src.M * 7 == B when set
 #define SDFX_FWD(INTERP_, ALIGN_, HASH_)                                                                               \
-    hipLaunchKernelGGL((k_grid_fwd<HALF, INTERP_, ALIGN_, HASH_>), dim3(grid), dim3(kTile), 0, st, inputs,            \
-                       static_cast<const T*>(table), static_cast<T*>(outputs), B, L, plan, out_layout, row_total, src)
+    do {                                                                                                               \
+        if (plan.lds_mask)                                                                                             \
+            hipLaunchKernelGGL((k_grid_fwd<HALF, INTERP_, ALIGN_, HASH_, true>), dim3(grid), dim3(kTile), plan.lds_bytes, st, inputs,   \
+                               static_cast<const T*>(table), static_cast<T*>(outputs), B, L, plan, out_layout, row_total, src);         \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_grid_fwd<HALF, INTERP_, ALIGN_, HASH_, false>), dim3(grid), dim3(kTile), 0, st, inputs,               \
+                               static_cast<const T*>(table), static_cast<T*>(outputs), B, L, plan, out_layout, row_total, src);         \
+    } while (0)
     const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
     switch (sel) {
         case 0: SDFX_FWD(0u, false, false); break;
