@@ -395,3 +395,41 @@ def test_freq_and_sh_modules_on_hip_match_reference(dev):
         (y * torch.from_numpy(gold[f"sh{degree}_gy"]).to(dev)).sum().backward()
         assert se.output_dim == int(gold[f"sh{degree}_output_dim"])
         assert max_rel(N_(y), gold[f"sh{degree}_y"]) <= 2e-6 and max_rel(N_(x.grad), gold[f"sh{degree}_dx"]) <= 1e-5
+
+
+# --------------------------------------------------------------------------------------------------- adan_ref
+def test_adan_kernels_reproduce_the_reference_optimizer(dev):
+    """csrc/optim.hip (k_grad_stats -> k_adan_prepare -> k_adan_update) against tests/golden/adan_ref.npz: the parameters after each of
+    six steps of the reference's OWN optimizer.Adan (optimizer.py:109-261; two groups, weight decay, global-norm clipping, one tensor
+    that gets its first gradient at step 3) — without the host-side foreach restatement in between. Loss scaling off (amp=False)
+    and, in a second pass, on with a power-of-two scale (exact in float32): the same parameters."""
+    importlib.import_module("stable-dreamfusion_amd")
+    from sdfx_nerf.optim import DeviceAdan
+    g = _G("adan_ref")
+    for amp, scale in ((False, 1.0), (True, 1024.0)):
+        params = [torch.nn.Parameter(torch.from_numpy(g[f"p0_{i}"].copy()).to(dev)) for i in range(4)]
+        opt = DeviceAdan([{"params": params[:1], "lr": 5e-2}, {"params": params[1:], "lr": 5e-3}], eps=1e-8, weight_decay=2e-5,
+                         max_grad_norm=5.0, amp=amp, init_scale=scale, growth_interval=1000)
+        for k in range(6):
+            for i, p in enumerate(params):
+                p.grad = None if (i == 3 and k < 2) else torch.from_numpy(g[f"g{k}_{i}"].copy()).to(dev) * scale
+            opt.step()
+            for i, p in enumerate(params):
+                assert np.allclose(N_(p), g[f"p{k + 1}_{i}"], rtol=2e-5, atol=2e-7), (amp, k, i)
+        assert opt.applied_steps() == 6 and opt.skipped_steps() == 0
+
+
+def test_compositor_reproduces_the_reference_cumprod_renderer(dev):
+    """tests/golden/run_composite_ref.npz: the weights / weights_sum / depth / image the reference's pure-torch renderer forms with
+    cumprod (NeRFRenderer.run, nerf/renderer.py:640-668) for 37 rays x 96 samples — the same quantities composite_rays_train
+    computes; the HIP compositor on the same sigmas / deltas."""
+    importlib.import_module("stable-dreamfusion_amd")
+    import raymarching as rm
+    g = _G("run_composite_ref")
+    N, S = g["sigmas"].shape
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rays = torch.stack([torch.arange(N, dtype=torch.int32) * S, torch.full((N,), S, dtype=torch.int32)], -1).to(dev)
+    ts = torch.stack([T(g["z_vals"]).reshape(-1), T(g["deltas"]).reshape(-1)], -1).contiguous()
+    w, ws, dp, im = rm.composite_rays_train(T(g["sigmas"]).reshape(-1), T(g["rgbs"]).reshape(-1, 3), ts, rays, 0.0)   # no early stop there
+    assert close(N_(w).reshape(N, S), g["weights"], rtol=1e-4, atol=1e-6)
+    assert close(N_(ws), g["weights_sum"], rtol=1e-4, atol=1e-6) and close(N_(im), g["image"], rtol=1e-4, atol=1e-6)
