@@ -132,7 +132,25 @@ __device__ __forceinline__ float density_blob(const StencilSrc& src, const float
     return blob_density * expf(-d * inv_2r2);
 }
 
+// the same from coordinates that are already in registers: `xin` = row b of x, or (with a stencil source) the base sample of row b
+__device__ __forceinline__ float density_blob_at(const StencilSrc& src, uint32_t b, const float xin[3], float blob_density, float inv_2r2) {
+    float p[3] = {xin[0], xin[1], xin[2]};
+    if (src.xyzs) stencil_world(src, stencil_slab(b, src.M), xin, p);
+    const float px = p[0], py = p[1], pz = p[2];
+    const float d = px * px + py * py + pz * pz;
+    return blob_density * expf(-d * inv_2r2);
+}
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// Stores through a buffer descriptor: a lane that must not store passes kNoStore as its byte offset and the hardware drops the
+// write (offset >= num_records). No branch around the store, so the compiler knows exactly how many memory operations follow a
+// prefetch and waits for the prefetch alone (`s_waitcnt vmcnt(n)`), not for the stores issued after it.
+constexpr uint32_t kNoStore = 0x80000000u;   // every buffer here is < 2 GB: the host functions take these kernels for B < kNatMaxRows only
+constexpr uint32_t kNatMaxRows = 1u << 25;   // 64 B of features per row
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t out_buffer(void* p, uint64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(uint32_t)bytes, 0x00020000);
+}
 
 // =========================================================================================
 // forward: features -> (sigma, albedo)
@@ -699,6 +717,7 @@ __device__ __forceinline__ void nat_relu_pack(const f32x16& a, const float* bias
 // formed for both halves at once (v_pk_min_u16, v_pk_sub_u16) and ANDed onto the packed gradient pair: 5 instructions per word
 // where compare + select + convert per element took 7.
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ uint32_t masked_pack_bits(uint32_t act, float g0, float g1) {
     us2 m = __builtin_bit_cast(us2, act & 0x7FFF7FFFu);
     m = __builtin_elementwise_min(m, us2{1, 1});
@@ -765,31 +784,55 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
         }
     };
 
+    // Persistent workgroups over the LIVE tiles with the next tile's inputs in flight (see k_field_forward_nat below): the row
+    // limit read once, no branch around a load (dead lanes read row 0, masked afterwards) or around a store (buffer descriptor).
+    const RowLimitNow rn = row_limit_now(rl);
+    const float* __restrict__ px = src.xyzs ? src.xyzs : x;
+    const __amdgpu_buffer_rsrc_t denc_buf = out_buffer(denc, (uint64_t)B * (kIn / 2) * 4);
     const uint32_t ntiles = (B + TS - 1) / TS;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (rows_dead(rl, tile * TS, TS)) continue;   // a tile of padding rows (workgroup-uniform)
-        uint32_t col[NB], row[NB];
-        bool live[NB];
+    auto next_live = [&](uint32_t tl) {
+        while (tl < ntiles && rows_dead(rn, tl * TS, TS)) tl += gridDim.x;   // tiles of padding rows (workgroup-uniform)
+        return tl;
+    };
+    uint32_t e_nx[NB][8];
+    float g_nx[NB][4], p_nx[NB][3];
+    uint32_t one[3] = {0u, 1u, 2u};   // opaque element offsets: dword loads, no register triples (see k_field_forward_nat)
+    asm volatile("" : "+s"(one[1]), "+s"(one[2]));
+    auto fetch = [&](uint32_t tl) {
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            col[c] = 32 * NB * wave + 32 * c + n;     // this lane's sample of column block c within the tile
-            row[c] = tile * TS + col[c];
-            live[c] = row[c] < B && row_live(rl, row[c]);
+            const uint32_t r = tl * TS + 32 * NB * wave + 32 * c + n;
+            const uint32_t rs = (r < B && row_live(rn, r)) ? r : 0u;
+#pragma unroll
+            for (int p = 0; p < 8; p++) e_nx[c][p] = enc[(size_t)(8 * hi + p) * B + rs];
+            g_nx[c][0] = dsigma[rs];
+#pragma unroll
+            for (int k = 0; k < 3; k++) g_nx[c][1 + k] = dalbedo[(size_t)rs * 3 + one[k]];
+            const uint32_t m = src.xyzs ? rs - stencil_slab(rs, src.M) * src.M : rs;
+#pragma unroll
+            for (int k = 0; k < 3; k++) p_nx[c][k] = px[(size_t)m * 3 + one[k]];
         }
+    };
+    uint32_t tile = next_live(blockIdx.x);
+    if (tile < ntiles) fetch(tile);
+    while (tile < ntiles) {
+        uint32_t col[NB], row[NB];
+        bool live[NB];
         // features: lane half hi holds levels 8 hi .. 8 hi + 7 (words 0..7; the array is 16 wide for the common operand type)
         uint32_t e[NB][16];
         float ds[NB], da[NB][3], bl[NB];
 #pragma unroll
         for (int c = 0; c < NB; c++) {
+            col[c] = 32 * NB * wave + 32 * c + n;     // this lane's sample of column block c within the tile
+            row[c] = tile * TS + col[c];
+            live[c] = row[c] < B && row_live(rn, row[c]);
 #pragma unroll
-            for (int p = 0; p < 8; p++) e[c][p] = live[c] ? enc[(size_t)(8 * hi + p) * B + row[c]] : 0u;
-            ds[c] = 0.f; da[c][0] = da[c][1] = da[c][2] = 0.f; bl[c] = 0.f;
-            if (hi == 0 && live[c]) {   // the hi = 0 lanes own the 4 outputs of a sample
-                ds[c] = dsigma[row[c]];
-                da[c][0] = dalbedo[(size_t)row[c] * 3]; da[c][1] = dalbedo[(size_t)row[c] * 3 + 1]; da[c][2] = dalbedo[(size_t)row[c] * 3 + 2];
-                bl[c] = density_blob(src, x, row[c], blob_density, inv_2r2);
-            }
+            for (int p = 0; p < 8; p++) e[c][p] = live[c] ? e_nx[c][p] : 0u;
+            ds[c] = g_nx[c][0]; da[c][0] = g_nx[c][1]; da[c][1] = g_nx[c][2]; da[c][2] = g_nx[c][3];
+            bl[c] = density_blob_at(src, row[c], p_nx[c], blob_density, inv_2r2);   // used by the hi = 0 lanes of live rows only
         }
+        const uint32_t tile_next = next_live(tile + gridDim.x);
+        if (tile_next < ntiles) fetch(tile_next);
 
         // ---- forward recompute ----
         uint32_t h1[NB][16], h2w[NB][16];
@@ -897,14 +940,14 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
         block(fW1T, 4, g1, a);
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            if (live[c]) {
+            const uint32_t off0 = live[c] ? (2u * hi * B + row[c]) * 4u : kNoStore;
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const uint32_t level = (q & 1) + 4 * (q >> 1) + 2 * hi;
-                    denc[(size_t)level * B + row[c]] = as_u32(pack(a[c][2 * q], a[c][2 * q + 1]));
-                }
+            for (int q = 0; q < 8; q++) {
+                const uint32_t level = (q & 1) + 4 * (q >> 1);   // + 2 hi, in off0 (kNoStore + 13 B 4 < 2^32 for B < 2^25: no wrap)
+                __builtin_amdgcn_raw_buffer_store_b32(as_u32(pack(a[c][2 * q], a[c][2 * q + 1])), denc_buf, (int)(off0 + level * B * 4u), 0, 0);
             }
         }
+        tile = tile_next;
     }
 
     float* out = partials + (size_t)blockIdx.x * kGradWords;
@@ -953,19 +996,59 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* 
             }
         }
     };
+    // Persistent workgroups over the LIVE tiles, the next tile's inputs (features, coordinates for the density blob) in flight
+    // while this one is computed: the limit is read once (row_limit_now), dead lanes read row 0 and are masked afterwards (no
+    // branch around a load), the outputs go through buffer descriptors (no branch around a store) — before, a tile began with
+    // two dependent reads of the row limit, then its feature loads, and ended with the coordinate load: four exposed latencies
+    // for ~0.5 us of arithmetic.
+    const RowLimitNow rn = row_limit_now(rl);
+    const float* __restrict__ px = src.xyzs ? src.xyzs : x;
+    const __amdgpu_buffer_rsrc_t sig_buf = out_buffer(sigma, (uint64_t)B * 4), alb_buf = out_buffer(albedo, (uint64_t)B * 12);
     const uint32_t ntiles = (B + TS - 1) / TS;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (rows_dead(rl, tile * TS, TS)) continue;
-        uint32_t row[NB];
-        bool live[NB];
-        uint32_t e[NB][16];
+    auto next_live = [&](uint32_t tl) {
+        while (tl < ntiles && rows_dead(rn, tl * TS, TS)) tl += gridDim.x;   // tiles of padding rows (workgroup-uniform)
+        return tl;
+    };
+    uint32_t e_nx[NB][8];
+    float p_nx[NB][3];
+    // element offsets the compiler cannot see through: three dword loads instead of one dwordx3, whose register TRIPLE it would
+    // copy into the loop-carried registers right behind the load — waiting for the prefetch where it is issued
+    uint32_t one[3] = {0u, 1u, 2u};
+    asm volatile("" : "+s"(one[1]), "+s"(one[2]));
+    auto fetch = [&](uint32_t tl) {
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            row[c] = tile * TS + 32 * NB * wave + 32 * c + n;
-            live[c] = row[c] < B && row_live(rl, row[c]);
+            const uint32_t r = tl * TS + 32 * NB * wave + 32 * c + n;
+            const uint32_t rs = (r < B && row_live(rn, r)) ? r : 0u;
 #pragma unroll
-            for (int p = 0; p < 8; p++) e[c][p] = live[c] ? enc[(size_t)(8 * hi + p) * B + row[c]] : 0u;
+            for (int p = 0; p < 8; p++) e_nx[c][p] = enc[(size_t)(8 * hi + p) * B + rs];
+            const uint32_t m = src.xyzs ? rs - stencil_slab(rs, src.M) * src.M : rs;
+#pragma unroll
+            for (int k = 0; k < 3; k++) p_nx[c][k] = px[(size_t)m * 3 + one[k]];
         }
+    };
+    uint32_t tile = next_live(blockIdx.x);
+    if (tile >= ntiles) return;
+    fetch(tile);
+    uint32_t row[NB];
+    bool live[NB];
+    uint32_t e[NB][16];
+    float pc[NB][3];
+    auto take = [&](uint32_t tl) {   // the fetched inputs become the current tile's (this is where the loads are waited for)
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            row[c] = tl * TS + 32 * NB * wave + 32 * c + n;
+            live[c] = row[c] < B && row_live(rn, row[c]);
+#pragma unroll
+            for (int p = 0; p < 8; p++) e[c][p] = live[c] ? e_nx[c][p] : 0u;
+#pragma unroll
+            for (int k = 0; k < 3; k++) pc[c][k] = p_nx[c][k];
+        }
+    };
+    take(tile);
+    do {
+        const uint32_t tile_next = next_live(tile + gridDim.x);
+        if (tile_next < ntiles) fetch(tile_next);
         uint32_t h1[NB][16], h2w[NB][16];
         f32x16 a[NB];
 #pragma unroll
@@ -982,19 +1065,22 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* 
         }
         block(fW3, 4, h2w, a);
 #pragma unroll
-        for (int c = 0; c < NB; c++) {
-            if (hi == 0 && live[c]) {
-                const float* b3 = sbias + 2 * kHid;
-                float h3[kOut];
+        for (int c = 0; c < NB; c++) {   // the hi = 0 lanes own the 4 outputs of a sample; the others compute along and store nothing
+            const float* b3 = sbias + 2 * kHid;
+            float h3[kOut];
 #pragma unroll
-                for (int o = 0; o < (int)kOut; o++) h3[o] = (float)(_Float16)(a[c][o] + b3[o]);
-                sigma[row[c]] = expf(h3[0] + density_blob(src, x, row[c], blob_density, inv_2r2));  // trunc_exp forward (activation.py:9-11)
-                albedo[(size_t)row[c] * 3 + 0] = sigmoidf_(h3[1]);
-                albedo[(size_t)row[c] * 3 + 1] = sigmoidf_(h3[2]);
-                albedo[(size_t)row[c] * 3 + 2] = sigmoidf_(h3[3]);
-            }
+            for (int o = 0; o < (int)kOut; o++) h3[o] = (float)(_Float16)(a[c][o] + b3[o]);
+            const bool st = hi == 0 && live[c];
+            const float sg = expf(h3[0] + density_blob_at(src, row[c], pc[c], blob_density, inv_2r2));  // trunc_exp forward (activation.py:9-11)
+            const u32x3 al = {__float_as_uint(sigmoidf_(h3[1])), __float_as_uint(sigmoidf_(h3[2])), __float_as_uint(sigmoidf_(h3[3]))};
+            uint32_t o4 = st ? row[c] * 4u : kNoStore, o12 = st ? row[c] * 12u : kNoStore;
+            asm volatile("" : "+v"(o4), "+v"(o12));   // keep them selects: the compiler otherwise branches into one store per arm
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sg), sig_buf, (int)o4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b96(al, alb_buf, (int)o12, 0, 0);
         }
-    }
+        tile = tile_next;
+        if (tile < ntiles) take(tile);
+    } while (tile < ntiles);
 }
 
 // sum the per-workgroup partials into the six parameter gradients: 64 entries per workgroup, the (up to 512) partials of an
@@ -1118,7 +1204,7 @@ int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const ui
         hipLaunchKernelGGL(k_field_forward, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
                            1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src());
-    } else if (enc_layout == 0 && native_forward() > 0) {
+    } else if (enc_layout == 0 && native_forward() > 0 && B < kNatMaxRows) {
         const int nb = native_forward();
         const uint32_t tiles = div_up(B, 128u * nb), blocks = tiles < 2048u ? tiles : 2048u;
         if (nb == 2)
@@ -1156,7 +1242,7 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
         } else {
             static const bool lds_frags = [] { const char* e = getenv("SDFX_FIELD_BWD_LDSFRAG"); return !(e && e[0] == '0'); }();
             static const bool native = [] { const char* e = getenv("SDFX_FIELD_BWD_NAT"); return !(e && e[0] == '0'); }();
-            if (native && enc_layout == 0) {
+            if (native && enc_layout == 0 && B < kNatMaxRows) {
                 static const int nb = [] { const char* e = getenv("SDFX_FIELD_BWD_NB"); return (e && e[0] == '2') ? 2 : 1; }();
                 const float i2 = 1.0f / (2 * blob_radius * blob_radius);
                 const uint32_t* ep = static_cast<const uint32_t*>(enc);

@@ -78,6 +78,27 @@ __device__ __forceinline__ bool rows_dead(const RowLimit& rl, uint32_t r0, uint3
     const uint32_t j0 = rl.period ? r0 % rl.period : r0;
     return j0 >= (uint32_t)rl.total[0] && (rl.period == 0 || j0 + n <= rl.period);
 }
+// The limit read ONCE into a scalar register. row_live / rows_dead above load `total[0]` at every use, and the compiler can
+// neither hoist that load over a kernel's stores nor make it a scalar load: a persistent tile loop paid two dependent L2 round
+// trips (rows_dead, then row_live) at the top of EVERY tile before its first useful load was issued. The value cannot change
+// while the kernel runs (it is written by the counting pass that precedes it on the stream).
+struct RowLimitNow {
+    uint32_t total, period;   // total = 0xffffffff: no limit
+};
+__device__ __forceinline__ RowLimitNow row_limit_now(const RowLimit& rl) {
+    RowLimitNow v;
+    v.period = rl.period;
+    v.total = rl.total ? __builtin_amdgcn_readfirstlane((uint32_t)rl.total[0]) : 0xffffffffu;
+    return v;
+}
+__device__ __forceinline__ bool row_live(const RowLimitNow& v, uint32_t r) {
+    const uint32_t j = v.period ? r % v.period : r;
+    return j < v.total;
+}
+__device__ __forceinline__ bool rows_dead(const RowLimitNow& v, uint32_t r0, uint32_t n) {
+    const uint32_t j0 = v.period ? r0 % v.period : r0;
+    return j0 >= v.total && (v.period == 0 || j0 + n <= v.period);
+}
 #endif
 
 #if defined(__HIPCC__)
