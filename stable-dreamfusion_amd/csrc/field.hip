@@ -705,28 +705,44 @@ __device__ __forceinline__ float row_sum_n(const _Float16* stage, uint32_t row) 
     return s0 + s1;
 }
 
-// relu(acc + bias) packed pairwise: words 8 mb .. 8 mb + 7 of a hidden vector
+// relu(acc + bias) packed pairwise: words 8 mb .. 8 mb + 7 of a hidden vector. Three packed instructions per word (v_pk_add_f32,
+// v_cvt_pk_f16_f32, v_pk_max_i16) where add, add, max, max, convert took five: the ReLU is taken on the half BITS — a negative
+// half (and -0) is a negative 16-bit integer, so max(bits, 0) is +0 for it and the value itself otherwise; rounding first and
+// clamping second gives the same half as clamping first (the conversion is monotonic and keeps the sign).
+// gfx950's packed conversion (v_cvt_pk_f16_f32: round to nearest even, both halves in one instruction). hipcc selects it for a
+// VECTOR conversion; for h2{(_Float16)a, (_Float16)b} it emits two v_cvt_f16_f32 and a v_perm_b32. (Not inline assembly: the
+// operands are often MFMA results, and the compiler does not insert the MFMA -> VALU wait states in front of an asm statement.)
+typedef float float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(float2_t{a, b}, h2));
+}
+typedef short s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nat_relu_pack(const f32x16& a, const float* bias32, int hi, uint32_t* out8) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const int r = 2 * q, row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        out8[q] = as_u32(pack(fmaxf(a[r] + bias32[row], 0.f), fmaxf(a[r + 1] + bias32[row + 1], 0.f)));
+        const float2_t s = float2_t{a[r], a[r + 1]} + float2_t{bias32[row], bias32[row + 1]};
+        const s2 bits = __builtin_bit_cast(s2, cvt_pk_f16(s.x, s.y));
+        out8[q] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(bits, s2{0, 0}));
     }
 }
-// masked_pack on the bits: the activations are ReLU outputs (>= +0 as halves), so "act > 0" is "magnitude bits != 0"; the mask is
-// formed for both halves at once (v_pk_min_u16, v_pk_sub_u16) and ANDed onto the packed gradient pair: 5 instructions per word
-// where compare + select + convert per element took 7.
+// relu'(act) * g packed: the activations are ReLU outputs (+0 or a positive half — see nat_relu_pack), so "act > 0" is "bits != 0":
+// min(bits, 1) is 0 / 1 per half (v_pk_min_u16) and the packed gradient pair is multiplied by it as 16-bit integers
+// (v_pk_mul_lo_u16): 3 instructions per word where compare + select + convert per element took 7. (Written as instructions:
+// from the vector expressions hipcc makes two compares and two selects.)
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ uint32_t masked_pack_bits(uint32_t act, float g0, float g1) {
-    us2 m = __builtin_bit_cast(us2, act & 0x7FFF7FFFu);
-    m = __builtin_elementwise_min(m, us2{1, 1});
-    m = us2{0, 0} - m;   // 0 or 0xFFFF per half
-    return as_u32(pack(g0, g1)) & __builtin_bit_cast(uint32_t, m);
+__device__ __forceinline__ uint32_t masked_pack_bits(uint32_t act, float g0, float g1, uint32_t ones) {
+    uint32_t m, r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(act), "v"(ones));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(cvt_pk_f16(g0, g1)), "v"(m));
+    return r;
 }
 __device__ __forceinline__ void nat_mask_pack(const f32x16& a, const uint32_t* act8, uint32_t* out8) {
+    uint32_t ones = 0x00010001u;
+    asm volatile("" : "+v"(ones));   // one register for the eight words (a packed instruction takes no 32-bit literal)
 #pragma unroll
-    for (int q = 0; q < 8; q++) out8[q] = masked_pack_bits(act8[q], a[2 * q], a[2 * q + 1]);
+    for (int q = 0; q < 8; q++) out8[q] = masked_pack_bits(act8[q], a[2 * q], a[2 * q + 1], ones);
 }
 
 // hidden vector (16 words of this lane) -> stage rows row0 + feature, column col
@@ -867,8 +883,8 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
                     const float sg = sigmoidf_(h3[1 + k]);
                     g[k] = da[c][k] * sg * (1.0f - sg);
                 }
-                d3[c][0] = as_u32(pack(g0, g[0]));
-                d3[c][1] = as_u32(pack(g[1], g[2]));
+                d3[c][0] = cvt_pk_f16(g0, g[0]);
+                d3[c][1] = cvt_pk_f16(g[1], g[2]);
             }
         }
 
@@ -944,7 +960,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const uint32_t level = (q & 1) + 4 * (q >> 1);   // + 2 hi, in off0 (kNoStore + 13 B 4 < 2^32 for B < 2^25: no wrap)
-                __builtin_amdgcn_raw_buffer_store_b32(as_u32(pack(a[c][2 * q], a[c][2 * q + 1])), denc_buf, (int)(off0 + level * B * 4u), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(cvt_pk_f16(a[c][2 * q], a[c][2 * q + 1]), denc_buf, (int)(off0 + level * B * 4u), 0, 0);
             }
         }
         tile = tile_next;
