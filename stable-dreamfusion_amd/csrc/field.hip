@@ -33,7 +33,7 @@ namespace {
 
 
 constexpr uint32_t kThreads = 256;
-constexpr uint32_t kMaxBlocks = 512;
+constexpr uint32_t kMaxBlocks = 768;   // persistent workgroups of the backward: 256 CUs x (2 or 3) — the partials scratch is sized for 768
 
 // ---- parameter packing -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_field_pack(const float* __restrict__ w1, const float* __restrict__ b1,
@@ -148,6 +148,12 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // prefetch and waits for the prefetch alone (`s_waitcnt vmcnt(n)`), not for the stores issued after it.
 constexpr uint32_t kNoStore = 0x80000000u;   // every buffer here is < 2 GB: the host functions take these kernels for B < kNatMaxRows only
 constexpr uint32_t kNatMaxRows = 1u << 25;   // 64 B of features per row
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t in_buffer(const void* p, uint64_t bytes) {   // loads: an out-of-range offset reads 0
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(uint32_t)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t b, uint32_t voff, uint32_t soff = 0) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, (int)voff, (int)soff, 0));
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t out_buffer(void* p, uint64_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(uint32_t)bytes, 0x00020000);
 }
@@ -759,8 +765,11 @@ __device__ __forceinline__ void nat_stage_hidden(_Float16* stage, uint32_t row0,
 
 // NB column blocks of 32 samples per wave: the tile of a workgroup is TS = 128 NB samples. NB = 1 halves the registers a
 // lane needs for activations (two workgroups, or more, per CU); NB = 2 reuses every weight fragment for two MFMAs.
-template <bool LDSF, int NB>
-__global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_nat(const uint32_t* __restrict__ enc, const float* __restrict__ x,
+// LDSF: where the 30 weight fragments (1 KB each) live — 0: global memory (L1), 1: all in LDS (66 KB per workgroup with the staging
+// tile: two workgroups per CU), 2: the 16 fragments of the forward recompute in LDS, the 14 of the backward layers from L1 (52 KB:
+// THREE workgroups per CU; needs <= 170 registers).
+template <int LDSF, int NB>
+__global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 : 1)) void k_field_backward_nat(const uint32_t* __restrict__ enc, const float* __restrict__ x,
                                                                                    const uint32_t* __restrict__ P, uint32_t B,
                                                                                    float blob_density, float inv_2r2,
                                                                                    const float* __restrict__ dsigma,
@@ -769,14 +778,12 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
                                                                                    RowLimit rl, StencilSrc src) {
     constexpr uint32_t TS = 128 * NB, RH = TS + 8;
     __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * RH];
-    __shared__ uint4 sfrag[LDSF ? kFrags * 64 : 1];
+    constexpr uint32_t kLdsFrags = LDSF == 1 ? kFrags : (LDSF == 2 ? fW3T : 0u);   // fragments [0, kLdsFrags) are LDS-resident
+    __shared__ uint4 sfrag[kLdsFrags ? kLdsFrags * 64 : 1];
     __shared__ float sbias[kBiasPad];
     const uint32_t t = threadIdx.x;
-    const uint4* F = reinterpret_cast<const uint4*>(P + kFragBaseN);
-    if (LDSF) {
-        for (uint32_t i = t; i < kFrags * 64; i += kThreads) sfrag[i] = F[i];
-        F = sfrag;
-    }
+    const uint4* Fg = reinterpret_cast<const uint4*>(P + kFragBaseN);
+    for (uint32_t i = t; i < kLdsFrags * 64; i += kThreads) sfrag[i] = Fg[i];
     if (t < kBiasPad) sbias[t] = t < 2 * kHid + kOut ? __builtin_bit_cast(float, P[kB1 + t]) : 0.f;
     __syncthreads();
     const int lane = (int)(t & 63), hi = lane >> 5;
@@ -791,6 +798,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             if (s < ks) {
+                const uint4* F = frag0 + s < kLdsFrags ? sfrag : Fg;
                 const h8 A = __builtin_bit_cast(h8, F[(size_t)(frag0 + s) * 64 + lane]);
 #pragma unroll
                 for (int c = 0; c < NB; c++)
@@ -803,8 +811,11 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
     // Persistent workgroups over the LIVE tiles with the next tile's inputs in flight (see k_field_forward_nat below): the row
     // limit read once, no branch around a load (dead lanes read row 0, masked afterwards) or around a store (buffer descriptor).
     const RowLimitNow rn = row_limit_now(rl);
-    const float* __restrict__ px = src.xyzs ? src.xyzs : x;
-    const __amdgpu_buffer_rsrc_t denc_buf = out_buffer(denc, (uint64_t)B * (kIn / 2) * 4);
+    // every operand through a buffer descriptor: 32-bit offsets (the level stride p B 4 rides in the scalar offset: no 64-bit
+    // address arithmetic per load), and a dead lane's out-of-range offset reads 0 — no masking afterwards
+    const __amdgpu_buffer_rsrc_t denc_buf = out_buffer(denc, (uint64_t)B * (kIn / 2) * 4), enc_buf = in_buffer(enc, (uint64_t)B * (kIn / 2) * 4),
+                                 ds_buf = in_buffer(dsigma, (uint64_t)B * 4), da_buf = in_buffer(dalbedo, (uint64_t)B * 12),
+                                 px_buf = src.xyzs ? in_buffer(src.xyzs, (uint64_t)src.M * 12) : in_buffer(x, (uint64_t)B * 12);
     const uint32_t ntiles = (B + TS - 1) / TS;
     auto next_live = [&](uint32_t tl) {
         while (tl < ntiles && rows_dead(rn, tl * TS, TS)) tl += gridDim.x;   // tiles of padding rows (workgroup-uniform)
@@ -818,15 +829,17 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
 #pragma unroll
         for (int c = 0; c < NB; c++) {
             const uint32_t r = tl * TS + 32 * NB * wave + 32 * c + n;
-            const uint32_t rs = (r < B && row_live(rn, r)) ? r : 0u;
+            const bool lv = r < B && row_live(rn, r);
+            const uint32_t ve = lv ? (r + 8u * hi * B) * 4u : kNoStore;   // + p B 4 as the scalar offset of the load
 #pragma unroll
-            for (int p = 0; p < 8; p++) e_nx[c][p] = enc[(size_t)(8 * hi + p) * B + rs];
-            g_nx[c][0] = dsigma[rs];
+            for (int p = 0; p < 8; p++) e_nx[c][p] = __builtin_amdgcn_raw_buffer_load_b32(enc_buf, (int)ve, (int)(p * B * 4u), 0);
+            g_nx[c][0] = buf_f32(ds_buf, lv ? r * 4u : kNoStore);
+            const uint32_t va = lv ? r * 12u : kNoStore;
 #pragma unroll
-            for (int k = 0; k < 3; k++) g_nx[c][1 + k] = dalbedo[(size_t)rs * 3 + one[k]];
-            const uint32_t m = src.xyzs ? rs - stencil_slab(rs, src.M) * src.M : rs;
+            for (int k = 0; k < 3; k++) g_nx[c][1 + k] = buf_f32(da_buf, va + one[k] * 4u);
+            const uint32_t vp = lv ? (src.xyzs ? r - stencil_slab(r, src.M) * src.M : r) * 12u : kNoStore;
 #pragma unroll
-            for (int k = 0; k < 3; k++) p_nx[c][k] = px[(size_t)m * 3 + one[k]];
+            for (int k = 0; k < 3; k++) p_nx[c][k] = buf_f32(px_buf, vp + one[k] * 4u);
         }
     };
     uint32_t tile = next_live(blockIdx.x);
@@ -843,7 +856,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
             row[c] = tile * TS + col[c];
             live[c] = row[c] < B && row_live(rn, row[c]);
 #pragma unroll
-            for (int p = 0; p < 8; p++) e[c][p] = live[c] ? e_nx[c][p] : 0u;
+            for (int p = 0; p < 8; p++) e[c][p] = e_nx[c][p];
             ds[c] = g_nx[c][0]; da[c][0] = g_nx[c][1]; da[c][1] = g_nx[c][2]; da[c][2] = g_nx[c][3];
             bl[c] = density_blob_at(src, row[c], p_nx[c], blob_density, inv_2r2);   // used by the hi = 0 lanes of live rows only
         }
@@ -1018,8 +1031,9 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* 
     // two dependent reads of the row limit, then its feature loads, and ended with the coordinate load: four exposed latencies
     // for ~0.5 us of arithmetic.
     const RowLimitNow rn = row_limit_now(rl);
-    const float* __restrict__ px = src.xyzs ? src.xyzs : x;
-    const __amdgpu_buffer_rsrc_t sig_buf = out_buffer(sigma, (uint64_t)B * 4), alb_buf = out_buffer(albedo, (uint64_t)B * 12);
+    const __amdgpu_buffer_rsrc_t sig_buf = out_buffer(sigma, (uint64_t)B * 4), alb_buf = out_buffer(albedo, (uint64_t)B * 12),
+                                 enc_buf = in_buffer(enc, (uint64_t)B * (kIn / 2) * 4),
+                                 px_buf = src.xyzs ? in_buffer(src.xyzs, (uint64_t)src.M * 12) : in_buffer(x, (uint64_t)B * 12);
     const uint32_t ntiles = (B + TS - 1) / TS;
     auto next_live = [&](uint32_t tl) {
         while (tl < ntiles && rows_dead(rn, tl * TS, TS)) tl += gridDim.x;   // tiles of padding rows (workgroup-uniform)
@@ -1035,12 +1049,13 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* 
 #pragma unroll
         for (int c = 0; c < NB; c++) {
             const uint32_t r = tl * TS + 32 * NB * wave + 32 * c + n;
-            const uint32_t rs = (r < B && row_live(rn, r)) ? r : 0u;
+            const bool lv = r < B && row_live(rn, r);
+            const uint32_t ve = lv ? (r + 8u * hi * B) * 4u : kNoStore;   // + p B 4 as the scalar offset of the load
 #pragma unroll
-            for (int p = 0; p < 8; p++) e_nx[c][p] = enc[(size_t)(8 * hi + p) * B + rs];
-            const uint32_t m = src.xyzs ? rs - stencil_slab(rs, src.M) * src.M : rs;
+            for (int p = 0; p < 8; p++) e_nx[c][p] = __builtin_amdgcn_raw_buffer_load_b32(enc_buf, (int)ve, (int)(p * B * 4u), 0);
+            const uint32_t vp = lv ? (src.xyzs ? r - stencil_slab(r, src.M) * src.M : r) * 12u : kNoStore;
 #pragma unroll
-            for (int k = 0; k < 3; k++) p_nx[c][k] = px[(size_t)m * 3 + one[k]];
+            for (int k = 0; k < 3; k++) p_nx[c][k] = buf_f32(px_buf, vp + one[k] * 4u);
         }
     };
     uint32_t tile = next_live(blockIdx.x);
@@ -1056,7 +1071,7 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* 
             row[c] = tl * TS + 32 * NB * wave + 32 * c + n;
             live[c] = row[c] < B && row_live(rn, row[c]);
 #pragma unroll
-            for (int p = 0; p < 8; p++) e[c][p] = live[c] ? e_nx[c][p] : 0u;
+            for (int p = 0; p < 8; p++) e[c][p] = e_nx[c][p];
 #pragma unroll
             for (int k = 0; k < 3; k++) pc[c][k] = p_nx[c][k];
         }
@@ -1139,15 +1154,16 @@ bool use_dot2() {
     return v != 0;
 }
 
-// SDFX_FIELD_FWD_NAT: 0 = the lane-per-sample forward, 1 / 2 = native layout with that many column blocks per wave (default 2)
+// SDFX_FIELD_FWD_NAT: 0 = the lane-per-sample forward, 1 / 2 = native layout with that many column blocks per wave (default 1:
+// 96 registers, five workgroups per CU — 98 us against 110 us for two blocks at 3.15 M rows once the inputs are prefetched)
 int native_forward() {
-    static const int v = [] { const char* e = getenv("SDFX_FIELD_FWD_NAT"); return e ? atoi(e) : 2; }();
+    static const int v = [] { const char* e = getenv("SDFX_FIELD_FWD_NAT"); return e ? atoi(e) : 1; }();
     return v;
 }
 
-uint32_t backward_blocks(uint32_t B) {
+uint32_t backward_blocks(uint32_t B, uint32_t cap = kMaxBlocks) {
     const uint32_t tiles = div_up(B, kThreads);
-    return tiles < kMaxBlocks ? tiles : kMaxBlocks;
+    return tiles < cap ? tiles : cap;
 }
 
 // The finite-difference stencil of network_grid.py:81-96 as one batch [7, M, 3]: the sample itself, then x +- eps along each
@@ -1222,7 +1238,9 @@ int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const ui
                            1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src());
     } else if (enc_layout == 0 && native_forward() > 0 && B < kNatMaxRows) {
         const int nb = native_forward();
-        const uint32_t tiles = div_up(B, 128u * nb), blocks = tiles < 2048u ? tiles : 2048u;
+        // persistent workgroups: SDFX_FIELD_FWD_BLOCKS (measurement aid; default 2048)
+        static const uint32_t cap = [] { const char* e = getenv("SDFX_FIELD_FWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : 2048u; }();
+        const uint32_t tiles = div_up(B, 128u * nb), blocks = tiles < cap ? tiles : cap;
         if (nb == 2)
             hipLaunchKernelGGL(k_field_forward_nat<2>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), static_cast<const uint32_t*>(enc), x,
                                packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src());
@@ -1249,17 +1267,19 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
     SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_backward: features misaligned");
     SDFX_REQUIRE(blob_radius > 0, "field_backward: blob_radius must be positive");
     hipStream_t st = as_stream(stream);
-    const uint32_t nblocks = B ? backward_blocks(B) : 0;
+    static const int lds_frags = [] { const char* e = getenv("SDFX_FIELD_BWD_LDSFRAG"); return e ? atoi(e) : 1; }();   // 0 / 1 / 2: k_field_backward_nat
+    static const bool native = [] { const char* e = getenv("SDFX_FIELD_BWD_NAT"); return !(e && e[0] == '0'); }();
+    static const int nb = [] { const char* e = getenv("SDFX_FIELD_BWD_NB"); return (e && e[0] == '2') ? 2 : 1; }();
+    const bool nat = !use_dot2() && native && enc_layout == 0 && B < kNatMaxRows;
+    // two workgroups per CU (three with the backward fragments out of LDS)
+    const uint32_t nblocks = B ? backward_blocks(B, nat && nb == 1 && lds_frags == 2 ? 768u : 512u) : 0;
     if (B) {
         if (use_dot2()) {
             hipLaunchKernelGGL(k_field_backward, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
                                enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
                                static_cast<uint32_t*>(denc), scratch, row_limit(), stencil_src());
         } else {
-            static const bool lds_frags = [] { const char* e = getenv("SDFX_FIELD_BWD_LDSFRAG"); return !(e && e[0] == '0'); }();
-            static const bool native = [] { const char* e = getenv("SDFX_FIELD_BWD_NAT"); return !(e && e[0] == '0'); }();
-            if (native && enc_layout == 0 && B < kNatMaxRows) {
-                static const int nb = [] { const char* e = getenv("SDFX_FIELD_BWD_NB"); return (e && e[0] == '2') ? 2 : 1; }();
+            if (nat) {
                 const float i2 = 1.0f / (2 * blob_radius * blob_radius);
                 const uint32_t* ep = static_cast<const uint32_t*>(enc);
                 uint32_t* dp = static_cast<uint32_t*>(denc);
@@ -1267,8 +1287,8 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
 #define SDFX_NAT(LDSF_, NB_)                                                                                                       \
     hipLaunchKernelGGL((k_field_backward_nat<LDSF_, NB_>), dim3(nblocks), dim3(kThreads), 0, st, ep, x, packed, B, blob_density, i2, \
                        dsigma, dalbedo, dp, scratch, rlim, stencil_src())
-                if (nb == 2) { if (lds_frags) SDFX_NAT(true, 2); else SDFX_NAT(false, 2); }
-                else { if (lds_frags) SDFX_NAT(true, 1); else SDFX_NAT(false, 1); }
+                if (nb == 2) { if (lds_frags) SDFX_NAT(1, 2); else SDFX_NAT(0, 2); }
+                else { if (lds_frags == 2) SDFX_NAT(2, 1); else if (lds_frags) SDFX_NAT(1, 1); else SDFX_NAT(0, 1); }
 #undef SDFX_NAT
             } else if (lds_frags)
                 hipLaunchKernelGGL(k_field_backward_mma<true>, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
