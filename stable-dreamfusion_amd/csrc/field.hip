@@ -693,6 +693,20 @@ __device__ __forceinline__ f32x16 contract_n(const _Float16* stage, uint32_t a_r
     }
     return acc;
 }
+// the same, and the A fragment once more against `sel` (a B operand that is (1, 1) in the lanes of one column, 0 elsewhere): column
+// c of accb += the sums of the 32 A rows over the tile's samples
+template <uint32_t RH, uint32_t TS>
+__device__ __forceinline__ void contract_nb(const _Float16* stage, uint32_t a_row0, uint32_t b_row0, f32x16& acc, f32x16& accb, uint32_t sel,
+                                            int lane, bool a_valid = true) {
+    const h8 S = words_h8(sel, sel, sel, sel);
+#pragma unroll
+    for (uint32_t step = 0; step < TS / 16; step++) {
+        h8 a = frag_n<RH>(stage, a_row0, step, lane);
+        if (!a_valid) a = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, frag_n<RH>(stage, b_row0, step, lane), acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, S, accb, 0, 0, 0);
+    }
+}
 // sum of one staged row over the tile's samples (bias gradient): v_dot2_f32_f16 against (1, 1) adds two halves into a float
 // accumulator exactly, one instruction per pair instead of two conversions and two additions
 template <uint32_t RH, uint32_t TS>
@@ -788,8 +802,16 @@ __global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 :
     __syncthreads();
     const int lane = (int)(t & 63), hi = lane >> 5;
     const uint32_t n = (uint32_t)lane & 31u, wave = t >> 6;
-    f32x16 acc2 = zero16(), accx = zero16();
-    float gb = 0.f;
+    f32x16 acc2 = zero16(), accx = zero16(), accb = zero16();
+    // Bias gradients = row sums of the staged gradients. They ride on the contractions: the A fragment a contraction has just read
+    // (32 gradient rows x 16 samples) is multiplied once more, by a B operand that is 1 in ONE column and 0 elsewhere, into a third
+    // accumulator whose column 0 collects d b2, column 1 d b1, column 2 d b3 of the rows this wave contracts. One MFMA per step in
+    // the shadow of the contraction's own dependent chain instead of 16 LDS reads + 64 v_dot2 by ONE wave per phase while the
+    // other three waited at the barrier.
+    const uint32_t one2 = 0x3C003C00u;   // (1.0h, 1.0h)
+    const uint32_t sel_w2 = ((wave & 1u) == 0u && n == 0u) ? one2 : 0u;   // waves 0 / 2 contract d h2 rows [0, 32) / [32, 64)
+    const uint32_t sel_w1 = (wave < 2u && n == 1u) ? one2 : 0u;           // waves 0 / 1 contract d h1 rows [0, 32) / [32, 64)
+    const uint32_t sel_w3 = (wave == 3u && n == 2u) ? one2 : 0u;          // waves 2 and 3 both hold the d h3 rows: wave 3 sums them
 
     // one 32-row block of a layer for the wave's column blocks: a[c] = sum_t A[frag0 + t] . X_c[4t .. 4t + 3]
     auto block = [&](uint32_t frag0, int ks, uint32_t (*xw)[16], f32x16* a) {
@@ -916,8 +938,7 @@ __global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 :
             }
         }
         __syncthreads();
-        if (wave >= 2) accx = contract_n<RH, TS>(stage, kHid, 32 * (wave - 2), accx, lane, (lane & 31) < (int)kOut);
-        if (t >= 128 && t < 128 + kOut) gb += row_sum_n<RH, TS>(stage, kHid + (t - 128));
+        if (wave >= 2) contract_nb<RH, TS>(stage, kHid, 32 * (wave - 2), accx, accb, sel_w3, lane, (lane & 31) < (int)kOut);
 
         // d h2 = relu'(h2) * W3^T d h3 (one K step: slots 0..3 of the hi = 0 lanes)
         uint32_t g2[NB][16];
@@ -936,8 +957,7 @@ __global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 :
             nat_stage_hidden<RH>(stage, kHid, col[c], hi, g2[c]);
         }
         __syncthreads();
-        acc2 = contract_n<RH, TS>(stage, kHid + 32 * (wave >> 1), 32 * (wave & 1), acc2, lane);
-        if (t < kHid) gb += row_sum_n<RH, TS>(stage, kHid + t);
+        contract_nb<RH, TS>(stage, kHid + 32 * (wave >> 1), 32 * (wave & 1), acc2, accb, sel_w2, lane);
 
         // d h1 = relu'(h1) * W2^T d h2
         uint32_t g1[NB][16];
@@ -962,8 +982,7 @@ __global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 :
             nat_stage_hidden<RH>(stage, kIn, col[c], hi, g1[c]);
         }
         __syncthreads();
-        if (wave < 2) accx = contract_n<RH, TS>(stage, kIn + 32 * wave, 0, accx, lane);
-        if (t >= 64 && t < 64 + kHid) gb += row_sum_n<RH, TS>(stage, kIn + (t - 64));
+        if (wave < 2) contract_nb<RH, TS>(stage, kIn + 32 * wave, 0, accx, accb, sel_w1, lane);
 
         // d features = W1^T d h1: word q of lane half hi is level (q & 1) + 4 (q >> 1) + 2 hi
         block(fW1T, 4, g1, a);
@@ -986,10 +1005,11 @@ __global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 :
         out[gW2 + (32 * (wave >> 1) + orow) * kHid + 32 * (wave & 1) + ocol] = acc2[r];
         if (wave < 2) out[gW1 + (32 * wave + orow) * kIn + ocol] = accx[r];
         else if (orow < kOut) out[gW3 + orow * kHid + 32 * (wave - 2) + ocol] = accx[r];
+        // the bias-gradient columns of accb (see above): element r of lane (n, hi) is row orow of column n
+        if (n == 0u && (wave & 1u) == 0u) out[gB2 + 32 * (wave >> 1) + orow] = accb[r];
+        if (n == 1u && wave < 2u) out[gB1 + 32 * wave + orow] = accb[r];
+        if (n == 2u && wave == 3u && orow < kOut) out[gB3 + orow] = accb[r];
     }
-    if (t < 64) out[gB2 + t] = gb;
-    else if (t < 128) out[gB1 + (t - 64)] = gb;
-    else if (t < 132) out[gB3 + (t - 128)] = gb;
 }
 
 // Forward in the same layout (persistent workgroups, the 16 forward fragments in LDS): no lane swaps, the layer results are packed
