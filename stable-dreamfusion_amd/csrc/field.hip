@@ -33,7 +33,7 @@ namespace {
 
 
 constexpr uint32_t kThreads = 256;
-constexpr uint32_t kMaxBlocks = 768;   // persistent workgroups of the backward: 256 CUs x (2 or 3) — the partials scratch is sized for 768
+constexpr uint32_t kMaxBlocks = 512;   // persistent workgroups of the backward: 256 CUs x 2
 
 // ---- parameter packing -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_field_pack(const float* __restrict__ w1, const float* __restrict__ b1,
@@ -779,11 +779,11 @@ __device__ __forceinline__ void nat_stage_hidden(_Float16* stage, uint32_t row0,
 
 // NB column blocks of 32 samples per wave: the tile of a workgroup is TS = 128 NB samples. NB = 1 halves the registers a
 // lane needs for activations (two workgroups, or more, per CU); NB = 2 reuses every weight fragment for two MFMAs.
-// LDSF: where the 30 weight fragments (1 KB each) live — 0: global memory (L1), 1: all in LDS (66 KB per workgroup with the staging
-// tile: two workgroups per CU), 2: the 16 fragments of the forward recompute in LDS, the 14 of the backward layers from L1 (52 KB:
-// THREE workgroups per CU; needs <= 170 registers).
+// LDSF: where the 30 weight fragments (1 KB each) live — 0: global memory (L1), 1: LDS (76 KB per workgroup with the staging tile:
+// two workgroups per CU). (A variant with only the forward recompute's 16 fragments in LDS ran three workgroups per CU at 52 KB /
+// 168 registers before the staging tile grew: no faster, profiles/r03_field_backward_experiments.txt.)
 template <int LDSF, int NB>
-__global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 : 1)) void k_field_backward_nat(const uint32_t* __restrict__ enc, const float* __restrict__ x,
+__global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_nat(const uint32_t* __restrict__ enc, const float* __restrict__ x,
                                                                                    const uint32_t* __restrict__ P, uint32_t B,
                                                                                    float blob_density, float inv_2r2,
                                                                                    const float* __restrict__ dsigma,
@@ -791,8 +791,9 @@ __global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 :
                                                                                    uint32_t* __restrict__ denc, float* __restrict__ partials,
                                                                                    RowLimit rl, StencilSrc src) {
     constexpr uint32_t TS = 128 * NB, RH = TS + 8;
-    __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRows * RH];
-    constexpr uint32_t kLdsFrags = LDSF == 1 ? kFrags : (LDSF == 2 ? fW3T : 0u);   // fragments [0, kLdsFrags) are LDS-resident
+    constexpr uint32_t kStageRowsNat = kHid + kOut + kIn + kHid;   // the second staging phase: h2 | d h3 | enc | d h1 = 164 rows
+    __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRowsNat * RH];
+    constexpr uint32_t kLdsFrags = LDSF == 1 ? kFrags : 0u;   // fragments [0, kLdsFrags) are LDS-resident
     __shared__ uint4 sfrag[kLdsFrags ? kLdsFrags * 64 : 1];
     __shared__ float sbias[kBiasPad];
     const uint32_t t = threadIdx.x;
@@ -923,22 +924,9 @@ __global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 :
             }
         }
 
-        // ---- dW3 += dh3 . h2^T ; db3 : rows [0,64) = h2, [64,68) = dh3 ----
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < NB; c++) {
-            nat_stage_hidden<RH>(stage, 0, col[c], hi, h2w[c]);
-            if (hi == 0) {
-#pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    const h2 u = as_h2(d3[c][p]);
-                    stage[(size_t)(kHid + 2 * p) * RH + col[c]] = u.x;
-                    stage[(size_t)(kHid + 2 * p + 1) * RH + col[c]] = u.y;
-                }
-            }
-        }
-        __syncthreads();
-        if (wave >= 2) contract_nb<RH, TS>(stage, kHid, 32 * (wave - 2), accx, accb, sel_w3, lane, (lane & 31) < (int)kOut);
+        // Two staging phases per tile (four barriers), each keeping all four waves busy. The three contractions used to be three
+        // phases, and d W3 (two 32-row blocks: waves 2, 3) and d W1 (waves 0, 1) each left half the workgroup waiting at the barrier;
+        // they now share the second phase: h2 and d h3 stay in registers until d h1 is known.
 
         // d h2 = relu'(h2) * W3^T d h3 (one K step: slots 0..3 of the hi = 0 lanes)
         uint32_t g2[NB][16];
@@ -949,7 +937,7 @@ __global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 :
             for (int c = 0; c < NB; c++) nat_mask_pack(a[c], h2w[c] + 8 * mb, g2[c] + 8 * mb);
         }
 
-        // ---- dW2 += dh2 . h1^T ; db2 : rows [0,64) = h1, [64,128) = dh2 ----
+        // ---- phase A: dW2 += dh2 . h1^T ; db2 : rows [0,64) = h1, [64,128) = dh2 ----
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NB; c++) {
@@ -968,21 +956,33 @@ __global__ __launch_bounds__(kThreads, LDSF == 2 && NB == 1 ? 3 : (NB == 1 ? 2 :
             for (int c = 0; c < NB; c++) nat_mask_pack(a[c], h1[c] + 8 * mb, g1[c] + 8 * mb);
         }
 
-        // ---- dW1 += dh1 . enc^T ; db1 : rows [0,32) = enc, [32,96) = dh1 ----
+        // ---- phase B: dW3 += dh3 . h2^T ; db3 (waves 2, 3) and dW1 += dh1 . enc^T ; db1 (waves 0, 1):
+        //      rows [0,64) = h2, [64,68) = dh3, [68,100) = enc, [100,164) = dh1 ----
+        constexpr uint32_t rD3 = kHid, rEnc = kHid + kOut, rG1 = kHid + kOut + kIn;
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NB; c++) {
+            nat_stage_hidden<RH>(stage, 0, col[c], hi, h2w[c]);
+            if (hi == 0) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const h2 u = as_h2(d3[c][p]);
+                    stage[(size_t)(rD3 + 2 * p) * RH + col[c]] = u.x;
+                    stage[(size_t)(rD3 + 2 * p + 1) * RH + col[c]] = u.y;
+                }
+            }
 #pragma unroll
             for (int p = 0; p < 8; p++) {   // level 8 hi + p = features 2 (8 hi + p), + 1
-                const uint32_t f = 2 * (8 * hi + p);
+                const uint32_t f = rEnc + 2 * (8 * hi + p);
                 const h2 u = as_h2(e[c][p]);
                 stage[(size_t)f * RH + col[c]] = u.x;
                 stage[(size_t)(f + 1) * RH + col[c]] = u.y;
             }
-            nat_stage_hidden<RH>(stage, kIn, col[c], hi, g1[c]);
+            nat_stage_hidden<RH>(stage, rG1, col[c], hi, g1[c]);
         }
         __syncthreads();
-        if (wave < 2) contract_nb<RH, TS>(stage, kIn + 32 * wave, 0, accx, accb, sel_w1, lane);
+        if (wave >= 2) contract_nb<RH, TS>(stage, rD3, 32 * (wave - 2), accx, accb, sel_w3, lane, (lane & 31) < (int)kOut);
+        else contract_nb<RH, TS>(stage, rG1 + 32 * wave, rEnc, accx, accb, sel_w1, lane);
 
         // d features = W1^T d h1: word q of lane half hi is level (q & 1) + 4 (q >> 1) + 2 hi
         block(fW1T, 4, g1, a);
@@ -1287,12 +1287,11 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
     SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_backward: features misaligned");
     SDFX_REQUIRE(blob_radius > 0, "field_backward: blob_radius must be positive");
     hipStream_t st = as_stream(stream);
-    static const int lds_frags = [] { const char* e = getenv("SDFX_FIELD_BWD_LDSFRAG"); return e ? atoi(e) : 1; }();   // 0 / 1 / 2: k_field_backward_nat
+    static const int lds_frags = [] { const char* e = getenv("SDFX_FIELD_BWD_LDSFRAG"); return (e && e[0] == '0') ? 0 : 1; }();
     static const bool native = [] { const char* e = getenv("SDFX_FIELD_BWD_NAT"); return !(e && e[0] == '0'); }();
     static const int nb = [] { const char* e = getenv("SDFX_FIELD_BWD_NB"); return (e && e[0] == '2') ? 2 : 1; }();
     const bool nat = !use_dot2() && native && enc_layout == 0 && B < kNatMaxRows;
-    // two workgroups per CU (three with the backward fragments out of LDS)
-    const uint32_t nblocks = B ? backward_blocks(B, nat && nb == 1 && lds_frags == 2 ? 768u : 512u) : 0;
+    const uint32_t nblocks = B ? backward_blocks(B, 512u) : 0;   // persistent: two workgroups per CU
     if (B) {
         if (use_dot2()) {
             hipLaunchKernelGGL(k_field_backward, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
@@ -1308,7 +1307,7 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
     hipLaunchKernelGGL((k_field_backward_nat<LDSF_, NB_>), dim3(nblocks), dim3(kThreads), 0, st, ep, x, packed, B, blob_density, i2, \
                        dsigma, dalbedo, dp, scratch, rlim, stencil_src())
                 if (nb == 2) { if (lds_frags) SDFX_NAT(1, 2); else SDFX_NAT(0, 2); }
-                else { if (lds_frags == 2) SDFX_NAT(2, 1); else if (lds_frags) SDFX_NAT(1, 1); else SDFX_NAT(0, 1); }
+                else { if (lds_frags) SDFX_NAT(1, 1); else SDFX_NAT(0, 1); }
 #undef SDFX_NAT
             } else if (lds_frags)
                 hipLaunchKernelGGL(k_field_backward_mma<true>, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
