@@ -678,57 +678,58 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 __device__ __forceinline__ h8 words_h8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return __builtin_bit_cast(h8, make_uint4(a, b, c, d)); }
 
-// the staging helpers of the kernel above for a tile of TS samples (row pitch RH = TS + 8 halves)
-template <uint32_t RH>
-__device__ __forceinline__ h8 frag_n(const _Float16* stage, uint32_t row, uint32_t step, int lane) {
-    return *reinterpret_cast<const h8*>(stage + (size_t)(row + (lane & 31)) * RH + step * 16 + 8 * (lane >> 5));
+// ---- staging of the weight-gradient contractions in the layout the values are BORN in, read back transposed ------------------
+// The contractions run over the samples (K = sample), so both MFMA operands want "lane = feature, 8 consecutive samples", while a
+// lane of this kernel holds ONE sample's features. The kernels above transpose on the way IN: one 16-bit LDS store per value
+// into [feature][sample] rows (148 ds_write_b16 per lane and 128-sample tile). Here a quantity is staged as "feature blocks" —
+// [sample][32 features] with a row pitch of kTrPitch = 72 bytes — which a lane fills with the 8-byte pieces it holds (4 consecutive
+// features: 37 ds_write_b64 per lane and tile, conflict-free: 16 consecutive samples at pitch 18 dwords hit 16 different bank
+// pairs), and the operands come back through gfx950's transposing read: ds_read_b64_tr_b16 hands lane c of a 16-lane group element
+// (c & 3) of the 8-byte piece addressed by lane 4 j + (c >> 2) of the group, for j = 0..3 (tools/ubench/tr_read.hip). With lane
+// 4 j + q of a group addressing sample s0 + j, features f0 + 4 q .. + 3, lane c receives feature f0 + c of samples s0 .. s0 + 3:
+// two reads = the 8 samples of an operand lane. Groups 0 / 1 of a wave take features +0 / +16, groups 2 / 3 the K half 8..15.
+constexpr uint32_t kTrPitch = 72;   // bytes per sample row of a feature block (64 of data)
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s4v* lds_s4v_ptr;
+// this lane's part of an operand address: sample 8 (group >> 1) + j, features 16 (group & 1) + 4 q  (row pitch `pitch` bytes)
+__device__ __forceinline__ uint32_t tr_lane_offset(int lane, uint32_t pitch, bool with_features) {
+    const uint32_t g = (uint32_t)lane >> 4, i = (uint32_t)lane & 15u, j = i >> 2, q = i & 3u;
+    return (8u * (g >> 1) + j) * pitch + (with_features ? (16u * (g & 1u) + 4u * q) * 2u : 0u);
 }
-template <uint32_t RH, uint32_t TS>
-__device__ __forceinline__ f32x16 contract_n(const _Float16* stage, uint32_t a_row0, uint32_t b_row0, f32x16 acc, int lane, bool a_valid = true) {
-#pragma unroll 4
-    for (uint32_t step = 0; step < TS / 16; step++) {
-        h8 a = frag_n<RH>(stage, a_row0, step, lane);
-        if (!a_valid) a = h8{0, 0, 0, 0, 0, 0, 0, 0};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, frag_n<RH>(stage, b_row0, step, lane), acc, 0, 0, 0);
-    }
-    return acc;
+// operand of K step `step` (16 samples) from a block at byte offset `off` (lane part included)
+template <uint32_t PITCH>
+__device__ __forceinline__ h8 frag_tr(const uint8_t* stage, uint32_t off, uint32_t step) {
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(stage + off + step * 16u * PITCH));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(stage + off + step * 16u * PITCH + 4u * PITCH));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2v = __builtin_bit_cast(uint2, hi);
+    return words_h8(l2.x, l2.y, h2v.x, h2v.y);
 }
-// the same, and the A fragment once more against `sel` (a B operand that is (1, 1) in the lanes of one column, 0 elsewhere): column
-// c of accb += the sums of the 32 A rows over the tile's samples
-template <uint32_t RH, uint32_t TS>
-__device__ __forceinline__ void contract_nb(const _Float16* stage, uint32_t a_row0, uint32_t b_row0, f32x16& acc, f32x16& accb, uint32_t sel,
-                                            int lane, bool a_valid = true) {
+// acc += A . B^T over the tile's samples, and the A fragment once more against `sel` (a B operand that is (1, 1) in the lanes of one
+// column, 0 elsewhere): column c of accb += the sums of the 32 A rows over the tile's samples (the bias gradients)
+template <uint32_t TS, uint32_t A_PITCH>
+__device__ __forceinline__ void contract_tr(const uint8_t* stage, uint32_t a_off, uint32_t b_off, f32x16& acc, f32x16& accb, uint32_t sel,
+                                            bool a_valid = true) {
     const h8 S = words_h8(sel, sel, sel, sel);
 #pragma unroll
     for (uint32_t step = 0; step < TS / 16; step++) {
-        h8 a = frag_n<RH>(stage, a_row0, step, lane);
+        h8 a = frag_tr<A_PITCH>(stage, a_off, step);
         if (!a_valid) a = h8{0, 0, 0, 0, 0, 0, 0, 0};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, frag_n<RH>(stage, b_row0, step, lane), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, frag_tr<kTrPitch>(stage, b_off, step), acc, 0, 0, 0);
         accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, S, accb, 0, 0, 0);
     }
 }
-// sum of one staged row over the tile's samples (bias gradient): v_dot2_f32_f16 against (1, 1) adds two halves into a float
-// accumulator exactly, one instruction per pair instead of two conversions and two additions
-template <uint32_t RH, uint32_t TS>
-__device__ __forceinline__ float row_sum_n(const _Float16* stage, uint32_t row) {
-    const uint4* r = reinterpret_cast<const uint4*>(stage + (size_t)row * RH);
-    const h2 one = h2{(_Float16)1.0f, (_Float16)1.0f};
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-    for (uint32_t i = 0; i < TS / 8; i++) {
-        const uint4 v = r[i];
-        s0 = __builtin_amdgcn_fdot2(as_h2(v.x), one, s0, false);
-        s1 = __builtin_amdgcn_fdot2(as_h2(v.y), one, s1, false);
-        s0 = __builtin_amdgcn_fdot2(as_h2(v.z), one, s0, false);
-        s1 = __builtin_amdgcn_fdot2(as_h2(v.w), one, s1, false);
+// hidden vector (16 words of this lane: features 32 b + 4 hi + 8 m .. + 3 in words 8 b + 2 m, + 1) -> feature blocks blk, blk + 1
+template <uint32_t TS>
+__device__ __forceinline__ void stage_hidden_tr(uint8_t* stage, uint32_t blk, uint32_t col, int hi, const uint32_t* w16) {
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+            *reinterpret_cast<uint2*>(stage + (blk + b) * TS * kTrPitch + col * kTrPitch + (8 * m + 4 * hi) * 2) =
+                make_uint2(w16[8 * b + 2 * m], w16[8 * b + 2 * m + 1]);
     }
-    return s0 + s1;
 }
 
-// relu(acc + bias) packed pairwise: words 8 mb .. 8 mb + 7 of a hidden vector. Three packed instructions per word (v_pk_add_f32,
-// v_cvt_pk_f16_f32, v_pk_max_i16) where add, add, max, max, convert took five: the ReLU is taken on the half BITS — a negative
-// half (and -0) is a negative 16-bit integer, so max(bits, 0) is +0 for it and the value itself otherwise; rounding first and
-// clamping second gives the same half as clamping first (the conversion is monotonic and keeps the sign).
 // gfx950's packed conversion (v_cvt_pk_f16_f32: round to nearest even, both halves in one instruction). hipcc selects it for a
 // VECTOR conversion; for h2{(_Float16)a, (_Float16)b} it emits two v_cvt_f16_f32 and a v_perm_b32. (Not inline assembly: the
 // operands are often MFMA results, and the compiler does not insert the MFMA -> VALU wait states in front of an asm statement.)
@@ -765,18 +766,6 @@ __device__ __forceinline__ void nat_mask_pack(const f32x16& a, const uint32_t* a
     for (int q = 0; q < 8; q++) out8[q] = masked_pack_bits(act8[q], a[2 * q], a[2 * q + 1], ones);
 }
 
-// hidden vector (16 words of this lane) -> stage rows row0 + feature, column col
-template <uint32_t RH>
-__device__ __forceinline__ void nat_stage_hidden(_Float16* stage, uint32_t row0, uint32_t col, int hi, const uint32_t* w16) {
-#pragma unroll
-    for (int p = 0; p < 16; p++) {
-        const uint32_t f = 32 * (p >> 3) + 4 * hi + 8 * ((p & 7) >> 1) + 2 * (p & 1);
-        const h2 v = as_h2(w16[p]);
-        stage[(size_t)(row0 + f) * RH + col] = v.x;
-        stage[(size_t)(row0 + f + 1) * RH + col] = v.y;
-    }
-}
-
 // NB column blocks of 32 samples per wave: the tile of a workgroup is TS = 128 NB samples. NB = 1 halves the registers a
 // lane needs for activations (two workgroups, or more, per CU); NB = 2 reuses every weight fragment for two MFMAs.
 // LDSF: where the 30 weight fragments (1 KB each) live — 0: global memory (L1), 1: LDS (76 KB per workgroup with the staging tile:
@@ -790,9 +779,10 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
                                                                                    const float* __restrict__ dalbedo,
                                                                                    uint32_t* __restrict__ denc, float* __restrict__ partials,
                                                                                    RowLimit rl, StencilSrc src) {
-    constexpr uint32_t TS = 128 * NB, RH = TS + 8;
-    constexpr uint32_t kStageRowsNat = kHid + kOut + kIn + kHid;   // the second staging phase: h2 | d h3 | enc | d h1 = 164 rows
-    __shared__ __attribute__((aligned(16))) _Float16 stage[kStageRowsNat * RH];
+    constexpr uint32_t TS = 128 * NB;
+    constexpr uint32_t kFB = TS * kTrPitch;                  // bytes of one feature block [TS samples][32 features]
+    constexpr uint32_t kD3 = 5 * kFB, kD3Pitch = 8;          // d h3 (4 features): [TS][4 halves] behind the five blocks
+    __shared__ __attribute__((aligned(16))) uint8_t stage[5 * kFB + TS * kD3Pitch];
     constexpr uint32_t kLdsFrags = LDSF == 1 ? kFrags : 0u;   // fragments [0, kLdsFrags) are LDS-resident
     __shared__ uint4 sfrag[kLdsFrags ? kLdsFrags * 64 : 1];
     __shared__ float sbias[kBiasPad];
@@ -813,6 +803,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
     const uint32_t sel_w2 = ((wave & 1u) == 0u && n == 0u) ? one2 : 0u;   // waves 0 / 2 contract d h2 rows [0, 32) / [32, 64)
     const uint32_t sel_w1 = (wave < 2u && n == 1u) ? one2 : 0u;           // waves 0 / 1 contract d h1 rows [0, 32) / [32, 64)
     const uint32_t sel_w3 = (wave == 3u && n == 2u) ? one2 : 0u;          // waves 2 and 3 both hold the d h3 rows: wave 3 sums them
+    const uint32_t tr_lane = tr_lane_offset(lane, kTrPitch, true), tr_lane_d3 = tr_lane_offset(lane, kD3Pitch, false);
 
     // one 32-row block of a layer for the wave's column blocks: a[c] = sum_t A[frag0 + t] . X_c[4t .. 4t + 3]
     auto block = [&](uint32_t frag0, int ks, uint32_t (*xw)[16], f32x16* a) {
@@ -937,15 +928,15 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
             for (int c = 0; c < NB; c++) nat_mask_pack(a[c], h2w[c] + 8 * mb, g2[c] + 8 * mb);
         }
 
-        // ---- phase A: dW2 += dh2 . h1^T ; db2 : rows [0,64) = h1, [64,128) = dh2 ----
+        // ---- phase A: dW2 += dh2 . h1^T ; db2 : feature blocks 0, 1 = h1, 2, 3 = dh2 ----
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            nat_stage_hidden<RH>(stage, 0, col[c], hi, h1[c]);
-            nat_stage_hidden<RH>(stage, kHid, col[c], hi, g2[c]);
+            stage_hidden_tr<TS>(stage, 0, col[c], hi, h1[c]);
+            stage_hidden_tr<TS>(stage, 2, col[c], hi, g2[c]);
         }
         __syncthreads();
-        contract_nb<RH, TS>(stage, kHid + 32 * (wave >> 1), 32 * (wave & 1), acc2, accb, sel_w2, lane);
+        contract_tr<TS, kTrPitch>(stage, (2 + (wave >> 1)) * kFB + tr_lane, (wave & 1) * kFB + tr_lane, acc2, accb, sel_w2);
 
         // d h1 = relu'(h1) * W2^T d h2
         uint32_t g1[NB][16];
@@ -957,32 +948,22 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
         }
 
         // ---- phase B: dW3 += dh3 . h2^T ; db3 (waves 2, 3) and dW1 += dh1 . enc^T ; db1 (waves 0, 1):
-        //      rows [0,64) = h2, [64,68) = dh3, [68,100) = enc, [100,164) = dh1 ----
-        constexpr uint32_t rD3 = kHid, rEnc = kHid + kOut, rG1 = kHid + kOut + kIn;
+        //      feature blocks 0, 1 = h2, 2 = enc, 3, 4 = dh1; dh3 (4 features) behind them ----
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            nat_stage_hidden<RH>(stage, 0, col[c], hi, h2w[c]);
-            if (hi == 0) {
+            stage_hidden_tr<TS>(stage, 0, col[c], hi, h2w[c]);
+            if (hi == 0) *reinterpret_cast<uint2*>(stage + kD3 + col[c] * kD3Pitch) = make_uint2(d3[c][0], d3[c][1]);
 #pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    const h2 u = as_h2(d3[c][p]);
-                    stage[(size_t)(rD3 + 2 * p) * RH + col[c]] = u.x;
-                    stage[(size_t)(rD3 + 2 * p + 1) * RH + col[c]] = u.y;
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < 8; p++) {   // level 8 hi + p = features 2 (8 hi + p), + 1
-                const uint32_t f = rEnc + 2 * (8 * hi + p);
-                const h2 u = as_h2(e[c][p]);
-                stage[(size_t)f * RH + col[c]] = u.x;
-                stage[(size_t)(f + 1) * RH + col[c]] = u.y;
-            }
-            nat_stage_hidden<RH>(stage, rG1, col[c], hi, g1[c]);
+            for (int m = 0; m < 4; m++)   // levels 8 hi + 2 m, + 1 = features 16 hi + 4 m .. + 3
+                *reinterpret_cast<uint2*>(stage + 2 * kFB + col[c] * kTrPitch + (16 * hi + 4 * m) * 2) = make_uint2(e[c][2 * m], e[c][2 * m + 1]);
+            stage_hidden_tr<TS>(stage, 3, col[c], hi, g1[c]);
         }
         __syncthreads();
-        if (wave >= 2) contract_nb<RH, TS>(stage, rD3, 32 * (wave - 2), accx, accb, sel_w3, lane, (lane & 31) < (int)kOut);
-        else contract_nb<RH, TS>(stage, rG1 + 32 * wave, rEnc, accx, accb, sel_w1, lane);
+        // the 4 rows of dh3 sit in the first piece of a row: every lane of a group addresses that piece (rows >= 4 of the operand
+        // are zeroed, they would read the neighbouring samples)
+        if (wave >= 2) contract_tr<TS, kD3Pitch>(stage, kD3 + tr_lane_d3, (wave - 2) * kFB + tr_lane, accx, accb, sel_w3, (lane & 31) < (int)kOut);
+        else contract_tr<TS, kTrPitch>(stage, (3 + wave) * kFB + tr_lane, 2 * kFB + tr_lane, accx, accb, sel_w1);
 
         // d features = W1^T d h1: word q of lane half hi is level (q & 1) + 4 (q >> 1) + 2 hi
         block(fW1T, 4, g1, a);
