@@ -821,6 +821,25 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
             }
         }
     };
+    // the two 32-row blocks of a 64-row layer with their MFMA chains interleaved: a dependent MFMA on the same accumulator waits for
+    // the previous one (16 passes), so two independent chains keep the matrix pipe busy and halve the stall in front of the packing
+    auto pair = [&](uint32_t fragA, uint32_t fragB, int ks, uint32_t (*xw)[16], f32x16* a0, f32x16* a1) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) { a0[c] = zero16(); a1[c] = zero16(); }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (s < ks) {
+                const h8 A0 = __builtin_bit_cast(h8, (fragA + s < kLdsFrags ? sfrag : Fg)[(size_t)(fragA + s) * 64 + lane]);
+                const h8 A1 = __builtin_bit_cast(h8, (fragB + s < kLdsFrags ? sfrag : Fg)[(size_t)(fragB + s) * 64 + lane]);
+#pragma unroll
+                for (int c = 0; c < NB; c++) {
+                    const h8 X = words_h8(xw[c][4 * s], xw[c][4 * s + 1], xw[c][4 * s + 2], xw[c][4 * s + 3]);
+                    a0[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, X, a0[c], 0, 0, 0);
+                    a1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, X, a1[c], 0, 0, 0);
+                }
+            }
+        }
+    };
 
     // Persistent workgroups over the LIVE tiles with the next tile's inputs in flight (see k_field_forward_nat below): the row
     // limit read once, no branch around a load (dead lanes read row 0, masked afterwards) or around a store (buffer descriptor).
@@ -879,19 +898,13 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
 
         // ---- forward recompute ----
         uint32_t h1[NB][16], h2w[NB][16];
-        f32x16 a[NB];
+        f32x16 a[NB], a1[NB];
+        pair(fW1, fW1 + 2, 2, e, a, a1);
 #pragma unroll
-        for (int mb = 0; mb < 2; mb++) {
-            block(fW1 + 2 * mb, 2, e, a);
+        for (int c = 0; c < NB; c++) { nat_relu_pack(a[c], sbias, hi, h1[c]); nat_relu_pack(a1[c], sbias + 32, hi, h1[c] + 8); }
+        pair(fW2, fW2 + 4, 4, h1, a, a1);
 #pragma unroll
-            for (int c = 0; c < NB; c++) nat_relu_pack(a[c], sbias + 32 * mb, hi, h1[c] + 8 * mb);
-        }
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++) {
-            block(fW2 + 4 * mb, 4, h1, a);
-#pragma unroll
-            for (int c = 0; c < NB; c++) nat_relu_pack(a[c], sbias + kHid + 32 * mb, hi, h2w[c] + 8 * mb);
-        }
+        for (int c = 0; c < NB; c++) { nat_relu_pack(a[c], sbias + kHid, hi, h2w[c]); nat_relu_pack(a1[c], sbias + kHid + 32, hi, h2w[c] + 8); }
         block(fW3, 4, h2w, a);
         // output activations' derivatives: d sigma / d z = exp(min(z, 15)) (activation.py:13-16); d sigmoid = s (1 - s)
         uint32_t d3[NB][16];
@@ -921,12 +934,9 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
 
         // d h2 = relu'(h2) * W3^T d h3 (one K step: slots 0..3 of the hi = 0 lanes)
         uint32_t g2[NB][16];
+        pair(fW3T, fW3T + 1, 1, d3, a, a1);
 #pragma unroll
-        for (int mb = 0; mb < 2; mb++) {
-            block(fW3T + mb, 1, d3, a);
-#pragma unroll
-            for (int c = 0; c < NB; c++) nat_mask_pack(a[c], h2w[c] + 8 * mb, g2[c] + 8 * mb);
-        }
+        for (int c = 0; c < NB; c++) { nat_mask_pack(a[c], h2w[c], g2[c]); nat_mask_pack(a1[c], h2w[c] + 8, g2[c] + 8); }
 
         // ---- phase A: dW2 += dh2 . h1^T ; db2 : feature blocks 0, 1 = h1, 2, 3 = dh2 ----
         __syncthreads();
@@ -940,12 +950,9 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
 
         // d h1 = relu'(h1) * W2^T d h2
         uint32_t g1[NB][16];
+        pair(fW2T, fW2T + 4, 4, g2, a, a1);
 #pragma unroll
-        for (int mb = 0; mb < 2; mb++) {
-            block(fW2T + 4 * mb, 4, g2, a);
-#pragma unroll
-            for (int c = 0; c < NB; c++) nat_mask_pack(a[c], h1[c] + 8 * mb, g1[c] + 8 * mb);
-        }
+        for (int c = 0; c < NB; c++) { nat_mask_pack(a[c], h1[c], g1[c]); nat_mask_pack(a1[c], h1[c] + 8, g1[c] + 8); }
 
         // ---- phase B: dW3 += dh3 . h2^T ; db3 (waves 2, 3) and dW1 += dh1 . enc^T ; db1 (waves 0, 1):
         //      feature blocks 0, 1 = h2, 2 = enc, 3, 4 = dh1; dh3 (4 features) behind them ----
@@ -1026,6 +1033,23 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* 
             }
         }
     };
+    auto pair = [&](uint32_t fragA, uint32_t fragB, int ks, uint32_t (*xw)[16], f32x16* a0, f32x16* a1) {   // see k_field_backward_nat
+#pragma unroll
+        for (int c = 0; c < NB; c++) { a0[c] = zero16(); a1[c] = zero16(); }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (s < ks) {
+                const h8 A0 = __builtin_bit_cast(h8, sfrag[(size_t)(fragA + s) * 64 + lane]);
+                const h8 A1 = __builtin_bit_cast(h8, sfrag[(size_t)(fragB + s) * 64 + lane]);
+#pragma unroll
+                for (int c = 0; c < NB; c++) {
+                    const h8 X = words_h8(xw[c][4 * s], xw[c][4 * s + 1], xw[c][4 * s + 2], xw[c][4 * s + 3]);
+                    a0[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, X, a0[c], 0, 0, 0);
+                    a1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, X, a1[c], 0, 0, 0);
+                }
+            }
+        }
+    };
     // Persistent workgroups over the LIVE tiles, the next tile's inputs (features, coordinates for the density blob) in flight
     // while this one is computed: the limit is read once (row_limit_now), dead lanes read row 0 and are masked afterwards (no
     // branch around a load), the outputs go through buffer descriptors (no branch around a store) — before, a tile began with
@@ -1082,19 +1106,13 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* 
         const uint32_t tile_next = next_live(tile + gridDim.x);
         if (tile_next < ntiles) fetch(tile_next);
         uint32_t h1[NB][16], h2w[NB][16];
-        f32x16 a[NB];
+        f32x16 a[NB], a1[NB];
+        pair(fW1, fW1 + 2, 2, e, a, a1);
 #pragma unroll
-        for (int mb = 0; mb < 2; mb++) {
-            block(fW1 + 2 * mb, 2, e, a);
+        for (int c = 0; c < NB; c++) { nat_relu_pack(a[c], sbias, hi, h1[c]); nat_relu_pack(a1[c], sbias + 32, hi, h1[c] + 8); }
+        pair(fW2, fW2 + 4, 4, h1, a, a1);
 #pragma unroll
-            for (int c = 0; c < NB; c++) nat_relu_pack(a[c], sbias + 32 * mb, hi, h1[c] + 8 * mb);
-        }
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++) {
-            block(fW2 + 4 * mb, 4, h1, a);
-#pragma unroll
-            for (int c = 0; c < NB; c++) nat_relu_pack(a[c], sbias + kHid + 32 * mb, hi, h2w[c] + 8 * mb);
-        }
+        for (int c = 0; c < NB; c++) { nat_relu_pack(a[c], sbias + kHid, hi, h2w[c]); nat_relu_pack(a1[c], sbias + kHid + 32, hi, h2w[c] + 8); }
         block(fW3, 4, h2w, a);
 #pragma unroll
         for (int c = 0; c < NB; c++) {   // the hi = 0 lanes own the 4 outputs of a sample; the others compute along and store nothing
