@@ -129,7 +129,8 @@ def test_native_layout_chain_equals_matrix_products():
 
 
 def test_staging_rows_cover_every_feature_once():
-    """nat_stage_hidden: word p of lane half hi goes to feature rows f, f + 1 with f = 32 (p >> 3) + 4 hi + 8 ((p & 7) >> 1) + 2 (p & 1)."""
+    """word p of lane half hi holds features f, f + 1 with f = 32 (p >> 3) + 4 hi + 8 ((p & 7) >> 1) + 2 (p & 1) (what stage_hidden_tr
+    relies on: words 8 b + 2 m, + 1 are the four consecutive features 32 b + 4 hi + 8 m .. + 3)."""
     rows = sorted(f + d for hi in range(2) for p in range(16) for d in (0, 1)
                   for f in [32 * (p >> 3) + 4 * hi + 8 * ((p & 7) >> 1) + 2 * (p & 1)])
     assert rows == list(range(64))
@@ -138,3 +139,94 @@ def test_staging_rows_cover_every_feature_once():
             f = 32 * (p >> 3) + 4 * hi + 8 * ((p & 7) >> 1) + 2 * (p & 1)
             t, j = (2 * p) >> 3, (2 * p) & 7                # slot pair (2p, 2p + 1) in K-step order
             assert f == phi_h(t, hi, j) and f + 1 == phi_h(t, hi, j + 1)
+
+
+# ---- round 3: operands staged as [sample][32 features] blocks, read back through ds_read_b64_tr_b16 -------------------------------
+TR_PITCH, TS = 72, 128
+
+
+def tr_read(lds, addr):
+    """ds_read_b64_tr_b16 as tools/ubench/tr_read.hip found it on the hardware: lane c of a 16-lane group receives, for j = 0..3,
+    element (c & 3) of the 8-byte piece addressed by lane 4 j + (c >> 2) of its group. lds: uint16 view; addr [64] byte addresses."""
+    out = np.zeros((64, 4), lds.dtype)
+    for lane in range(64):
+        g, c = lane >> 4, lane & 15
+        for j in range(4):
+            src = 16 * g + 4 * j + (c >> 2)
+            out[lane, j] = lds[addr[src] // 2 + (c & 3)]
+    return out
+
+
+def tr_lane_offset(lane, pitch, with_features):
+    g, i = lane >> 4, lane & 15
+    j, q = i >> 2, i & 3
+    return (8 * (g >> 1) + j) * pitch + ((16 * (g & 1) + 4 * q) * 2 if with_features else 0)
+
+
+def frag_tr(lds, off, step, pitch):
+    a0 = np.array([off[l] + step * 16 * pitch for l in range(64)])
+    return np.concatenate([tr_read(lds, a0), tr_read(lds, a0 + 4 * pitch)], axis=1)      # [64, 8]
+
+
+def test_probe_pattern_of_the_transposing_read():
+    """the first pattern of tools/ubench/tr_read.hip (lane l addresses byte 8 l, LDS holds its own element indices): lane c of group g
+    read 64 g + c + 16 j"""
+    lds = np.arange(4096)
+    got = tr_read(lds, [8 * l for l in range(64)])
+    for lane in range(64):
+        assert list(got[lane]) == [64 * (lane >> 4) + (lane & 15) + 16 * j for j in range(4)]
+
+
+def test_transposing_read_staging_contracts_over_samples():
+    """stage_hidden_tr + frag_tr + the MFMA layouts give dW[i][j] = sum over the tile's 128 samples of g[i][s] h[j][s] for every 32 x 32
+    block pair of two staged 64-feature quantities, and the 4-row d h3 block (8-byte pitch, every lane of a group addressing the
+    row's only piece) against a 32-row h block with the operand rows >= 4 zeroed."""
+    rng = np.random.default_rng(1)
+    H, G = rng.normal(size=(K_HID, TS)), rng.normal(size=(K_HID, TS))
+    G3 = rng.normal(size=(K_OUT, TS))
+    kFB = TS * TR_PITCH
+    lds = np.zeros((5 * kFB + TS * 8) // 2)
+
+    def stage_hidden(blk, M):     # every lane (n, hi) of the four waves writes its 16 words as eight 8-byte pieces
+        for wave in range(4):
+            for lane in range(64):
+                n, hi = lane & 31, lane >> 5
+                col = 32 * wave + n
+                for b in range(2):
+                    for m in range(4):
+                        f0 = 32 * b + 4 * hi + 8 * m                      # words 8 b + 2 m, + 1 = features f0 .. f0 + 3 (test above)
+                        byte = (blk + b) * kFB + col * TR_PITCH + (8 * m + 4 * hi) * 2
+                        lds[byte // 2:byte // 2 + 4] = M[f0:f0 + 4, col]
+
+    stage_hidden(0, H)
+    stage_hidden(2, G)
+    for s in range(TS):
+        lds[(5 * kFB + s * 8) // 2:(5 * kFB + s * 8) // 2 + 4] = G3[:, s]
+    lane_off = [tr_lane_offset(l, TR_PITCH, True) for l in range(64)]
+    lane_off_d3 = [tr_lane_offset(l, 8, False) for l in range(64)]
+
+    def contract(a_base, a_pitch, a_lane, b_base, a_rows_valid=32):
+        acc = np.zeros((64, 16))
+        for step in range(TS // 16):
+            A = frag_tr(lds, [a_base + o for o in a_lane], step, a_pitch)
+            B = frag_tr(lds, [b_base + o for o in lane_off], step, TR_PITCH)
+            for lane in range(64):
+                if (lane & 31) >= a_rows_valid:
+                    A[lane] = 0
+            acc = mfma(A, B, acc)
+        D = np.zeros((32, 32))
+        for lane in range(64):
+            n, hi = lane & 31, lane >> 5
+            for r in range(16):
+                D[d_row(r, hi), n] = acc[lane, r]
+        return D
+
+    W = G @ H.T
+    for bi in range(2):
+        for bj in range(2):
+            D = contract((2 + bi) * kFB, TR_PITCH, lane_off, bj * kFB)
+            assert np.allclose(D, W[32 * bi:32 * bi + 32, 32 * bj:32 * bj + 32])
+    W3 = G3 @ H.T
+    for bj in range(2):
+        D = contract(5 * kFB, 8, lane_off_d3, bj * kFB, a_rows_valid=K_OUT)
+        assert np.allclose(D[:K_OUT], W3[:, 32 * bj:32 * bj + 32]) and np.all(D[K_OUT:] == 0)
