@@ -449,9 +449,12 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
                                 *reinterpret_cast<const __half2*>(&v));
                 continue;
             }
-            const uint32_t r = (it[u].row & (kBucketRows - 1)) * 2;
+            // channel-major accumulators (acc[ch * kBucketRows + row]): a 64-bit slot covers two banks, so with the two channels of
+            // a row side by side only rows 0..7 (mod 8) are distinct bank groups — 64 random rows collide 8 ways on average; with
+            // one array per channel it is rows mod 16
+            const uint32_t r = it[u].row & (kBucketRows - 1);
             if (lo & 0x7FFFu) atomicAdd(&acc[r], (unsigned long long)half_to_fixed(lo));      // ds_add_u64
-            if (hi & 0x7FFFu) atomicAdd(&acc[r + 1], (unsigned long long)half_to_fixed(hi));
+            if (hi & 0x7FFFu) atomicAdd(&acc[kBucketRows + r], (unsigned long long)half_to_fixed(hi));
         }
     }
     }
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
     const uint32_t shared_first = bin.acc_first[j.level];
     if (j.used == 1 || shared_first == kNoSharedAcc) {
         for (uint32_t r = threadIdx.x; r < kBucketRows; r += kReduceThreadsFixed) {
-            const long long ia = (long long)acc[r * 2], ib = (long long)acc[r * 2 + 1];
+            const long long ia = (long long)acc[r], ib = (long long)acc[kBucketRows + r];
             if (ia == 0 && ib == 0) continue;
             const uint32_t row = first_row + r;
             if (row >= level_rows) continue;
@@ -477,8 +480,8 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
     // independent of how the bucket was split and of the order of arrival. (A last-arriver flush inside this kernel
     // needs a device-scope release per workgroup, i.e. an L2 write-back on this multi-XCD part: +170 us measured.)
     unsigned long long* gacc = shared_acc + ((size_t)shared_first + first_row) * 2;
-    for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) {
-        const unsigned long long v = acc[i];
+    for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) {   // the global accumulator stays [row][channel]
+        const unsigned long long v = acc[(i & 1u) * kBucketRows + (i >> 1)];
         if (v) atomicAdd(&gacc[i], v);
     }
 }
