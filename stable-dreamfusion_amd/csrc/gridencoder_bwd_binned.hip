@@ -613,7 +613,9 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
         // A level of a few buckets (the 16^3 level has two) receives all 8*B contributions in those few lists: with
         // 131072 items per workgroup only a few dozen workgroups would run (measured: 677 of 1756 us for that
         // level alone). Such levels are cut finer and flushed atomically.
-        b.per_split[l] = nb <= kCoarseBuckets ? kItemsPerSplitCoarse : kItemsPerSplit;
+        // SDFX_GRIDBWD_COARSE_SPLIT: items per K2 workgroup at the levels of few buckets (measurement aid)
+        static const uint32_t coarse_split = [] { const char* e = getenv("SDFX_GRIDBWD_COARSE_SPLIT"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : kItemsPerSplitCoarse; }();
+        b.per_split[l] = nb <= kCoarseBuckets ? coarse_split : kItemsPerSplit;
         b.acc_first[l] = kNoSharedAcc;
         if (nb <= kCoarseBuckets) {
             b.acc_first[l] = acc_rows;
