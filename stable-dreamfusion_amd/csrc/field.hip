@@ -666,7 +666,8 @@ __global__ __launch_bounds__(kThreads) void k_field_backward_mma(const uint32_t*
 // 32-row block. Packed pairwise they ARE the B operand of the next layer if that layer's weight fragments have their K columns
 // in the same order (the second fragment set k_field_pack writes): no swaps, no temporaries, results consumed where they land.
 // The per-sample scalars (activations' derivatives of the 4 outputs) live in the hi = 0 lanes. The weight-gradient contractions
-// use the same [feature][sample] LDS staging, accumulators and output layout as above.
+// keep the accumulators and the output layout of the kernel above; their operands are staged in the lanes' own layout and read
+// back transposed (round 3: "staging of the weight-gradient contractions" below).
 // =========================================================================================
 constexpr uint32_t kBiasPad = 2 * kHid + 32;   // b1 | b2 | b3 padded to a 32-row block (rows >= 4 are zero)
 
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
     };
 
     // Persistent workgroups over the LIVE tiles with the next tile's inputs in flight (see k_field_forward_nat below): the row
-    // limit read once, no branch around a load (dead lanes read row 0, masked afterwards) or around a store (buffer descriptor).
+    // limit read once, no branch around a load or a store (buffer descriptors: a dead lane's out-of-range offset reads 0 / is dropped).
     const RowLimitNow rn = row_limit_now(rl);
     // every operand through a buffer descriptor: 32-bit offsets (the level stride p B 4 rides in the scalar offset: no 64-bit
     // address arithmetic per load), and a dead lane's out-of-range offset reads 0 — no masking afterwards
@@ -1051,8 +1052,8 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* 
         }
     };
     // Persistent workgroups over the LIVE tiles, the next tile's inputs (features, coordinates for the density blob) in flight
-    // while this one is computed: the limit is read once (row_limit_now), dead lanes read row 0 and are masked afterwards (no
-    // branch around a load), the outputs go through buffer descriptors (no branch around a store) — before, a tile began with
+    // while this one is computed: the limit is read once (row_limit_now), inputs and outputs go through buffer descriptors (a dead
+    // lane's out-of-range offset reads 0 / drops the store: no branch around a memory operation) — before, a tile began with
     // two dependent reads of the row limit, then its feature loads, and ended with the coordinate load: four exposed latencies
     // for ~0.5 us of arithmetic.
     const RowLimitNow rn = row_limit_now(rl);
