@@ -61,20 +61,18 @@ struct BinPlan {
 constexpr uint32_t kMaxSub = kXcds;
 
 template <bool HALF> struct Item;
-template <> struct Item<true> {   // {row in level, half2 contribution}
-    uint32_t row;
-    uint32_t val;
-    static __device__ __forceinline__ Item make(uint32_t row, float a, float b) {
-        Item it;
-        it.row = row;
-        const __half2 h = __halves2half2(__float2half_rn(a), __float2half_rn(b));
-        it.val = *reinterpret_cast<const uint32_t*>(&h);
-        return it;
-    }
-    __device__ __forceinline__ float2 value() const {
-        const __half2 h = *reinterpret_cast<const __half2*>(&val);
-        return make_float2(__low2float(h), __high2float(h));
-    }
+// Half tables: one item carries the TWO corners of an x-pair, (x, y, z) and (x + 1, y, z). Their rows always lie in the same
+// 2048-row bucket at a hashed level (x + 1 differs from x in a run of low bits, and the hash XORs y, z terms that the pair
+// shares) and almost always at a dense one (rows r, r + 1), so 12 bytes {row0 | (row0 ^ row1) << 20, half2, half2} replace two
+// 8-byte items: 6 bytes per contribution instead of 8 through HBM both ways — K2 streams the lists at the HBM read rate and K1's
+// fine levels write them at close to the write rate (profiles/r03_scatter_pmc_wave_states.txt) — and half as many histogram
+// atomics, staging slots and list entries. A pair that straddles a bucket boundary goes out as two items whose second value is 0.
+template <> struct Item<true> {
+    uint32_t rows;   // row0 in the level (20 bits) | (row0 ^ row1) << 20 (11 bits: same bucket)
+    uint32_t val0, val1;
+    __device__ __forceinline__ uint32_t row0() const { return rows & 0xFFFFFu; }
+    __device__ __forceinline__ uint32_t row1() const { return (rows & 0xFFFFFu) ^ (rows >> 20); }
+    __device__ __forceinline__ uint32_t bucket() const { return (rows & 0xFFFFFu) >> SDFX_BUCKET_LOG2; }
 };
 template <> struct Item<false> {  // {row in level, float2 contribution}
     uint32_t row;
@@ -85,6 +83,7 @@ template <> struct Item<false> {  // {row in level, float2 contribution}
         return it;
     }
     __device__ __forceinline__ float2 value() const { return make_float2(a, b); }
+    __device__ __forceinline__ uint32_t bucket() const { return row >> SDFX_BUCKET_LOG2; }
 };
 
 // value of lane (l - n) of the same 16-lane row, `self` where there is none (DPP row_shr: a VALU move, no LDS traffic)
@@ -152,16 +151,21 @@ struct BinLevels {
     LevelConst lv[kMaxLevels];   // per-level constants of the forward (grid_point.h): one 32-byte scalar load per workgroup
 };
 
-template <bool HALF> __device__ __forceinline__ Item<HALF> make_item(uint32_t row, float2_t v);
-template <> __device__ __forceinline__ Item<true> make_item<true>(uint32_t row, float2_t v) {
-    Item<true> it;
-    it.row = row;
-    half2_t h;   // both channels rounded to half (nearest even) by one instruction
+__device__ __forceinline__ uint32_t round_half2(float2_t v) {   // both channels rounded to half (nearest even) by one instruction
+    half2_t h;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(v.x), "v"(v.y));
-    it.val = __builtin_bit_cast(uint32_t, h);
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ Item<true> make_pair_item(uint32_t row0, uint32_t row1, uint32_t val0, uint32_t val1) {
+    Item<true> it;
+    it.rows = row0 | ((row0 ^ row1) << 20);
+    it.val0 = val0; it.val1 = val1;
     return it;
 }
-template <> __device__ __forceinline__ Item<false> make_item<false>(uint32_t row, float2_t v) { return Item<false>::make(row, v.x, v.y); }
+// add one rounded contribution straight to the table (list over capacity: complete for any input distribution)
+__device__ __forceinline__ void add_direct(__half* gtab, uint32_t row, uint32_t val) {
+    unsafeAtomicAdd(reinterpret_cast<__half2*>(gtab + (size_t)row * 2), *reinterpret_cast<const __half2*>(&val));
+}
 
 // ---------------------------------------------------------------------------------------------
 // K1: contributions -> binned items
@@ -236,10 +240,23 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
         for (uint32_t idx = 0; idx < NCORN; idx++) fold_runs(runs, v[idx]);
         emit = runs.tail;
     }
-    uint32_t rank[NCORN];
+    // items of this lane: one per corner (float tables) or one per x-pair of corners (half tables, see Item<true>)
+    constexpr uint32_t NIT = HALF ? NCORN / 2 : NCORN;
+    uint32_t ibucket[NIT], rank[NIT];
+    bool split[NIT];
+#pragma unroll
+    for (uint32_t i = 0; i < NIT; i++) {
+        if constexpr (HALF) {
+            ibucket[i] = rows[2 * i] >> kBucketRowsLog2;
+            split[i] = (rows[2 * i + 1] >> kBucketRowsLog2) != ibucket[i];   // the pair straddles two buckets (dense levels, rarely)
+        } else {
+            ibucket[i] = rows[i] >> kBucketRowsLog2;
+            split[i] = false;
+        }
+    }
     if (emit) {
 #pragma unroll
-        for (uint32_t idx = 0; idx < NCORN; idx++) rank[idx] = atomicAdd(&hist[rows[idx] >> kBucketRowsLog2], 1u);  // LDS
+        for (uint32_t i = 0; i < NIT; i++) rank[i] = atomicAdd(&hist[ibucket[i]], 1u);  // LDS
     }
     __syncthreads();
     // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's (sub-)list; and an exclusive
@@ -263,31 +280,43 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
     // Stage the items in LDS grouped by bucket, then stream them out: consecutive staging slots of one bucket go to
     // consecutive slots of its list, so a wave store covers a few contiguous runs instead of 64 unrelated 8-byte
     // writes (the scattered version was bound by L2 write transactions: one per item).
-    if (emit) {
-#pragma unroll
-        for (uint32_t idx = 0; idx < NCORN; idx++)
-            stage[boff[rows[idx] >> kBucketRowsLog2] + rank[idx]] = make_item<HALF>(rows[idx], v[idx]);
-    }
-    __syncthreads();
-
     const uint32_t cap = bin.cap[level];
     Item<HALF>* level_items = items + (size_t)bin.item_first[level] * 1024u;
     T* gtab = grad_table + (size_t)lc.row0 * C;
+    if (emit) {
+#pragma unroll
+        for (uint32_t i = 0; i < NIT; i++) {
+            if constexpr (HALF) {
+                const uint32_t v0 = round_half2(v[2 * i]), v1 = round_half2(v[2 * i + 1]);
+                stage[boff[ibucket[i]] + rank[i]] = make_pair_item(rows[2 * i], split[i] ? rows[2 * i] : rows[2 * i + 1], v0, split[i] ? 0u : v1);
+                if (split[i]) {   // the second corner goes to its own bucket's list, reserved by this lane (exactness: never an atomic add)
+                    const uint32_t b1 = rows[2 * i + 1] >> kBucketRowsLog2;
+                    const uint32_t slot = atomicAdd(&cursors[(bin.bucket_first[level] + b1) * bin.nsub + sub], 1u);
+                    if (slot < cap) level_items[((size_t)b1 * bin.nsub + sub) * cap + slot] = make_pair_item(rows[2 * i + 1], rows[2 * i + 1], v1, 0u);
+                    else add_direct(gtab, rows[2 * i + 1], v1);
+                }
+            } else {
+                stage[boff[ibucket[i]] + rank[i]] = Item<false>::make(rows[i], v[i].x, v[i].y);
+            }
+        }
+    }
+    __syncthreads();
+
     const uint32_t total = *block_total;
     for (uint32_t k = threadIdx.x; k < total; k += kBinThreads) {
         const Item<HALF> it = stage[k];
-        const uint32_t bucket = it.row >> kBucketRowsLog2;
+        const uint32_t bucket = it.bucket();
         const uint32_t slot = gbase[bucket] + (k - boff[bucket]);
         if (slot < cap) {
             level_items[((size_t)bucket * bin.nsub + sub) * cap + slot] = it;
         } else {  // (sub-)list over capacity: add directly (complete for any input distribution)
-            T* dst = gtab + (size_t)it.row * C;
-            const float2 val = it.value();
             if constexpr (HALF) {
-                unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), __halves2half2(__float2half_rn(val.x), __float2half_rn(val.y)));
+                add_direct(gtab, it.row0(), it.val0);
+                if (it.val1 & 0x7FFF7FFFu) add_direct(gtab, it.row1(), it.val1);
             } else {
-                unsafeAtomicAdd(dst, val.x);
-                unsafeAtomicAdd(dst + 1, val.y);
+                T* dst = gtab + (size_t)it.row * C;
+                unsafeAtomicAdd(dst, it.a);
+                unsafeAtomicAdd(dst + 1, it.b);
             }
         }
     }
@@ -308,7 +337,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename 
     __shared__ uint32_t boff[kMaxBucketsPerLevel];
     __shared__ uint32_t wave_tot[kBinThreads / 64];
     __shared__ uint32_t block_total;
-    __shared__ Item<HALF> stage[kBinThreads * 8];   // 32 KiB (half items) / 48 KiB (float items)
+    __shared__ Item<HALF> stage[kBinThreads * (HALF ? 4 : 8)];   // 24 KiB (half: 4 pair items per sample) / 48 KiB (float items)
 
     uint32_t level, tile;
     if (!plan_item(plan, level, tile)) return;   // wave-uniform (depends on blockIdx only)
@@ -440,21 +469,25 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
             have[u] = i < r_hi;
             it[u] = src[have[u] ? i : r_lo];
         }
-#pragma unroll
-        for (uint32_t u = 0; u < kUnroll; u++) {
-            if (!have[u]) continue;
-            const uint32_t v = it[u].val, lo = v & 0xFFFFu, hi = v >> 16;
+        // one rounded contribution (two halves) of row `row` (in the level)
+        auto add = [&](uint32_t v, uint32_t row) {
+            const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
             if (((lo & 0x7C00u) == 0x7C00u) || ((hi & 0x7C00u) == 0x7C00u)) {  // inf / nan: straight to the table
-                unsafeAtomicAdd(reinterpret_cast<__half2*>(grad_table + ((size_t)row0 + it[u].row) * 2),
-                                *reinterpret_cast<const __half2*>(&v));
-                continue;
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(grad_table + ((size_t)row0 + row) * 2), *reinterpret_cast<const __half2*>(&v));
+                return;
             }
             // channel-major accumulators (acc[ch * kBucketRows + row]): a 64-bit slot covers two banks, so with the two channels of
             // a row side by side only rows 0..7 (mod 8) are distinct bank groups — 64 random rows collide 8 ways on average; with
             // one array per channel it is rows mod 16
-            const uint32_t r = it[u].row & (kBucketRows - 1);
+            const uint32_t r = row & (kBucketRows - 1);
             if (lo & 0x7FFFu) atomicAdd(&acc[r], (unsigned long long)half_to_fixed(lo));      // ds_add_u64
             if (hi & 0x7FFFu) atomicAdd(&acc[kBucketRows + r], (unsigned long long)half_to_fixed(hi));
+        };
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; u++) {
+            if (!have[u]) continue;
+            add(it[u].val0, it[u].row0());
+            if (it[u].val1 & 0x7FFF7FFFu) add(it[u].val1, it[u].row1());
         }
     }
     }
@@ -587,7 +620,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce_ticket(float
 }
 
 // host: bucket geometry for a chunk of `chunk` samples
-BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uint32_t nsub, uint64_t* total_items_1024,
+BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uint32_t nsub, bool pair_items, uint64_t* total_items_1024,
                       uint32_t* total_buckets, uint32_t* total_splits, uint32_t* shared_acc_rows = nullptr,
                       uint32_t* coarse_buckets = nullptr) {
     BinPlan b;
@@ -601,7 +634,7 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
         const uint32_t nb = (rows + kBucketRows - 1) >> kBucketRowsLog2;
         b.bucket_first[l] = buckets;
         b.split_first[l] = wgs;
-        const uint64_t worst = (uint64_t)8 * chunk;  // every contribution of the chunk lands in this level
+        const uint64_t worst = (uint64_t)(pair_items ? 4 : 8) * chunk;  // every contribution of the chunk lands in this level (half tables: two per item)
         // uniform share + 25 % + slack; coarse levels rely on the run folding, and on the atomic fallback beyond that
         uint64_t cap = (worst + nb - 1) / nb;
         cap = cap + cap / 4 + 256;
@@ -674,7 +707,7 @@ uint64_t header_bytes(uint32_t shared_acc_rows) {
 uint64_t scratch_bytes_for(const GridPlan& plan, uint32_t levels, uint32_t chunk, bool half) {
     uint64_t items;
     uint32_t nb, wg, acc_rows;
-    make_bin_plan(plan, levels, chunk, k1_flat() ? kMaxSub : 1u, &items, &nb, &wg, &acc_rows);
+    make_bin_plan(plan, levels, chunk, k1_flat() ? kMaxSub : 1u, half, &items, &nb, &wg, &acc_rows);
     return header_bytes(acc_rows) + items * 1024u * (half ? sizeof(Item<true>) : sizeof(Item<false>));
 }
 
@@ -823,7 +856,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         if (!flat && k1_balance_enabled()) balance_plan(plan, max_level, k1_level_cost(max_level));
         uint64_t items_1024;
         uint32_t nbuckets, nsplits, acc_rows, coarse_buckets;
-        const BinPlan bin = make_bin_plan(plan, max_level, chunk, flat ? kMaxSub : 1u, &items_1024, &nbuckets, &nsplits, &acc_rows,
+        const BinPlan bin = make_bin_plan(plan, max_level, chunk, flat ? kMaxSub : 1u, is_half != 0, &items_1024, &nbuckets, &nsplits, &acc_rows,
                                           &coarse_buckets);
         void* items = static_cast<char*>(scratch) + header_bytes(acc_rows);
         zero_device(scratch, header_bytes(is_half ? acc_rows : 0), st);  // cursors, accumulators
