@@ -8,7 +8,8 @@
 // call at 4.2e5 samples (rocprof, profiles/r01_v1_*). This file replaces it by a two-kernel
 // "bin, then reduce in LDS" scatter:
 //
-//   K1 bin     every (sample, level, corner) contribution becomes an 8/12-byte item {row, value}.
+//   K1 bin     every (sample, level, corner) contribution becomes an item: float tables {row, float2} (12 bytes), half tables
+//              one 12-byte item per x-PAIR of corners {row0 | (row0 ^ row1) << 20, half2, half2} (see Item<true>).
 //              Lanes hold consecutive samples of a ray, so at coarse and middle levels runs of lanes
 //              hit the same table row: a wave-level segmented scan folds each run into one item.
 //              Items are binned by row range (2048 rows per bucket) with an LDS histogram and ONE
