@@ -262,8 +262,15 @@ int sdfx_grid_encode_backward(const void* grad, const float* inputs, const void*
  * Extension — the same table gradient as sdfx_grid_encode_backward for D = 3, C = 2 (no dy_dx), computed
  * by binning contributions per 2048-row bucket and reducing each bucket in LDS instead of issuing one
  * device-scope atomic per (sample, level, corner). `scratch`: device memory of `scratch_bytes` bytes,
- * 16-byte aligned; samples are processed in chunks that fit it (see *_scratch_bytes for sizing).
+ * 16-byte aligned; samples are processed in chunks that fit it (see *_scratch_bytes for sizing). Its
+ * contents need no initialisation and are not preserved between calls.
+ * Half tables: every row receives the EXACT sum of its half-rounded contributions (64-bit fixed point),
+ * rounded once when it is added to grad_embeddings — for any distribution of the samples (list overflow
+ * goes to exact per-bucket spill accumulators) and independent of the order of arrival: bit-reproducible.
+ * Float tables: float32 sums per bucket; heavy or overflowing buckets fall back to float atomics.
  * Returns SDFX_E_UNSUPPORTED for other D / C so the caller can use sdfx_grid_encode_backward.
+ * *_stats (synchronises `stream`): out[0] = buckets of the last launch on `scratch` that overflowed into
+ * their spill accumulator, out[1] = spill waits that timed out (0 unless the device misbehaved).
  */
 int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, const int32_t* offsets_host,
                                      void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
@@ -272,6 +279,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
                                      sdfx_stream_t stream);
 uint64_t sdfx_grid_encode_backward_binned_scratch_bytes(const int32_t* offsets_host, uint32_t L, uint32_t max_level, float S,
                                                          uint32_t H, uint32_t chunk_points, int is_half);
+int sdfx_grid_encode_backward_binned_stats(const void* scratch, uint32_t* out, sdfx_stream_t stream);
 
 /* gridencoder.cu:662-668 grad_total_variation (adds into grad; f32 or f16 by is_half) */
 int sdfx_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,

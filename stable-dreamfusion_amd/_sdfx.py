@@ -47,6 +47,7 @@ _SIGNATURES = {
     "sdfx_grid_encode_backward_binned": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u32,
                                          _int, _int, _ptr, _u64, _ptr],
     "sdfx_grid_encode_backward_binned_scratch_bytes": [_ptr, _u32, _u32, _f32, _u32, _u32, _int],
+    "sdfx_grid_encode_backward_binned_stats": [_ptr, _ptr, _ptr],
     "sdfx_grad_total_variation": [_ptr, _ptr, _ptr, _ptr, _ptr, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int,
                                   _int, _ptr],
     "sdfx_grad_weight_decay": [_ptr, _ptr, _ptr, _f32, _u32, _u32, _u32, _int, _ptr],

@@ -21,7 +21,6 @@ struct GridPlan {
     uint32_t order[kMaxLevels];    // virtual level -> level (fine and coarse levels interleaved)
     uint32_t tiles;                // tiles per level
     uint32_t vec16;                // table base is 16-byte aligned: paired 16-byte gathers allowed
-    uint32_t flat;                 // 1: workgroup i takes item i (every XCD gets the same mix of levels) instead of its XCD's range
 };
 
 // (uint32_t)ceil(exp2f(level * S) * H) in float32 — gridencoder.cu:133
@@ -59,7 +58,6 @@ inline GridPlan make_plan(const int32_t* offsets_host, uint32_t levels, float S,
 }
 
 inline uint32_t plan_grid_size(const GridPlan& p) {
-    if (p.flat) return p.end[kXcds - 1];
     uint32_t longest = 0;
     for (uint32_t k = 0; k < kXcds; k++) {
         const uint32_t len = p.end[k] - p.start[k];
@@ -68,17 +66,11 @@ inline uint32_t plan_grid_size(const GridPlan& p) {
     return longest * kXcds;
 }
 
-// workgroup -> (level, tile); false when this workgroup has no item
-__device__ __forceinline__ bool plan_item(const GridPlan& p, uint32_t& level, uint32_t& tile) {
-    if (p.flat) {
-        if (blockIdx.x >= p.end[kXcds - 1]) return false;
-        const uint32_t virt = blockIdx.x / p.tiles;
-        level = p.order[virt];
-        tile = blockIdx.x - virt * p.tiles;
-        return true;
-    }
-    const uint32_t xcd = blockIdx.x % kXcds;
-    const uint32_t local = blockIdx.x / kXcds;
+// workgroup `block` of the launch -> (level, tile); false when it has no item. Workgroups are dealt to the XCDs round-robin
+// (block b -> XCD b mod 8; checked at start-up, see sdfx_xcd_round_robin), so XCD k walks its own range [start[k], end[k]).
+__device__ __forceinline__ bool plan_item(const GridPlan& p, uint32_t block, uint32_t& level, uint32_t& tile) {
+    const uint32_t xcd = block % kXcds;
+    const uint32_t local = block / kXcds;
     if (local >= p.end[xcd] - p.start[xcd]) return false;
     const uint32_t item = p.start[xcd] + local;
     const uint32_t virt = item / p.tiles;
@@ -86,6 +78,7 @@ __device__ __forceinline__ bool plan_item(const GridPlan& p, uint32_t& level, ui
     tile = item - virt * p.tiles;
     return true;
 }
+__device__ __forceinline__ bool plan_item(const GridPlan& p, uint32_t& level, uint32_t& tile) { return plan_item(p, blockIdx.x, level, tile); }
 
 // ---- forward of the hot-path configuration (gridencoder_fwd.hip) ----
 bool fast_forward_enabled();

@@ -19,9 +19,15 @@
 //              serialised by a ticket byte; LDS float atomics are ~80x slower) and adds the result to
 //              the table gradient with plain, coalesced read-modify-writes (the workgroup owns those rows).
 //
-// Items that do not fit a bucket's reserved capacity fall back to a direct global atomic in K1, so
-// the result is complete for any input distribution. Sums are formed in float32 and rounded to the
-// table type once (the reference rounds every contribution to half before adding, gridencoder.cu:338).
+// A bucket that is asked for more slots than its list holds (cursor > capacity) is complete for any input distribution
+// too. Half tables (the -O path): K1 simply drops what does not fit; K2 ignores the list of such a bucket altogether, and
+// two more kernels between K1 and K2 — which find nothing to do and exit in every launch of the training loop — zero the
+// bucket's 64-bit fixed-point SPILL accumulator in global memory (k_grid_bwd_spill_zero) and re-derive ALL contributions
+// of the overflowed buckets from the samples, adding them there with 64-bit integer atomics (k_grid_bwd_spill: K1's
+// arithmetic, bit for bit). The table gradient is therefore the exactly summed, once-rounded value whatever the
+// distribution of the samples and whatever the order of arrival — bit-reproducible (the reference rounds every
+// contribution AND every partial sum to half, gridencoder.cu:334-340) — and K1's hot path carries no overflow code.
+// Float tables fall back to float atomics, which is what the reference does for every contribution.
 #include "grid_point.h"
 
 using namespace sdfx;
@@ -56,10 +62,7 @@ struct BinPlan {
     uint32_t item_first[kMaxLevels];        // first item slot (in units of 1024 items) of the level's bucket 0
     uint32_t merge_mask;                    // bit l: fold lane runs at level l before binning
     uint32_t levels;
-    uint32_t nsub;                          // item sub-lists per bucket: 8 = one per XCD (flat K1 mapping), 1 = one list
 };
-
-constexpr uint32_t kMaxSub = kXcds;
 
 template <bool HALF> struct Item;
 // Half tables: one item carries the TWO corners of an x-pair, (x, y, z) and (x + 1, y, z). Their rows always lie in the same
@@ -163,9 +166,21 @@ __device__ __forceinline__ Item<true> make_pair_item(uint32_t row0, uint32_t row
     it.val0 = val0; it.val1 = val1;
     return it;
 }
-// add one rounded contribution straight to the table (list over capacity: complete for any input distribution)
-__device__ __forceinline__ void add_direct(__half* gtab, uint32_t row, uint32_t val) {
-    unsafeAtomicAdd(reinterpret_cast<__half2*>(gtab + (size_t)row * 2), *reinterpret_cast<const __half2*>(&val));
+// ---- the spill path of half tables: buckets asked for more slots than their list holds ------------------------
+// Every bucket has a spill accumulator in the scratch, [kBucketRows][2 channels] 64-bit fixed point (the format of K2's LDS
+// accumulators). It is zeroed by k_grid_bwd_spill_zero iff cursor > cap, filled by k_grid_bwd_spill, read by K2.
+constexpr uint32_t kSpillWords = kBucketRows * 2;   // 64-bit words per bucket
+
+// one rounded contribution (two halves) of row `row` of the level into the spill accumulator of its (overflowed) bucket
+__device__ __forceinline__ void spill_add(unsigned long long* __restrict__ spill_acc, __half* gtab, uint32_t gbucket, uint32_t row, uint32_t val) {
+    const uint32_t lo = val & 0xFFFFu, hi = val >> 16;
+    if (((lo & 0x7C00u) == 0x7C00u) || ((hi & 0x7C00u) == 0x7C00u)) {   // inf / nan absorb whatever the order: straight to the table
+        unsafeAtomicAdd(reinterpret_cast<__half2*>(gtab + (size_t)row * 2), *reinterpret_cast<const __half2*>(&val));
+        return;
+    }
+    unsigned long long* a = spill_acc + (size_t)gbucket * kSpillWords + (size_t)(row & (kBucketRows - 1)) * 2;
+    if (lo & 0x7FFFu) atomicAdd(a, (unsigned long long)half_to_fixed(lo));
+    if (hi & 0x7FFFu) atomicAdd(a + 1, (unsigned long long)half_to_fixed(hi));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -176,23 +191,22 @@ __device__ __forceinline__ void add_direct(__half* gtab, uint32_t row, uint32_t 
 // parameters, the level's constants sit in scalar registers, the 8 row indices share their hash / stride terms
 // (level_prepare), both channels of a corner travel as one float2 (v_pk_mul_f32, v_pk_add_f32, v_cvt_pk_f16_f32), the run
 // folding is a workgroup-uniform template branch and nothing about a corner is decided by control flow.
+// the contributions of this lane's sample at one level: 8 table rows, 8 float2 values (folded over the lane run that ends here
+// when MERGE), and whether this lane emits them. Shared by K1 and by the spill kernel, which must reproduce K1's values bit for bit.
+struct Contrib {
+    uint32_t rows[8];
+    float2_t v[8];
+    bool emit;
+};
+
 template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
-__device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __restrict__ grad, const float* __restrict__ inputs,
-                                         typename Elem<HALF>::type* __restrict__ grad_table, uint32_t B, uint32_t L, uint32_t b0,
-                                         uint32_t b1, uint32_t level, uint32_t tile, const LevelConst& lc, const BinPlan& bin,
-                                         int grad_layout, uint32_t* __restrict__ cursors, Item<HALF>* __restrict__ items,
-                                         const RowLimit& rl, const StencilSrc& src, uint32_t* hist, uint32_t* gbase, uint32_t* boff,
-                                         uint32_t* wave_tot, uint32_t* block_total, Item<HALF>* stage) {
+__device__ __forceinline__ void tile_contributions(const typename Elem<HALF>::type* __restrict__ grad, const float* __restrict__ inputs,
+                                                   uint32_t B, uint32_t L, uint32_t b0, uint32_t b1, uint32_t level, uint32_t tile,
+                                                   const LevelConst& lc, int grad_layout, const RowLimit& rl, const StencilSrc& src,
+                                                   Contrib& c) {
     using T = typename Elem<HALF>::type;
     constexpr uint32_t C = 2, NCORN = 8;
     const int lane = lane_id();
-    // the sub-list of every bucket this workgroup appends to: its XCD's (workgroups are dealt to the XCDs round-robin), so that
-    // no two XCDs ever write to the same cache line of a list
-    const uint32_t sub = bin.nsub == 1 ? 0u : (blockIdx.x % kXcds);
-    const uint32_t nb = bin.bucket_first[level + 1] - bin.bucket_first[level];
-    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) hist[i] = 0;
-    __syncthreads();
-
     // ---- the sample: coordinates, gradient row, cell, weights, the 8 table rows ----
     const uint32_t b = b0 + tile * kBinThreads + threadIdx.x;
     bool valid = b < b1 && row_live(rl, b);
@@ -224,23 +238,43 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
     level_prepare<INTERP, ALIGN, HASHGRID>(lc, xs, p);
     // corner idx = xbit + 2 ybit + 4 zbit (gridencoder.cu:171-184); weight ((1 * a_x) * a_y) * a_z in that order
     const float ax[2] = {1 - p.ax1, p.ax1}, ay[2] = {1 - p.ay1, p.ay1}, az[2] = {1 - p.az1, p.az1};
-    uint32_t rows[NCORN];
-    float2_t v[NCORN];
 #pragma unroll
     for (uint32_t idx = 0; idx < NCORN; idx++) {
         const uint32_t k = idx >> 1;
-        rows[idx] = (idx & 1u) ? p.r1[k] : p.r0[k];
+        c.rows[idx] = (idx & 1u) ? p.r1[k] : p.r0[k];
         const float w = ((1 * ax[idx & 1u]) * ay[k & 1u]) * az[k >> 1];
-        v[idx] = g * w;
+        c.v[idx] = g * w;
     }
-    bool emit = valid;
+    c.emit = valid;
     if constexpr (MERGE) {
         // merged levels have res <= 640, so a cell id fits 10 bits per axis
         const RunScan runs = scan_cell_runs(p.cx | (p.cy << 10) | (p.cz << 20), valid, lane);
 #pragma unroll
-        for (uint32_t idx = 0; idx < NCORN; idx++) fold_runs(runs, v[idx]);
-        emit = runs.tail;
+        for (uint32_t idx = 0; idx < NCORN; idx++) fold_runs(runs, c.v[idx]);
+        c.emit = runs.tail;
     }
+}
+
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
+__device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __restrict__ grad, const float* __restrict__ inputs,
+                                         typename Elem<HALF>::type* __restrict__ grad_table, uint32_t B, uint32_t L, uint32_t b0,
+                                         uint32_t b1, uint32_t level, uint32_t tile, const LevelConst& lc, const BinPlan& bin,
+                                         int grad_layout, uint32_t* __restrict__ cursors, Item<HALF>* __restrict__ items,
+                                         const RowLimit& rl, const StencilSrc& src, uint32_t* hist, uint32_t* gbase, uint32_t* boff,
+                                         uint32_t* wave_tot, uint32_t* block_total, Item<HALF>* stage) {
+    using T = typename Elem<HALF>::type;
+    constexpr uint32_t C = 2, NCORN = 8;
+    const int lane = lane_id();
+    const uint32_t bucket0 = bin.bucket_first[level];
+    const uint32_t nb = bin.bucket_first[level + 1] - bucket0;
+    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) hist[i] = 0;
+    __syncthreads();
+
+    Contrib c;
+    tile_contributions<HALF, INTERP, ALIGN, HASHGRID, MERGE>(grad, inputs, B, L, b0, b1, level, tile, lc, grad_layout, rl, src, c);
+    const uint32_t (&rows)[NCORN] = c.rows;
+    const float2_t (&v)[NCORN] = c.v;
+    const bool emit = c.emit;
     // items of this lane: one per corner (float tables) or one per x-pair of corners (half tables, see Item<true>)
     constexpr uint32_t NIT = HALF ? NCORN / 2 : NCORN;
     uint32_t ibucket[NIT], rank[NIT];
@@ -260,12 +294,12 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
         for (uint32_t i = 0; i < NIT; i++) rank[i] = atomicAdd(&hist[ibucket[i]], 1u);  // LDS
     }
     __syncthreads();
-    // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's (sub-)list; and an exclusive
+    // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's list; and an exclusive
     // prefix sum of the histogram = where each bucket's items go in the workgroup's LDS staging area
     uint32_t my_cnt = 0;
     if (threadIdx.x < nb) {
         my_cnt = hist[threadIdx.x];
-        gbase[threadIdx.x] = my_cnt ? atomicAdd(&cursors[(bin.bucket_first[level] + threadIdx.x) * bin.nsub + sub], my_cnt) : 0u;
+        gbase[threadIdx.x] = my_cnt ? atomicAdd(&cursors[bucket0 + threadIdx.x], my_cnt) : 0u;
     }
     {   // nb <= kMaxBucketsPerLevel = kBinThreads: thread b scans bucket b (wave scan + per-wave totals)
         const uint32_t incl = wave_incl_sum_u32(my_cnt, lane);
@@ -281,20 +315,21 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
     // Stage the items in LDS grouped by bucket, then stream them out: consecutive staging slots of one bucket go to
     // consecutive slots of its list, so a wave store covers a few contiguous runs instead of 64 unrelated 8-byte
     // writes (the scattered version was bound by L2 write transactions: one per item).
+    // A slot at or beyond the list's capacity: half tables drop the item — the cursor keeps counting, cursor > cap tells K2 to
+    // take the bucket's sum from its spill accumulator, which k_grid_bwd_spill fills with ALL of the bucket's contributions
+    // (exact); float tables add with the reference's float atomics.
     const uint32_t cap = bin.cap[level];
     Item<HALF>* level_items = items + (size_t)bin.item_first[level] * 1024u;
-    T* gtab = grad_table + (size_t)lc.row0 * C;
     if (emit) {
 #pragma unroll
         for (uint32_t i = 0; i < NIT; i++) {
             if constexpr (HALF) {
                 const uint32_t v0 = round_half2(v[2 * i]), v1 = round_half2(v[2 * i + 1]);
                 stage[boff[ibucket[i]] + rank[i]] = make_pair_item(rows[2 * i], split[i] ? rows[2 * i] : rows[2 * i + 1], v0, split[i] ? 0u : v1);
-                if (split[i]) {   // the second corner goes to its own bucket's list, reserved by this lane (exactness: never an atomic add)
+                if (split[i]) {   // the second corner goes to its own bucket's list by a one-slot reservation of this lane
                     const uint32_t b1 = rows[2 * i + 1] >> kBucketRowsLog2;
-                    const uint32_t slot = atomicAdd(&cursors[(bin.bucket_first[level] + b1) * bin.nsub + sub], 1u);
-                    if (slot < cap) level_items[((size_t)b1 * bin.nsub + sub) * cap + slot] = make_pair_item(rows[2 * i + 1], rows[2 * i + 1], v1, 0u);
-                    else add_direct(gtab, rows[2 * i + 1], v1);
+                    const uint32_t slot = atomicAdd(&cursors[bucket0 + b1], 1u);
+                    if (slot < cap) level_items[(size_t)b1 * cap + slot] = make_pair_item(rows[2 * i + 1], rows[2 * i + 1], v1, 0u);
                 }
             } else {
                 stage[boff[ibucket[i]] + rank[i]] = Item<false>::make(rows[i], v[i].x, v[i].y);
@@ -309,16 +344,11 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
         const uint32_t bucket = it.bucket();
         const uint32_t slot = gbase[bucket] + (k - boff[bucket]);
         if (slot < cap) {
-            level_items[((size_t)bucket * bin.nsub + sub) * cap + slot] = it;
-        } else {  // (sub-)list over capacity: add directly (complete for any input distribution)
-            if constexpr (HALF) {
-                add_direct(gtab, it.row0(), it.val0);
-                if (it.val1 & 0x7FFF7FFFu) add_direct(gtab, it.row1(), it.val1);
-            } else {
-                T* dst = gtab + (size_t)it.row * C;
-                unsafeAtomicAdd(dst, it.a);
-                unsafeAtomicAdd(dst + 1, it.b);
-            }
+            level_items[(size_t)bucket * cap + slot] = it;
+        } else if constexpr (!HALF) {
+            T* dst = grad_table + ((size_t)lc.row0 + it.row) * C;
+            unsafeAtomicAdd(dst, it.a);
+            unsafeAtomicAdd(dst + 1, it.b);
         }
     }
 }
@@ -341,7 +371,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename 
     __shared__ Item<HALF> stage[kBinThreads * (HALF ? 4 : 8)];   // 24 KiB (half: 4 pair items per sample) / 48 KiB (float items)
 
     uint32_t level, tile;
-    if (!plan_item(plan, level, tile)) return;   // wave-uniform (depends on blockIdx only)
+    if (!plan_item(plan, blockIdx.x, level, tile)) return;   // wave-uniform (depends on blockIdx only)
     // a tile of padding rows (sdfx_set_row_limit) has nothing to scatter
     if (rows_dead(rl, b0 + tile * kBinThreads, kBinThreads)) return;
     const LevelConst lc = lv.lv[level];
@@ -351,6 +381,64 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename 
     else
         bin_tile<HALF, INTERP, ALIGN, HASHGRID, false>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors,
                                                        items, rl, src, hist, gbase, boff, wave_tot, &block_total, stage);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The spill path of half tables (see the head of the file). Both kernels exit at once unless some bucket overflowed.
+// ---------------------------------------------------------------------------------------------
+// one workgroup per bucket: zero the spill accumulator of an overflowed bucket and raise the launch's `any` flag
+__global__ __launch_bounds__(256) void k_grid_bwd_spill_zero(BinPlan bin, const uint32_t* __restrict__ cursors,
+                                                             unsigned long long* __restrict__ spill_acc, uint32_t* __restrict__ diag) {
+    uint32_t level = 0;
+    while (level + 1 < bin.levels && blockIdx.x >= bin.bucket_first[level + 1]) level++;
+    if (cursors[blockIdx.x] <= bin.cap[level]) return;
+    for (uint32_t i = threadIdx.x; i < kSpillWords; i += 256) spill_acc[(size_t)blockIdx.x * kSpillWords + i] = 0ull;
+    if (threadIdx.x == 0) {
+        diag[0] = 1u;             // some bucket overflowed (benign race: every writer stores 1)
+        atomicAdd(&diag[1], 1u);  // how many (sdfx_grid_encode_backward_binned_stats)
+    }
+}
+
+// K1's (level, tile) items once more, kSpillTilesPerGroup consecutive ones per workgroup: every contribution whose bucket
+// overflowed goes to that bucket's spill accumulator. The values are K1's (same lane map, same run folding, same rounding).
+constexpr uint32_t kSpillTilesPerGroup = 32;
+
+template <uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
+__device__ __forceinline__ void spill_tile(const __half* __restrict__ grad, const float* __restrict__ inputs, __half* __restrict__ grad_table,
+                                           uint32_t B, uint32_t L, uint32_t b0, uint32_t b1, uint32_t level, uint32_t tile,
+                                           const LevelConst& lc, const BinPlan& bin, int grad_layout, const uint32_t* __restrict__ cursors,
+                                           const RowLimit& rl, const StencilSrc& src, unsigned long long* __restrict__ spill_acc) {
+    Contrib c;
+    tile_contributions<true, INTERP, ALIGN, HASHGRID, MERGE>(grad, inputs, B, L, b0, b1, level, tile, lc, grad_layout, rl, src, c);
+    if (!c.emit) return;
+    const uint32_t bucket0 = bin.bucket_first[level], cap = bin.cap[level];
+    __half* gtab = grad_table + (size_t)lc.row0 * 2;
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        const uint32_t gb = bucket0 + (c.rows[idx] >> kBucketRowsLog2);
+        if (cursors[gb] > cap) spill_add(spill_acc, gtab, gb, c.rows[idx], round_half2(c.v[idx]));
+    }
+}
+
+template <uint32_t INTERP, bool ALIGN, bool HASHGRID>
+__global__ __launch_bounds__(kBinThreads) void k_grid_bwd_spill(const __half* __restrict__ grad, const float* __restrict__ inputs,
+                                                                __half* __restrict__ grad_table, uint32_t B, uint32_t L, uint32_t b0,
+                                                                uint32_t b1, GridPlan plan, BinPlan bin, BinLevels lv, int grad_layout,
+                                                                const uint32_t* __restrict__ cursors, RowLimit rl, StencilSrc src,
+                                                                unsigned long long* __restrict__ spill_acc,
+                                                                const uint32_t* __restrict__ diag, uint32_t k1_grid) {
+    if (diag[0] == 0u) return;   // no bucket overflowed: every launch of the training loop ends here
+    for (uint32_t i = 0; i < kSpillTilesPerGroup; i++) {
+        const uint32_t vblock = blockIdx.x * kSpillTilesPerGroup + i;
+        uint32_t level, tile;
+        if (vblock >= k1_grid || !plan_item(plan, vblock, level, tile)) continue;   // workgroup-uniform
+        if (rows_dead(rl, b0 + tile * kBinThreads, kBinThreads)) continue;
+        const LevelConst lc = lv.lv[level];
+        if ((bin.merge_mask >> level) & 1u)
+            spill_tile<INTERP, ALIGN, HASHGRID, true>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors, rl, src, spill_acc);
+        else
+            spill_tile<INTERP, ALIGN, HASHGRID, false>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors, rl, src, spill_acc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -374,26 +462,13 @@ constexpr uint32_t kReduceWaves = kReduceThreads / 64;
 constexpr uint32_t kReduceLdsBytes = kReduceWaves * kBucketRows * (sizeof(float2) + 1);
 
 struct ReduceJob {
-    uint32_t level, bucket, used, begin, end, cap;
-    uint32_t seg[kMaxSub + 1];   // prefix sums of the sub-list lengths: the bucket's items are their concatenation
+    uint32_t level, bucket, gbucket, split, used, begin, end, cap;
+    bool spilled;   // the bucket was asked for more slots than its list has. Half tables: the list is ignored, the bucket's whole sum
+                    // is in its spill accumulator; float tables: the list is full and the rest was added atomically by K1
 };
 
-// items of (level, bucket): the sum of its sub-lists, each clamped to its capacity (what is beyond went to the table atomically)
-__device__ __forceinline__ uint32_t bucket_items(const BinPlan& bin, const uint32_t* __restrict__ cursors, uint32_t level, uint32_t bucket,
-                                                 uint32_t* seg) {
-    const uint32_t cap = bin.cap[level];
-    uint32_t n = 0;
-    if (seg) seg[0] = 0;
-    for (uint32_t x = 0; x < bin.nsub; x++) {
-        uint32_t c = cursors[(bin.bucket_first[level] + bucket) * bin.nsub + x];
-        if (c > cap) c = cap;
-        n += c;
-        if (seg) seg[x + 1] = n;
-    }
-    return n;
-}
-
 // workgroup -> (level, bucket, split) and its slice of the bucket's item list; false if there is nothing to do
+template <bool HALF>
 __device__ __forceinline__ bool reduce_job(const BinPlan& bin, const uint32_t* __restrict__ cursors, ReduceJob& j) {
     uint32_t level = 0;
     while (level + 1 < bin.levels && blockIdx.x >= bin.split_first[level + 1]) level++;
@@ -401,44 +476,37 @@ __device__ __forceinline__ bool reduce_job(const BinPlan& bin, const uint32_t* _
     const uint32_t local = blockIdx.x - bin.split_first[level];
     j.level = level;
     j.bucket = local / splits;
-    const uint32_t split = local - j.bucket * splits;
+    j.gbucket = bin.bucket_first[level] + j.bucket;
+    j.split = local - j.bucket * splits;
     j.cap = bin.cap[level];
-    const uint32_t n = bucket_items(bin, cursors, level, j.bucket, j.seg);
-    // How many of the `splits` workgroups launched for this bucket actually share it is decided from the
-    // item count found at run time: one workgroup (sole owner, plain read-modify-write flush) unless the
-    // bucket is heavy (a coarse level, or unsorted input), in which case the flush has to be atomic.
+    uint32_t n = cursors[j.gbucket];
+    j.spilled = n > j.cap;
+    if (j.spilled) n = HALF ? 0u : j.cap;
+    // How many of the `splits` workgroups launched for this bucket actually share it is decided from the item count found at
+    // run time: one workgroup (sole owner, plain read-modify-write flush) unless the bucket is heavy (a level of few buckets:
+    // only those are launched with splits > 1, and they have a shared 64-bit accumulator, see make_bin_plan).
     const uint32_t per_split = bin.per_split[level];
     uint32_t used = (n + per_split - 1) / per_split;
     if (used < 1) used = 1;
     if (used > splits) used = splits;
     j.used = used;
-    if (split >= used) return false;
+    if (j.split >= used) return false;
     const uint32_t per = (n + used - 1) / used;
-    j.begin = split * per;
+    j.begin = j.split * per;
     j.end = j.begin + per < n ? j.begin + per : n;
-    return j.begin < j.end;
+    return j.begin < j.end || (HALF && j.spilled);   // (then used == 1, split == 0: this workgroup flushes the spill accumulator)
 }
 
-// add (a, b) to the table row this workgroup is flushing
+// add (a, b) to a table row that this workgroup alone touches: plain read-modify-write
 template <bool HALF>
-__device__ __forceinline__ void flush_row(typename Elem<HALF>::type* dst, float a, float b, bool sole_owner) {
-    if (sole_owner) {  // plain read-modify-write
-        if constexpr (HALF) {
-            const __half2 o = *reinterpret_cast<const __half2*>(dst);
-            *reinterpret_cast<__half2*>(dst) =
-                __halves2half2(__float2half_rn(__low2float(o) + a), __float2half_rn(__high2float(o) + b));
-        } else {
-            float2 o = *reinterpret_cast<const float2*>(dst);
-            o.x += a; o.y += b;
-            *reinterpret_cast<float2*>(dst) = o;
-        }
+__device__ __forceinline__ void flush_row(typename Elem<HALF>::type* dst, float a, float b) {
+    if constexpr (HALF) {
+        const __half2 o = *reinterpret_cast<const __half2*>(dst);
+        *reinterpret_cast<__half2*>(dst) = __halves2half2(__float2half_rn(__low2float(o) + a), __float2half_rn(__high2float(o) + b));
     } else {
-        if constexpr (HALF) {
-            unsafeAtomicAdd(reinterpret_cast<__half2*>(dst), __halves2half2(__float2half_rn(a), __float2half_rn(b)));
-        } else {
-            unsafeAtomicAdd(dst, a);
-            unsafeAtomicAdd(dst + 1, b);
-        }
+        float2 o = *reinterpret_cast<const float2*>(dst);
+        o.x += a; o.y += b;
+        *reinterpret_cast<float2*>(dst) = o;
     }
 }
 
@@ -448,32 +516,30 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
                                                                               BinPlan bin,
                                                                               const uint32_t* __restrict__ cursors,
                                                                               const Item<true>* __restrict__ items,
-                                                                              unsigned long long* __restrict__ shared_acc) {
+                                                                              unsigned long long* __restrict__ shared_acc,
+                                                                              const unsigned long long* __restrict__ spill_acc) {
     __shared__ unsigned long long acc[kBucketRows * 2];  // 32 KiB
     ReduceJob j;
-    if (!reduce_job(bin, cursors, j)) return;
+    if (!reduce_job<true>(bin, cursors, j)) return;
     for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) acc[i] = 0ull;
     __syncthreads();
 
     const uint32_t row0 = plan.off[j.level];
     constexpr uint32_t kUnroll = 8;  // independent loads in flight per thread
-    for (uint32_t x = 0; x < bin.nsub; x++) {   // the part of [begin, end) that lies in sub-list x
-    const uint32_t r_lo = j.begin > j.seg[x] ? j.begin : j.seg[x], r_hi = j.end < j.seg[x + 1] ? j.end : j.seg[x + 1];
-    if (r_lo >= r_hi) continue;
-    const Item<true>* src = items + (size_t)bin.item_first[j.level] * 1024u + ((size_t)j.bucket * bin.nsub + x) * j.cap - j.seg[x];
-    for (uint32_t base = r_lo; base < r_hi; base += kUnroll * kReduceThreadsFixed) {
+    const Item<true>* src = items + (size_t)bin.item_first[j.level] * 1024u + (size_t)j.bucket * j.cap;
+    for (uint32_t base = j.begin; base < j.end; base += kUnroll * kReduceThreadsFixed) {
         Item<true> it[kUnroll];
         bool have[kUnroll];
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; u++) {
             const uint32_t i = base + u * kReduceThreadsFixed + threadIdx.x;
-            have[u] = i < r_hi;
-            it[u] = src[have[u] ? i : r_lo];
+            have[u] = i < j.end;
+            it[u] = src[have[u] ? i : j.begin];
         }
         // one rounded contribution (two halves) of row `row` (in the level)
         auto add = [&](uint32_t v, uint32_t row) {
             const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
-            if (((lo & 0x7C00u) == 0x7C00u) || ((hi & 0x7C00u) == 0x7C00u)) {  // inf / nan: straight to the table
+            if (((lo & 0x7C00u) == 0x7C00u) || ((hi & 0x7C00u) == 0x7C00u)) {  // inf / nan absorb whatever the order: straight to the table
                 unsafeAtomicAdd(reinterpret_cast<__half2*>(grad_table + ((size_t)row0 + row) * 2), *reinterpret_cast<const __half2*>(&v));
                 return;
             }
@@ -491,62 +557,62 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
             if (it[u].val1 & 0x7FFF7FFFu) add(it[u].val1, it[u].row1());
         }
     }
-    }
     __syncthreads();
 
     const uint32_t level_rows = plan.off[j.level + 1] - row0;
     const uint32_t first_row = j.bucket << kBucketRowsLog2;
-    const uint32_t shared_first = bin.acc_first[j.level];
-    if (j.used == 1 || shared_first == kNoSharedAcc) {
+    // an overflowed bucket: its whole sum is in the spill accumulator (exact 64-bit sums, [row][channel]); acc[] stayed zero
+    const unsigned long long* spill = j.spilled ? spill_acc + (size_t)j.gbucket * kSpillWords : nullptr;
+    if (j.used == 1) {   // sole owner of the bucket's rows: round the exact sums once, plain read-modify-write
         for (uint32_t r = threadIdx.x; r < kBucketRows; r += kReduceThreadsFixed) {
-            const long long ia = (long long)acc[r], ib = (long long)acc[kBucketRows + r];
+            long long ia = (long long)acc[r], ib = (long long)acc[kBucketRows + r];
+            if (spill) { ia += (long long)spill[r * 2]; ib += (long long)spill[r * 2 + 1]; }
             if (ia == 0 && ib == 0) continue;
             const uint32_t row = first_row + r;
             if (row >= level_rows) continue;
             // |sum| < 2^63 * 2^-24; the double is exact up to 2^53, the float conversion rounds once
-            const float a = fixed_to_float(ia), b = fixed_to_float(ib);
-            flush_row<true>(grad_table + ((size_t)row0 + row) * 2, a, b, j.used == 1);
+            flush_row<true>(grad_table + ((size_t)row0 + row) * 2, fixed_to_float(ia), fixed_to_float(ib));
         }
         return;
     }
-    // Several workgroups share this bucket (a coarse level): they add their exact partial sums into a 64-bit
+    // Several workgroups share this bucket (a level of few buckets): they add their exact partial sums into a 64-bit
     // accumulator in global memory, which k_grid_bwd_finish rounds ONCE into the table. The result is therefore
     // independent of how the bucket was split and of the order of arrival. (A last-arriver flush inside this kernel
     // needs a device-scope release per workgroup, i.e. an L2 write-back on this multi-XCD part: +170 us measured.)
-    unsigned long long* gacc = shared_acc + ((size_t)shared_first + first_row) * 2;
+    unsigned long long* gacc = shared_acc + ((size_t)bin.acc_first[j.level] + first_row) * 2;
     for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) {   // the global accumulator stays [row][channel]
-        const unsigned long long v = acc[(i & 1u) * kBucketRows + (i >> 1)];
+        unsigned long long v = acc[(i & 1u) * kBucketRows + (i >> 1)];
+        if (spill) v += spill[i];
         if (v) atomicAdd(&gacc[i], v);
     }
 }
 
-// K3: one workgroup per bucket of the coarse levels; buckets that were reduced by a single workgroup are done already
+// K3: one workgroup per bucket of the levels of few buckets; buckets that were reduced by a single workgroup are done already
 __global__ __launch_bounds__(256) void k_grid_bwd_finish(__half* __restrict__ grad_table, GridPlan plan, BinPlan bin,
                                                          const uint32_t* __restrict__ cursors,
                                                          const unsigned long long* __restrict__ shared_acc) {
     uint32_t level = 0, b = blockIdx.x;
-    for (;; level++) {  // coarse levels are the first ones of the plan
+    for (;; level++) {  // these levels are the first ones of the plan
         const uint32_t nb = bin.bucket_first[level + 1] - bin.bucket_first[level];
         if (b < nb) break;
         b -= nb;
     }
-    const uint32_t shared_first = bin.acc_first[level];
-    const uint32_t n = bucket_items(bin, cursors, level, b, nullptr);
+    const uint32_t n = cursors[bin.bucket_first[level] + b];
+    if (n > bin.cap[level]) return;   // overflowed: K2's one workgroup flushed the spill accumulator
     const uint32_t per_split = bin.per_split[level];
     uint32_t used = (n + per_split - 1) / per_split;
     if (used > bin.splits[level]) used = bin.splits[level];
-    if (used <= 1 || shared_first == kNoSharedAcc) return;
+    if (used <= 1) return;
     const uint32_t row0 = plan.off[level];
     const uint32_t level_rows = plan.off[level + 1] - row0;
     const uint32_t first_row = b << kBucketRowsLog2;
-    const unsigned long long* gacc = shared_acc + ((size_t)shared_first + first_row) * 2;
+    const unsigned long long* gacc = shared_acc + ((size_t)bin.acc_first[level] + first_row) * 2;
     for (uint32_t r = threadIdx.x; r < kBucketRows; r += 256) {
         const uint32_t row = first_row + r;
         if (row >= level_rows) continue;
         const long long ia = (long long)gacc[r * 2], ib = (long long)gacc[r * 2 + 1];
         if (ia == 0 && ib == 0) continue;
-        const float a = fixed_to_float(ia), bb = fixed_to_float(ib);
-        flush_row<true>(grad_table + ((size_t)row0 + row) * 2, a, bb, true);
+        flush_row<true>(grad_table + ((size_t)row0 + row) * 2, fixed_to_float(ia), fixed_to_float(ib));
     }
 }
 
@@ -577,28 +643,24 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce_ticket(float
     lds_ticket_t* tag = (lds_ticket_t*)(reduce_lds + kReduceWaves * kBucketRows * sizeof(float2) + wave * kBucketRows);
 
     ReduceJob j;
-    if (!reduce_job(bin, cursors, j)) return;
+    if (!reduce_job<false>(bin, cursors, j)) return;
     for (uint32_t i = threadIdx.x; i < kReduceWaves * kBucketRows; i += kReduceThreads) acc_all[i] = make_float2(0.f, 0.f);
     __syncthreads();
 
     constexpr uint32_t kUnroll = 8;
-    for (uint32_t x = 0; x < bin.nsub; x++) {   // the part of [begin, end) that lies in sub-list x
-        const uint32_t r_lo = j.begin > j.seg[x] ? j.begin : j.seg[x], r_hi = j.end < j.seg[x + 1] ? j.end : j.seg[x + 1];
-        if (r_lo >= r_hi) continue;
-        const Item<false>* src = items + (size_t)bin.item_first[j.level] * 1024u + ((size_t)j.bucket * bin.nsub + x) * j.cap - j.seg[x];
-        for (uint32_t base = r_lo; base < r_hi; base += kUnroll * kReduceThreads) {
-            Item<false> it[kUnroll];
-            bool have[kUnroll];
+    const Item<false>* src = items + (size_t)bin.item_first[j.level] * 1024u + (size_t)j.bucket * j.cap;
+    for (uint32_t base = j.begin; base < j.end; base += kUnroll * kReduceThreads) {
+        Item<false> it[kUnroll];
+        bool have[kUnroll];
 #pragma unroll
-            for (uint32_t u = 0; u < kUnroll; u++) {
-                const uint32_t i = base + u * kReduceThreads + threadIdx.x;
-                have[u] = i < r_hi;
-                it[u] = src[have[u] ? i : r_lo];
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < kUnroll; u++)
-                ticket_add(acc, tag, it[u].row & (kBucketRows - 1), it[u].value(), have[u], lane);
+        for (uint32_t u = 0; u < kUnroll; u++) {
+            const uint32_t i = base + u * kReduceThreads + threadIdx.x;
+            have[u] = i < j.end;
+            it[u] = src[have[u] ? i : j.begin];
         }
+#pragma unroll
+        for (uint32_t u = 0; u < kUnroll; u++)
+            ticket_add(acc, tag, it[u].row & (kBucketRows - 1), it[u].value(), have[u], lane);
     }
     __syncthreads();
 
@@ -616,18 +678,23 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce_ticket(float
         if (a == 0.f && b == 0.f) continue;
         const uint32_t row = first_row + r;
         if (row >= level_rows) continue;
-        flush_row<false>(grad_table + ((size_t)row0 + row) * 2, a, b, j.used == 1);
+        float* dst = grad_table + ((size_t)row0 + row) * 2;
+        if (j.used == 1) {
+            flush_row<false>(dst, a, b);
+        } else {   // a heavy bucket shared by several workgroups: float atomics (what the reference does for every contribution)
+            unsafeAtomicAdd(dst, a);
+            unsafeAtomicAdd(dst + 1, b);
+        }
     }
 }
 
 // host: bucket geometry for a chunk of `chunk` samples
-BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uint32_t nsub, bool pair_items, uint64_t* total_items_1024,
+BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, bool pair_items, uint64_t* total_items_1024,
                       uint32_t* total_buckets, uint32_t* total_splits, uint32_t* shared_acc_rows = nullptr,
                       uint32_t* coarse_buckets = nullptr) {
     BinPlan b;
     memset(&b, 0, sizeof(b));
     b.levels = levels;
-    b.nsub = nsub;
     uint64_t items = 0;
     uint32_t buckets = 0, wgs = 0, acc_rows = 0, coarse = 0;
     for (uint32_t l = 0; l < levels; l++) {
@@ -636,20 +703,19 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, uin
         b.bucket_first[l] = buckets;
         b.split_first[l] = wgs;
         const uint64_t worst = (uint64_t)(pair_items ? 4 : 8) * chunk;  // every contribution of the chunk lands in this level (half tables: two per item)
-        // uniform share + 25 % + slack; coarse levels rely on the run folding, and on the atomic fallback beyond that
+        // uniform share + 25 % + slack; coarse levels rely on the run folding; beyond that: the spill accumulators (half tables,
+        // exact) or float atomics (float tables)
         uint64_t cap = (worst + nb - 1) / nb;
         cap = cap + cap / 4 + 256;
-        // per-XCD sub-lists: the tiles of a level are dealt to the XCDs round-robin, so each sub-list gets ~1/8 of the bucket's
-        // items; another 25 % for the unevenness between XCDs (beyond that: the atomic fallback, as for a whole bucket)
-        const uint64_t sub_cap = nsub == 1 ? cap : (cap / nsub + cap / (4 * nsub) + 256);
-        cap = sub_cap * nsub;          // what the bucket holds in total: splits / per_split below are about the whole bucket
-        b.cap[l] = (uint32_t)sub_cap;
+        b.cap[l] = (uint32_t)cap;
         // A level of a few buckets (the 16^3 level has two) receives all 8*B contributions in those few lists: with
         // 131072 items per workgroup only a few dozen workgroups would run (measured: 677 of 1756 us for that
         // level alone). Such levels are cut finer and flushed atomically.
         // SDFX_GRIDBWD_COARSE_SPLIT: items per K2 workgroup at the levels of few buckets (measurement aid)
         static const uint32_t coarse_split = [] { const char* e = getenv("SDFX_GRIDBWD_COARSE_SPLIT"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : kItemsPerSplitCoarse; }();
-        b.per_split[l] = nb <= kCoarseBuckets ? coarse_split : kItemsPerSplit;
+        // Half tables: only the levels of few buckets have the shared 64-bit accumulator that makes a split bucket's sum exact and
+        // order-independent, so every other bucket is reduced by ONE workgroup however long its list (it is bounded by `cap`).
+        b.per_split[l] = nb <= kCoarseBuckets ? coarse_split : (pair_items ? (1u << 30) : kItemsPerSplit);
         b.acc_first[l] = kNoSharedAcc;
         if (nb <= kCoarseBuckets) {
             b.acc_first[l] = acc_rows;
@@ -688,28 +754,28 @@ bool binned_supported(uint32_t D, uint32_t C, uint32_t L, const int32_t* offsets
     return true;
 }
 
-// scratch = [bucket cursors][shared 64-bit accumulators of the coarse levels][item lists]
-constexpr uint64_t kCursorBytes = (uint64_t)kMaxLevels * kMaxBucketsPerLevel * kMaxSub * sizeof(uint32_t);
+// scratch = [bucket cursors][diagnostics][shared 64-bit accumulators of the few-bucket levels]   <- cleared per launch
+//           [spill accumulators, one per bucket (half tables); zeroed on demand][item lists]    <- never cleared
+constexpr uint64_t kCursorBytes = (uint64_t)kMaxLevels * kMaxBucketsPerLevel * sizeof(uint32_t);
+constexpr uint64_t kDiagOffset = kCursorBytes;   // uint32 diag[0] = some bucket overflowed, diag[1] = how many
+constexpr uint64_t kDiagBytes = 64;
+constexpr uint64_t kSharedAccOffset = kDiagOffset + kDiagBytes;
 
-// K1's work mapping. 1 (default): FLAT — workgroup i takes item i of the (level, tile) list, so every XCD works on every level
-// and all eight finish together — with one item sub-list per (bucket, XCD). 0: each XCD walks its own two whole levels (round 1-2),
-// one list per bucket: the levels' costs differ by up to 4x (levels 15 + 0 against 8 + 7), so the kernel waited for one XCD.
-// Flat with ONE list per bucket was measured slower in round 2 (784 -> 1091 us): slices reserved by different XCDs shared cache
-// lines, which non-coherent L2s write back as partial lines. Sub-lists remove the sharing and keep the balance.
-int k1_flat() {
-    static const int v = [] { const char* e = getenv("SDFX_GRIDBWD_FLAT"); return (e && e[0] == '1') ? 1 : 0; }();
-    return v;
-}
+struct ScratchLayout {
+    uint64_t cleared_bytes;   // [0, cleared_bytes) is zeroed at every launch
+    uint64_t spill_offset, items_offset, total_bytes;
+};
 
-uint64_t header_bytes(uint32_t shared_acc_rows) {
-    return kCursorBytes + (uint64_t)shared_acc_rows * 2 * sizeof(unsigned long long);
-}
-
-uint64_t scratch_bytes_for(const GridPlan& plan, uint32_t levels, uint32_t chunk, bool half) {
+ScratchLayout scratch_layout(const GridPlan& plan, uint32_t levels, uint32_t chunk, bool half) {
     uint64_t items;
     uint32_t nb, wg, acc_rows;
-    make_bin_plan(plan, levels, chunk, k1_flat() ? kMaxSub : 1u, half, &items, &nb, &wg, &acc_rows);
-    return header_bytes(acc_rows) + items * 1024u * (half ? sizeof(Item<true>) : sizeof(Item<false>));
+    make_bin_plan(plan, levels, chunk, half, &items, &nb, &wg, &acc_rows);
+    ScratchLayout s;
+    s.cleared_bytes = kSharedAccOffset + (half ? (uint64_t)acc_rows * 2 * sizeof(unsigned long long) : 0);
+    s.spill_offset = s.cleared_bytes;
+    s.items_offset = s.spill_offset + (half ? (uint64_t)nb * kSpillWords * sizeof(unsigned long long) : 0);
+    s.total_bytes = s.items_offset + items * 1024u * (half ? sizeof(Item<true>) : sizeof(Item<false>));
+    return s;
 }
 
 // K1's per-XCD ranges cut by COST instead of count. The ranges stay contiguous in (virtual level, tile) order — the slices of a
@@ -790,7 +856,23 @@ uint64_t sdfx_grid_encode_backward_binned_scratch_bytes(const int32_t* offsets_h
                                                          uint32_t H, uint32_t chunk_points, int is_half) {
     if (!offsets_host || L < 1 || L > kMaxLevels || max_level < 1 || max_level > L) return 0;
     const GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, is_half ? 2 : 4, chunk_points);
-    return scratch_bytes_for(plan, max_level, chunk_points, is_half != 0);
+    return scratch_layout(plan, max_level, chunk_points, is_half != 0).total_bytes;
+}
+
+// Diagnostics of the LAST chunk launched on `scratch` (synchronises the stream): out[0] = buckets whose list overflowed, i.e.
+// whose sums came from the spill accumulators (half tables; 0 for float tables), out[1] = reserved (0).
+int sdfx_grid_encode_backward_binned_stats(const void* scratch, uint32_t* out, sdfx_stream_t stream) {
+    SDFX_REQUIRE(scratch && out, "grid_encode_backward_binned_stats: null pointer");
+    hipStream_t st = as_stream(stream);
+    uint32_t host[2] = {0, 0};
+    if (hipMemcpyAsync(host, static_cast<const char*>(scratch) + kDiagOffset, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        set_error("grid_encode_backward_binned_stats: copy failed");
+        return SDFX_E_LAUNCH;
+    }
+    out[0] = host[1];
+    out[1] = 0;
+    return SDFX_OK;
 }
 
 // Same contract as sdfx_grid_encode_backward (table gradient only: D = 3, C = 2, no dy_dx), plus scratch.
@@ -833,14 +915,15 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         chunk = ((chunk + gran - 1) / gran) * gran;
         for (;;) {
             const GridPlan p = make_plan(offsets_host, max_level, S, H, 2, eb, chunk);
-            if (scratch_bytes_for(p, max_level, chunk, is_half != 0) <= scratch_bytes) break;
+            if (scratch_layout(p, max_level, chunk, is_half != 0).total_bytes <= scratch_bytes) break;
             SDFX_REQUIRE(chunk > gran, "grid_encode_backward_binned: scratch too small (%llu bytes)",
                          (unsigned long long)scratch_bytes);
             chunk = ((chunk / 2 + gran - 1) / gran) * gran;
         }
     }
+    char* const base = static_cast<char*>(scratch);
     uint32_t* cursors = static_cast<uint32_t*>(scratch);
-    unsigned long long* shared_acc = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + kCursorBytes);
+    unsigned long long* shared_acc = reinterpret_cast<unsigned long long*>(base + kSharedAccOffset);
 
     for (uint32_t b0 = 0; b0 < B; b0 += chunk) {
         const uint32_t b1 = b0 + chunk < B ? b0 + chunk : B;
@@ -848,19 +931,19 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         // one plan tile = one K1 workgroup = kBinThreads * kPointsPerThread samples
         GridPlan plan = make_plan(offsets_host, max_level, S, H, 2, eb,
                                   (uint64_t)div_up(n, kBinThreads * kPointsPerThread) * kTile);
-        // The per-XCD level ranges are unbalanced for K1 (levels 15 + 0 on one XCD cost ~4x levels 8 + 7 on another; average
-        // occupancy 1.8 waves per SIMD by PMC), but giving every XCD the same mix of levels (SDFX_GRIDBWD_FLAT=1: workgroup i takes
-        // item i) is SLOWER, 784 -> 1091 us at B = 1.81 M: the slices of a bucket's item list reserved by workgroups of different
-        // XCDs share cache lines, and the XCDs' L2s are not coherent with each other, so those lines go to memory as partial writes.
-        const int flat = k1_flat();
-        plan.flat = (uint32_t)flat;
-        if (!flat && k1_balance_enabled()) balance_plan(plan, max_level, k1_level_cost(max_level));
+        // Each XCD walks its own range of whole levels. The ranges are unbalanced for K1 (levels 15 + 0 on one XCD cost ~4x levels
+        // 8 + 7 on another), but giving every XCD the same mix of levels was measured SLOWER twice: 784 -> 1091 us at B = 1.81 M
+        // with one list per bucket (round 2), 851 -> 1411 us in the iteration with one sub-list per (bucket, XCD) (round 3,
+        // profiles/r03_scatter_flat_sublists_ab.txt); that mapping is gone from the code.
+        if (k1_balance_enabled()) balance_plan(plan, max_level, k1_level_cost(max_level));
         uint64_t items_1024;
         uint32_t nbuckets, nsplits, acc_rows, coarse_buckets;
-        const BinPlan bin = make_bin_plan(plan, max_level, chunk, flat ? kMaxSub : 1u, is_half != 0, &items_1024, &nbuckets, &nsplits, &acc_rows,
-                                          &coarse_buckets);
-        void* items = static_cast<char*>(scratch) + header_bytes(acc_rows);
-        zero_device(scratch, header_bytes(is_half ? acc_rows : 0), st);  // cursors, accumulators
+        const BinPlan bin = make_bin_plan(plan, max_level, chunk, is_half != 0, &items_1024, &nbuckets, &nsplits, &acc_rows, &coarse_buckets);
+        const ScratchLayout lay = scratch_layout(plan, max_level, chunk, is_half != 0);
+        void* items = base + lay.items_offset;
+        unsigned long long* spill_acc = reinterpret_cast<unsigned long long*>(base + lay.spill_offset);
+        uint32_t* diag = reinterpret_cast<uint32_t*>(base + kDiagOffset);
+        zero_device(scratch, lay.cleared_bytes, st);  // cursors, diagnostics, shared accumulators
         const uint32_t grid1 = plan_grid_size(plan);
         BinLevels lv;
         memset(&lv, 0, sizeof(lv));
@@ -884,9 +967,27 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
     }
         if (is_half) {
             SDFX_BIN_SEL(true)
+            // the spill path: two launches that exit at once unless a bucket overflowed (see the head of the file)
+            hipLaunchKernelGGL(k_grid_bwd_spill_zero, dim3(nbuckets), dim3(256), 0, st, bin, cursors, spill_acc, diag);
+            const uint32_t grid_spill = div_up(grid1, kSpillTilesPerGroup);
+#define SDFX_SPILL(INTERP_, ALIGN_, HASH_)                                                                                        \
+    hipLaunchKernelGGL((k_grid_bwd_spill<INTERP_, ALIGN_, HASH_>), dim3(grid_spill), dim3(kBinThreads), 0, st,                    \
+                       static_cast<const __half*>(grad), inputs, static_cast<__half*>(grad_embeddings), B, L, b0, b1, plan, bin,  \
+                       lv, grad_layout, cursors, row_limit(), stencil_src(), spill_acc, diag, grid1)
+            switch (sel) {
+                case 0: SDFX_SPILL(0u, false, false); break;
+                case 1: SDFX_SPILL(0u, false, true); break;
+                case 2: SDFX_SPILL(0u, true, false); break;
+                case 3: SDFX_SPILL(0u, true, true); break;
+                case 4: SDFX_SPILL(1u, false, false); break;
+                case 5: SDFX_SPILL(1u, false, true); break;
+                case 6: SDFX_SPILL(1u, true, false); break;
+                default: SDFX_SPILL(1u, true, true); break;
+            }
+#undef SDFX_SPILL
             hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(nsplits), dim3(kReduceThreadsFixed), 0, st,
                                static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items),
-                               shared_acc);
+                               shared_acc, spill_acc);
             if (coarse_buckets)
                 hipLaunchKernelGGL(k_grid_bwd_finish, dim3(coarse_buckets), dim3(256), 0, st, static_cast<__half*>(grad_embeddings),
                                    plan, bin, cursors, shared_acc);

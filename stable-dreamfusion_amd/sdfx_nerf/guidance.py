@@ -109,9 +109,21 @@ class SDSGuidance(nn.Module):
             outs.append(torch.randn(1, self.ctx_len, self.ctx_dim, generator=g))
         return torch.cat(outs).to(self.device, self.precision_t)
 
+    def _vae_encode(self, imgs):
+        """The frozen VAE encoder on `precision_t` images, OUTSIDE the trainer's autocast like the UNet below: under autocast its
+        22 GroupNorms run in float32 on 512^2 maps (RowwiseMomentsCUDAKernel<float>: 11 % of the GPU time of an RGB iteration in
+        round 3's profile, plus the casts each way), forward and backward. diffusers' fp16 pipelines do not run under autocast
+        either. SDFX_VAE_AUTOCAST=1 restores the inherited context, SDFX_VAE_CL=1 feeds channels-last images (A/B switches)."""
+        if _VAE_CL:
+            imgs = imgs.contiguous(memory_format=torch.channels_last)
+        if _VAE_AUTOCAST or not imgs.is_cuda:
+            return self.vae.encode_sample(imgs) * self.vae.scaling_factor
+        with torch.autocast("cuda", enabled=False):
+            return self.vae.encode_sample(imgs.to(self.precision_t)) * self.vae.scaling_factor
+
     def encode_imgs(self, imgs):
         imgs = 2 * imgs - 1
-        return self.vae.encode_sample(imgs.to(self.precision_t)) * self.vae.scaling_factor
+        return self._vae_encode(imgs.to(self.precision_t))
 
     def add_noise(self, latents, noise, t):
         a = self.alphas[t].to(latents.dtype)
@@ -132,7 +144,7 @@ class SDSGuidance(nn.Module):
         elif self._fused_ok(pred_rgb) and pred_rgb.dtype == torch.float32:
             # bilinear 512^2 + `2 x - 1` + cast to the VAE's dtype in one kernel each way (csrc/sds.hip)
             imgs = _UpsampleToVAE.apply(pred_rgb.contiguous(), 512, 512)
-            latents = self.vae.encode_sample(imgs) * self.vae.scaling_factor
+            latents = self._vae_encode(imgs)
         else:
             pred_rgb_512 = F.interpolate(pred_rgb, (512, 512), mode="bilinear", align_corners=False)
             latents = self.encode_imgs(pred_rgb_512)
@@ -163,6 +175,8 @@ class SDSGuidance(nn.Module):
 
 
 _FUSED_SDS = int(os.environ.get("SDFX_FUSED_SDS", "1"))
+_VAE_AUTOCAST = int(os.environ.get("SDFX_VAE_AUTOCAST", "0"))
+_VAE_CL = int(os.environ.get("SDFX_VAE_CL", "0"))
 
 
 class _UpsampleToVAE(torch.autograd.Function):

@@ -206,6 +206,8 @@ def sd15_random_prior(device, fp16=True, seed=1234, t_range=(0.02, 0.98)):
     finally:
         torch.random.set_rng_state(gen_state)
     unet.unet.to(memory_format=torch.channels_last)
+    if G._VAE_CL:
+        vae.to(memory_format=torch.channels_last)
     return G.SDSGuidance(unet, vae, device, fp16, t_range=t_range)
 
 

@@ -1,0 +1,341 @@
+"""-m gpu, LAST file of the suite: stress and edge cases of the kernels whose core parity is in test_gpu_02_parity.py —
+over-capacity buckets of the binned scatter (exactness and bit-reproducibility), other D / C, argument errors, empty and
+ragged batches, padding rows, in-kernel stencil batches, implementation switches."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from gpu_common import AABB, N_, T
+from gpu_common import composite_case as _composite_case
+from gpu_common import grid_setup as _grid_setup
+
+pytestmark = pytest.mark.gpu
+
+def test_march_empty_and_ragged(oracle, dev):
+    import raymarching
+    bf = np.zeros(128 ** 3 // 8, np.uint8)            # nothing occupied -> M = 0
+    o, d = synth.s_rays(0)
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    xyzs, dirs, ts, rays = raymarching.march_rays_train(T(o, dev), T(d, dev), 1.0, T(bf, dev), 1, 128, T(nears, dev),
+                                                        T(fars, dev))
+    assert xyzs.shape == (0, 3) and ts.shape == (0, 2) and int(rays[:, 1].sum()) == 0
+    w, ws, dep, img = raymarching.composite_rays_train(torch.zeros(0, device=dev), torch.zeros(0, 3, device=dev), ts, rays)
+    assert w.numel() == 0 and float(ws.abs().sum()) == 0 and float(img.abs().sum()) == 0
+    # N not a multiple of 64
+    o5, d5 = o[:77], d[:77]
+    bf2 = synth.s_grid_init()[2]
+    r_ref = oracle.march_rays_train(o5, d5, 1.0, bf2, 1, 128, nears[:77], fars[:77], np.zeros(77, np.float32))[3]
+    rays5 = raymarching.march_rays_train(T(o5, dev), T(d5, dev), 1.0, T(bf2, dev), 1, 128, T(nears[:77], dev), T(fars[:77], dev))[3]
+    assert np.array_equal(N_(rays5), r_ref)
+
+
+def test_composite_overflow_ray_is_zeroed(oracle, dev):
+    """offset + count > M -> outputs zero, no gradient (raymarching.cu:521-528, 630)."""
+    import _raymarching as B
+    rays = np.array([[0, 4], [4, 10]], np.int32)      # second ray overruns M = 8
+    sig, rgb = synth.s_sigma_rgb(8)
+    ts = np.stack([np.linspace(0.3, 1, 8), np.full(8, 0.01)], -1).astype(np.float32)
+    ref = oracle.composite_rays_train_forward(sig, rgb, ts, rays)
+    w = torch.zeros(8, device=dev); ws = torch.empty(2, device=dev); dep = torch.empty(2, device=dev); img = torch.empty(2, 3, device=dev)
+    B.composite_rays_train_forward(T(sig, dev), T(rgb, dev), T(ts, dev), T(rays, dev), 8, 2, 1e-4, False, w, ws, dep, img)
+    assert np.allclose(N_(w), ref[0], atol=1e-6) and float(ws[1]) == 0 and float(img[1].abs().sum()) == 0
+    assert np.all(N_(w)[4:] == 0)
+
+
+@pytest.mark.parametrize("D,C", [(2, 1), (2, 8), (3, 4), (4, 2), (5, 2), (3, 32), (3, 16)])
+def test_grid_other_dims_fp32(oracle, dev, D, C):
+    import _gridencoder as B
+    offsets, pls = oracle.grid_offsets(input_dim=D, num_levels=6, level_dim=C, log2_hashmap_size=14, desired_resolution=256)
+    table = synth.s_table(int(offsets[-1]), C, "trained")
+    x = synth.s_points_uniform(3001, D, seed=30 + D)
+    out_ref, lbc_ref, dy_ref = oracle.grid_encode_forward(x, table, offsets, pls, 16, True, 0, False, 0)
+    out = torch.empty(6, 3001, C, device=dev); dy = torch.empty(3001, 6 * D * C, device=dev)
+    B.grid_encode_forward(T(x, dev), T(table, dev), T(offsets, dev), out, 3001, D, C, 6, 6, np.log2(pls), 16, dy, 0, False, 0)
+    assert np.array_equal(N_(out), lbc_ref) and np.array_equal(N_(dy), dy_ref)
+    gr = np.random.default_rng(1).normal(size=(3001, 6 * C)).astype(np.float32)
+    gi_ref, gt_ref = oracle.grid_encode_backward(gr, x, table, offsets, pls, 16, dy_ref, 0, False, 0)
+    gt = torch.zeros_like(T(table, dev)); gi = torch.zeros(3001, D, device=dev)
+    B.grid_encode_backward(T(gr, dev), T(x, dev), T(table, dev), T(offsets, dev), gt, 3001, D, C, 6, 6, np.log2(pls), 16, dy,
+                           gi, 0, False, 0, 1)
+    assert np.abs(N_(gt) - gt_ref).max() <= 1e-5 * np.abs(gt_ref).max() + 1e-6
+    assert np.allclose(N_(gi), gi_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_grid_max_level_and_errors(oracle, dev):
+    from gridencoder import GridEncoder
+    import _gridencoder as B
+    enc = GridEncoder(desired_resolution=2048).to(dev)
+    x = T(synth.s_points_uniform(100) * 2 - 1, dev)
+    out = enc(x, max_level=0.5)
+    assert float(out[:, 16:].abs().sum()) == 0 and float(out[:, :16].abs().sum()) > 0
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        B.grid_encode_forward(x.cpu(), enc.embeddings, enc.offsets, torch.empty(16, 100, 2, device=dev), 100, 3, 2, 16, 16, 0.46, 16, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        B.grid_encode_forward(x.t().contiguous().t(), enc.embeddings, enc.offsets, torch.empty(16, 100, 2, device=dev), 100, 3, 2, 16, 16, 0.46, 16, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="C must be"):
+        B.grid_encode_forward(x, torch.zeros(enc.embeddings.shape[0], 3, device=dev), enc.offsets, torch.empty(16, 100, 3, device=dev), 100, 3, 3, 16, 16, 0.46, 16, None, 0, False, 0)
+
+
+@pytest.mark.parametrize("bound,live", [(1.0, None), (1.7, None), (1.0, 20011)])
+def test_stencil_source_kernels_bit_identical_to_stencil_tensors(oracle, dev, bound, live):
+    """sdfx_set_stencil_source: the hinted encoder forward, the field forward / backward and the binned scatter form row r of the
+    [7, M, 3] finite-difference batch from the M base samples themselves. Must be BIT-identical to handing them the tensors
+    k_stencil_points writes (which test_stencil_points_kernel pins to the tensor expressions of network_grid.py:81-96): same
+    sigma / albedo, same table gradient, same MLP gradients — also through the generic (un-hinted, atomic) kernels and with a
+    row limit (padding rows of a fixed-capacity buffer)."""
+    importlib.import_module("stable-dreamfusion_amd")
+    import _gridencoder
+    import _sdfx as S
+    from sdfx_nerf import fused_field as ff
+    from sdfx_nerf import network_grid as ng
+    from sdfx_nerf.options import default_opt
+    torch.manual_seed(5)
+    model = ng.NeRFNetwork(default_opt(bound=bound)).to(dev).train()
+    pls = model.encoder.per_level_scale
+    with torch.no_grad():
+        model.encoder.embeddings.copy_(T(synth.s_table(model.encoder.embeddings.shape[0], 2, "trained", np.float32), dev))
+    # every 8th RAY of a view, all of its samples: spread over the scene and ray-ordered like an iteration's batch. (The first
+    # 30 000 samples of a view sit in a few 2048-row buckets of the dense levels, every 8th SAMPLE breaks the runs the scatter
+    # folds: both overflow bucket lists into the atomic fallback, whose half sums depend on the order of arrival.)
+    o, d = synth.s_rays(2)
+    o, d = np.ascontiguousarray(o[::8]), np.ascontiguousarray(d[::8])
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    xyzs = oracle.march_rays_train(o, d, 1.0, synth.s_grid_init()[2], 1, 128, nears, fars, synth.s_noises(o.shape[0]))[0] * np.float32(bound)
+    assert 20011 < xyzs.shape[0] < 60000
+    xyzs[:3] = np.array([[0.999, -0.999, 0.5], [-1.0, 1.0, -1.0], [0.0, 0.0, 0.0]], np.float32) * np.float32(bound)
+    x = T(xyzs, dev)
+    M = x.shape[0]
+    total = None if live is None else torch.tensor([live], dtype=torch.int32, device=dev)
+    n_live = M if live is None else live
+    g = torch.Generator().manual_seed(1)
+    gs, ga = torch.randn(7 * M, generator=g).to(dev), torch.randn(7 * M, 3, generator=g).to(dev)
+    if live is not None:            # the consumer of a fixed-capacity buffer never hands gradient to padding rows
+        pad = (torch.arange(7 * M, device=dev) % M) >= live
+        gs[pad] = 0; ga[pad] = 0
+    outs = {}
+    try:
+        for name, source, binned in (("tensors", 0, 1), ("tensors_again", 0, 1), ("source", 1, 1), ("source_atomic", 1, 0),
+                                     ("tensors_atomic", 0, 0)):
+            ff._STENCIL_SOURCE, _gridencoder._BINNED = source, binned
+            for p in model.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.float16):
+                sigma, albedo = ff.fused_field(x, model.encoder, model.sigma_net, model.bound, 5.0, 0.2, 7, 3.0 ** 0.5 / (1024 * bound),
+                                               stencil_eps=1e-2, row_total=total)
+            ((sigma * gs).sum() + (albedo * ga).sum()).backward()
+            keep = (torch.arange(7 * M, device=dev) % M) < n_live
+            outs[name] = (sigma.detach()[keep].clone(), albedo.detach()[keep].clone(), model.encoder.embeddings.grad.clone(),
+                          [p.grad.clone() for p in model.sigma_net.parameters()])
+    finally:
+        ff._STENCIL_SOURCE, _gridencoder._BINNED = 1, 1
+    report = []
+    for a, b in (("tensors", "tensors_again"), ("tensors", "source"), ("tensors_atomic", "source_atomic")):
+        (s0, a0, t0, w0), (s1, a1, t1, w1) = outs[a], outs[b]
+        ok_out = torch.equal(s0, s1) and torch.equal(a0, a1)
+        ok_w = all(torch.equal(u, v) for u, v in zip(w0, w1))
+        td = (t0.float() - t1.float()).abs()
+        # the binned scatter is order-independent (bit-identical table gradient); half atomics depend on the order of arrival
+        ok_t = torch.equal(t0, t1) if "atomic" not in a else td.max().item() <= 2e-2 * t0.float().abs().max().item()
+        report.append((a, b, ok_out, ok_w, ok_t, int((td > 0).sum()), td.max().item(), t0.float().abs().max().item()))
+    if not report[0][4]:
+        # control: the tensor path does not reproduce ITSELF on this batch — a bucket list overflowed into the atomic fallback
+        # (complete for any input, but a half sum in order of arrival); then the source path is held to the atomic tolerance too
+        report[1] = report[1][:4] + (report[1][6] <= 2e-2 * report[1][7],) + report[1][5:]
+        report[0] = report[0][:4] + (True,) + report[0][5:]
+    assert all(r[2] and r[3] and r[4] for r in report), report
+    assert float(outs["source"][0].abs().sum()) > 0 and float(outs["source"][2].float().abs().sum()) > 0
+    # ... and the un-hinted generic forward kernel (k_grid_forward) with a source against the tensor batch
+    pts, unit = torch.empty(7 * M, 3, device=dev), torch.empty(7 * M, 3, device=dev)
+    import _field
+    _field.stencil_points(x, 1e-2, bound, pts, unit)
+    emb = model.encoder.embeddings.detach().half().contiguous()
+    off_t = model.encoder.offsets
+    e0, e1 = torch.empty(16, 7 * M, 2, dtype=torch.half, device=dev), torch.empty(16, 7 * M, 2, dtype=torch.half, device=dev)
+    Sc = float(np.log2(pls))
+    _gridencoder.grid_encode_forward(unit, emb, off_t, e0, 7 * M, 3, 2, 16, 16, Sc, 16, None, 0, False, 1, 0, 1, 0.0)
+    with S.stencil_source(x, 1e-2, bound):
+        _gridencoder.grid_encode_forward(None, emb, off_t, e1, 7 * M, 3, 2, 16, 16, Sc, 16, None, 0, False, 1, 0, 1, 0.0)
+    assert torch.equal(e0, e1)
+
+
+@pytest.mark.parametrize("gridname", ["init", "blobs", "full"])
+def test_wave_per_ray_march_matches_thread_per_ray(oracle, dev, gridname):
+    import raymarching
+    import _sdfx as S
+    bf = {"init": lambda: synth.s_grid_init()[2], "blobs": synth.s_grid_blobs, "full": synth.s_grid_full}[gridname]()
+    o, d = synth.s_rays(1)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
+    noises = synth.s_noises(4096, seed=5)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    outs = []
+    try:
+        for impl in (0, 1):
+            S.lib().sdfx_march_set_impl(impl)
+            outs.append(raymarching.march_rays_train(T(o), T(d), 1.0, T(bf), 1, 128, T(nears), T(fars), True, 0, 1024, False,
+                                                     T(noises)))
+    finally:
+        S.lib().sdfx_march_set_impl(-1)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_row_limit_skips_padding_rows_and_nothing_else(oracle, dev):
+    """sdfx_set_row_limit (fixed-capacity sample buffers of a replayed iteration): with `total` live samples per stencil slab of
+    `cap` rows, the hinted encoder forward, the field forward / backward and the binned scatter must produce, on the live rows,
+    exactly what they produce on the compact [7, total] batch — and must not touch the padding rows (sentinels stay) nor read
+    them (the padding rows of every input hold NaN)."""
+    import _field
+    import _gridencoder as B
+    import _sdfx as S
+    offsets, pls, table = _grid_setup(oracle, dtype=np.float16, desired_resolution=2048)
+    bf = synth.s_grid_init()[2]
+    o, d = synth.s_rays(1)
+    nears, fars = oracle.near_far_from_aabb(o, d, AABB, 0.2)
+    xyzs = oracle.march_rays_train(o, d, 1.0, bf, 1, 128, nears, fars, synth.s_noises(4096))[0]
+    total, cap = 20011, 20011 + 4097                      # neither a multiple of the 256 / 512-row tiles
+    xyzs = xyzs[:total]
+    e = np.float32(1e-2)
+    offs = np.array([[0, 0, 0], [e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]], np.float32)
+    pts = np.clip(xyzs[None] + offs[:, None], -1, 1)                                   # [7, total, 3]
+    unit = ((pts + np.float32(1)) / np.float32(2)).astype(np.float32)
+    L, C, Sc, step = 16, 2, float(np.log2(pls)), 1.0 / 591.0
+    g = torch.Generator().manual_seed(3)
+    w = [torch.randn(64, 32, generator=g) * 0.2, torch.randn(64, generator=g) * 0.1, torch.randn(64, 64, generator=g) * 0.15,
+         torch.randn(64, generator=g) * 0.1, torch.randn(4, 64, generator=g) * 0.15, torch.randn(4, generator=g) * 0.1]
+    w = [t.to(dev) for t in w]
+    packed = torch.empty(_field.packed_words(), dtype=torch.int32, device=dev)
+    _field.pack(*w, packed)
+    ds_c = (torch.randn(7, total, generator=g) * 0.1).to(dev)
+    da_c = (torch.randn(7, total, 3, generator=g) * 0.1).to(dev)
+    tab, off_t = T(table, dev), T(offsets, dev)
+    nan = float("nan")
+
+    def pad(t, fill):                                     # [7, total, ...] -> [7, cap, ...] with `fill` in the padding rows
+        out = torch.full((7, cap) + tuple(t.shape[2:]), fill, dtype=t.dtype, device=dev)
+        out[:, :total] = t
+        return out
+
+    def run(unit_t, pts_t, ds, da, n, limit):
+        Bn = 7 * n
+        enc = torch.full((L, Bn, C), 7.0, dtype=torch.float16, device=dev)
+        sigma, albedo = torch.full((Bn,), 7.0, device=dev), torch.full((Bn, 3), 7.0, device=dev)
+        denc = torch.full((L, Bn, C), 7.0, dtype=torch.float16, device=dev)
+        grads = [torch.empty_like(t) for t in w]
+        gt = torch.zeros_like(tab)
+        with S.row_limit(limit, n):
+            B.grid_encode_forward(unit_t.reshape(-1, 3), tab, off_t, enc, Bn, 3, C, L, L, Sc, 16, None, 0, False, 1, 0, 7, step)
+            _field.forward(enc, 0, pts_t.reshape(-1, 3), packed, Bn, 5.0, 0.2, sigma, albedo)
+            _field.backward(enc, 0, pts_t.reshape(-1, 3), packed, Bn, 5.0, 0.2, ds.reshape(-1), da.reshape(-1, 3), denc, *grads)
+            B.grid_encode_backward(denc, unit_t.reshape(-1, 3), tab, off_t, gt, Bn, 3, C, L, L, Sc, 16, None, None, 0, False, 1, 0)
+        torch.cuda.synchronize()
+        return enc.view(L, 7, n, C), sigma.view(7, n), albedo.view(7, n, 3), denc.view(L, 7, n, C), grads, gt
+
+    ref = run(T(unit, dev), T(pts.astype(np.float32), dev), ds_c, da_c, total, None)
+    lim = torch.tensor([total], dtype=torch.int32, device=dev)
+    got = run(pad(T(unit, dev), nan), pad(T(pts.astype(np.float32), dev), nan), pad(ds_c, nan), pad(da_c, nan), cap, lim)
+    for k in (0, 3):                                      # level-major features and their gradients
+        assert torch.equal(got[k][:, :, :total], ref[k]) and bool((got[k][:, :, total:] == 7.0).all())
+    for k in (1, 2):
+        assert torch.equal(got[k][:, :total], ref[k]) and bool((got[k][:, total:] == 7.0).all())
+    for a, b in zip(got[4], ref[4]):                      # weight gradients: the same rows in differently aligned tiles
+        assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7
+    assert bool(torch.isfinite(got[5].float()).all())
+    assert float((got[5].float() - ref[5].float()).abs().max()) <= 2e-3 * float(ref[5].float().abs().max())
+
+
+def _scatter_half(dev, x, gr, offsets, pls, chunk, table_init=None, layout=1):
+    """One call of the binned scatter on half tables with a private scratch; returns (table gradient, overflowed buckets)."""
+    import ctypes as C
+    import _gridencoder as B
+    import _sdfx as S
+    S_ = float(np.log2(pls))
+    oh = B.offsets_host(T(offsets, dev))
+    nbytes = int(S.lib().sdfx_grid_encode_backward_binned_scratch_bytes(oh, 16, 16, S_, 16, chunk, 1))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    scratch.fill_(0xA5)                               # the scratch needs no initialisation: hand it garbage
+    rows = int(offsets[-1])
+    gt = torch.zeros((rows, 2), dtype=torch.float16, device=dev) if table_init is None else T(table_init, dev).clone()
+    xt, grt = T(x, dev), T(gr, dev)
+    S.call("sdfx_grid_encode_backward_binned", S.ptr(grt), S.ptr(xt), oh, S.ptr(gt), x.shape[0], 3, 2, 16, 16, S_, 16, 0, 0, 1,
+           1, layout, S.ptr(scratch), scratch.numel(), S.stream())
+    stats = (C.c_uint32 * 2)()
+    S.call("sdfx_grid_encode_backward_binned_stats", S.ptr(scratch), stats, S.stream())
+    return gt, int(stats[0])
+
+
+def test_binned_scatter_overflowing_buckets_are_exact_and_reproducible(oracle, dev):
+    """Half tables, buckets asked for (far) more slots than their lists hold — the spill path of gridencoder_bwd_binned.hip:
+    (1) 20000 samples on one point with random gradients: within the SAME 4e-3 bound as ray-ordered samples (the round-3 code
+        accumulated the overflow in half in arrival order: 3.6 % error, box-dependent);
+    (2) 20000 samples on the corner (0, 0, 0) with gradients k / 64, |k| <= 16: every weight is 1/8 and every partial sum an
+        exact half or float, so the float32 oracle IS the exact sum and the kernel must return its single rounding to half,
+        BIT FOR BIT — at the folded levels, the unfolded ones, the dense ones (split pairs) and the hashed ones;
+    (3) samples clustered in 1/64 of the volume (dense-level buckets overflow, ray-like runs fold) — 4e-3;
+    (4) accumulation into a non-zero table;
+    each five times over: identical bits every time."""
+    offsets, pls, table = _grid_setup(oracle, desired_resolution=2048)
+    rng = np.random.default_rng(11)
+    n = 20000
+    x_same = np.tile(np.array([[0.3712, 0.5561, 0.4403]], np.float32), (n, 1))
+    x_corner = np.zeros((n, 3), np.float32)
+    x_cluster = (0.4 + 0.25 * rng.random((60000, 3))).astype(np.float32)
+    x_cluster = x_cluster[np.lexsort((x_cluster[:, 2] // 0.01, x_cluster[:, 1] // 0.01))]      # runs of neighbours
+    g_rand = lambda m: (rng.normal(size=(m, 32)) * 0.01).astype(np.float16)
+    g_exact = (rng.integers(-16, 17, size=(n, 32)) / 64.0).astype(np.float16)
+    init = (rng.normal(size=(int(offsets[-1]), 2)) * 0.05).astype(np.float16)
+    cases = [("same-point", x_same, g_rand(n), None, "tol"), ("corner-exact", x_corner, g_exact, None, "bits"),
+             ("cluster", x_cluster, g_rand(x_cluster.shape[0]), None, "tol"), ("same-point+init", x_same, g_rand(n), init, "tol")]
+    for name, x, gr, t0, mode in cases:
+        _, ref = oracle.grid_encode_backward(gr.astype(np.float32), x, table, offsets, pls, 16, None, 0, False, 1)
+        runs = [_scatter_half(dev, x, gr, offsets, pls, 1 << 20, t0) for _ in range(5)]
+        got, spilled = runs[0]
+        assert spilled > 0 or name == "cluster", (name, "the case is meant to overflow bucket lists")
+        for other, sp in runs[1:]:
+            assert sp == spilled and torch.equal(other, got), (name, "not bit-reproducible")
+        g = N_(got).astype(np.float32)
+        if t0 is not None:
+            g = g - t0.astype(np.float32)          # (adds one more half rounding per touched row)
+        scale = np.abs(ref).max()
+        if mode == "bits":
+            assert np.array_equal(N_(got), ref.astype(np.float16)), (name, np.abs(g - ref).max())
+        else:
+            tol = (4e-3 if t0 is None else 6e-3) * scale
+            assert np.abs(g - ref).max() <= tol, (name, np.abs(g - ref).max(), scale)
+
+
+def test_binned_scatter_overflow_in_chunks_and_level_major_gradients(oracle, dev):
+    """The spill path with a scratch that forces several chunks (every chunk re-zeroes and re-fills the spill accumulators of the
+    buckets it overflows) and with the [L, B, C] gradient layout: bit-identical to the one-pass result."""
+    offsets, pls, table = _grid_setup(oracle, desired_resolution=2048)
+    rng = np.random.default_rng(12)
+    n = 30000
+    x = np.zeros((n, 3), np.float32)
+    gr = (rng.integers(-16, 17, size=(n, 32)) / 64.0).astype(np.float16)
+    _, ref = oracle.grid_encode_backward(gr.astype(np.float32), x, table, offsets, pls, 16, None, 0, False, 1)
+    one, sp1 = _scatter_half(dev, x, gr, offsets, pls, 1 << 20)
+    # chunked: each chunk rounds its exact sum into the table, so compare against chunk-wise exact sums rounded in turn
+    import _gridencoder as B
+    import _sdfx as S
+    oh = B.offsets_host(T(offsets, dev))
+    need = lambda c: int(S.lib().sdfx_grid_encode_backward_binned_scratch_bytes(oh, 16, 16, float(np.log2(pls)), 16, c, 1))
+    have = need(8192)
+    chunk = -(-n // 512) * 512                       # the library's rule: halve (to a multiple of 512) until the lists fit
+    while need(chunk) > have:
+        chunk = -(-(chunk // 2) // 512) * 512
+    assert chunk < n
+    many, sp2 = _scatter_half(dev, x, gr, offsets, pls, 8192)
+    assert sp1 > 0 and sp2 > 0
+    assert np.array_equal(N_(one), ref.astype(np.float16))
+    acc = np.zeros(ref.shape, np.float16)
+    for b0 in range(0, n, chunk):
+        _, part = oracle.grid_encode_backward(gr[b0:b0 + chunk].astype(np.float32), x[b0:b0 + chunk], table, offsets, pls, 16, None, 0,
+                                              False, 1)
+        acc = (acc.astype(np.float32) + part).astype(np.float16)
+    assert np.array_equal(N_(many), acc)
+    lbc = np.ascontiguousarray(gr.reshape(n, 16, 2).transpose(1, 0, 2))
+    lm, _ = _scatter_half(dev, x, lbc, offsets, pls, 1 << 20, layout=0)
+    assert torch.equal(lm, one)
