@@ -496,7 +496,7 @@ int sdfx_grid_encode_forward_hint(const float* inputs, const void* embeddings, c
     a.inputs = inputs; a.table = embeddings; a.outputs = outputs; a.B = B; a.L = L;
     a.plan = make_plan(offsets_host, max_level, S, H, C, eb, B);
     a.plan.vec16 = (reinterpret_cast<uintptr_t>(embeddings) % 16) == 0 ? 1u : 0u;
-    if (getenv("SDFX_GRID_NOVEC16")) a.plan.vec16 = 0;  // debugging aid: force the one-gather-per-corner path
+    if (dev_switch("SDFX_GRID_NOVEC16", 0)) a.plan.vec16 = 0;  // debugging aid (devtools build): force the one-gather-per-corner path
     a.dy_dx = dy_dx; a.gridtype = gridtype; a.align_corners = align_corners; a.interp = interp;
     a.out_layout = out_layout; a.st = as_stream(stream); a.grid = plan_grid_size(a.plan);
     if (is_half) { SDFX_DISPATCH_DC(true, launch_forward, a) } else { SDFX_DISPATCH_DC(false, launch_forward, a) }

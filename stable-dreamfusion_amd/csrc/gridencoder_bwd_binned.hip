@@ -712,7 +712,7 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, boo
         // 131072 items per workgroup only a few dozen workgroups would run (measured: 677 of 1756 us for that
         // level alone). Such levels are cut finer and flushed atomically.
         // SDFX_GRIDBWD_COARSE_SPLIT: items per K2 workgroup at the levels of few buckets (measurement aid)
-        static const uint32_t coarse_split = [] { const char* e = getenv("SDFX_GRIDBWD_COARSE_SPLIT"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : kItemsPerSplitCoarse; }();
+        const uint32_t coarse_split = [] { const int v = dev_switch("SDFX_GRIDBWD_COARSE_SPLIT", 0); return v > 0 ? (uint32_t)v : kItemsPerSplitCoarse; }();
         // Half tables: only the levels of few buckets have the shared 64-bit accumulator that makes a split bucket's sum exact and
         // order-independent, so every other bucket is reduced by ONE workgroup however long its list (it is bounded by `cap`).
         b.per_split[l] = nb <= kCoarseBuckets ? coarse_split : (pair_items ? (1u << 30) : kItemsPerSplit);
@@ -732,7 +732,7 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, boo
         wgs += nb * splits;
         // fold lane runs where neighbouring samples (~1/600 of the unit cube apart) usually share a cell
         // (scan_cell_runs packs a cell id into 10 bits per axis: res <= 1023; SDFX_GRIDBWD_MERGE_RES moves the threshold for A/B runs)
-        static const uint32_t merge_res = [] { const char* e = getenv("SDFX_GRIDBWD_MERGE_RES"); const int v = e ? atoi(e) : 640; return (uint32_t)(v < 0 ? 0 : (v > 1023 ? 1023 : v)); }();
+        const uint32_t merge_res = [] { const int v = dev_switch("SDFX_GRIDBWD_MERGE_RES", 640); return (uint32_t)(v < 0 ? 0 : (v > 1023 ? 1023 : v)); }();
         if (plan.res[l] <= merge_res) b.merge_mask |= 1u << l;
     }
     b.bucket_first[levels] = buckets;
@@ -813,7 +813,7 @@ const float* k1_level_cost(uint32_t levels) {
     static const bool init = [] {
         const float measured[16] = {51, 41, 52, 19, 5, 5, 29, 26, 27, 29, 32, 36, 25, 30, 34, 59};
         for (uint32_t l = 0; l < kMaxLevels; l++) table[l] = l < 16 ? measured[l] : 30.f;
-        if (const char* e = getenv("SDFX_GRIDBWD_LEVEL_COST")) {
+        if (const char* e = dev_string("SDFX_GRIDBWD_LEVEL_COST")) {
             uint32_t l = 0;
             while (*e && l < kMaxLevels) {
                 char* end = nullptr;
@@ -829,10 +829,9 @@ const float* k1_level_cost(uint32_t levels) {
     return table;
 }
 
-// SDFX_GRIDBWD_BALANCE=1: cost-balanced ranges (measured next round; default: equal tile counts)
+// SDFX_GRIDBWD_BALANCE=1 (devtools build): cost-balanced ranges; default: equal tile counts
 bool k1_balance_enabled() {
-    static const int v = [] { const char* e = getenv("SDFX_GRIDBWD_BALANCE"); return (e && e[0] == '1') ? 1 : 0; }();
-    return v != 0;
+    return dev_switch("SDFX_GRIDBWD_BALANCE", 0) == 1;
 }
 
 }  // namespace

@@ -331,14 +331,14 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
     p.tiles = T; p.levels = levels;
     {
         // SDFX_GRID_LDS = largest level table (bytes) to keep in LDS: 16384 = level 0 of the -O grid, 49152 = levels 0 and 1
-        static const uint32_t lds = [] { const char* e = getenv("SDFX_GRID_LDS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : (v > 65536 ? 65536 : v)); }();
+        const uint32_t lds = [] { const int v = dev_switch("SDFX_GRID_LDS", 0); return (uint32_t)(v < 0 ? 0 : (v > 65536 ? 65536 : v)); }();
         if (lds && elem_bytes == 2)
             for (uint32_t l = 0; l < levels; l++)
                 if ((uint64_t)p.lv[l].size * 4u <= lds) { p.lds_mask |= 1u << l; if (p.lv[l].size * 4u > p.lds_bytes) p.lds_bytes = (p.lv[l].size * 4u + 15u) & ~15u; }
     }
     {
-        static const int sm = [] { const char* e = getenv("SDFX_GRID_PLAN"); return (e && !strcmp(e, "sample_major")) ? 1 : 0; }();
-        p.sample_major = (uint32_t)sm;
+        const char* e = dev_string("SDFX_GRID_PLAN");   // devtools build only
+        p.sample_major = (e && !strcmp(e, "sample_major")) ? 1u : 0u;
     }
 
     // ---- the sequence of levels and what a tile of each costs ----
@@ -386,15 +386,7 @@ uint32_t fwd_grid_size(const FwdPlan& p) {
     return longest * kXcds;
 }
 
-// ---- implementation switches (testing / measurement aid; sdfx_grid_set_impl) ----
-int g_fwd_impl = -1, g_balance = -1;
-int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-int sw(int forced, const char* env, int dflt) {
-    return forced >= 0 ? forced : env_int(env, dflt);
-}
+// ---- implementation switches: dev_switch (sdfx_common.h) — constants in the product library ----
 
 template <bool HALF>
 void launch(const float* inputs, const void* table, void* outputs, uint32_t B, uint32_t L, const FwdPlan& plan, uint32_t gridtype,
@@ -434,7 +426,7 @@ void launch(const float* inputs, const void* table, void* outputs, uint32_t B, u
 namespace sdfx {
 namespace grid {
 
-bool fast_forward_enabled() { return sw(g_fwd_impl, "SDFX_GRID_FWD", 1) == 1; }
+bool fast_forward_enabled() { return dev_switch("SDFX_GRID_FWD", 1) == 1; }
 
 // D = 3, C = 2, no dy_dx. `slabs`, `step`: locality hints (sdfx_grid_encode_forward_hint); results do not depend on them.
 // Returns false when the plan does not fit (more than kMaxSegs levels in one XCD's range): the caller uses k_grid_forward.
@@ -443,12 +435,12 @@ bool launch_forward_d3c2(const float* inputs, const void* table, const int32_t* 
                          uint32_t interp, int is_half, int out_layout, uint32_t slabs, float step, hipStream_t st) {
     // SDFX_GRID_VALU_LINES: VALU time of one wave of one level in units of table lines (232 instructions / 2.4 cycles a
     // line = 97; measured optimum of the split on MI355X: 75 -> 315 us, 97 -> 287 us, 120 -> 308 us at B = 1.8 M)
-    static const double valu_lines = (double)env_int("SDFX_GRID_VALU_LINES", 97);
+    const double valu_lines = (double)dev_switch("SDFX_GRID_VALU_LINES", 97);
     FwdPlan plan = make_fwd_plan(offsets_host, max_level, S, H, is_half ? 2u : 4u, B, slabs, step,
-                                 sw(g_balance, "SDFX_GRID_BALANCE", 1) == 1, valu_lines);
+                                 dev_switch("SDFX_GRID_BALANCE", 1) == 1, valu_lines);
     if (plan.ntiles[0] == 0xffffffffu) return false;
     plan.vec16 = (reinterpret_cast<uintptr_t>(table) % 16) == 0 ? 1u : 0u;
-    if (env_int("SDFX_GRID_PLAN_DEBUG", 0)) {   // one line per XCD: its segments
+    if (dev_switch("SDFX_GRID_PLAN_DEBUG", 0)) {   // one line per XCD: its segments
         for (uint32_t k = 0; k < kXcds; k++) {
             fprintf(stderr, "[grid plan] B=%u slabs=%u step=%g xcd %u: %u workgroups:", B, plan.slabs, (double)step, k, plan.ntiles[k]);
             for (uint32_t sgi = 0; sgi < kMaxSegs; sgi++) {
@@ -473,7 +465,7 @@ extern "C" int sdfx_grid_forward_plan(const int32_t* offsets_host, uint32_t max_
                                       uint32_t* tiles_per_level) {
     if (!offsets_host || !segments || max_level < 1 || max_level > kMaxLevels || B == 0) return -1;
     const FwdPlan plan = make_fwd_plan(offsets_host, max_level, S, H, is_half ? 2u : 4u, B, slabs, step,
-                                       sw(g_balance, "SDFX_GRID_BALANCE", 1) == 1, (double)env_int("SDFX_GRID_VALU_LINES", 97));
+                                       dev_switch("SDFX_GRID_BALANCE", 1) == 1, (double)dev_switch("SDFX_GRID_VALU_LINES", 97));
     if (plan.ntiles[0] == 0xffffffffu) return -3;
     const uint64_t slots = plan.slabs == kGroup ? (uint64_t)div_up(plan.slab_points, kGroupsPerWave) * 64u : B;
     if (tiles_per_level) *tiles_per_level = div_up(slots, (uint64_t)kTile);
@@ -490,4 +482,4 @@ extern "C" int sdfx_grid_forward_plan(const int32_t* offsets_host, uint32_t max_
     return (int)n;
 }
 
-extern "C" void sdfx_grid_set_impl(int fwd_impl, int balance) { g_fwd_impl = fwd_impl; g_balance = balance; }
+

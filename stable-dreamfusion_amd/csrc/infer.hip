@@ -190,7 +190,7 @@ int sdfx_render_infer(const float* rays_o, const float* rays_d, const float* nea
     zero_device(next_ray_counter, sizeof(uint32_t), st);
     const uint32_t* P_ = field_packed;
     const __half* T_ = static_cast<const __half*>(embeddings_half);
-    static const int waves = [] { const char* e = getenv("SDFX_INFER_WAVES"); const int w = e ? atoi(e) : 3; return w < 2 ? 2 : (w > 4 ? 4 : w); }();
+    const int waves = [] { const int w = dev_switch("SDFX_INFER_WAVES", 3); return w < 2 ? 2 : (w > 4 ? 4 : w); }();
     // persistent workgroups: enough waves to fill the chip at the chosen occupancy, never more than the rays need
     const uint32_t max_blocks = 256u * (uint32_t)waves;
     const uint32_t blocks = div_up(N, kThreads) < max_blocks ? div_up(N, kThreads) : max_blocks;

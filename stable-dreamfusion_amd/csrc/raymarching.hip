@@ -127,7 +127,9 @@ __global__ void k_flatten_rays(const int32_t* __restrict__ rays, uint32_t N, uin
 // training march
 // =========================================================================================
 
-// Pass 1: count the occupied samples of each ray (raymarching.cu:337-475 with xyzs == nullptr).
+#ifdef SDFX_DEVTOOLS
+// Pass 1, thread per ray — the literal shape of the reference's kernel (raymarching.cu:337-475 with xyzs == nullptr), superseded
+// by k_march_count_wave below and kept in the devtools library only (SDFX_MARCH_WAVE=0; tools/march_bench.py and the A/B test).
 // One wave per workgroup so the 64-ray groups land on as many CUs as possible; every ray
 // records the ray time of each emitted sample in tbuf[n, step] when a scratch buffer is given.
 __global__ __launch_bounds__(64) void k_march_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -153,10 +155,11 @@ __global__ __launch_bounds__(64) void k_march_count(const float* __restrict__ ra
     }
     rays[n * 2 + 1] = (int32_t)step;
 }
+#endif
 
 // Pass 1, one WAVE per ray (the default since round 2: 107-184 us against 250-330 us for the thread-per-ray kernel on
 // the init / blobs / full grids, identical counts, offsets and sample times on the MI355X — tests/test_gpu_parity.py,
-// tools/march_bench.py; sdfx_march_set_impl(0) / SDFX_MARCH_WAVE=0 select the thread-per-ray kernel). Every ray time the march visits lies on one occupancy-independent lattice (march_advance), so 64 consecutive
+// tools/march_bench.py; SDFX_MARCH_WAVE=0 selects the thread-per-ray kernel in the devtools library). Every ray time the march visits lies on one occupancy-independent lattice (march_advance), so 64 consecutive
 // lattice points are probed at once — each lane: is my cell occupied, and if not, how many lattice points does the
 // serial march skip from here (the literal do-while of raymarching.cu:459-462)? — and the serial decision chain is
 // then replayed over the 64 results with scalar ballots / readlanes. The dependent global loads of the bitfield, which
@@ -656,18 +659,7 @@ __global__ __launch_bounds__(kCompactBlock) void k_compact_scatter(const int32_t
 // =========================================================================================
 // C ABI
 // =========================================================================================
-namespace {
-int g_march_impl = -1;  // -1: follow SDFX_MARCH_WAVE (default 1 = wave per ray), 0 / 1 forced by sdfx_march_set_impl
-bool march_wave_impl() {
-    if (g_march_impl >= 0) return g_march_impl == 1;
-    static const bool env = [] { const char* e = getenv("SDFX_MARCH_WAVE"); return !e || atoi(e) != 0; }();
-    return env;
-}
-}  // namespace
-
 extern "C" {
-
-void sdfx_march_set_impl(int impl) { g_march_impl = impl; }
 
 int sdfx_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
                             float* nears, float* fars, sdfx_stream_t stream) {
@@ -733,12 +725,14 @@ int sdfx_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
     const MarchParams p = make_march_params(bound, contract, dt_gamma, max_steps, C, H);
     hipStream_t st = as_stream(stream);
     if (xyzs == nullptr) {  // pass 1
-        if (march_wave_impl())
-            hipLaunchKernelGGL(k_march_count_wave, dim3(div_up((uint64_t)N * kWave, 256)), dim3(256), 0, st, rays_o, rays_d, grid,
-                               p, max_steps, N, nears, fars, noises, rays, scratch);
-        else
+#ifdef SDFX_DEVTOOLS
+        if (dev_switch("SDFX_MARCH_WAVE", 1) == 0)
             hipLaunchKernelGGL(k_march_count, dim3(div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N,
                                nears, fars, noises, rays, scratch);
+        else
+#endif
+            hipLaunchKernelGGL(k_march_count_wave, dim3(div_up((uint64_t)N * kWave, 256)), dim3(256), 0, st, rays_o, rays_d, grid,
+                               p, max_steps, N, nears, fars, noises, rays, scratch);
         hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, rays, N, counter);
         return check_launch("march_rays_train(count)");
     }

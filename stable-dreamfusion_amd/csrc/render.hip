@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kRayWaves * 64) void k_render_train_bwd(RenderArgs 
 // sibling waves per ray (SDFX_RENDER_WAVES = 1, 2, 4, 8; measurement aid — every value gives the same results up to the order
 // in which the ray sums are added)
 int ray_waves() {
-    static const int v = [] { const char* e = getenv("SDFX_RENDER_WAVES"); const int w = e ? atoi(e) : 2; return (w == 1 || w == 4 || w == 8) ? w : 2; }();
+    const int v = [] { const int w = dev_switch("SDFX_RENDER_WAVES", 2); return (w == 1 || w == 4 || w == 8) ? w : 2; }();
     return v;
 }
 

@@ -28,6 +28,19 @@ int check_launch(const char* what);
 
 static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// ---- measurement / testing switches ----------------------------------------------------------
+// The product library (the default build) has NO process-global switches: dev_switch() is the constant default, so every
+// `if (dev_switch(...))` folds away and no launch reads the environment. A library built with -DSDFX_DEVTOOLS
+// (libsdfx_hip_dev.so, `build.py --devtools`; what tools/ and the A/B tests load through SDFX_LIB) resolves a switch from
+// sdfx_dev_set(name, value) if it was called, else from the environment variable of that name READ ONCE at first use.
+#ifdef SDFX_DEVTOOLS
+int dev_switch(const char* name, int dflt);
+const char* dev_string(const char* name);   // environment only (nullptr when unset); read at every call
+#else
+constexpr int dev_switch(const char*, int dflt) { return dflt; }
+constexpr const char* dev_string(const char*) { return nullptr; }
+#endif
+
 // Padding rows of fixed-capacity sample buffers (sdfx_set_row_limit): row r of a [k, period, ...] buffer is padding when
 // (r % period) >= total[0] (period 0: r >= total[0]); total == nullptr: no limit. Kernels that honour it neither read nor
 // write padding rows, so every producer / consumer pair of such a buffer must honour the same limit.

@@ -116,3 +116,43 @@ nz = np.nonzero(gt.any(axis=1))[0]
 res["grad_rows"] = nz.astype(np.int32); res["grad_vals"] = gt[nz]
 np.savez_compressed(os.path.join(OUT, "refk_grid.npz"), **res)
 print("refk_grid.npz", len(nz), "touched rows")
+
+# ---- grad_total_variation / grad_weight_decay (gridencoder.cu:525-713), freq and SH encoders ---------------
+# (round 4: rows a6, a13, a14 of SURVEY.md section 8 pinned to reference-kernel outputs, not only to the oracle)
+fe, se = load("_refnc_freqencoder"), load("_refnc_shencoder")
+offs8, pls8 = O.grid_offsets(num_levels=8, log2_hashmap_size=15, desired_resolution=512)
+S8 = float(np.log2(pls8))
+tab8 = synth.s_table(int(offs8[-1]), 2, "trained", np.float32)
+g0 = np.random.default_rng(2).normal(size=tab8.shape).astype(np.float32)
+enc = {}
+for gridtype, align, tag in ((0, False, "hash"), (1, True, "tiled_align")):
+    xtv = synth.s_points_uniform(5000, seed=40)
+    g = T(g0).clone()
+    ge.grad_total_variation(T(xtv), T(tab8), g, T(offs8), 1e-3, 5000, 3, 2, 8, S8, 16, gridtype, align)
+    d = g.cpu().numpy() - g0
+    nz = np.nonzero(d.any(axis=1))[0]
+    enc[f"tv_{tag}_rows"] = nz.astype(np.int32); enc[f"tv_{tag}_vals"] = g.cpu().numpy()[nz]
+g = T(g0).clone()
+ge.grad_weight_decay(T(tab8), g, T(offs8), 0.1, int(offs8[-1]), 2, 8)
+enc["wd_head"] = g.cpu().numpy()[:20000]
+enc["wd_checksum"] = np.array([g.cpu().numpy().view(np.uint32).astype(np.uint64).sum()], np.uint64)
+
+xd = (np.random.default_rng(3).random((4097, 3)) * 2 - 1).astype(np.float32)
+fo = torch.empty(4097, 39, device=dev)
+fe.freq_encode_forward(T(xd), 4097, 3, 6, 39, fo)
+gf = np.random.default_rng(4).normal(size=(4097, 39)).astype(np.float32)
+fgi = torch.zeros(4097, 3, device=dev)
+fe.freq_encode_backward(T(gf), fo, 4097, 3, 6, 39, fgi)
+enc["freq_x"] = xd; enc["freq_out"] = fo.cpu().numpy(); enc["freq_grad"] = gf; enc["freq_grad_inputs"] = fgi.cpu().numpy()
+xn = (xd / np.linalg.norm(xd, axis=1, keepdims=True)).astype(np.float32)
+for deg in (4, 8):
+    so = torch.empty(4097, deg * deg, device=dev); sdy = torch.empty(4097, 3 * deg * deg, device=dev)
+    se.sh_encode_forward(T(xn), so, 4097, 3, deg, sdy)
+    gs_ = np.random.default_rng(5 + deg).normal(size=(4097, deg * deg)).astype(np.float32)
+    sgi = torch.zeros(4097, 3, device=dev)
+    se.sh_encode_backward(T(gs_), T(xn), 4097, 3, deg, sdy, sgi)
+    enc[f"sh{deg}_out"] = so.cpu().numpy(); enc[f"sh{deg}_dy"] = sdy.cpu().numpy()[:512]
+    enc[f"sh{deg}_grad"] = gs_; enc[f"sh{deg}_grad_inputs"] = sgi.cpu().numpy()
+enc["sh_x"] = xn
+np.savez_compressed(os.path.join(OUT, "refk_encoders.npz"), **enc)
+print("refk_encoders.npz", {k: v.shape for k, v in enc.items()})
