@@ -68,6 +68,12 @@ void sdfx_set_stencil_source(const float* xyzs, uint32_t M, float epsilon, float
 /* version / build info string (arch, git-less) */
 const char* sdfx_build_info(void);
 
+/* Whether the dispatcher deals the workgroups of a launch to the eight XCDs round-robin (workgroup b -> XCD (b + c) mod 8), which
+ * is what the level-per-XCD work plans of the encoder kernels assume for L2 residency of the tables. One probe launch on the
+ * current device at the first call (reads HW_REG_XCC_ID per workgroup), cached: 1 = holds, 0 = does not, -1 = probe failed.
+ * Results never depend on it; bench.py reports it and tests/test_gpu_02_parity.py asserts it on the hardware under test. */
+int sdfx_xcd_round_robin(void);
+
 /* ------------------------------------------------------------------ raymarching: utils */
 
 /* raymarching.cu:148-156 near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars) */
@@ -149,10 +155,6 @@ int sdfx_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int b
                         float* rays_t, const float* sigmas, const float* rgbs, const float* ts, float* weights_sum,
                         float* depth, float* image, sdfx_stream_t stream);
 
-/* testing aid: counting pass of sdfx_march_rays_train: 0 = one thread per ray, 1 = one wave per ray (the default;
- * identical output, 2-3x faster on MI355X), -1 = follow env SDFX_MARCH_WAVE (unset = 1) */
-void sdfx_march_set_impl(int impl);
-
 /*
  * Extension — stable compaction of the alive-ray list.  The reference does this with a
  * boolean mask in Python, `rays_alive = rays_alive[rays_alive >= 0]` (nerf/renderer.py:791).
@@ -199,13 +201,6 @@ int sdfx_render_infer(const float* rays_o, const float* rays_d, const float* nea
                       float* depth, float* image, int32_t* n_samples, sdfx_stream_t stream);
 
 /* ------------------------------------------------------------------------- gridencoder */
-
-/* testing / measurement aid: switches of the D = 3, C = 2 forward (csrc/gridencoder_fwd.hip); -1 = default / environment.
- *   fwd_impl   0 = generic kernel (any D, C) always, 1 = k_grid_fwd for hinted batches (default; env SDFX_GRID_FWD)
- *   balance    1 = cut the level sequence into 8 per-XCD ranges of equal modelled COST (default; needs a step hint),
- *              0 = equal tile counts (env SDFX_GRID_BALANCE)
- * Results are identical for every setting. */
-void sdfx_grid_set_impl(int fwd_impl, int balance);
 
 /* Host-only (no GPU work): the per-XCD work list sdfx_grid_encode_forward_hint would use for these arguments, 4 integers per
  * segment (xcd, level, first tile, tiles); an XCD walks its segments in order. Returns the number of segments, < 0 on error. */
@@ -331,8 +326,6 @@ int sdfx_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, 
  *   dw1..db3   float32 parameter gradients (overwritten)
  */
 uint32_t sdfx_field_packed_words(void);
-/* testing aid: 0 = matrix-core kernels (default), 1 = per-thread v_dot2 kernels, -1 = follow env SDFX_FIELD_IMPL */
-void sdfx_field_set_impl(int impl);
 uint64_t sdfx_field_backward_scratch_bytes(uint32_t B);
 /* Extension — the 7-point finite-difference stencil batch of network_grid.py:81-96 from the M sample positions: points [7, M, 3]
  * = (x, x + eps e_x, x - eps e_x, ... e_z), the six offset points clamped to [-bound, bound] (network_grid.py:84-89), and

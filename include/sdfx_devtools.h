@@ -1,0 +1,38 @@
+/*
+ * sdfx_devtools.h — entry points that exist ONLY in the devtools build of the library
+ * (stable-dreamfusion_amd/csrc/libsdfx_hip_dev.so: `python stable-dreamfusion_amd/build.py --devtools`, -DSDFX_DEVTOOLS).
+ *
+ * The product library (libsdfx_hip.so, include/sdfx.h) has no process-global implementation switches and never reads the
+ * environment: every switch below is a compile-time constant there. The devtools library carries the superseded kernels
+ * (thread-per-ray march count, per-thread v_dot2 field kernels) and the measurement knobs that tools/ and the A/B tests of
+ * tests/test_gpu_zz_stress.py use; select it with SDFX_LIB=<path to libsdfx_hip_dev.so>.
+ *
+ * A switch is resolved from sdfx_dev_set() if it was called, else from the environment variable of the same name read ONCE
+ * at its first use, else it keeps the product default:
+ *   SDFX_MARCH_WAVE        1 (default) wave-per-ray counting pass, 0 thread-per-ray            raymarching.hip
+ *   SDFX_GRID_FWD          1 (default) k_grid_fwd for hinted batches, 0 generic kernel         gridencoder_fwd.hip
+ *   SDFX_GRID_BALANCE      1 (default) cost-balanced per-XCD level ranges, 0 equal counts      gridencoder_fwd.hip
+ *   SDFX_GRID_VALU_LINES   97: VALU cost of a tile in line units (plan model)                  gridencoder_fwd.hip
+ *   SDFX_GRID_LDS          0: largest level table (bytes) gathered from LDS (slower)           gridencoder_fwd.hip
+ *   SDFX_GRID_PLAN         (string, environment only) "sample_major" (slower)                  gridencoder_fwd.hip
+ *   SDFX_GRID_PLAN_DEBUG   print the per-XCD segments                                          gridencoder_fwd.hip
+ *   SDFX_GRID_NOVEC16      1: one gather per corner in the generic kernels                     gridencoder.hip
+ *   SDFX_GRIDBWD_MERGE_RES / _COARSE_SPLIT / _BALANCE / _LEVEL_COST (string)                   gridencoder_bwd_binned.hip
+ *   SDFX_FIELD_IMPL        0 (default) matrix-core kernels, 1 per-thread v_dot2 kernels        field.hip
+ *   SDFX_FIELD_FWD_NAT / _FWD_BLOCKS / _BWD_NAT / _BWD_NB / _BWD_LDSFRAG                      field.hip
+ *   SDFX_RENDER_WAVES, SDFX_INFER_WAVES                                                        render.hip, infer.hip
+ */
+#ifndef SDFX_DEVTOOLS_H
+#define SDFX_DEVTOOLS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void sdfx_dev_set(const char* name, int value);
+void sdfx_dev_unset(const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -22,10 +22,10 @@ if PACKAGE_DIR not in _sys.path:
 OPERATOR_PACKAGES = ("raymarching", "gridencoder", "freqencoder", "shencoder")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, devtools: bool = False) -> str:
     """Compile libsdfx_hip.so for gfx950 (hipcc). Returns its path."""
     import importlib.util as _u
     spec = _u.spec_from_file_location("_sdfx_build", _os.path.join(PACKAGE_DIR, "build.py"))
     mod = _u.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.build(force=force, verbose=verbose)
+    return mod.build(force=force, verbose=verbose, devtools=devtools)

@@ -19,6 +19,7 @@ _u32, _f32, _int, _ptr, _u64 = C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_u
 
 # name -> argtypes (every entry point returns int unless listed in _RESTYPES)
 _SIGNATURES = {
+    "sdfx_xcd_round_robin": [],
     "sdfx_near_far_from_aabb": [_ptr, _ptr, _ptr, _u32, _f32, _ptr, _ptr, _ptr],
     "sdfx_sph_from_ray": [_ptr, _ptr, _f32, _u32, _ptr, _ptr],
     "sdfx_morton3D": [_ptr, _u32, _ptr, _ptr],
@@ -56,7 +57,6 @@ _SIGNATURES = {
     "sdfx_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "sdfx_sh_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "sdfx_field_packed_words": [],
-    "sdfx_field_set_impl": [_int],
     "sdfx_field_backward_scratch_bytes": [_u32],
     "sdfx_field_stencil_points": [_ptr, _u32, _f32, _f32, C.c_double, _ptr, _ptr, _ptr],
     "sdfx_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -87,8 +87,6 @@ _SIGNATURES = {
     "sdfx_entropy_backward": [_ptr, _u32, _ptr, _ptr, _ptr, _ptr],
     "sdfx_set_row_limit": [_ptr, _u32],
     "sdfx_set_stencil_source": [_ptr, _u32, _f32, _f32, C.c_double],
-    "sdfx_march_set_impl": [_int],
-    "sdfx_grid_set_impl": [_int, _int],
     "sdfx_grid_backward_plan": [_ptr, _u32, _f32, _u32, _u32, _int, _ptr, _ptr],
     "sdfx_grid_forward_plan": [_ptr, _u32, _f32, _u32, _int, _u32, _u32, _f32, _ptr, _u32, _ptr],
     "sdfx_marching_tets_scratch_bytes": [_u32, _u32],
@@ -183,6 +181,33 @@ class stencil_source:
     def __exit__(self, *exc):
         if self.xyzs is not None:
             lib().sdfx_set_stencil_source(None, 0, 0.0, 0.0, 0.0)
+        return False
+
+
+DEV_LIB_PATH = os.path.join(_HERE, "csrc", "libsdfx_hip_dev.so")
+
+
+def is_devtools() -> bool:
+    """True when the loaded library is the devtools build (include/sdfx_devtools.h; SDFX_LIB=<...>/libsdfx_hip_dev.so)."""
+    return hasattr(lib(), "sdfx_dev_set")
+
+
+class dev_switch:
+    """`with dev_switch(NAME=value, ...): ...` — sdfx_dev_set around the calls inside; the devtools library only."""
+
+    def __init__(self, **values):
+        if not is_devtools():
+            raise RuntimeError("implementation switches exist only in libsdfx_hip_dev.so (SDFX_LIB=" + DEV_LIB_PATH + ")")
+        self.values = values
+
+    def __enter__(self):
+        for k, v in self.values.items():
+            lib().sdfx_dev_set(k.encode(), int(v))
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.values:
+            lib().sdfx_dev_unset(k.encode())
         return False
 
 

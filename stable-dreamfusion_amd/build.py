@@ -1,6 +1,9 @@
 """Build libsdfx_hip.so (the C-ABI HIP library) in-tree for gfx950 with hipcc.
 
-    python stable-dreamfusion_amd/build.py [--force] [--verbose]
+    python stable-dreamfusion_amd/build.py [--force] [--verbose] [--devtools]
+
+--devtools builds libsdfx_hip_dev.so instead: the same sources with -DSDFX_DEVTOOLS (implementation switches, measurement
+knobs, superseded kernels; include/sdfx_devtools.h). The product library has none of them.
 
 hipcc cross-compiles without a GPU; the resulting .so sits next to the sources (git-ignored,
 but shipped to the GPU box with the repository snapshot).
@@ -17,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB = os.path.join(CSRC, "libsdfx_hip.so")
+DEV_LIB = os.path.join(CSRC, "libsdfx_hip_dev.so")
 SOURCES = ["sdfx_core.hip", "raymarching.hip", "gridencoder.hip", "gridencoder_fwd.hip", "gridencoder_bwd_binned.hip", "encoders.hip", "field.hip", "optim.hip", "shade.hip", "render.hip", "occupancy.hip", "infer.hip", "head.hip", "sds.hip", "dmtet.hip", "raster.hip"]
 ARCH = "gfx950"
 # -ffp-contract=off: the march / encode arithmetic must not gain FMAs the source does not spell
@@ -37,30 +41,31 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src: str, force: bool, verbose: bool) -> str:
+def _compile(src: str, force: bool, verbose: bool, devtools: bool = False) -> str:
     path = os.path.join(CSRC, src)
-    obj = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
+    obj = os.path.join(CSRC, "build_dev" if devtools else "build", src.replace(".hip", ".o"))
     os.makedirs(os.path.dirname(obj), exist_ok=True)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime()):
         return obj
-    cmd = [hipcc()] + FLAGS + ["-c", path, "-o", obj]
+    cmd = [hipcc()] + FLAGS + (["-DSDFX_DEVTOOLS"] if devtools else []) + ["-c", path, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, devtools: bool = False) -> str:
     sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    lib = DEV_LIB if devtools else LIB
     with cf.ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, verbose), sources))
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        objs = list(ex.map(lambda s: _compile(s, force, verbose, devtools), sources))
+    if force or not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, devtools="--devtools" in sys.argv))

@@ -676,19 +676,12 @@ __global__ __launch_bounds__(64 * kReduceSplit) void k_field_wgrad_reduce(const 
     else db3[i - gB3] = s;
 }
 
-int g_field_impl = -1;  // -1: from SDFX_FIELD_IMPL (default mma); 0: mma; 1: dot2
-bool use_dot2() {
-    if (g_field_impl >= 0) return g_field_impl == 1;
-    static const int v = [] { const char* e = getenv("SDFX_FIELD_IMPL"); return (e && e[0] == 'd') ? 1 : 0; }();
-    return v != 0;
-}
-
+// Switches of the devtools library (constants in the product library, see dev_switch in sdfx_common.h):
+// SDFX_FIELD_IMPL=1: the per-thread v_dot2 kernels of field_dot2.inc.h.
 // SDFX_FIELD_FWD_NAT: 0 = the lane-per-sample forward, 1 / 2 = native layout with that many column blocks per wave (default 1:
 // 96 registers, five workgroups per CU — 98 us against 110 us for two blocks at 3.15 M rows once the inputs are prefetched)
-int native_forward() {
-    static const int v = [] { const char* e = getenv("SDFX_FIELD_FWD_NAT"); return e ? atoi(e) : 1; }();
-    return v;
-}
+bool use_dot2() { return dev_switch("SDFX_FIELD_IMPL", 0) == 1; }
+int native_forward() { return dev_switch("SDFX_FIELD_FWD_NAT", 1); }
 
 uint32_t backward_blocks(uint32_t B, uint32_t cap = kMaxBlocks) {
     const uint32_t tiles = div_up(B, kThreads);
@@ -728,9 +721,6 @@ extern "C" {
 
 uint32_t sdfx_field_packed_words(void) { return kPackedWords; }
 
-/* testing aid: 0 = matrix-core kernels (default), 1 = per-thread v_dot2 kernels, -1 = follow SDFX_FIELD_IMPL */
-void sdfx_field_set_impl(int impl) { g_field_impl = impl; }
-
 uint64_t sdfx_field_backward_scratch_bytes(uint32_t B) { return (uint64_t)backward_blocks(B ? B : 1) * kGradWords * sizeof(float); }
 
 int sdfx_field_stencil_points(const float* xyzs, uint32_t M, float epsilon, float bound, double two_bound, float* points, float* unit,
@@ -761,14 +751,18 @@ int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const ui
     SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_forward: features misaligned");
     SDFX_REQUIRE(blob_radius > 0, "field_forward: blob_radius must be positive");
     if (B == 0) return SDFX_OK;
+#ifdef SDFX_DEVTOOLS
     if (use_dot2()) {
         hipLaunchKernelGGL(k_field_forward, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
                            1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src());
-    } else if (enc_layout == 0 && native_forward() > 0 && B < kNatMaxRows) {
+        return check_launch("field_forward");
+    }
+#endif
+    if (enc_layout == 0 && native_forward() > 0 && B < kNatMaxRows) {
         const int nb = native_forward();
         // persistent workgroups: SDFX_FIELD_FWD_BLOCKS (measurement aid; default 2048)
-        static const uint32_t cap = [] { const char* e = getenv("SDFX_FIELD_FWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : 2048u; }();
+        const uint32_t cap = [] { const int v = dev_switch("SDFX_FIELD_FWD_BLOCKS", 0); return v > 0 ? (uint32_t)v : 2048u; }();
         const uint32_t tiles = div_up(B, 128u * nb), blocks = tiles < cap ? tiles : cap;
         if (nb == 2)
             hipLaunchKernelGGL(k_field_forward_nat<2>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), static_cast<const uint32_t*>(enc), x,
@@ -796,17 +790,20 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
     SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_backward: features misaligned");
     SDFX_REQUIRE(blob_radius > 0, "field_backward: blob_radius must be positive");
     hipStream_t st = as_stream(stream);
-    static const int lds_frags = [] { const char* e = getenv("SDFX_FIELD_BWD_LDSFRAG"); return (e && e[0] == '0') ? 0 : 1; }();
-    static const bool native = [] { const char* e = getenv("SDFX_FIELD_BWD_NAT"); return !(e && e[0] == '0'); }();
-    static const int nb = [] { const char* e = getenv("SDFX_FIELD_BWD_NB"); return (e && e[0] == '2') ? 2 : 1; }();
+    const int lds_frags = dev_switch("SDFX_FIELD_BWD_LDSFRAG", 1) != 0;
+    const bool native = dev_switch("SDFX_FIELD_BWD_NAT", 1) != 0;
+    const int nb = dev_switch("SDFX_FIELD_BWD_NB", 1) == 2 ? 2 : 1;
     const bool nat = !use_dot2() && native && enc_layout == 0 && B < kNatMaxRows;
     const uint32_t nblocks = B ? backward_blocks(B, 512u) : 0;   // persistent: two workgroups per CU
     if (B) {
+#ifdef SDFX_DEVTOOLS
         if (use_dot2()) {
             hipLaunchKernelGGL(k_field_backward, dim3(nblocks), dim3(kThreads), 0, st, static_cast<const uint32_t*>(enc),
                                enc_layout, x, packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), dsigma, dalbedo,
                                static_cast<uint32_t*>(denc), scratch, row_limit(), stencil_src());
-        } else {
+        } else
+#endif
+        {
             if (nat) {
                 const float i2 = 1.0f / (2 * blob_radius * blob_radius);
                 const uint32_t* ep = static_cast<const uint32_t*>(enc);

@@ -25,6 +25,13 @@ def test_library_is_the_hip_build(dev):
     assert "libsdfx_hip.so" in maps
 
 
+def test_workgroups_are_dealt_to_the_xcds_round_robin(dev):
+    """The level-per-XCD work plans of the encoder kernels (grid_common.h: plan_item) assume workgroup b runs on XCD (b + c) mod 8.
+    Results do not depend on it, the L2 residency of the tables does: if a driver ever dispatches differently, this says so."""
+    import _sdfx
+    assert _sdfx.lib().sdfx_xcd_round_robin() == 1
+
+
 def test_near_far_morton_packbits_flatten_sph(oracle, dev):
     import raymarching
     o, d = synth.s_rays(4)

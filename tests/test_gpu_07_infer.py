@@ -34,24 +34,31 @@ def _frame_rays(hw, view=3):
 
 
 def test_persistent_kernel_equals_host_loop(dev, oracle):
+    """k_render_infer (csrc/infer.hip) against the host loop of march_rays / field / composite_rays launches on the same frame.
+    The persistent kernel inlines the per-thread v_dot2 arithmetic of the field; the host loop of the PRODUCT library runs the
+    matrix-core kernels (same fp16 operands and fp32 accumulation, another summation order: a hidden activation can round to
+    the neighbouring half), hence 5e-3 there. With the devtools library (SDFX_LIB=libsdfx_hip_dev.so, SDFX_FIELD_IMPL=1) the host
+    loop runs the very same v_dot2 arithmetic and the two must agree to 1e-5."""
+    import contextlib
     model, ng = _model(dev)
     import _sdfx as S
     o, d = synth.s_rays(5)
     ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
     out = {}
+    exact = S.is_devtools()
     try:
-        S.lib().sdfx_field_set_impl(1)                         # v_dot2 field kernels: the arithmetic csrc/infer.hip inlines
-        for fused in (1, 0):
-            ng._FUSED_INFER = fused
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-                r = model.render(ro[None], rd[None], None, 64, 64, staged=False, perturb=False, bg_color=1.0, ambient_ratio=1.0,
-                                 shading="albedo")
-            out[fused] = (r["image"].float().clone(), r["depth"].float().clone(), r["weights_sum"].float().clone())
+        with (S.dev_switch(SDFX_FIELD_IMPL=1) if exact else contextlib.nullcontext()):
+            for fused in (1, 0):
+                ng._FUSED_INFER = fused
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                    r = model.render(ro[None], rd[None], None, 64, 64, staged=False, perturb=False, bg_color=1.0, ambient_ratio=1.0,
+                                     shading="albedo")
+                out[fused] = (r["image"].float().clone(), r["depth"].float().clone(), r["weights_sum"].float().clone())
     finally:
-        S.lib().sdfx_field_set_impl(-1)
         ng._FUSED_INFER = 1
+    tol = 1e-5 if exact else 5e-3
     for a, b in zip(out[1], out[0]):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), float((a - b).abs().max())
+        assert torch.allclose(a, b, rtol=tol, atol=tol), float((a - b).abs().max())
     assert float(out[1][2].max()) > 0.5                        # the frame is not empty
 
 

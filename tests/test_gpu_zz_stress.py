@@ -171,14 +171,13 @@ def test_wave_per_ray_march_matches_thread_per_ray(oracle, dev, gridname):
     nears, fars = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
     noises = synth.s_noises(4096, seed=5)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if not S.is_devtools():
+        pytest.skip("the thread-per-ray kernel exists only in libsdfx_hip_dev.so (run with SDFX_LIB=" + S.DEV_LIB_PATH + ")")
     outs = []
-    try:
-        for impl in (0, 1):
-            S.lib().sdfx_march_set_impl(impl)
+    for impl in (0, 1):
+        with S.dev_switch(SDFX_MARCH_WAVE=impl):
             outs.append(raymarching.march_rays_train(T(o), T(d), 1.0, T(bf), 1, 128, T(nears), T(fars), True, 0, 1024, False,
                                                      T(noises)))
-    finally:
-        S.lib().sdfx_march_set_impl(-1)
     for a, b in zip(*outs):
         assert torch.equal(a, b)
 

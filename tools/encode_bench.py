@@ -4,7 +4,8 @@ usage: python tools/encode_bench.py [uniform|ray|stencil] [f16|f32] [launches] [
   uniform  2^21 uniform random points (the occupancy refresh's shape)
   ray      the samples of one 4096-ray view through S-grid-init, in ray order
   stencil  those samples and their six finite-difference neighbours, batched [7, M, 3] as the iteration does
-Each variant = the two switches of sdfx_grid_set_impl (-1 = default) + hint (0: none, 1: slabs = 7 / step = 1/591 where
+Each variant = the switches SDFX_GRID_FWD / SDFX_GRID_BALANCE of the DEVTOOLS library (-1 = default; run with
+SDFX_LIB=stable-dreamfusion_amd/csrc/libsdfx_hip_dev.so) + hint (0: none, 1: slabs = 7 / step = 1/591 where
 they apply); every variant is timed (rounds interleaved) and its output compared bit for bit with the first one."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,7 +45,11 @@ outs = {}
 for rnd in range(3):            # rounds interleaved so that clock / thermal drift hits every variant alike
     for var in variants:
         impl, bal, hint = var
-        _sdfx.lib().sdfx_grid_set_impl(impl, bal)
+        for name, val in (("SDFX_GRID_FWD", impl), ("SDFX_GRID_BALANCE", bal)):
+            if val >= 0:
+                _sdfx.lib().sdfx_dev_set(name.encode(), val)
+            else:
+                _sdfx.lib().sdfx_dev_unset(name.encode())
         slabs = 7 if (hint and kind == "stencil") else 1
         step = STEP if (hint and kind != "uniform") else 0.0
         out = torch.empty(16, B, 2, device=dev, dtype=dt)
@@ -62,4 +67,5 @@ for var in variants:
     print(f"encode_fwd {kind} {dt} B={B} impl,balance,hint={var}: {ms*1e3:.1f} us/launch (min of 3 rounds; "
           f"{[round(t*1e3) for t in times[var]]}), {B/ms/1e6:.2f} Gpts/s, {B*bpp/ms/1e6:.0f} GB/s algorithmic "
           f"({B*bpp/ms/1e6/8000:.3f} of 8 TB/s)  identical to first: {same}", flush=True)
-_sdfx.lib().sdfx_grid_set_impl(-1, -1)
+for name in ("SDFX_GRID_FWD", "SDFX_GRID_BALANCE"):
+    _sdfx.lib().sdfx_dev_unset(name.encode())

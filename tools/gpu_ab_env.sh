@@ -4,6 +4,8 @@
 TAG=${1:-ab}; VAR=$2; A=$3; B=$4; TESTS=${5:-}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
+# the SDFX_* kernel switches exist only in the devtools library (include/sdfx_devtools.h)
+export SDFX_LIB=${SDFX_LIB:-$PWD/stable-dreamfusion_amd/csrc/libsdfx_hip_dev.so}
 REPO=$PWD
 if [ -n "$TESTS" ]; then
   python -m pytest $TESTS -q -m gpu --no-header -p no:cacheprovider 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-600 | tee $OUT/tests.log

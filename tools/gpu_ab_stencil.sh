@@ -4,7 +4,7 @@ TAG=${1:-ab_stencil}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_trainer.py tests/test_gpu_render.py -q -m gpu --no-header -p no:cacheprovider 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-500 | tee $OUT/tests.log
+python -m pytest tests/test_gpu_02_parity.py tests/test_gpu_05_trainer.py tests/test_gpu_03_render.py -q -m gpu --no-header -p no:cacheprovider 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-500 | tee $OUT/tests.log
 for V in 0 1; do
   SDFX_STENCIL_SOURCE=$V python bench.py --steps 40 --warmup 8 --guidance synthetic --no-cpu-baseline --no-kernel-bench --no-reference-flow > $OUT/bench_src$V.json 2> $OUT/bench_src$V.err
   python tools/pick_bench.py < $OUT/bench_src$V.json 2>&1 | cut -c1-400 | tee -a $OUT/summary.txt

@@ -4,6 +4,8 @@
 TAG=${1:-render_sweep}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
+# the SDFX_* kernel switches exist only in the devtools library (include/sdfx_devtools.h)
+export SDFX_LIB=${SDFX_LIB:-$PWD/stable-dreamfusion_amd/csrc/libsdfx_hip_dev.so}
 REPO=$PWD
 cd /tmp
 for W in 1 2 4 8; do

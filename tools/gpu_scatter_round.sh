@@ -4,7 +4,7 @@ TAG=${1:-scatter}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_vs_reference_kernels.py tests/test_gpu_reference_goldens.py -q -m gpu --no-header -p no:cacheprovider 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tee $OUT/tests.log
+python -m pytest tests/test_gpu_02_parity.py tests/test_gpu_00_vs_reference_kernels.py tests/test_gpu_01_reference_goldens.py tests/test_gpu_zz_stress.py -q -m gpu --no-header -p no:cacheprovider 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tee $OUT/tests.log
 PER_LEVEL=${PER_LEVEL:-} python tools/gridbwd_bench.py 20 2>&1 | tail -18 | tee $OUT/bench.txt
 cd /tmp
 for SET in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"; do

@@ -3,9 +3,11 @@
 TAG=${1:-scatter_sweep}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
+# the SDFX_* kernel switches exist only in the devtools library (include/sdfx_devtools.h)
+export SDFX_LIB=${SDFX_LIB:-$PWD/stable-dreamfusion_amd/csrc/libsdfx_hip_dev.so}
 REPO=$PWD
-python -m pytest tests/test_gpu_parity.py -q -m gpu --no-header -p no:cacheprovider -k "stencil_source or grid_backward or binned" 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-600 | tee $OUT/tests.log
-SDFX_LIB=$REPO/stable-dreamfusion_amd/csrc/libsdfx_hip_b12.so python -m pytest tests/test_gpu_parity.py -q -m gpu --no-header -p no:cacheprovider -k "grid_backward or binned" 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-300 | tee -a $OUT/tests.log
+python -m pytest tests/test_gpu_02_parity.py tests/test_gpu_zz_stress.py -q -m gpu --no-header -p no:cacheprovider -k "stencil_source or grid_backward or binned" 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-600 | tee $OUT/tests.log
+SDFX_LIB=$REPO/stable-dreamfusion_amd/csrc/libsdfx_hip_b12.so python -m pytest tests/test_gpu_02_parity.py tests/test_gpu_zz_stress.py -q -m gpu --no-header -p no:cacheprovider -k "grid_backward or binned" 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-300 | tee -a $OUT/tests.log
 cd /tmp
 run() {  # label, env...
   L=$1; shift

@@ -41,7 +41,7 @@ for gname, bf in (("init", synth.s_grid_init()[2]), ("blobs", synth.s_grid_blobs
     bfd = T(bf)
     outs = {}
     for impl in (0, 1):
-        S.lib().sdfx_march_set_impl(impl)
+        S.lib().sdfx_dev_set(b"SDFX_MARCH_WAVE", impl)   # devtools library: SDFX_LIB=.../libsdfx_hip_dev.so
         try:
             full = lambda: raymarching.march_rays_train(od, dd, 1.0, bfd, 1, 128, nears, fars, True, 0, 1024, False, noises)
             outs[impl] = full()
@@ -58,6 +58,6 @@ for gname, bf in (("init", synth.s_grid_init()[2]), ("blobs", synth.s_grid_blobs
             print(f"{gname:6s} impl={impl} M={outs[impl][0].shape[0]:8d}  count-pass {t_count:8.1f} us   two-pass operator {t_full:8.1f} us",
                   flush=True)
         finally:
-            S.lib().sdfx_march_set_impl(-1)
+            S.lib().sdfx_dev_unset(b"SDFX_MARCH_WAVE")
     same = all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
     print(f"{gname:6s} identical outputs: {same}", flush=True)
