@@ -439,6 +439,18 @@ def job_elapsed(local_elapsed: float, dist, device) -> float:
     return float(t.item())
 
 
+def rank_times(own_elapsed: float, steps: int, dist, world: int):
+    """ms per step of every rank's OWN work (clock stopped after its last synchronize, before the closing barrier; index = rank):
+    the skew behind the MAX that `value` is formed from — on the first real 8-GPU run a slow rank (a GPU sharing its xGMI links,
+    a throttled socket) shows up here, not only as a lower aggregate."""
+    ms = round(own_elapsed / steps * 1e3, 3)
+    if dist is None:
+        return [ms]
+    out = [None] * world
+    dist.all_gather_object(out, ms)
+    return out
+
+
 def job_throughput(world: int, steps: int, elapsed: float) -> float:
     """Whole-job iterations per second: every rank does `steps` iterations of its own scene in `elapsed`."""
     return world * steps / elapsed
@@ -720,6 +732,7 @@ def main():
             job.sync()                             # phase boundary: one device synchronisation inside the region
         marks.append((name, k, time.perf_counter()))
     job.sync()
+    elapsed_own = time.perf_counter() - t0       # this rank's own work; the job's time is taken after the barrier below
     if dist is not None:
         dist.barrier()
     job.sync()
@@ -732,6 +745,7 @@ def main():
     host_steps = max(host_now.get("steps", 0) - host_before.get("steps", 0), 1)
     host_us = {k: round((v - host_before.get(k, 0.0)) / host_steps * 1e6, 1) for k, v in host_now.items() if k != "steps"}
     elapsed = job_elapsed(elapsed_local, dist, dev)
+    per_rank_ms = rank_times(elapsed_own, args.steps, dist, world)
     phases, prev = {}, t0
     for name, k, t in marks:
         dt = job_elapsed(t - prev, dist, dev)
@@ -739,7 +753,8 @@ def main():
         prev = t
     result = {
         "metric": "sds_iters_per_sec", "value": job_throughput(world, args.steps, elapsed), "unit": "iters/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_per_rank": per_rank_ms, "ms_per_step_rank_min_max": [min(per_rank_ms), max(per_rank_ms)], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f16 table/features, f32 coordinates+compositing", "data": "synthetic",
         "phases": phases, "rays_per_s": world * args.steps * (512 * 512 if args.stage == "dmtet" else 4096) / elapsed,
         "samples_per_iter": samples / max(args.steps, 1),
@@ -905,6 +920,11 @@ def main():
         "workload": workload + "; timed steps = " + " + ".join(f"{k} {n}" for n, k in plan), "stage": args.stage,
         "guidance": job.guidance_kind + prior_txt, "prior": args.prior,
         "rays_per_iter": 512 * 512 if args.stage == "dmtet" else 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid, "phase": args.phase}
+    try:   # the dispatch assumption behind the level-per-XCD plans (include/sdfx.h): 1 = workgroup b runs on XCD (b + c) mod 8
+        import _sdfx
+        result["xcd_round_robin"] = int(_sdfx.lib().sdfx_xcd_round_robin())
+    except Exception:  # noqa: BLE001
+        result["xcd_round_robin"] = None
     sec = enc["avg_us"] * 1e-6
     result["roofline"] = {
         "bound": "hbm", "kernel": enc_kernel, "achieved": enc["GBps"],
@@ -952,7 +972,9 @@ def main():
             lam = cb["shadings"]["lambertian"]
             result["cpu_baseline"] = {
                 "value": 1.0 / lam["s_per_iter_median"], "unit": "iters/s", "cores": cb["cores"],
-                "kind": cb["kind"] + " -O2",
+                # "reference": /root/reference's own Python ran (this container); on the GPU box the reference is absent and the
+                # restatement oracle/o2_path.py runs, pinned to the reference by tests/golden/o2_ref.npz
+                "kind": "reference (-O2, its own code)" if cb["kind"] == "reference" else "restated (-O2 port, golden-pinned)",
                 "sample": f"the reference's -O2 vanilla-NeRF path ({'its own code, /root/reference' if cb['kind'] == 'reference' else 'oracle/o2_path.py, pinned to it by tests/golden/o2_ref.npz'}): "
                           f"4096 rays x (64 + 32) samples, render + backward with a dummy SDS gradient, fp32, "
                           f"torch threads = {cb['cores']} = the fastest of the probe {cb['thread_probe_s_per_albedo_iter']} s per 'albedo' iteration "
@@ -962,7 +984,7 @@ def main():
                           f"'albedo': {cb['shadings']['albedo']['s_per_iter_median']:.2f} s; {cb['seconds']:.0f} s of CPU work in total",
                 "rays_per_s": {k: round(v["rays_per_s"], 1) for k, v in cb["shadings"].items()}}
         except Exception as exc:  # noqa: BLE001
-            result["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port -O2",
+            result["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "restated (-O2 port, golden-pinned)",
                                       "sample": f"failed: {type(exc).__name__}: {exc}"}
     print(json.dumps(result))
     if dist is not None:
