@@ -531,6 +531,22 @@ int sdfx_antialias_backward(const float* color, const float* rast, const float* 
                             uint32_t N, uint32_t C, uint32_t H, uint32_t W, const float* grad_out, float* grad_color, float* grad_pos,
                             sdfx_stream_t stream);
 
+/* ---------------------------------------------------------------- frozen prior: GroupNorm + SiLU (extension) */
+
+/*
+ * Extension (no reference kernel: the reference gets these layers from diffusers, guidance/sd_utils.py:37-65) —
+ * y = act(GroupNorm_G(x) * gamma + beta) on fp16 CHANNELS-LAST activations x[N, HW, C] (NHWC memory), act = SiLU when
+ * `silu` != 0 else identity, and its input gradient; gamma / beta fp16, frozen (no parameter gradients). Statistics in
+ * float32 / double, combined in a fixed order (bit-reproducible). Needs C % 8 == 0, C % G == 0, C <= 2560, G <= 64.
+ * mean_rstd[N, G, 2] float32 receives what the backward needs (NULL when no backward will follow).
+ * scratch: sdfx_group_norm_scratch_bytes(N, HW, C, G) bytes of float32, uninitialised.
+ */
+uint64_t sdfx_group_norm_scratch_bytes(uint32_t N, uint32_t HW, uint32_t C, uint32_t G);
+int sdfx_group_norm_forward(const void* x, const void* gamma, const void* beta, uint32_t N, uint32_t HW, uint32_t C, uint32_t G, float eps,
+                            int silu, void* y, float* mean_rstd, float* scratch, sdfx_stream_t stream);
+int sdfx_group_norm_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean_rstd, uint32_t N,
+                             uint32_t HW, uint32_t C, uint32_t G, int silu, void* dx, float* scratch, sdfx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,9 @@ _SIGNATURES = {
     "sdfx_interpolate_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr],
     "sdfx_antialias_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _ptr, _ptr],
     "sdfx_antialias_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_group_norm_scratch_bytes": [_u32, _u32, _u32, _u32],
+    "sdfx_group_norm_forward": [_ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _int, _ptr, _ptr, _ptr, _ptr],
+    "sdfx_group_norm_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _int, _ptr, _ptr, _ptr],
     "sdfx_adan_ctl_words": [],
     "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],
     "sdfx_adan_prepare": [_ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _u32, _ptr],
@@ -114,6 +117,7 @@ _RESTYPES = {
     "sdfx_rasterize_scratch_bytes": _u64,
     "sdfx_field_packed_words": _u32,
     "sdfx_field_backward_scratch_bytes": _u64,
+    "sdfx_group_norm_scratch_bytes": _u64,
     "sdfx_adan_ctl_words": _u32,
 }
 

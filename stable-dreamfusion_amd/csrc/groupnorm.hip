@@ -1,0 +1,332 @@
+// groupnorm.hip — GroupNorm (+ SiLU) on channels-last fp16 activations, forward and input-gradient, for the frozen prior.
+//
+// What it replaces: `F.silu(nn.GroupNorm(32, C)(x))` inside the SD-1.5 UNet / VAE-encoder restatement (sdfx_nerf/sd15_arch.py;
+// the reference gets the same layers from diffusers, guidance/sd_utils.py:37-65). With channels-last activations — what MIOpen's
+// NHWC implicit-GEMM convolutions want — stock PyTorch-ROCm runs one GroupNorm as: copy to NCHW, RowwiseMoments (one workgroup
+// per (sample, group): 32 or 64 workgroups on 256 CUs; 244 us on a 512^2 x 128 map), ComputeFusedParams, the normalising
+// elementwise kernel, SiLU, and a transpose back for the next convolution — 61 times per UNet evaluation, 22 + 22 times per VAE
+// encode + backward: ~25 % of the GPU time of an SDS iteration in round 3's kernel trace (profiles/r03_bench_kernel_stats_sd15.csv).
+// Here it is two streaming kernels each way that stay in NHWC:
+//   forward   k_gn_stats   per (sample, pixel slab): per-group sum and sum of squares, float32, written as partials (no atomics:
+//                          the combination order is fixed, the result bit-reproducible)
+//             k_gn_finalize  combines the partials in double: mean / rstd per (sample, group)
+//             k_gn_apply   y = silu(x * a_c + b_c) with the fused parameters a_c = rstd_g gamma_c, b_c = beta_c - mean_g a_c
+//                          (PyTorch's ComputeFusedParams form), 16-byte loads / stores
+//   backward  k_gn_bwd_stats / k_gn_finalize / k_gn_bwd_apply   dx = rstd (dxh - mean_g(dxh) - xh mean_g(dxh xh)), dxh = dy silu'(z) gamma,
+//             z recomputed from x (nothing but x and the 2 x 32 statistics is kept from the forward). The prior is frozen:
+//             no gamma / beta gradients.
+// Every thread owns 8 consecutive channels (one 16-byte vector) of the pixels it walks, so its per-channel parameters live in
+// registers. HBM-bound: 2 reads + 1 write of the map forward, 4 reads + 1 write backward.
+#include "sdfx_common.h"
+
+using namespace sdfx;
+
+namespace {
+
+constexpr uint32_t kMaxGroups = 64;
+constexpr uint32_t kMaxThreads = 320;        // C / 8 <= 320 vectors per pixel (C <= 2560: the widest concatenation of the UNet)
+constexpr uint32_t kMaxSlabs = 1024;         // pixel slabs (workgroups) per sample
+
+struct GnShape {
+    uint32_t N, HW, C, G;
+    uint32_t cpg;        // channels per group
+    uint32_t cvs;        // 16-byte vectors per pixel (C / 8)
+    uint32_t ppi;        // pixels a workgroup covers per iteration
+    uint32_t threads;    // ppi * cvs rounded up to whole waves
+    uint32_t slabs;      // workgroups per sample
+    uint32_t P;          // pixels per slab (a multiple of ppi)
+};
+
+bool make_shape(uint32_t N, uint32_t HW, uint32_t C, uint32_t G, GnShape& s) {
+    if (N == 0 || HW == 0 || C == 0 || G == 0 || G > kMaxGroups || C % G || C % 8 || C / 8 > kMaxThreads) return false;
+    s.N = N; s.HW = HW; s.C = C; s.G = G;
+    s.cpg = C / G;
+    s.cvs = C / 8;
+    s.ppi = s.cvs >= 256 ? 1u : 256u / s.cvs;
+    s.threads = ((s.ppi * s.cvs + 63u) / 64u) * 64u;
+    // >= 64 KiB of the map per workgroup, <= kMaxSlabs slabs per sample, whole iterations
+    uint64_t slabs = ((uint64_t)HW * C + 32767u) / 32768u;
+    if (slabs < 1) slabs = 1;
+    if (slabs > kMaxSlabs) slabs = kMaxSlabs;
+    uint32_t P = (uint32_t)((HW + slabs - 1) / slabs);
+    P = ((P + s.ppi - 1) / s.ppi) * s.ppi;
+    s.P = P;
+    s.slabs = (HW + P - 1) / P;
+    return true;
+}
+
+struct h8v { uint4 w; };
+__device__ __forceinline__ void unpack8(const uint4& w, float (&f)[8]) {
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const __half2 h = *reinterpret_cast<const __half2*>(&u[i]);
+        f[2 * i] = __low2float(h);
+        f[2 * i + 1] = __high2float(h);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint32_t u[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const __half2 h = __floats2half2_rn(f[2 * i], f[2 * i + 1]);
+        u[i] = *reinterpret_cast<const uint32_t*>(&h);
+    }
+    return make_uint4(u[0], u[1], u[2], u[3]);
+}
+__device__ __forceinline__ float sigmoid_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// this thread's place: pixel offset pp within an iteration, vector cv of the pixel; false for the idle tail of the last wave
+__device__ __forceinline__ bool my_place(const GnShape& s, uint32_t& pp, uint32_t& cv) {
+    pp = threadIdx.x / s.cvs;
+    cv = threadIdx.x - pp * s.cvs;
+    return threadIdx.x < s.ppi * s.cvs;
+}
+
+// per-group sums of two per-channel quantities over the workgroup: part = LDS [2][ppi][C]; result to out[g * 2 + which]
+__device__ __forceinline__ void reduce_to_groups(const GnShape& s, float* part, const float (&a)[8], const float (&b)[8], bool active,
+                                                 uint32_t pp, uint32_t cv, float* __restrict__ out) {
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            part[(size_t)pp * s.C + cv * 8 + i] = a[i];
+            part[(size_t)(s.ppi + pp) * s.C + cv * 8 + i] = b[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * s.G) {
+        const uint32_t g = threadIdx.x >> 1, which = threadIdx.x & 1u;
+        float acc = 0.f;
+        for (uint32_t p = 0; p < s.ppi; p++) {
+            const float* row = part + (size_t)(which * s.ppi + p) * s.C + g * s.cpg;
+            for (uint32_t c = 0; c < s.cpg; c++) acc += row[c];
+        }
+        out[g * 2 + which] = acc;
+    }
+}
+
+// ---- forward ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kMaxThreads) void k_gn_stats(const __half* __restrict__ x, GnShape s, float* __restrict__ partial) {
+    extern __shared__ float part[];
+    const uint32_t n = blockIdx.x / s.slabs, slab = blockIdx.x - n * s.slabs;
+    uint32_t pp, cv;
+    const bool active = my_place(s, pp, cv);
+    float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
+        const uint4* base = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
+        for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
+            float f[8];
+            unpack8(base[(size_t)p * s.cvs], f);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { sum[i] += f[i]; sq[i] += f[i] * f[i]; }
+        }
+    }
+    reduce_to_groups(s, part, sum, sq, active, pp, cv, partial + ((size_t)n * s.slabs + slab) * s.G * 2);
+}
+
+// One workgroup per sample: the slab partials of every group combined in a fixed order, in double. mode 0 (forward):
+// (E[x], E[x^2]) -> (mean, rstd); mode 1 (backward): the two means as they are.
+constexpr uint32_t kFinalizeSplit = 8;
+__global__ __launch_bounds__(2 * kMaxGroups * kFinalizeSplit) void k_gn_finalize(const float* __restrict__ partial, GnShape s, float eps, int mode,
+                                                                                float* __restrict__ out) {
+    __shared__ double acc[2 * kMaxGroups * kFinalizeSplit];
+    const uint32_t n = blockIdx.x, k = threadIdx.x / kFinalizeSplit, j = threadIdx.x % kFinalizeSplit;   // k = g * 2 + which
+    if (k < 2 * s.G) {
+        const float* p = partial + (size_t)n * s.slabs * s.G * 2 + k;
+        double a = 0.0;
+        for (uint32_t w = j; w < s.slabs; w += kFinalizeSplit) a += (double)p[(size_t)w * s.G * 2];
+        acc[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (k < 2 * s.G && j == 0 && (k & 1u) == 0) {   // one thread per group
+        double e0 = 0.0, e1 = 0.0;
+        for (uint32_t i = 0; i < kFinalizeSplit; i++) { e0 += acc[k * kFinalizeSplit + i]; e1 += acc[(k + 1) * kFinalizeSplit + i]; }
+        const double cnt = (double)s.HW * s.cpg;
+        e0 /= cnt; e1 /= cnt;
+        float* o = out + ((size_t)n * s.G + (k >> 1)) * 2;
+        if (mode == 0) {
+            double var = e1 - e0 * e0;
+            var = var > 0.0 ? var : 0.0;
+            o[0] = (float)e0;
+            o[1] = (float)(1.0 / sqrt(var + (double)eps));
+        } else {
+            o[0] = (float)e0;
+            o[1] = (float)e1;
+        }
+    }
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(kMaxThreads) void k_gn_apply(const __half* __restrict__ x, GnShape s, const float* __restrict__ mean_rstd,
+                                                           const __half* __restrict__ gamma, const __half* __restrict__ beta,
+                                                           __half* __restrict__ y) {
+    const uint32_t n = blockIdx.x / s.slabs, slab = blockIdx.x - n * s.slabs;
+    uint32_t pp, cv;
+    if (!my_place(s, pp, cv)) return;
+    float a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t c = cv * 8 + i, g = c / s.cpg;
+        a[i] = mean_rstd[((size_t)n * s.G + g) * 2 + 1] * __half2float(gamma[c]);
+        b[i] = __half2float(beta[c]) - mean_rstd[((size_t)n * s.G + g) * 2] * a[i];
+    }
+    const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
+    const uint4* src = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
+    uint4* dst = reinterpret_cast<uint4*>(y + (size_t)n * s.HW * s.C) + cv;
+    for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
+        float f[8];
+        unpack8(src[(size_t)p * s.cvs], f);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float z = f[i] * a[i] + b[i];
+            f[i] = ACT ? z * sigmoid_(z) : z;
+        }
+        dst[(size_t)p * s.cvs] = pack8(f);
+    }
+}
+
+// ---- backward (input gradient only) -----------------------------------------------------------
+// per element: xh = (x - mean) rstd, z = xh gamma + beta, dz = dy silu'(z) (or dy), dxh = dz gamma
+template <bool ACT>
+__device__ __forceinline__ void elem_bwd(float x, float dy, float mean, float rstd, float gamma, float beta, float& xh, float& dxh) {
+    xh = (x - mean) * rstd;
+    float dz = dy;
+    if (ACT) {
+        const float z = xh * gamma + beta, sg = sigmoid_(z);
+        dz = dy * sg * (1.0f + z * (1.0f - sg));
+    }
+    dxh = dz * gamma;
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_stats(const __half* __restrict__ x, const __half* __restrict__ dy, GnShape s,
+                                                               const float* __restrict__ mean_rstd, const __half* __restrict__ gamma,
+                                                               const __half* __restrict__ beta, float* __restrict__ partial) {
+    extern __shared__ float part[];
+    const uint32_t n = blockIdx.x / s.slabs, slab = blockIdx.x - n * s.slabs;
+    uint32_t pp, cv;
+    const bool active = my_place(s, pp, cv);
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        float mean[8], rstd[8], ga[8], be[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t c = cv * 8 + i, g = c / s.cpg;
+            mean[i] = mean_rstd[((size_t)n * s.G + g) * 2]; rstd[i] = mean_rstd[((size_t)n * s.G + g) * 2 + 1];
+            ga[i] = __half2float(gamma[c]); be[i] = __half2float(beta[c]);
+        }
+        const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
+        const uint4* xs = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
+        const uint4* ds = reinterpret_cast<const uint4*>(dy + (size_t)n * s.HW * s.C) + cv;
+        for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
+            float fx[8], fd[8];
+            unpack8(xs[(size_t)p * s.cvs], fx);
+            unpack8(ds[(size_t)p * s.cvs], fd);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float xh, dxh;
+                elem_bwd<ACT>(fx[i], fd[i], mean[i], rstd[i], ga[i], be[i], xh, dxh);
+                s1[i] += dxh; s2[i] += dxh * xh;
+            }
+        }
+    }
+    reduce_to_groups(s, part, s1, s2, active, pp, cv, partial + ((size_t)n * s.slabs + slab) * s.G * 2);
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_apply(const __half* __restrict__ x, const __half* __restrict__ dy, GnShape s,
+                                                               const float* __restrict__ mean_rstd, const float* __restrict__ mom,
+                                                               const __half* __restrict__ gamma, const __half* __restrict__ beta,
+                                                               __half* __restrict__ dx) {
+    // mom[n][g][0] = mean(dxh), [1] = mean(dxh xh) over the group
+    const uint32_t n = blockIdx.x / s.slabs, slab = blockIdx.x - n * s.slabs;
+    uint32_t pp, cv;
+    if (!my_place(s, pp, cv)) return;
+    float mean[8], rstd[8], ga[8], be[8], m1[8], m2[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t c = cv * 8 + i, g = c / s.cpg;
+        mean[i] = mean_rstd[((size_t)n * s.G + g) * 2]; rstd[i] = mean_rstd[((size_t)n * s.G + g) * 2 + 1];
+        ga[i] = __half2float(gamma[c]); be[i] = __half2float(beta[c]);
+        m1[i] = mom[((size_t)n * s.G + g) * 2]; m2[i] = mom[((size_t)n * s.G + g) * 2 + 1];
+    }
+    const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
+    const uint4* xs = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
+    const uint4* ds = reinterpret_cast<const uint4*>(dy + (size_t)n * s.HW * s.C) + cv;
+    uint4* dst = reinterpret_cast<uint4*>(dx + (size_t)n * s.HW * s.C) + cv;
+    for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
+        float fx[8], fd[8];
+        unpack8(xs[(size_t)p * s.cvs], fx);
+        unpack8(ds[(size_t)p * s.cvs], fd);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float xh, dxh;
+            elem_bwd<ACT>(fx[i], fd[i], mean[i], rstd[i], ga[i], be[i], xh, dxh);
+            fx[i] = rstd[i] * (dxh - m1[i] - xh * m2[i]);
+        }
+        dst[(size_t)p * s.cvs] = pack8(fx);
+    }
+}
+
+uint32_t stats_lds_bytes(const GnShape& s) { return 2u * s.ppi * s.C * (uint32_t)sizeof(float); }
+
+}  // namespace
+
+extern "C" {
+
+// bytes of float32 scratch for one call: the per-slab partial sums, then one [N, G, 2] block of combined moments
+uint64_t sdfx_group_norm_scratch_bytes(uint32_t N, uint32_t HW, uint32_t C, uint32_t G) {
+    GnShape s;
+    if (!make_shape(N, HW, C, G, s)) return 0;
+    return ((uint64_t)N * s.slabs * G * 2 + (uint64_t)N * G * 2) * sizeof(float);
+}
+
+// y[N, HW, C] = act(GroupNorm_G(x[N, HW, C]) * gamma + beta), fp16 channels-last, act = SiLU when `silu` else identity;
+// mean_rstd[N, G, 2] (float32) receives the statistics the backward needs (may be NULL)
+int sdfx_group_norm_forward(const void* x, const void* gamma, const void* beta, uint32_t N, uint32_t HW, uint32_t C, uint32_t G, float eps,
+                            int silu, void* y, float* mean_rstd, float* scratch, sdfx_stream_t stream) {
+    SDFX_REQUIRE(x && gamma && beta && y && scratch, "group_norm_forward: null pointer");
+    GnShape s;
+    SDFX_REQUIRE(make_shape(N, HW, C, G, s), "group_norm_forward: needs C %% 8 == 0, C %% G == 0, C <= %u, G <= %u (got N=%u HW=%u C=%u G=%u)",
+                 kMaxThreads * 8, kMaxGroups, N, HW, C, G);
+    SDFX_REQUIRE((reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0, "group_norm_forward: x / y misaligned");
+    hipStream_t st = as_stream(stream);
+    const __half* xp = static_cast<const __half*>(x);
+    float* mr = mean_rstd ? mean_rstd : scratch + (size_t)N * s.slabs * G * 2;
+    hipLaunchKernelGGL(k_gn_stats, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, s, scratch);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(N), dim3(2 * G * kFinalizeSplit), 0, st, scratch, s, eps, 0, mr);
+    if (silu)
+        hipLaunchKernelGGL(k_gn_apply<true>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, s, mr, static_cast<const __half*>(gamma),
+                           static_cast<const __half*>(beta), static_cast<__half*>(y));
+    else
+        hipLaunchKernelGGL(k_gn_apply<false>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, s, mr, static_cast<const __half*>(gamma),
+                           static_cast<const __half*>(beta), static_cast<__half*>(y));
+    return check_launch("group_norm_forward");
+}
+
+// dx[N, HW, C] of the same op from x, dy and the forward's mean_rstd (gamma / beta are frozen: no parameter gradients)
+int sdfx_group_norm_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean_rstd, uint32_t N,
+                             uint32_t HW, uint32_t C, uint32_t G, int silu, void* dx, float* scratch, sdfx_stream_t stream) {
+    SDFX_REQUIRE(x && dy && gamma && beta && mean_rstd && dx && scratch, "group_norm_backward: null pointer");
+    GnShape s;
+    SDFX_REQUIRE(make_shape(N, HW, C, G, s), "group_norm_backward: needs C %% 8 == 0, C %% G == 0, C <= %u, G <= %u", kMaxThreads * 8, kMaxGroups);
+    SDFX_REQUIRE((reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(dy) % 16) == 0 &&
+                     (reinterpret_cast<uintptr_t>(dx) % 16) == 0, "group_norm_backward: x / dy / dx misaligned");
+    hipStream_t st = as_stream(stream);
+    const __half *xp = static_cast<const __half*>(x), *dp = static_cast<const __half*>(dy);
+    const __half *gp = static_cast<const __half*>(gamma), *bp = static_cast<const __half*>(beta);
+    float* mom = scratch + (size_t)N * s.slabs * G * 2;
+    if (silu)
+        hipLaunchKernelGGL(k_gn_bwd_stats<true>, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, dp, s, mean_rstd, gp, bp, scratch);
+    else
+        hipLaunchKernelGGL(k_gn_bwd_stats<false>, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, dp, s, mean_rstd, gp, bp, scratch);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(N), dim3(2 * G * kFinalizeSplit), 0, st, scratch, s, 0.f, 1, mom);
+    if (silu)
+        hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, dp, s, mean_rstd, mom, gp, bp, static_cast<__half*>(dx));
+    else
+        hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, dp, s, mean_rstd, mom, gp, bp, static_cast<__half*>(dx));
+    return check_launch("group_norm_backward");
+}
+
+}  // extern "C"

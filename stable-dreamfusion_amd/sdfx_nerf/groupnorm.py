@@ -1,0 +1,83 @@
+"""GroupNorm (+ SiLU) of the frozen prior on channels-last fp16 activations: csrc/groupnorm.hip behind an `nn.GroupNorm`.
+
+`GroupNormAct(32, C, act=True)(x)` == `F.silu(F.group_norm(x, 32, weight, bias, eps))`. On a CUDA fp16 tensor in channels-last
+memory format, with frozen affine parameters, the forward and the input gradient are the two-pass NHWC kernels of
+csrc/groupnorm.hip (the output stays channels-last, which is what MIOpen's NHWC convolutions take without a transpose);
+everything else (CPU, float32, NCHW-contiguous inputs, trainable parameters, shapes the kernels do not take) goes through
+PyTorch's own ops, so the module is a drop-in `nn.GroupNorm` (same parameters, same state_dict keys).
+SDFX_GROUPNORM=0 forces the PyTorch ops everywhere (A/B switch)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_FUSED = int(os.environ.get("SDFX_GROUPNORM", "1"))
+_SCRATCH = {}   # device index -> float32 scratch, grown on demand (partials of ONE call; every call rewrites what it reads)
+
+
+def _scratch(device, nbytes):
+    buf = _SCRATCH.get(device.index)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _SCRATCH[device.index] = buf
+    return buf
+
+
+class _GroupNormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, act):
+        import _sdfx as S
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)                                    # preserves the channels-last strides
+        need_bwd = ctx.needs_input_grad[0]                         # (grad mode is off inside forward(): ask the context)
+        mean_rstd = torch.empty(N, groups, 2, dtype=torch.float32, device=x.device) if need_bwd else None
+        nbytes = int(S.lib().sdfx_group_norm_scratch_bytes(N, H * W, C, groups))
+        S.call("sdfx_group_norm_forward", S.ptr(x), S.ptr(weight), S.ptr(bias), N, H * W, C, groups, float(eps), int(act), S.ptr(y),
+               S.ptr(mean_rstd), S.ptr(_scratch(x.device, nbytes)), S.stream())
+        if need_bwd:
+            ctx.save_for_backward(x, weight, bias, mean_rstd)
+            ctx.groups, ctx.act = groups, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import _sdfx as S
+        x, weight, bias, mean_rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.to(torch.float16).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        nbytes = int(S.lib().sdfx_group_norm_scratch_bytes(N, H * W, C, ctx.groups))
+        S.call("sdfx_group_norm_backward", S.ptr(x), S.ptr(dy), S.ptr(weight), S.ptr(bias), S.ptr(mean_rstd), N, H * W, C, ctx.groups,
+               int(ctx.act), S.ptr(dx), S.ptr(_scratch(x.device, nbytes)), S.stream())
+        return dx, None, None, None, None, None
+
+
+def fused_ok(x, weight, bias, groups) -> bool:
+    """The conditions under which csrc/groupnorm.hip takes the call (see the module docstring)."""
+    if not (_FUSED and x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and weight is not None and bias is not None):
+        return False
+    if weight.requires_grad or bias.requires_grad or weight.dtype != torch.float16 or bias.dtype != torch.float16:
+        return False
+    N, C, H, W = x.shape
+    if N == 0 or H * W == 0 or C % 8 or C % groups or C > 2560 or groups > 64:
+        return False
+    # dense NHWC memory (a [N, C, 1, 1] tensor is both contiguous and channels-last: either way its memory is [N, HW, C])
+    return x.is_contiguous(memory_format=torch.channels_last)
+
+
+class GroupNormAct(nn.GroupNorm):
+    """`nn.GroupNorm` followed by SiLU when `act` (the pair the ResNet blocks of the SD-1.5 UNet / VAE apply), fused on the
+    channels-last fp16 path."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5, act=False):
+        super().__init__(num_groups, num_channels, eps=eps, affine=True)
+        self.act = bool(act)
+
+    def forward(self, x):
+        if fused_ok(x, self.weight, self.bias, self.num_groups):
+            return _GroupNormActFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.act)
+        y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+        return F.silu(y) if self.act else y

@@ -22,25 +22,28 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import guidance as G
+from .groupnorm import GroupNormAct
 
 
-def _gn(c):
-    return nn.GroupNorm(32, c, eps=1e-5)
+def _gn(c, act=False):
+    """GroupNorm(32, c), followed by SiLU when `act`: an `nn.GroupNorm` whose channels-last fp16 path is csrc/groupnorm.hip
+    (sdfx_nerf/groupnorm.py); identical parameters and state_dict keys."""
+    return GroupNormAct(32, c, eps=1e-5, act=act)
 
 
 class ResBlock(nn.Module):
     def __init__(self, cin, cout, temb=None):
         super().__init__()
-        self.norm1, self.conv1 = _gn(cin), nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm1, self.conv1 = _gn(cin, act=True), nn.Conv2d(cin, cout, 3, padding=1)
         self.temb = nn.Linear(temb, cout) if temb else None
-        self.norm2, self.conv2 = _gn(cout), nn.Conv2d(cout, cout, 3, padding=1)
+        self.norm2, self.conv2 = _gn(cout, act=True), nn.Conv2d(cout, cout, 3, padding=1)
         self.skip = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, emb=None):
-        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv1(self.norm1(x))                       # norm1 / norm2 include the SiLU
         if self.temb is not None:
             h = h + self.temb(F.silu(emb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = self.conv2(self.norm2(h))
         return (x if self.skip is None else self.skip(x)) + h
 
 
@@ -109,7 +112,7 @@ class UNetSD15(nn.Module):
                                               TransformerBlock(co, ctx_dim, heads) if attn else None,
                                               nn.Conv2d(co, co, 3, padding=1) if (k == res_per_level and lvl > 0) else None]))
                 c = co
-        self.norm_out, self.conv_out = _gn(c), nn.Conv2d(c, out_ch, 3, padding=1)
+        self.norm_out, self.conv_out = _gn(c, act=True), nn.Conv2d(c, out_ch, 3, padding=1)
 
     def time_embedding(self, t):
         half = self.base // 2
@@ -139,7 +142,7 @@ class UNetSD15(nn.Module):
                 h = attn(h, ctx)
             if upconv is not None:
                 h = upconv(F.interpolate(h, scale_factor=2.0, mode="nearest"))
-        return self.conv_out(F.silu(self.norm_out(h)))
+        return self.conv_out(self.norm_out(h))
 
 
 class VAEEncoderSD15(nn.Module):
@@ -159,7 +162,7 @@ class VAEEncoderSD15(nn.Module):
                 blocks.append(nn.Conv2d(c, c, 3, stride=2, padding=0))   # asymmetric pad (0, 1, 0, 1) applied in forward
         self.blocks = nn.ModuleList(blocks)
         self.mid1, self.mid_norm, self.mid_attn, self.mid2 = ResBlock(c, c), _gn(c), Attention(c, None, heads=1), ResBlock(c, c)
-        self.norm_out, self.conv_out, self.quant = _gn(c), nn.Conv2d(c, 2 * z, 3, padding=1), nn.Conv2d(2 * z, 2 * z, 1)
+        self.norm_out, self.conv_out, self.quant = _gn(c, act=True), nn.Conv2d(c, 2 * z, 3, padding=1), nn.Conv2d(2 * z, 2 * z, 1)
         self.z = z
 
     def encode_sample(self, x):
@@ -170,7 +173,7 @@ class VAEEncoderSD15(nn.Module):
         B, C, H, W = h.shape
         h = h + self.mid_attn(self.mid_norm(h).flatten(2).transpose(1, 2)).transpose(1, 2).reshape(B, C, H, W)
         h = self.mid2(h)
-        moments = self.quant(self.conv_out(F.silu(self.norm_out(h))))
+        moments = self.quant(self.conv_out(self.norm_out(h)))
         return moments[:, :self.z]
 
 

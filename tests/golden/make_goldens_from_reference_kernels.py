@@ -154,5 +154,7 @@ for deg in (4, 8):
     enc[f"sh{deg}_out"] = so.cpu().numpy(); enc[f"sh{deg}_dy"] = sdy.cpu().numpy()[:512]
     enc[f"sh{deg}_grad"] = gs_; enc[f"sh{deg}_grad_inputs"] = sgi.cpu().numpy()
 enc["sh_x"] = xn
+# per-point arrays: the kernels ran on 4097 points (a ragged last block), the first 1024 rows are kept
+enc = {k: (v[:1024] if (k.startswith(("freq_", "sh")) and v.shape[0] == 4097) else v) for k, v in enc.items()}
 np.savez_compressed(os.path.join(OUT, "refk_encoders.npz"), **enc)
 print("refk_encoders.npz", {k: v.shape for k, v in enc.items()})

@@ -22,7 +22,8 @@ def test_library_is_the_hip_build(dev):
     info = _sdfx.lib().sdfx_build_info().decode()
     assert "gfx950" in info
     maps = open("/proc/self/maps").read()
-    assert "libsdfx_hip.so" in maps
+    assert os.path.basename(_sdfx.LIB_PATH) in maps and os.path.basename(_sdfx.LIB_PATH).startswith("libsdfx_hip")
+    assert ("+devtools" in info) == _sdfx.is_devtools()      # the product library has no implementation switches
 
 
 def test_workgroups_are_dealt_to_the_xcds_round_robin(dev):

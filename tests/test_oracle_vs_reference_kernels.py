@@ -75,3 +75,52 @@ def test_grid_encoder_matches_reference_kernel_outputs(oracle):
     assert int(gt.any(axis=1).sum()) == int(g["grad_touched"][0])                       # same set of table rows touched
     got = gt[g["grad_rows"]]
     assert np.abs(got - g["grad_vals"]).max() <= 1e-5 * np.abs(g["grad_vals"]).max()    # atomic order on the GPU side
+
+
+# ---- round 4: rows a6 / a13 / a14 — tv, weight decay, frequency and SH encoders (tests/golden/refk_encoders.npz) ----
+def _enc_gold():
+    return np.load(os.path.join(G, "refk_encoders.npz"))
+
+
+def _tv_setup(oracle):
+    offs8, pls8 = oracle.grid_offsets(num_levels=8, log2_hashmap_size=15, desired_resolution=512)
+    tab8 = synth.s_table(int(offs8[-1]), 2, "trained", np.float32)
+    g0 = np.random.default_rng(2).normal(size=tab8.shape).astype(np.float32)
+    return offs8, pls8, tab8, g0
+
+
+def test_total_variation_and_weight_decay_match_reference_kernel_outputs(oracle):
+    """gridencoder.cu:525-713 run on the MI355X against the C restatement: weight decay bit for bit (one fused expression per
+    entry), total variation to float32 atomic-order accuracy."""
+    gold = _enc_gold()
+    offs8, pls8, tab8, g0 = _tv_setup(oracle)
+    g = g0.copy()
+    oracle.grad_weight_decay(tab8, g, offs8, 0.1)
+    assert np.array_equal(g[:20000], gold["wd_head"])
+    assert int(g.view(np.uint32).astype(np.uint64).sum()) == int(gold["wd_checksum"][0])
+    xtv = synth.s_points_uniform(5000, seed=40)
+    for gridtype, align, tag in ((0, False, "hash"), (1, True, "tiled_align")):
+        g = g0.copy()
+        oracle.grad_total_variation(xtv, tab8, g, offs8, 1e-3, pls8, 16, gridtype, align)
+        rows = gold[f"tv_{tag}_rows"]
+        touched = np.nonzero((g - g0).any(axis=1))[0]
+        assert np.array_equal(touched, rows), tag
+        want = gold[f"tv_{tag}_vals"]
+        assert np.abs(g[rows] - want).max() <= 1e-5 * np.abs(want).max(), tag
+
+
+def test_frequency_and_sh_encoders_match_reference_kernel_outputs(oracle):
+    """freqencoder.cu:30-94 and shencoder.cu:27-382 run on the MI355X (-ffp-contract=off) against the C restatement."""
+    gold = _enc_gold()
+    x = gold["freq_x"]
+    out = oracle.freq_encode_forward(x, 6)
+    assert np.abs(out - gold["freq_out"]).max() <= 2e-5          # the reference uses the fast __sinf / __cosf intrinsics
+    gi = oracle.freq_encode_backward(gold["freq_grad"], gold["freq_out"], 3, 6)
+    assert np.abs(gi - gold["freq_grad_inputs"]).max() <= 1e-4 * np.abs(gold["freq_grad_inputs"]).max()
+    xn = gold["sh_x"]
+    for deg in (4, 8):
+        o, dy = oracle.sh_encode_forward(xn, deg, True)
+        assert np.abs(o - gold[f"sh{deg}_out"]).max() <= 2e-5
+        assert np.abs(dy[:512] - gold[f"sh{deg}_dy"]).max() <= 2e-4
+        gi = oracle.sh_encode_backward(gold[f"sh{deg}_grad"], xn, deg, dy)
+        assert np.abs(gi - gold[f"sh{deg}_grad_inputs"]).max() <= 1e-4 * np.abs(gold[f"sh{deg}_grad_inputs"]).max()

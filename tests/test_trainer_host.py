@@ -321,3 +321,23 @@ def test_train_step_schedule_and_loss_reproduce_the_reference_trainer(mods):
         assert seen["guidance_scale"] == opt.guidance_scale and seen["grad_scale"] == opt.lambda_guidance
         ref = float(g[f"c{ci}_loss"])
         assert abs(float(loss) - ref) <= 1e-5 * abs(ref), (ci, float(loss), ref)
+
+
+def test_group_norm_act_module_is_a_drop_in_group_norm_off_the_fused_path():
+    """sdfx_nerf/groupnorm.GroupNormAct on CPU / float32 / NCHW inputs is nn.GroupNorm (+ SiLU): same parameters, same
+    state_dict keys, same numbers — the HIP kernels take only channels-last fp16 CUDA tensors with frozen parameters."""
+    import torch
+    import torch.nn.functional as F
+    from sdfx_nerf.groupnorm import GroupNormAct, fused_ok
+    torch.manual_seed(0)
+    ref = torch.nn.GroupNorm(32, 64, eps=1e-5)
+    with torch.no_grad():
+        ref.weight.normal_(); ref.bias.normal_()
+    x = torch.randn(2, 64, 5, 7)
+    for act in (False, True):
+        m = GroupNormAct(32, 64, eps=1e-5, act=act)
+        m.load_state_dict(ref.state_dict())
+        assert set(m.state_dict()) == set(ref.state_dict())
+        assert not fused_ok(x, m.weight, m.bias, 32)
+        want = F.silu(ref(x)) if act else ref(x)
+        assert torch.equal(m(x), want)
