@@ -163,6 +163,9 @@ def install_timers(timer):
     # the operator packages bound `_backend` at import time to the module objects, so they see the wrappers
 
 
+GATHER_PEAK_GBPS = 32500.0   # 128-byte lines per second the 256 CUs look up at best, x 128 B (profiles/r02_gather_policy.txt: 32-33 TB/s)
+
+
 def event_time_ms(fn, iters=20, warmup=3):
     for _ in range(warmup):
         fn()
@@ -224,16 +227,39 @@ def kernel_microbench(dev):
         sg, cg = to(sig).requires_grad_(), to(rgb).requires_grad_()
         fwd = lambda: raymarching.composite_rays_train(sg, cg, ts, rays, 1e-4, False)
         ms = event_time_ms(lambda: fwd(), iters=20)
-        out[f"composite_fwd_{gname}"] = {"ms": ms, "M": M, "Mrays_per_s": 4096 / ms / 1e3,
-                                         "GBps": (M * 28 + 4096 * 28) / ms / 1e6}
-        w, ws, dep, img = fwd()
-        gw, gws, gd, gi = torch.randn_like(w), torch.randn_like(ws), torch.randn_like(dep), torch.randn_like(img)
+        w, ws, dep, img = (t.detach() for t in fwd())
+        # Early termination (T < 1e-4, raymarching.cu:559-561) skips the tail of a ray: a throughput formed with ALL M samples
+        # overstates the bytes moved (round 3 printed 5 TB/s for the backward on the `full` grid). Samples a ray actually walks
+        # = those with a non-zero weight, plus at most the one that trips the threshold.
+        M_proc = min(int((w != 0).sum().item()) + 4096, M)
         import _raymarching
+        gw, gws, gd, gi = torch.randn_like(w), torch.randn_like(ws), torch.randn_like(dep), torch.randn_like(img)
         gs, gc = torch.zeros_like(sg), torch.zeros_like(cg)
-        ms = event_time_ms(lambda: _raymarching.composite_rays_train_backward(gw, gws, gd, gi, sg.detach(), cg.detach(), ts, rays,
-                                                                              ws, dep, img, M, 4096, 1e-4, False, gs, gc), iters=20)
-        out[f"composite_bwd_{gname}"] = {"ms": ms, "M": M, "Mrays_per_s": 4096 / ms / 1e3,
-                                         "GBps": (M * 44 + 4096 * 48) / ms / 1e6}
+        bwd = lambda s_=sg.detach(), c_=cg.detach(), t_=ts: _raymarching.composite_rays_train_backward(
+            gw, gws, gd, gi, s_, c_, t_, rays, ws, dep, img, M, 4096, 1e-4, False, gs, gc)
+        ms_b = event_time_ms(bwd, iters=20)
+        # The same kernels on COLD inputs: in the iteration sigma / albedo were just written by the field kernel on other XCDs
+        # (through HBM: the XCDs' L2s are not coherent), whereas a launch loop over one set of inputs reads them from its own L2.
+        # Rotating over input copies that together exceed L2 + the 256 MB memory-side cache reproduces the in-step condition.
+        copies = max(2, int(320e6 // max(M * (4 + 12 + 8), 1)) + 1)
+        sets = [(sg.detach().clone(), cg.detach().clone(), ts.clone()) for _ in range(copies)]
+        k = [0]
+
+        def fwd_cold():
+            a, b, c = sets[k[0] % copies]; k[0] += 1
+            _raymarching.composite_rays_train_forward(a, b, c, rays, M, 4096, 1e-4, False, w, ws, dep, img)
+
+        def bwd_cold():
+            a, b, c = sets[k[0] % copies]; k[0] += 1
+            bwd(a, b, c)
+        ms_cold = event_time_ms(fwd_cold, iters=2 * copies, warmup=copies)
+        ms_b_cold = event_time_ms(bwd_cold, iters=2 * copies, warmup=copies)
+        out[f"composite_fwd_{gname}"] = {"ms": ms, "ms_cold_inputs": ms_cold, "M": M, "M_processed": M_proc, "Mrays_per_s": 4096 / ms / 1e3,
+                                         "GBps": (M_proc * 28 + 4096 * 28) / ms / 1e6,
+                                         "GBps_cold_inputs": (M_proc * 28 + 4096 * 28) / ms_cold / 1e6}
+        out[f"composite_bwd_{gname}"] = {"ms": ms_b, "ms_cold_inputs": ms_b_cold, "M": M, "M_processed": M_proc, "Mrays_per_s": 4096 / ms_b / 1e3,
+                                         "GBps": (M_proc * 44 + 4096 * 48) / ms_b / 1e6,
+                                         "GBps_cold_inputs": (M_proc * 44 + 4096 * 48) / ms_b_cold / 1e6}
     return out
 
 
@@ -658,6 +684,9 @@ def main():
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU"
         torch.cuda.set_device(local_rank)
+        # MIOpen solver selection for the frozen prior's convolutions: 0 (default) = immediate mode (heuristic pick), 1 = find
+        # mode (torch.backends.cudnn.benchmark: every distinct convolution is timed once at its first call). A/B switch.
+        torch.backends.cudnn.benchmark = os.environ.get("SDFX_CONV_FIND", "0") == "1"
         dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
@@ -872,7 +901,7 @@ def main():
     # requests at 64 B, MI355X_MICROARCH.md "HBM"). The file stores, per kernel, the counters AND the work of the launches they
     # were averaged over (`points_per_launch`); traffic is scaled per point to the launch size this run reports, so that
     # `traffic`, `algorithmic_bytes_per_launch` and `avg_launch_us` describe the same launch. null when the file is absent.
-    traffic_file = next((f for f in ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
+    traffic_file = next((f for f in ("profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
                          if os.path.exists(os.path.join(ROOT, f))), None)
     pmc = {}
     if traffic_file:
@@ -935,6 +964,24 @@ def main():
         "points_per_launch": enc_points,
         "algorithmic_bytes_per_launch": (enc["bytes"] / enc["launches"]) if enc.get("launches") else None,
         "avg_launch_us": enc["avg_us"], "launches": enc["launches"], "measured_in": roofline_pass, "algorithmic_bytes_per_point": 588}
+    # What binds the encode is not HBM (hbm_frac above) but the rate at which a CU's vector-memory pipe looks up DISTINCT 128-byte
+    # lines: 2.4 cycles per line whatever the width or the cache level that answers (tools/ubench/gather_policy.hip: 4096
+    # workgroups sustain 32-33 TB/s of lines, profiles/r02_gather_policy.txt). Lines per launch = rocprofv3
+    # TCP_TOTAL_CACHE_ACCESSES_sum of the same PMC run as `traffic`, scaled per point to this launch; TA busy fraction from the
+    # same file when collected.
+    pm = pmc.get(pmc_key) or {}
+    lines_pp = (pm["TCP_TOTAL_CACHE_ACCESSES_sum_avg"] / pm["points_per_launch"]) if (pm.get("TCP_TOTAL_CACHE_ACCESSES_sum_avg") and pm.get("points_per_launch")) else None
+    if lines_pp and sec > 0:
+        lines = lines_pp * enc_points
+        ta_busy = None
+        if pm.get("TA_BUSY_avr_avg") and pm.get("GRBM_GUI_ACTIVE_avg"):
+            ta_busy = pm["TA_BUSY_avr_avg"] / pm["GRBM_GUI_ACTIVE_avg"]
+        result["roofline"]["gather"] = {
+            "bound": "vector-memory line rate (TA / TCP: 128-byte lines looked up per second)",
+            "lines_per_launch": lines, "lines_per_point": lines_pp, "achieved": lines * 128.0 / sec / 1e9, "peak": GATHER_PEAK_GBPS,
+            "unit": "GB/s of 128-byte lines", "frac": lines * 128.0 / sec / 1e9 / GATHER_PEAK_GBPS, "ta_busy_frac": ta_busy,
+            "l2_read_requests_per_point": (pm["TCP_TCC_READ_REQ_sum_avg"] / pm["points_per_launch"]) if pm.get("TCP_TCC_READ_REQ_sum_avg") else None,
+            "source": f"{traffic_file} (TCP_TOTAL_CACHE_ACCESSES_sum, TA_BUSY_avr / GRBM_GUI_ACTIVE; peak: profiles/r02_gather_policy.txt)"}
     # north_star's second kernel: the compositor. On the training path it is fused with normal + shading + regulariser sums
     # (csrc/render.hip), so two byte counts are given: SURVEY.md §8(d)'s compositor bytes (what the reference's kernel alone
     # would move: 28 / 44 B per sample + 28 / 48 B per ray) and the fused kernel's own compulsory bytes (64 / 100 B per sample

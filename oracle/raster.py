@@ -28,10 +28,12 @@ def _pixel_xy(pos, H, W):
 
 
 def rasterize_ids(pos: np.ndarray, tri: np.ndarray, H: int, W: int):
-    """ids [H, W] int64 (-1 = background): the triangle nearest to the eye at every pixel centre (ties: the lower index)."""
+    """ids [H, W] int64 (-1 = background): the triangle nearest to the eye at every pixel centre (depth ties: the lower index;
+    centres exactly on an edge: the top-left fill rule)."""
     pos = pos.astype(np.float64)
-    sx, sy = _pixel_xy(pos, H, W)
-    zw = pos[:, 2] / pos[:, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):     # vertices with w <= 0 are rejected per triangle below
+        sx, sy = _pixel_xy(pos, H, W)
+        zw = pos[:, 2] / pos[:, 3]
     zbuf = np.full((H, W), np.inf)
     ids = np.full((H, W), -1, np.int64)
     for f in range(tri.shape[0]):
@@ -51,7 +53,14 @@ def rasterize_ids(pos: np.ndarray, tri: np.ndarray, H: int, W: int):
         b0 = ((xs[1] - px) * (ys[2] - py) - (ys[1] - py) * (xs[2] - px)) / area
         b1 = ((xs[2] - px) * (ys[0] - py) - (ys[2] - py) * (xs[0] - px)) / area
         b2 = 1.0 - b0 - b1
-        inside = (b0 >= 0) & (b1 >= 0) & (b2 >= 0)
+        # fill rule (top-left in pixel-index space): strictly inside, or exactly on an edge whose interior side is +x, or — for
+        # a horizontal edge — +y (the row index). The gradients of the barycentrics are constants of the triangle.
+        grads = (((ys[1] - ys[2]) / area, (xs[2] - xs[1]) / area), ((ys[2] - ys[0]) / area, (xs[0] - xs[2]) / area),
+                 ((ys[0] - ys[1]) / area, (xs[1] - xs[0]) / area))
+        inside = np.ones_like(b0, dtype=bool)
+        for bary_i, (gx, gy) in zip((b0, b1, b2), grads):
+            owns = bool(gx > 0 or (gx == 0 and gy > 0))
+            inside &= (bary_i > 0) | ((bary_i == 0) & owns)
         z = b0 * zw[a] + b1 * zw[b] + b2 * zw[c]                      # z/w is affine in screen space
         inside &= (z >= -1) & (z <= 1)
         sub_z, sub_i = zbuf[y0:y1 + 1, x0:x1 + 1], ids[y0:y1 + 1, x0:x1 + 1]

@@ -39,6 +39,7 @@ __device__ __forceinline__ uint32_t tet_index(const float* __restrict__ sdf, con
     return idx;
 }
 
+static_assert(kWave == 64, "block_sum / block_excl index their per-wave slots with threadIdx.x >> 6 (gfx950: wave64)");
 // block sum of a per-thread count (all threads get the total)
 __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* sh) {
     v = wave_sum(v);

@@ -44,8 +44,8 @@ bool make_shape(uint32_t N, uint32_t HW, uint32_t C, uint32_t G, GnShape& s) {
     s.cvs = C / 8;
     s.ppi = s.cvs >= 256 ? 1u : 256u / s.cvs;
     s.threads = ((s.ppi * s.cvs + 63u) / 64u) * 64u;
-    // >= 64 KiB of the map per workgroup, <= kMaxSlabs slabs per sample, whole iterations
-    uint64_t slabs = ((uint64_t)HW * C + 32767u) / 32768u;
+    // >= 32 KiB of the map per workgroup, <= kMaxSlabs slabs per sample, whole iterations
+    uint64_t slabs = ((uint64_t)HW * C + 16383u) / 16384u;
     if (slabs < 1) slabs = 1;
     if (slabs > kMaxSlabs) slabs = kMaxSlabs;
     uint32_t P = (uint32_t)((HW + slabs - 1) / slabs);
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_stats(const __half* __restri
     if (active) {
         const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
         const uint4* base = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
-        for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
+    #pragma unroll 2
+    for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
             float f[8];
             unpack8(base[(size_t)p * s.cvs], f);
 #pragma unroll
@@ -157,23 +158,66 @@ __global__ __launch_bounds__(2 * kMaxGroups * kFinalizeSplit) void k_gn_finalize
     }
 }
 
+// The same combination inside a consumer kernel, for samples cut into few slabs (every map of the UNet): each workgroup combines
+// the [slabs][2 G] partials of its sample itself — a few KB from L2 — instead of waiting for a 2-workgroup kernel in between
+// (8 us per GroupNorm in the first trace of this file, profiles/r04_*). Fixed order, so every workgroup gets the same bits.
+// out (LDS, 2 G floats): mode 0 (mean, rstd), mode 1 the two means. `scr` = LDS doubles [threads / (2 G)][2 G].
+constexpr uint32_t kInlineSlabs = 128;
+__device__ __forceinline__ void moments_inline(const GnShape& s, const float* __restrict__ partial, uint32_t n, float eps, int mode,
+                                               double* scr, float* out) {
+    const uint32_t K = 2 * s.G, J = s.threads / K, k = threadIdx.x % K, j = threadIdx.x / K;
+    if (j < J) {
+        const float* p = partial + (size_t)n * s.slabs * K + k;
+        double a = 0.0;
+        for (uint32_t w = j; w < s.slabs; w += J) a += (double)p[(size_t)w * K];
+        scr[j * K + k] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < s.G) {
+        double e0 = 0.0, e1 = 0.0;
+        for (uint32_t i = 0; i < J; i++) { e0 += scr[i * K + threadIdx.x * 2]; e1 += scr[i * K + threadIdx.x * 2 + 1]; }
+        const double cnt = (double)s.HW * s.cpg;
+        e0 /= cnt; e1 /= cnt;
+        if (mode == 0) {
+            double var = e1 - e0 * e0;
+            var = var > 0.0 ? var : 0.0;
+            e1 = 1.0 / sqrt(var + (double)eps);
+        }
+        out[threadIdx.x * 2] = (float)e0;
+        out[threadIdx.x * 2 + 1] = (float)e1;
+    }
+    __syncthreads();
+}
+constexpr uint32_t kInlineScratchDoubles = (kMaxThreads / 2 + 1) * 2 * 2;   // J * 2 G <= threads
+
 template <bool ACT>
-__global__ __launch_bounds__(kMaxThreads) void k_gn_apply(const __half* __restrict__ x, GnShape s, const float* __restrict__ mean_rstd,
+__global__ __launch_bounds__(kMaxThreads) void k_gn_apply(const __half* __restrict__ x, GnShape s, const float* __restrict__ partial,
+                                                           float* __restrict__ mean_rstd, int inline_moments, float eps,
                                                            const __half* __restrict__ gamma, const __half* __restrict__ beta,
                                                            __half* __restrict__ y) {
+    __shared__ double scr[kInlineScratchDoubles];
+    __shared__ float mom[2 * kMaxGroups];
     const uint32_t n = blockIdx.x / s.slabs, slab = blockIdx.x - n * s.slabs;
+    if (inline_moments) {
+        moments_inline(s, partial, n, eps, 0, scr, mom);
+        if (slab == 0 && mean_rstd && threadIdx.x < 2 * s.G) mean_rstd[(size_t)n * s.G * 2 + threadIdx.x] = mom[threadIdx.x];   // for the backward
+    } else {
+        if (threadIdx.x < 2 * s.G) mom[threadIdx.x] = mean_rstd[(size_t)n * s.G * 2 + threadIdx.x];
+        __syncthreads();
+    }
     uint32_t pp, cv;
     if (!my_place(s, pp, cv)) return;
     float a[8], b[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t c = cv * 8 + i, g = c / s.cpg;
-        a[i] = mean_rstd[((size_t)n * s.G + g) * 2 + 1] * __half2float(gamma[c]);
-        b[i] = __half2float(beta[c]) - mean_rstd[((size_t)n * s.G + g) * 2] * a[i];
+        a[i] = mom[g * 2 + 1] * __half2float(gamma[c]);
+        b[i] = __half2float(beta[c]) - mom[g * 2] * a[i];
     }
     const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
     const uint4* src = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
     uint4* dst = reinterpret_cast<uint4*>(y + (size_t)n * s.HW * s.C) + cv;
+#pragma unroll 2
     for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
         float f[8];
         unpack8(src[(size_t)p * s.cvs], f);
@@ -219,7 +263,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_stats(const __half* __re
         const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
         const uint4* xs = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
         const uint4* ds = reinterpret_cast<const uint4*>(dy + (size_t)n * s.HW * s.C) + cv;
-        for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
+    #pragma unroll 2
+    for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
             float fx[8], fd[8];
             unpack8(xs[(size_t)p * s.cvs], fx);
             unpack8(ds[(size_t)p * s.cvs], fd);
@@ -236,11 +281,20 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_stats(const __half* __re
 
 template <bool ACT>
 __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_apply(const __half* __restrict__ x, const __half* __restrict__ dy, GnShape s,
-                                                               const float* __restrict__ mean_rstd, const float* __restrict__ mom,
+                                                               const float* __restrict__ mean_rstd, const float* __restrict__ partial,
+                                                               const float* __restrict__ mom_global, int inline_moments,
                                                                const __half* __restrict__ gamma, const __half* __restrict__ beta,
                                                                __half* __restrict__ dx) {
-    // mom[n][g][0] = mean(dxh), [1] = mean(dxh xh) over the group
+    // mom[g][0] = mean(dxh), [1] = mean(dxh xh) over the group of sample n
+    __shared__ double scr[kInlineScratchDoubles];
+    __shared__ float mom[2 * kMaxGroups];
     const uint32_t n = blockIdx.x / s.slabs, slab = blockIdx.x - n * s.slabs;
+    if (inline_moments) {
+        moments_inline(s, partial, n, 0.f, 1, scr, mom);
+    } else {
+        if (threadIdx.x < 2 * s.G) mom[threadIdx.x] = mom_global[(size_t)n * s.G * 2 + threadIdx.x];
+        __syncthreads();
+    }
     uint32_t pp, cv;
     if (!my_place(s, pp, cv)) return;
     float mean[8], rstd[8], ga[8], be[8], m1[8], m2[8];
@@ -249,12 +303,13 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_apply(const __half* __re
         const uint32_t c = cv * 8 + i, g = c / s.cpg;
         mean[i] = mean_rstd[((size_t)n * s.G + g) * 2]; rstd[i] = mean_rstd[((size_t)n * s.G + g) * 2 + 1];
         ga[i] = __half2float(gamma[c]); be[i] = __half2float(beta[c]);
-        m1[i] = mom[((size_t)n * s.G + g) * 2]; m2[i] = mom[((size_t)n * s.G + g) * 2 + 1];
+        m1[i] = mom[g * 2]; m2[i] = mom[g * 2 + 1];
     }
     const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
     const uint4* xs = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
     const uint4* ds = reinterpret_cast<const uint4*>(dy + (size_t)n * s.HW * s.C) + cv;
     uint4* dst = reinterpret_cast<uint4*>(dx + (size_t)n * s.HW * s.C) + cv;
+#pragma unroll 2
     for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
         float fx[8], fd[8];
         unpack8(xs[(size_t)p * s.cvs], fx);
@@ -270,6 +325,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_apply(const __half* __re
 }
 
 uint32_t stats_lds_bytes(const GnShape& s) { return 2u * s.ppi * s.C * (uint32_t)sizeof(float); }
+// the consumer kernels combine the partials themselves: few slabs, and at least two threads per (group, moment) to split them over
+bool inline_ok(const GnShape& s) { return s.slabs <= kInlineSlabs && s.threads >= 4 * s.G; }
 
 }  // namespace
 
@@ -293,15 +350,16 @@ int sdfx_group_norm_forward(const void* x, const void* gamma, const void* beta, 
     SDFX_REQUIRE((reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0, "group_norm_forward: x / y misaligned");
     hipStream_t st = as_stream(stream);
     const __half* xp = static_cast<const __half*>(x);
-    float* mr = mean_rstd ? mean_rstd : scratch + (size_t)N * s.slabs * G * 2;
+    const int inl = inline_ok(s) ? 1 : 0;
+    float* mr = (mean_rstd || inl) ? mean_rstd : scratch + (size_t)N * s.slabs * G * 2;
     hipLaunchKernelGGL(k_gn_stats, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, s, scratch);
-    hipLaunchKernelGGL(k_gn_finalize, dim3(N), dim3(2 * G * kFinalizeSplit), 0, st, scratch, s, eps, 0, mr);
+    if (!inl) hipLaunchKernelGGL(k_gn_finalize, dim3(N), dim3(2 * G * kFinalizeSplit), 0, st, scratch, s, eps, 0, mr);
     if (silu)
-        hipLaunchKernelGGL(k_gn_apply<true>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, s, mr, static_cast<const __half*>(gamma),
-                           static_cast<const __half*>(beta), static_cast<__half*>(y));
+        hipLaunchKernelGGL(k_gn_apply<true>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, s, scratch, mr, inl, eps,
+                           static_cast<const __half*>(gamma), static_cast<const __half*>(beta), static_cast<__half*>(y));
     else
-        hipLaunchKernelGGL(k_gn_apply<false>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, s, mr, static_cast<const __half*>(gamma),
-                           static_cast<const __half*>(beta), static_cast<__half*>(y));
+        hipLaunchKernelGGL(k_gn_apply<false>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, s, scratch, mr, inl, eps,
+                           static_cast<const __half*>(gamma), static_cast<const __half*>(beta), static_cast<__half*>(y));
     return check_launch("group_norm_forward");
 }
 
@@ -321,11 +379,14 @@ int sdfx_group_norm_backward(const void* x, const void* dy, const void* gamma, c
         hipLaunchKernelGGL(k_gn_bwd_stats<true>, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, dp, s, mean_rstd, gp, bp, scratch);
     else
         hipLaunchKernelGGL(k_gn_bwd_stats<false>, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, dp, s, mean_rstd, gp, bp, scratch);
-    hipLaunchKernelGGL(k_gn_finalize, dim3(N), dim3(2 * G * kFinalizeSplit), 0, st, scratch, s, 0.f, 1, mom);
+    const int inl = inline_ok(s) ? 1 : 0;
+    if (!inl) hipLaunchKernelGGL(k_gn_finalize, dim3(N), dim3(2 * G * kFinalizeSplit), 0, st, scratch, s, 0.f, 1, mom);
     if (silu)
-        hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, dp, s, mean_rstd, mom, gp, bp, static_cast<__half*>(dx));
+        hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, dp, s, mean_rstd, scratch, mom, inl, gp, bp,
+                           static_cast<__half*>(dx));
     else
-        hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, dp, s, mean_rstd, mom, gp, bp, static_cast<__half*>(dx));
+        hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, dp, s, mean_rstd, scratch, mom, inl, gp, bp,
+                           static_cast<__half*>(dx));
     return check_launch("group_norm_backward");
 }
 

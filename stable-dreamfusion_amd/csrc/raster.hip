@@ -12,7 +12,8 @@
 //
 // Formulation (2D homogeneous rasterisation, Olano & Greer 1997): with M = [x; y; w] (rows) of the three vertices (columns) and
 // p = (px, py, 1) the pixel centre in NDC, q = M^-1 p are the un-normalised perspective-correct barycentrics: the pixel is inside
-// iff all q_i have the sign of 1 (q >= 0 after dividing by det), b = q / (q0 + q1 + q2), z/w = (b . z) / (b . w).
+// iff all q_i have the sign of 1 (centres exactly ON an edge: the top-left rule, see bary()), b = q / (q0 + q1 + q2),
+// z/w = (b . z) / (b . w).
 // Backward: d(M^-1 p) = -M^-1 dM q, so dL/dM = -(M^-T g_q) q^T with g_q = (g_b - (g_b . b) 1) / sum(q), g_b = (g_u, g_v, 0).
 //
 // Kernels: k_rast_clear -> k_rast_triangles (one thread per triangle walks its bounding box; the nearest (z/w, id) wins a 64-bit
@@ -64,7 +65,23 @@ __device__ __forceinline__ bool bary(const Tri& t, float px, float py, float q[3
     q[1] = xr[2] * yr[0] - xr[0] * yr[2];
     q[2] = xr[0] * yr[1] - xr[1] * yr[0];
     s = q[0] + q[1] + q[2];
-    return (q[0] >= 0.f && q[1] >= 0.f && q[2] >= 0.f && s > 0.f) || (q[0] <= 0.f && q[1] <= 0.f && q[2] <= 0.f && s < 0.f);
+    if (!(s > 0.f || s < 0.f)) return false;   // degenerate (zero area) or NaN
+    const float sg = s > 0.f ? 1.f : -1.f;
+    // Fill rule (top-left, in pixel-index space: x to the right, y = row index): a pixel centre strictly inside is covered; one
+    // EXACTLY on an edge is covered iff the triangle's interior lies to its right (a left edge), or — for a horizontal edge — at
+    // larger row indices (a top edge). q_i sg grows into the interior from the edge opposite vertex i, so the side is the sign of
+    // its gradient: d q_0 / d px = w_2 yr_1 - w_1 yr_2, d q_0 / d py = w_1 xr_2 - w_2 xr_1, cyclically. Two triangles that share an
+    // edge therefore never both cover a centre on it, whatever their depths and order.
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float qi = q[i] * sg;
+        if (qi > 0.f) continue;
+        if (qi < 0.f) return false;
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        const float gx = (t.m[2][k] * yr[j] - t.m[2][j] * yr[k]) * sg, gy = (t.m[2][j] * xr[k] - t.m[2][k] * xr[j]) * sg;
+        if (!(gx > 0.f || (gx == 0.f && gy > 0.f))) return false;
+    }
+    return true;
 }
 
 __device__ __forceinline__ float pixel_ndc(uint32_t i, uint32_t n) { return (2.0f * ((float)i + 0.5f)) / (float)n - 1.0f; }
@@ -242,10 +259,15 @@ __device__ __forceinline__ AAPair aa_pair(const AAMesh& m, const float* __restri
     float best = 2.f;
     for (int k = 0; k < 3; k++) {
         const int32_t va = m.tri[3 * tri + k], vb = m.tri[3 * tri + (k + 1) % 3], vo = m.tri[3 * tri + (k + 2) % 3];
+        const int32_t v2 = m.adj_opp[3 * tri + k];
+        // an edge with a vertex at or behind the eye plane (w <= 0) has no screen-space image: skip it, as load_tri rejects such
+        // triangles for rasterisation (a neighbour triangle may still have one)
+        if (!(m.pos[(size_t)va * 4 + 3] > 0.f && m.pos[(size_t)vb * 4 + 3] > 0.f && m.pos[(size_t)vo * 4 + 3] > 0.f &&
+              (v2 < 0 || m.pos[(size_t)v2 * 4 + 3] > 0.f)))
+            continue;
         float ax, ay, bx, by;
         screen_xy(m, va, ax, ay); screen_xy(m, vb, bx, by);
         const float ex = bx - ax, ey = by - ay;
-        const int32_t v2 = m.adj_opp[3 * tri + k];
         if (v2 >= 0) {   // a neighbour across the edge: a silhouette only if it folds back to our side
             float ox_, oy_, px_, py_;
             screen_xy(m, vo, ox_, oy_); screen_xy(m, v2, px_, py_);

@@ -113,8 +113,10 @@ class SDSGuidance(nn.Module):
         """The frozen VAE encoder on `precision_t` images, OUTSIDE the trainer's autocast like the UNet below: under autocast its
         22 GroupNorms run in float32 on 512^2 maps (RowwiseMomentsCUDAKernel<float>: 11 % of the GPU time of an RGB iteration in
         round 3's profile, plus the casts each way), forward and backward. diffusers' fp16 pipelines do not run under autocast
-        either. SDFX_VAE_AUTOCAST=1 restores the inherited context, SDFX_VAE_CL=1 feeds channels-last images (A/B switches)."""
-        if _VAE_CL and imgs.is_cuda:
+        either. SDFX_VAE_AUTOCAST=1 restores the inherited context (A/B switch). A VAE whose weights were converted to channels-last
+        (sd15_arch.sd15_random_prior: `vae.channels_last_input`) is fed channels-last images; any other VAE gets them as they come
+        (a channels-last image into NCHW-weight convolutions made MIOpen's backward abort in the DMTet test)."""
+        if getattr(self.vae, "channels_last_input", False) and imgs.is_cuda:   # set by the factory that converted the VAE's weights
             imgs = imgs.contiguous(memory_format=torch.channels_last)
         if _VAE_AUTOCAST or not imgs.is_cuda:
             return self.vae.encode_sample(imgs) * self.vae.scaling_factor

@@ -107,14 +107,36 @@ class NeRFRenderer(nn.Module):
         import numpy as np
         from . import dmtet as D
         N = int(self.opt.tet_grid_size)
-        path = os.path.join("tets", f"{N}_tets.npz")
-        tets = np.load(path) if os.path.exists(path) else D.kuhn_tet_grid(max(N // 2, 1))
+        # `opt.tets_dir` if given, else ./tets (where the reference looks, nerf/renderer.py:296), else <repository>/tets
+        here = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        dirs = [d for d in (getattr(self.opt, "tets_dir", None), "tets", os.path.join(here, "tets")) if d]
+        path = next((os.path.join(d, f"{N}_tets.npz") for d in dirs if os.path.exists(os.path.join(d, f"{N}_tets.npz"))), None)
+        if path is not None:
+            tets, self.tet_grid_source = np.load(path), path
+        else:
+            tets = D.kuhn_tet_grid(max(N // 2, 1))
+            self.tet_grid_source = f"kuhn_tet_grid({max(N // 2, 1)})"
+            import warnings
+            warnings.warn(f"DMTet: tets/{N}_tets.npz not found in {dirs}; using the generated Kuhn grid "
+                          f"({tets['vertices'].shape[0]} vertices). `sdf` / `deform` then have that many rows: a checkpoint trained "
+                          f"on the reference's grid (277 410 vertices for N = 128) will not load into it.", stacklevel=2)
         self.register_buffer("verts", -torch.tensor(tets["vertices"], dtype=torch.float32) * 2, persistent=False)   # covers [-1, 1]
         self.register_buffer("indices", torch.tensor(tets["indices"], dtype=torch.long), persistent=False)
         self.register_buffer("tet_scale", torch.tensor([1, 1, 1], dtype=torch.float32), persistent=False)
         self.dmtet_model = D.DMTet(None)
         self.sdf = nn.Parameter(torch.zeros_like(self.verts[..., 0]), requires_grad=True)
         self.deform = nn.Parameter(torch.zeros_like(self.verts), requires_grad=True)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # a DMTet checkpoint made on another tetrahedral grid: say which, instead of PyTorch's bare size-mismatch line
+        if getattr(self, "dmtet", False):
+            for name in ("sdf", "deform"):
+                t = state_dict.get(prefix + name)
+                if t is not None and t.shape[0] != getattr(self, name).shape[0]:
+                    raise RuntimeError(f"DMTet checkpoint has {t.shape[0]} grid vertices ({prefix}{name}), this model's grid "
+                                       f"({self.tet_grid_source}) has {getattr(self, name).shape[0]}: load it with the same "
+                                       f"tets/{int(self.opt.tet_grid_size)}_tets.npz the checkpoint was trained on")
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     @torch.no_grad()
     def init_tet(self, mesh=None):
@@ -144,6 +166,27 @@ class NeRFRenderer(nn.Module):
         sdf = self.sdf
         deform = torch.tanh(self.deform) / self.opt.tet_grid_size
         verts, faces = self.dmtet_model(self.verts + deform, sdf, self.indices)
+
+        if faces.shape[0] == 0:
+            # marching tetrahedra found no surface (every sdf of one sign: e.g. before init_tet): nothing to rasterise. The frame is
+            # the background, the opacity zero; `sdf` / `deform` get zero gradients.
+            z = (sdf.sum() + deform.sum()) * 0
+            B = mvp.shape[0]
+            if bg_color is None:
+                bg_color = self.background(rays_d) if self.opt.bg_radius > 0 else 1
+            if torch.is_tensor(bg_color) and len(bg_color.shape) > 1:
+                bg_color = bg_color.view(-1, h, w, 3)
+            results["depth"] = torch.zeros(B, h, w, 1, device=verts.device) + z
+            results["image"] = torch.zeros(B, h, w, 3, device=verts.device) + bg_color + z
+            results["weights_sum"] = torch.zeros(B, h, w, device=verts.device) + z
+            if self.opt.lambda_2d_normal_smooth > 0 or self.opt.lambda_normal > 0:
+                results["normal_image"] = torch.zeros(B, h, w, 3, device=verts.device) + z
+            if self.training:
+                if getattr(self.opt, "lambda_mesh_normal", 0) > 0:
+                    results["normal_loss"] = z
+                if getattr(self.opt, "lambda_mesh_laplacian", 0) > 0:
+                    results["lap_loss"] = z
+            return results
 
         i0, i1, i2 = faces[:, 0], faces[:, 1], faces[:, 2]
         v0, v1, v2 = verts[i0, :], verts[i1, :], verts[i2, :]

@@ -211,6 +211,7 @@ def sd15_random_prior(device, fp16=True, seed=1234, t_range=(0.02, 0.98)):
     unet.unet.to(memory_format=torch.channels_last)
     if G._VAE_CL:
         vae.to(memory_format=torch.channels_last)
+        vae.channels_last_input = True
     return G.SDSGuidance(unet, vae, device, fp16, t_range=t_range)
 
 

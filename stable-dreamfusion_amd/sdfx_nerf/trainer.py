@@ -494,11 +494,12 @@ class TrainStep:
         self.scaler.unscale_(self.optimizer)
         if opt.grad_clip >= 0:
             torch.nn.utils.clip_grad_value_(self.model.parameters(), opt.grad_clip)
-        if opt.lambda_tv > 0:
-            lambda_tv = min(1.0, self.global_step / (0.5 * opt.iters)) * opt.lambda_tv
-            self.model.encoder.grad_total_variation(lambda_tv, None, self.model.bound)
-        if opt.lambda_wd > 0:
-            self.model.encoder.grad_weight_decay(opt.lambda_wd)
+        if not getattr(opt, "dmtet", False):   # nerf/utils.py post_train_step: `if not self.opt.dmtet and self.opt.backbone == 'grid'`
+            if opt.lambda_tv > 0:
+                lambda_tv = min(1.0, self.global_step / (0.5 * opt.iters)) * opt.lambda_tv
+                self.model.encoder.grad_total_variation(lambda_tv, None, self.model.bound)
+            if opt.lambda_wd > 0:
+                self.model.encoder.grad_weight_decay(opt.lambda_wd)
         self.scaler.step(self.optimizer)
         self.scaler.update()
         self.last = {"num_samples": int(self._num_samples), "shading": kinds[0], "graph_class": kinds[0]}

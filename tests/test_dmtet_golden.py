@@ -133,3 +133,12 @@ def test_run_dmtet_restatement_reproduces_the_reference(mods, monkeypatch, shadi
     for got, key in ((r.sdf.grad, "dsdf"), (r.deform.grad, "ddeform"), (theta.grad, "dtheta")):
         ref = GOLD[f"{shading}_{key}"]
         assert np.abs(got.numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, key
+
+
+def test_oracle_rasteriser_meets_the_hand_derived_known_answers():
+    """tests/golden/raster_kat.json (top-left fill rule, shared-edge single coverage, degenerate triangles, antialiasing of a
+    silhouette that ends inside its own pixel / reaches into the next): expectations derived by hand from the geometry, met by
+    the numpy / torch restatement here and by csrc/raster.hip in tests/test_gpu_08_dmtet.py."""
+    import raster_kat
+    from oracle import raster as R
+    raster_kat.check(lambda pos, tri, res: R.Dr.rasterize(None, pos, tri, res)[0], R.Dr.antialias)

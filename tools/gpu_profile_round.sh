@@ -19,6 +19,14 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- $PMC_CMD > $OUT/pmc_$C.log 2>&1
   echo "pmc $C exit $?" | tee -a $OUT/summary.txt
 done
+# the gather roofline of the encode forward (round 4): 128-byte lines the vector-memory pipe looked up (TCP_TOTAL_CACHE_ACCESSES),
+# lines that went on to L2 (TCP_TCC_READ_REQ), and how busy the texture-address units were (TA_BUSY over GRBM_GUI_ACTIVE)
+i=0
+for SET in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" "TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum"; do
+  i=$((i+1))
+  timeout 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_gather$i -o pmc -- $PMC_CMD > $OUT/pmc_gather$i.log 2>&1
+  echo "pmc gather set $i ($SET) exit $?" | tee -a $OUT/summary.txt
+done
 python3 - <<PY | tee -a $OUT/summary.txt
 import csv, glob, json, collections
 out = {}
@@ -31,12 +39,21 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
             n = r["Kernel_Name"]
             for key in ("k_grid_fwd", "k_grid_forward", "k_grid_bwd_bin", "k_grid_bwd_reduce", "k_field_backward_nat", "k_field_forward_nat",
                         "k_render_train_fwd", "k_render_train_bwd", "k_composite_train_fwd", "k_composite_train_bwd", "k_march_count",
-                        "k_adan_update"):
+                        "k_adan_update", "k_grid_bwd_spill", "k_gn_stats", "k_gn_apply", "k_gn_bwd"):
                 if key in n:
                     per[key].append(float(r["Counter_Value"]))
         for k, v in per.items():
             out.setdefault(k, {})[C + "_KB_avg"] = sum(v) / len(v)
             out[k]["launches"] = len(v)
+for f in glob.glob("$OUT/pmc_gather*/*counter_collection.csv"):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        for key in ("k_grid_fwd", "k_grid_bwd_bin", "k_grid_bwd_reduce"):
+            if key in r["Kernel_Name"]:
+                per[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in per.items():
+        for c, v in cs.items():
+            out.setdefault(k, {})[c + "_avg"] = sum(v) / len(v)
 # the work of the launches the counters were averaged over, from the bytes each kernel WRITES per unit (bench.py scales the
 # traffic per unit to the launch size it reports): encode forward 16 levels x 2 halves = 64 B per point; fused render forward one
 # float weight per sample (+ 28 B per ray), backward 7 + 3 floats per sample
