@@ -25,7 +25,7 @@ namespace {
 
 constexpr uint32_t kMaxGroups = 64;
 constexpr uint32_t kMaxThreads = 320;        // C / 8 <= 320 vectors per pixel (C <= 2560: the widest concatenation of the UNet)
-constexpr uint32_t kMaxSlabs = 1024;         // pixel slabs (workgroups) per sample
+constexpr uint32_t kMaxSlabs = 256;          // pixel slabs (workgroups) per sample: one per CU for the largest maps (the VAE's 512^2 x 128)
 
 struct GnShape {
     uint32_t N, HW, C, G;
@@ -158,11 +158,11 @@ __global__ __launch_bounds__(2 * kMaxGroups * kFinalizeSplit) void k_gn_finalize
     }
 }
 
-// The same combination inside a consumer kernel, for samples cut into few slabs (every map of the UNet): each workgroup combines
-// the [slabs][2 G] partials of its sample itself — a few KB from L2 — instead of waiting for a 2-workgroup kernel in between
-// (8 us per GroupNorm in the first trace of this file, profiles/r04_*). Fixed order, so every workgroup gets the same bits.
+// The same combination inside a consumer kernel: each workgroup combines the [slabs][2 G] partials of its sample itself — at most
+// 64 KB from L2 — instead of waiting for a 1- or 2-workgroup kernel in between (8 us per GroupNorm of the UNet, 25 us per norm of
+// the VAE's 1024-slab maps in the first traces of this file). Fixed order, so every workgroup gets the same bits.
 // out (LDS, 2 G floats): mode 0 (mean, rstd), mode 1 the two means. `scr` = LDS doubles [threads / (2 G)][2 G].
-constexpr uint32_t kInlineSlabs = 128;
+constexpr uint32_t kInlineSlabs = 256;   // = kMaxSlabs: k_gn_finalize remains only for maps too narrow to split the combination (threads < 4 G)
 __device__ __forceinline__ void moments_inline(const GnShape& s, const float* __restrict__ partial, uint32_t n, float eps, int mode,
                                                double* scr, float* out) {
     const uint32_t K = 2 * s.G, J = s.threads / K, k = threadIdx.x % K, j = threadIdx.x / K;
