@@ -539,13 +539,17 @@ int sdfx_antialias_backward(const float* color, const float* rast, const float* 
  * `silu` != 0 else identity, and its input gradient; gamma / beta fp16, frozen (no parameter gradients). Statistics in
  * float32 / double, combined in a fixed order (bit-reproducible). Needs C % 8 == 0, C % G == 0, C <= 2560, G <= 64.
  * mean_rstd[N, G, 2] float32 receives what the backward needs (NULL when no backward will follow).
+ * pre[N, C] fp16 or NULL: the norm is taken of x + pre[n, c] (a convolution's bias + the time-embedding projection of a ResNet
+ * block, which then need no elementwise launch of their own); the backward takes the same vector.
  * scratch: sdfx_group_norm_scratch_bytes(N, HW, C, G) bytes of float32, uninitialised.
+ * sdfx_add_bias_residual: out = a + b + bias[c] on the same layout (the tail of a ResNet / transformer block); out may alias a or b.
  */
 uint64_t sdfx_group_norm_scratch_bytes(uint32_t N, uint32_t HW, uint32_t C, uint32_t G);
-int sdfx_group_norm_forward(const void* x, const void* gamma, const void* beta, uint32_t N, uint32_t HW, uint32_t C, uint32_t G, float eps,
-                            int silu, void* y, float* mean_rstd, float* scratch, sdfx_stream_t stream);
-int sdfx_group_norm_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean_rstd, uint32_t N,
-                             uint32_t HW, uint32_t C, uint32_t G, int silu, void* dx, float* scratch, sdfx_stream_t stream);
+int sdfx_group_norm_forward(const void* x, const void* pre, const void* gamma, const void* beta, uint32_t N, uint32_t HW, uint32_t C, uint32_t G,
+                            float eps, int silu, void* y, float* mean_rstd, float* scratch, sdfx_stream_t stream);
+int sdfx_group_norm_backward(const void* x, const void* pre, const void* dy, const void* gamma, const void* beta, const float* mean_rstd,
+                             uint32_t N, uint32_t HW, uint32_t C, uint32_t G, int silu, void* dx, float* scratch, sdfx_stream_t stream);
+int sdfx_add_bias_residual(const void* a, const void* b, const void* bias, uint32_t N, uint32_t HW, uint32_t C, void* out, sdfx_stream_t stream);
 
 #ifdef __cplusplus
 }

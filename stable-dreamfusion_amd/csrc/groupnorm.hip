@@ -15,6 +15,10 @@
 //   backward  k_gn_bwd_stats / k_gn_finalize / k_gn_bwd_apply   dx = rstd (dxh - mean_g(dxh) - xh mean_g(dxh xh)), dxh = dy silu'(z) gamma,
 //             z recomputed from x (nothing but x and the 2 x 32 statistics is kept from the forward). The prior is frozen:
 //             no gamma / beta gradients.
+// Optional `pre[N, C]` (fp16): the norm is taken of x + pre[n, c] — a convolution's bias and the time-embedding projection of a
+// ResNet block, which the stock graph adds with two elementwise launches over the whole map. Free here: a per-channel constant
+// shifts the thread's sums after its loop (sum += n e, sq += 2 e sum + n e^2) and folds into b_c (forward) or the mean (backward).
+// k_add_bias_residual: out = a + b + bias_c, the tail of a ResNet / transformer block (residual + the last convolution's bias).
 // Every thread owns 8 consecutive channels (one 16-byte vector) of the pixels it walks, so its per-channel parameters live in
 // registers. HBM-bound: 2 reads + 1 write of the map forward, 4 reads + 1 write backward.
 #include "sdfx_common.h"
@@ -106,7 +110,8 @@ __device__ __forceinline__ void reduce_to_groups(const GnShape& s, float* part, 
 }
 
 // ---- forward ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kMaxThreads) void k_gn_stats(const __half* __restrict__ x, GnShape s, float* __restrict__ partial) {
+__global__ __launch_bounds__(kMaxThreads) void k_gn_stats(const __half* __restrict__ x, const __half* __restrict__ pre, GnShape s,
+                                                           float* __restrict__ partial) {
     extern __shared__ float part[];
     const uint32_t n = blockIdx.x / s.slabs, slab = blockIdx.x - n * s.slabs;
     uint32_t pp, cv;
@@ -115,12 +120,20 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_stats(const __half* __restri
     if (active) {
         const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
         const uint4* base = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
-    #pragma unroll 2
-    for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
+        uint32_t np = 0;
+#pragma unroll 2
+        for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
             float f[8];
             unpack8(base[(size_t)p * s.cvs], f);
 #pragma unroll
             for (int i = 0; i < 8; i++) { sum[i] += f[i]; sq[i] += f[i] * f[i]; }
+            np++;
+        }
+        if (pre) {   // moments of x + e from those of x: e is constant over this thread's pixels
+            float e[8];
+            unpack8(reinterpret_cast<const uint4*>(pre + (size_t)n * s.C)[cv], e);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { sq[i] += 2.0f * e[i] * sum[i] + (float)np * e[i] * e[i]; sum[i] += (float)np * e[i]; }
         }
     }
     reduce_to_groups(s, part, sum, sq, active, pp, cv, partial + ((size_t)n * s.slabs + slab) * s.G * 2);
@@ -194,7 +207,7 @@ template <bool ACT>
 __global__ __launch_bounds__(kMaxThreads) void k_gn_apply(const __half* __restrict__ x, GnShape s, const float* __restrict__ partial,
                                                            float* __restrict__ mean_rstd, int inline_moments, float eps,
                                                            const __half* __restrict__ gamma, const __half* __restrict__ beta,
-                                                           __half* __restrict__ y) {
+                                                           const __half* __restrict__ pre, __half* __restrict__ y) {
     __shared__ double scr[kInlineScratchDoubles];
     __shared__ float mom[2 * kMaxGroups];
     const uint32_t n = blockIdx.x / s.slabs, slab = blockIdx.x - n * s.slabs;
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_apply(const __half* __restri
     for (int i = 0; i < 8; i++) {
         const uint32_t c = cv * 8 + i, g = c / s.cpg;
         a[i] = mom[g * 2 + 1] * __half2float(gamma[c]);
-        b[i] = __half2float(beta[c]) - mom[g * 2] * a[i];
+        b[i] = __half2float(beta[c]) - (mom[g * 2] - (pre ? __half2float(pre[(size_t)n * s.C + c]) : 0.f)) * a[i];   // (x + e - mean) a + beta
     }
     const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
     const uint4* src = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
@@ -246,7 +259,8 @@ __device__ __forceinline__ void elem_bwd(float x, float dy, float mean, float rs
 template <bool ACT>
 __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_stats(const __half* __restrict__ x, const __half* __restrict__ dy, GnShape s,
                                                                const float* __restrict__ mean_rstd, const __half* __restrict__ gamma,
-                                                               const __half* __restrict__ beta, float* __restrict__ partial) {
+                                                               const __half* __restrict__ beta, const __half* __restrict__ pre,
+                                                               float* __restrict__ partial) {
     extern __shared__ float part[];
     const uint32_t n = blockIdx.x / s.slabs, slab = blockIdx.x - n * s.slabs;
     uint32_t pp, cv;
@@ -257,14 +271,15 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_stats(const __half* __re
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint32_t c = cv * 8 + i, g = c / s.cpg;
-            mean[i] = mean_rstd[((size_t)n * s.G + g) * 2]; rstd[i] = mean_rstd[((size_t)n * s.G + g) * 2 + 1];
+            mean[i] = mean_rstd[((size_t)n * s.G + g) * 2] - (pre ? __half2float(pre[(size_t)n * s.C + c]) : 0.f);   // xh = (x + e - mean) rstd
+            rstd[i] = mean_rstd[((size_t)n * s.G + g) * 2 + 1];
             ga[i] = __half2float(gamma[c]); be[i] = __half2float(beta[c]);
         }
         const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
         const uint4* xs = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
         const uint4* ds = reinterpret_cast<const uint4*>(dy + (size_t)n * s.HW * s.C) + cv;
-    #pragma unroll 2
-    for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
+#pragma unroll 2
+        for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
             float fx[8], fd[8];
             unpack8(xs[(size_t)p * s.cvs], fx);
             unpack8(ds[(size_t)p * s.cvs], fd);
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_apply(const __half* __re
                                                                const float* __restrict__ mean_rstd, const float* __restrict__ partial,
                                                                const float* __restrict__ mom_global, int inline_moments,
                                                                const __half* __restrict__ gamma, const __half* __restrict__ beta,
-                                                               __half* __restrict__ dx) {
+                                                               const __half* __restrict__ pre, __half* __restrict__ dx) {
     // mom[g][0] = mean(dxh), [1] = mean(dxh xh) over the group of sample n
     __shared__ double scr[kInlineScratchDoubles];
     __shared__ float mom[2 * kMaxGroups];
@@ -301,7 +316,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_apply(const __half* __re
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t c = cv * 8 + i, g = c / s.cpg;
-        mean[i] = mean_rstd[((size_t)n * s.G + g) * 2]; rstd[i] = mean_rstd[((size_t)n * s.G + g) * 2 + 1];
+        mean[i] = mean_rstd[((size_t)n * s.G + g) * 2] - (pre ? __half2float(pre[(size_t)n * s.C + c]) : 0.f);
+        rstd[i] = mean_rstd[((size_t)n * s.G + g) * 2 + 1];
         ga[i] = __half2float(gamma[c]); be[i] = __half2float(beta[c]);
         m1[i] = mom[g * 2]; m2[i] = mom[g * 2 + 1];
     }
@@ -324,6 +340,20 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_apply(const __half* __re
     }
 }
 
+// out[n, p, c] = a + b + bias[c]: 16-byte vectors, one float32 sum, one rounding
+__global__ __launch_bounds__(256) void k_add_bias_residual(const uint4* __restrict__ a, const uint4* __restrict__ b, const __half* __restrict__ bias,
+                                                            uint64_t nvec, uint32_t cvs, uint4* __restrict__ out) {
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (uint64_t)gridDim.x * 256) {
+        float fa[8], fb[8], fc[8];
+        unpack8(a[v], fa);
+        unpack8(b[v], fb);
+        unpack8(reinterpret_cast<const uint4*>(bias)[v % cvs], fc);
+#pragma unroll
+        for (int i = 0; i < 8; i++) fa[i] = fa[i] + fb[i] + fc[i];
+        out[v] = pack8(fa);
+    }
+}
+
 uint32_t stats_lds_bytes(const GnShape& s) { return 2u * s.ppi * s.C * (uint32_t)sizeof(float); }
 // the consumer kernels combine the partials themselves: few slabs, and at least two threads per (group, moment) to split them over
 bool inline_ok(const GnShape& s) { return s.slabs <= kInlineSlabs && s.threads >= 4 * s.G; }
@@ -341,31 +371,33 @@ uint64_t sdfx_group_norm_scratch_bytes(uint32_t N, uint32_t HW, uint32_t C, uint
 
 // y[N, HW, C] = act(GroupNorm_G(x[N, HW, C]) * gamma + beta), fp16 channels-last, act = SiLU when `silu` else identity;
 // mean_rstd[N, G, 2] (float32) receives the statistics the backward needs (may be NULL)
-int sdfx_group_norm_forward(const void* x, const void* gamma, const void* beta, uint32_t N, uint32_t HW, uint32_t C, uint32_t G, float eps,
-                            int silu, void* y, float* mean_rstd, float* scratch, sdfx_stream_t stream) {
+int sdfx_group_norm_forward(const void* x, const void* pre, const void* gamma, const void* beta, uint32_t N, uint32_t HW, uint32_t C, uint32_t G,
+                            float eps, int silu, void* y, float* mean_rstd, float* scratch, sdfx_stream_t stream) {
     SDFX_REQUIRE(x && gamma && beta && y && scratch, "group_norm_forward: null pointer");
     GnShape s;
     SDFX_REQUIRE(make_shape(N, HW, C, G, s), "group_norm_forward: needs C %% 8 == 0, C %% G == 0, C <= %u, G <= %u (got N=%u HW=%u C=%u G=%u)",
                  kMaxThreads * 8, kMaxGroups, N, HW, C, G);
-    SDFX_REQUIRE((reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0, "group_norm_forward: x / y misaligned");
+    SDFX_REQUIRE((reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0 &&
+                     (reinterpret_cast<uintptr_t>(pre) % 16) == 0, "group_norm_forward: x / y / pre misaligned");
     hipStream_t st = as_stream(stream);
     const __half* xp = static_cast<const __half*>(x);
+    const __half* pp_ = static_cast<const __half*>(pre);
     const int inl = inline_ok(s) ? 1 : 0;
     float* mr = (mean_rstd || inl) ? mean_rstd : scratch + (size_t)N * s.slabs * G * 2;
-    hipLaunchKernelGGL(k_gn_stats, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, s, scratch);
+    hipLaunchKernelGGL(k_gn_stats, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, pp_, s, scratch);
     if (!inl) hipLaunchKernelGGL(k_gn_finalize, dim3(N), dim3(2 * G * kFinalizeSplit), 0, st, scratch, s, eps, 0, mr);
     if (silu)
         hipLaunchKernelGGL(k_gn_apply<true>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, s, scratch, mr, inl, eps,
-                           static_cast<const __half*>(gamma), static_cast<const __half*>(beta), static_cast<__half*>(y));
+                           static_cast<const __half*>(gamma), static_cast<const __half*>(beta), pp_, static_cast<__half*>(y));
     else
         hipLaunchKernelGGL(k_gn_apply<false>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, s, scratch, mr, inl, eps,
-                           static_cast<const __half*>(gamma), static_cast<const __half*>(beta), static_cast<__half*>(y));
+                           static_cast<const __half*>(gamma), static_cast<const __half*>(beta), pp_, static_cast<__half*>(y));
     return check_launch("group_norm_forward");
 }
 
 // dx[N, HW, C] of the same op from x, dy and the forward's mean_rstd (gamma / beta are frozen: no parameter gradients)
-int sdfx_group_norm_backward(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean_rstd, uint32_t N,
-                             uint32_t HW, uint32_t C, uint32_t G, int silu, void* dx, float* scratch, sdfx_stream_t stream) {
+int sdfx_group_norm_backward(const void* x, const void* pre, const void* dy, const void* gamma, const void* beta, const float* mean_rstd,
+                             uint32_t N, uint32_t HW, uint32_t C, uint32_t G, int silu, void* dx, float* scratch, sdfx_stream_t stream) {
     SDFX_REQUIRE(x && dy && gamma && beta && mean_rstd && dx && scratch, "group_norm_backward: null pointer");
     GnShape s;
     SDFX_REQUIRE(make_shape(N, HW, C, G, s), "group_norm_backward: needs C %% 8 == 0, C %% G == 0, C <= %u, G <= %u", kMaxThreads * 8, kMaxGroups);
@@ -373,21 +405,35 @@ int sdfx_group_norm_backward(const void* x, const void* dy, const void* gamma, c
                      (reinterpret_cast<uintptr_t>(dx) % 16) == 0, "group_norm_backward: x / dy / dx misaligned");
     hipStream_t st = as_stream(stream);
     const __half *xp = static_cast<const __half*>(x), *dp = static_cast<const __half*>(dy);
-    const __half *gp = static_cast<const __half*>(gamma), *bp = static_cast<const __half*>(beta);
+    const __half *gp = static_cast<const __half*>(gamma), *bp = static_cast<const __half*>(beta), *pp_ = static_cast<const __half*>(pre);
     float* mom = scratch + (size_t)N * s.slabs * G * 2;
     if (silu)
-        hipLaunchKernelGGL(k_gn_bwd_stats<true>, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, dp, s, mean_rstd, gp, bp, scratch);
+        hipLaunchKernelGGL(k_gn_bwd_stats<true>, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, dp, s, mean_rstd, gp, bp, pp_, scratch);
     else
-        hipLaunchKernelGGL(k_gn_bwd_stats<false>, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, dp, s, mean_rstd, gp, bp, scratch);
+        hipLaunchKernelGGL(k_gn_bwd_stats<false>, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, dp, s, mean_rstd, gp, bp, pp_, scratch);
     const int inl = inline_ok(s) ? 1 : 0;
     if (!inl) hipLaunchKernelGGL(k_gn_finalize, dim3(N), dim3(2 * G * kFinalizeSplit), 0, st, scratch, s, 0.f, 1, mom);
     if (silu)
-        hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, dp, s, mean_rstd, scratch, mom, inl, gp, bp,
+        hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, dp, s, mean_rstd, scratch, mom, inl, gp, bp, pp_,
                            static_cast<__half*>(dx));
     else
-        hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, dp, s, mean_rstd, scratch, mom, inl, gp, bp,
+        hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(N * s.slabs), dim3(s.threads), 0, st, xp, dp, s, mean_rstd, scratch, mom, inl, gp, bp, pp_,
                            static_cast<__half*>(dx));
     return check_launch("group_norm_backward");
+}
+
+// out[N, HW, C] = a + b + bias[C] on fp16 channels-last maps (C % 8 == 0; out may alias a or b)
+int sdfx_add_bias_residual(const void* a, const void* b, const void* bias, uint32_t N, uint32_t HW, uint32_t C, void* out, sdfx_stream_t stream) {
+    SDFX_REQUIRE(a && b && bias && out, "add_bias_residual: null pointer");
+    SDFX_REQUIRE(C % 8 == 0 && C > 0, "add_bias_residual: C must be a positive multiple of 8 (got %u)", C);
+    SDFX_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(bias) |
+                   reinterpret_cast<uintptr_t>(out)) % 16) == 0, "add_bias_residual: misaligned pointer");
+    const uint64_t nvec = (uint64_t)N * HW * (C / 8);
+    if (nvec == 0) return SDFX_OK;
+    const uint32_t blocks = (uint32_t)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_add_bias_residual, dim3(blocks), dim3(256), 0, as_stream(stream), static_cast<const uint4*>(a), static_cast<const uint4*>(b),
+                       static_cast<const __half*>(bias), nvec, C / 8, static_cast<uint4*>(out));
+    return check_launch("add_bias_residual");
 }
 
 }  // extern "C"

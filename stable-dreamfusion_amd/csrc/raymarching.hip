@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void k_march_count(const float* __restrict__ ra
 #endif
 
 // Pass 1, one WAVE per ray (the default since round 2: 107-184 us against 250-330 us for the thread-per-ray kernel on
-// the init / blobs / full grids, identical counts, offsets and sample times on the MI355X — tests/test_gpu_parity.py,
+// the init / blobs / full grids, identical counts, offsets and sample times on the MI355X — tests/test_gpu_02_parity.py,
 // tools/march_bench.py; SDFX_MARCH_WAVE=0 selects the thread-per-ray kernel in the devtools library). Every ray time the march visits lies on one occupancy-independent lattice (march_advance), so 64 consecutive
 // lattice points are probed at once — each lane: is my cell occupied, and if not, how many lattice points does the
 // serial march skip from here (the literal do-while of raymarching.cu:459-462)? — and the serial decision chain is

@@ -16,13 +16,17 @@ prediction, damped, to the consistent stand-in of `guidance.SyntheticUNet`; see 
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import guidance as G
-from .groupnorm import GroupNormAct
+from .groupnorm import GroupNormAct, add_bias_residual, fused_ok
+
+
+_BLOCK_FUSION = int(os.environ.get("SDFX_BLOCK_FUSION", "1"))   # A/B switch of ResBlock._forward_fused / the transformer's fused tail
 
 
 def _gn(c, act=False):
@@ -40,11 +44,30 @@ class ResBlock(nn.Module):
         self.skip = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, emb=None):
+        if _BLOCK_FUSION and fused_ok(x, self.norm1.weight, self.norm1.bias, 32) and not self.conv1.bias.requires_grad:
+            return self._forward_fused(x, emb)
         h = self.conv1(self.norm1(x))                       # norm1 / norm2 include the SiLU
         if self.temb is not None:
             h = h + self.temb(F.silu(emb))[:, :, None, None]
         h = self.conv2(self.norm2(h))
         return (x if self.skip is None else self.skip(x)) + h
+
+    def _forward_fused(self, x, emb):
+        """The same block on the channels-last fp16 path with three elementwise launches less: conv1's bias and the time-embedding
+        projection are one [N, C] vector that norm2 adds while it reads its input (frozen weights: conv1's bias is folded into the
+        projection's bias once), and conv2's bias joins the residual sum."""
+        conv = lambda c, t: F.conv2d(t, c.weight, None, c.stride, c.padding)
+        h = conv(self.conv1, self.norm1(x))
+        if self.temb is not None:
+            ver = (self.temb.bias._version, self.conv1.bias._version, self.temb.bias.data_ptr(), self.conv1.bias.data_ptr())
+            if getattr(self, "_folded_bias_of", None) != ver:        # (re)built when either parameter was replaced or written to
+                self._folded_bias, self._folded_bias_of = (self.temb.bias + self.conv1.bias).detach(), ver
+            fb = self._folded_bias
+            pre = F.linear(F.silu(emb), self.temb.weight, fb)            # [N, C]
+        else:
+            pre = self.conv1.bias.detach()[None].expand(x.shape[0], -1).contiguous()
+        h = conv(self.conv2, self.norm2(h, pre=pre))
+        return add_bias_residual(x if self.skip is None else self.skip(x), h, self.conv2.bias)
 
 
 class Attention(nn.Module):
@@ -81,7 +104,10 @@ class TransformerBlock(nn.Module):
         h = h + self.attn2(self.n2(h), ctx)
         a, gate = self.ff_in(self.n3(h)).chunk(2, dim=-1)
         h = h + self.ff_out(a * F.gelu(gate))
-        return x + self.proj_out(h.transpose(1, 2).reshape(B, C, H, W))
+        h = h.transpose(1, 2).reshape(B, C, H, W)
+        if _BLOCK_FUSION and fused_ok(x, self.norm.weight, self.norm.bias, 32) and not self.proj_out.bias.requires_grad:
+            return add_bias_residual(x, F.conv2d(h, self.proj_out.weight, None), self.proj_out.bias)
+        return x + self.proj_out(h)
 
 
 class UNetSD15(nn.Module):

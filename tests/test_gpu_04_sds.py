@@ -176,6 +176,24 @@ def test_group_norm_kernels_match_torch_float32(dev, shape, act):
     assert torch.equal(y2, y) and torch.equal(x.grad, dx)
     with torch.no_grad():                                       # the inference path keeps no statistics
         assert torch.equal(m(x.detach()), y)
+    # the norm of x + pre[n, c] (a convolution's bias + the time-embedding projection folded into the norm's read of x)
+    pre = (0.5 * torch.randn(N, C, generator=g)).half().to(dev)
+    x.grad = None
+    yp = m(x, pre=pre)
+    yp.backward(dy)
+    xr2 = (x.detach().float() + pre.float()[:, :, None, None]).requires_grad_(True)
+    yr2 = torch.nn.functional.group_norm(xr2, 32, m.weight.float(), m.bias.float(), m.eps)
+    yr2 = torch.nn.functional.silu(yr2) if act else yr2
+    yr2.backward(dy.float())
+    assert torch.all((yp.float() - yr2).abs() <= 1.5e-3 * yr2.abs() + 2e-4), float((yp.float() - yr2).abs().max())
+    assert float((x.grad.float() - xr2.grad).abs().max()) <= 1e-2 * float(xr2.grad.abs().max()) + 1e-6
+    # a + b + bias in one launch
+    from sdfx_nerf.groupnorm import add_bias_residual
+    b2 = torch.randn(shape, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(C, generator=g).half().to(dev)
+    got = add_bias_residual(x.detach(), b2, bias)
+    want = (x.detach().float() + b2.float() + bias.float()[None, :, None, None])
+    assert got.is_contiguous(memory_format=torch.channels_last) and float((got.float() - want).abs().max()) <= 1e-3 * float(want.abs().max()) + 1e-4
 
 
 def test_sd15_restatement_with_fused_norms_matches_stock_ops(dev):
