@@ -70,6 +70,9 @@ class ResBlock(nn.Module):
         return add_bias_residual(x if self.skip is None else self.skip(x), h, self.conv2.bias)
 
 
+_WIDE_HEAD_MATMUL = int(os.environ.get("SDFX_WIDE_HEAD_MATMUL", "1"))   # A/B switch, see Attention.forward
+
+
 class Attention(nn.Module):
     def __init__(self, dim, ctx_dim=None, heads=8):
         super().__init__()
@@ -83,7 +86,15 @@ class Attention(nn.Module):
         ctx = x if ctx is None else ctx
         B, N, C = x.shape
         split = lambda t: t.view(B, -1, self.heads, C // self.heads).transpose(1, 2)
-        out = F.scaled_dot_product_attention(split(self.q(x)), split(self.k(ctx)), split(self.v(ctx)))
+        q, k, v = split(self.q(x)), split(self.k(ctx)), split(self.v(ctx))
+        if _WIDE_HEAD_MATMUL and C // self.heads > 256 and q.is_cuda:
+            # One 512-wide head over 4096 tokens (the VAE's mid block): flash attention has no tile shape for such a head — its
+            # backward pair took 1.1 ms of an RGB iteration (profiles/r04_rgb_phase_kernel_stats.csv: bwd_kernel_dk_dv + bwd_kernel_dq)
+            # for 85 GFLOP — while the three GEMMs of the explicit form run at hipBLASLt's rate and the 4096^2 score matrix is 32 MB.
+            w = torch.softmax(torch.matmul(q * (1.0 / math.sqrt(q.shape[-1])), k.transpose(-1, -2)), dim=-1)
+            out = torch.matmul(w, v)
+        else:
+            out = F.scaled_dot_product_attention(q, k, v)
         return self.o(out.transpose(1, 2).reshape(B, N, C))
 
 
