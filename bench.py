@@ -978,18 +978,24 @@ def main():
     # TCP_TOTAL_CACHE_ACCESSES_sum of the same PMC run as `traffic`, scaled per point to this launch; TA busy fraction from the
     # same file when collected.
     pm = pmc.get(pmc_key) or {}
-    lines_pp = (pm["TCP_TOTAL_CACHE_ACCESSES_sum_avg"] / pm["points_per_launch"]) if (pm.get("TCP_TOTAL_CACHE_ACCESSES_sum_avg") and pm.get("points_per_launch")) else None
-    if lines_pp and sec > 0:
+    if pm.get("TA_BUSY_avr_avg") and pm.get("GRBM_GUI_ACTIVE_avg") and pm.get("points_per_launch") and sec > 0:
+        # TA_BUSY_avr = busy cycles of a texture-address unit (one per CU), averaged over the units; GRBM_GUI_ACTIVE is summed over
+        # the 8 XCDs. A TA is busy 2.4 cycles per distinct line (the ubench), so busy cycles / 2.4 = lines that CU looked up —
+        # 26.5 per point over the 16 levels for the iteration's stencil batches, which is what the address simulation of
+        # DESIGN.md section 4.3 predicts (25.9) — and busy / active = the fraction of the kernel's time the pipe that bounds it works.
+        ta_busy = pm["TA_BUSY_avr_avg"] / (pm["GRBM_GUI_ACTIVE_avg"] / 8.0)
+        lines_pp = pm["TA_BUSY_avr_avg"] / 2.4 * 256.0 / pm["points_per_launch"]
         lines = lines_pp * enc_points
-        ta_busy = None
-        if pm.get("TA_BUSY_avr_avg") and pm.get("GRBM_GUI_ACTIVE_avg"):
-            ta_busy = pm["TA_BUSY_avr_avg"] / pm["GRBM_GUI_ACTIVE_avg"]
         result["roofline"]["gather"] = {
-            "bound": "vector-memory line rate (TA / TCP: 128-byte lines looked up per second)",
-            "lines_per_launch": lines, "lines_per_point": lines_pp, "achieved": lines * 128.0 / sec / 1e9, "peak": GATHER_PEAK_GBPS,
-            "unit": "GB/s of 128-byte lines", "frac": lines * 128.0 / sec / 1e9 / GATHER_PEAK_GBPS, "ta_busy_frac": ta_busy,
+            "bound": "vector-memory line rate: a CU's texture-address unit looks up one distinct 128-byte line per 2.4 cycles",
+            "ta_busy_frac": ta_busy, "frac": lines * 128.0 / sec / 1e9 / GATHER_PEAK_GBPS,
+            "lines_per_point": lines_pp, "lines_per_launch": lines, "achieved": lines * 128.0 / sec / 1e9, "peak": GATHER_PEAK_GBPS,
+            "unit": "GB/s of 128-byte lines",
+            "tcp_cache_accesses_per_point": (pm["TCP_TOTAL_CACHE_ACCESSES_sum_avg"] / pm["points_per_launch"]) if pm.get("TCP_TOTAL_CACHE_ACCESSES_sum_avg") else None,
             "l2_read_requests_per_point": (pm["TCP_TCC_READ_REQ_sum_avg"] / pm["points_per_launch"]) if pm.get("TCP_TCC_READ_REQ_sum_avg") else None,
-            "source": f"{traffic_file} (TCP_TOTAL_CACHE_ACCESSES_sum, TA_BUSY_avr / GRBM_GUI_ACTIVE; peak: profiles/r02_gather_policy.txt)"}
+            "source": f"{traffic_file}: rocprofv3 --pmc TA_BUSY_avr GRBM_GUI_ACTIVE / TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum at "
+                      f"{round(pm['points_per_launch'])} points per launch (ta_busy_frac is of THAT run; lines scaled per point to this "
+                      f"launch); peak: profiles/r02_gather_policy.txt"}
     # north_star's second kernel: the compositor. On the training path it is fused with normal + shading + regulariser sums
     # (csrc/render.hip), so two byte counts are given: SURVEY.md §8(d)'s compositor bytes (what the reference's kernel alone
     # would move: 28 / 44 B per sample + 28 / 48 B per ray) and the fused kernel's own compulsory bytes (64 / 100 B per sample
