@@ -962,6 +962,19 @@ def main():
         result["xcd_round_robin"] = int(_sdfx.lib().sdfx_xcd_round_robin())
     except Exception:  # noqa: BLE001
         result["xcd_round_robin"] = None
+    try:   # how often the table-gradient scatter left its fast path in this process (all passes): buckets / launches that overflowed
+        import ctypes
+        import _gridencoder
+        import _sdfx
+        bufs = _gridencoder._BINNED_SCRATCH.get(dev.index) or []
+        if bufs:
+            st = (ctypes.c_uint32 * 4)()
+            _sdfx.call("sdfx_grid_encode_backward_binned_stats", _sdfx.ptr(bufs[-1]), st, _sdfx.stream())
+            result["scatter_overflow"] = {"buckets_total": int(st[2]), "launches_total": int(st[3]),
+                                          "note": "exact spill path (DESIGN.md section 4.3): counts since the library was loaded, over "
+                                                  "every pass of this run (calibration, priming, timed region, secondary passes)"}
+    except Exception:  # noqa: BLE001
+        pass
     sec = enc["avg_us"] * 1e-6
     result["roofline"] = {
         "bound": "hbm", "kernel": enc_kernel, "achieved": enc["GBps"],

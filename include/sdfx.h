@@ -264,8 +264,8 @@ int sdfx_grid_encode_backward(const void* grad, const float* inputs, const void*
  * goes to exact per-bucket spill accumulators) and independent of the order of arrival: bit-reproducible.
  * Float tables: float32 sums per bucket; heavy or overflowing buckets fall back to float atomics.
  * Returns SDFX_E_UNSUPPORTED for other D / C so the caller can use sdfx_grid_encode_backward.
- * *_stats (synchronises `stream`): out[0] = buckets of the last launch on `scratch` that overflowed into
- * their spill accumulator, out[1] = spill waits that timed out (0 unless the device misbehaved).
+ * *_stats (synchronises `stream`), out[4]: [0] = buckets of the last launch on `scratch` that overflowed into their spill
+ * accumulator, [1] = 0 (reserved), [2] / [3] = buckets / launches that overflowed on this device since the library was loaded.
  */
 int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, const int32_t* offsets_host,
                                      void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,

@@ -386,6 +386,9 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename 
 // ---------------------------------------------------------------------------------------------
 // The spill path of half tables (see the head of the file). Both kernels exit at once unless some bucket overflowed.
 // ---------------------------------------------------------------------------------------------
+// since the library was loaded, on this device: [0] buckets that overflowed, [1] launches in which some bucket did
+__device__ uint32_t g_spill_totals[2];
+
 // one workgroup per bucket: zero the spill accumulator of an overflowed bucket and raise the launch's `any` flag
 __global__ __launch_bounds__(256) void k_grid_bwd_spill_zero(BinPlan bin, const uint32_t* __restrict__ cursors,
                                                              unsigned long long* __restrict__ spill_acc, uint32_t* __restrict__ diag) {
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(256) void k_grid_bwd_spill_zero(BinPlan bin, const 
     if (threadIdx.x == 0) {
         diag[0] = 1u;             // some bucket overflowed (benign race: every writer stores 1)
         atomicAdd(&diag[1], 1u);  // how many (sdfx_grid_encode_backward_binned_stats)
+        atomicAdd(&g_spill_totals[0], 1u);
     }
 }
 
@@ -427,7 +431,8 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_spill(const __half* __
                                                                 const uint32_t* __restrict__ cursors, RowLimit rl, StencilSrc src,
                                                                 unsigned long long* __restrict__ spill_acc,
                                                                 const uint32_t* __restrict__ diag, uint32_t k1_grid) {
-    if (diag[0] == 0u) return;   // no bucket overflowed: every launch of the training loop ends here
+    if (diag[0] == 0u) return;   // no bucket overflowed: nearly every launch of the training loop ends here
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_spill_totals[1], 1u);
     for (uint32_t i = 0; i < kSpillTilesPerGroup; i++) {
         const uint32_t vblock = blockIdx.x * kSpillTilesPerGroup + i;
         uint32_t level, tile;
@@ -706,7 +711,11 @@ BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, boo
         // uniform share + 25 % + slack; coarse levels rely on the run folding; beyond that: the spill accumulators (half tables,
         // exact) or float atomics (float tables)
         uint64_t cap = (worst + nb - 1) / nb;
-        cap = cap + cap / 4 + 256;
+        // Levels of few buckets are the DENSE ones (rows = cells, not hashes): the samples of a scene sit in a fraction of the
+        // volume, so the buckets of that region get several times the uniform share even after the run folding — 3-4 % of the
+        // training iterations overflowed a bucket there with + 25 % (round 4: the spill kernel's trace durations). They are few
+        // buckets, so twice the share costs little memory; hashed levels spread whatever the scene is.
+        cap = (nb <= kCoarseBuckets ? 2 * cap + cap / 2 : cap + cap / 4) + 256;
         b.cap[l] = (uint32_t)cap;
         // A level of a few buckets (the 16^3 level has two) receives all 8*B contributions in those few lists: with
         // 131072 items per workgroup only a few dozen workgroups would run (measured: 677 of 1756 us for that
@@ -858,8 +867,9 @@ uint64_t sdfx_grid_encode_backward_binned_scratch_bytes(const int32_t* offsets_h
     return scratch_layout(plan, max_level, chunk_points, is_half != 0).total_bytes;
 }
 
-// Diagnostics of the LAST chunk launched on `scratch` (synchronises the stream): out[0] = buckets whose list overflowed, i.e.
-// whose sums came from the spill accumulators (half tables; 0 for float tables), out[1] = reserved (0).
+// Diagnostics (synchronises the stream), out[4]: [0] = buckets of the LAST chunk launched on `scratch` whose list overflowed, i.e.
+// whose sums came from the spill accumulators (half tables; 0 for float tables), [1] = reserved (0), [2] / [3] = buckets / launches
+// that overflowed on this device since the library was loaded.
 int sdfx_grid_encode_backward_binned_stats(const void* scratch, uint32_t* out, sdfx_stream_t stream) {
     SDFX_REQUIRE(scratch && out, "grid_encode_backward_binned_stats: null pointer");
     hipStream_t st = as_stream(stream);
@@ -871,6 +881,13 @@ int sdfx_grid_encode_backward_binned_stats(const void* scratch, uint32_t* out, s
     }
     out[0] = host[1];
     out[1] = 0;
+    uint32_t totals[2] = {0, 0};
+    if (hipMemcpyFromSymbol(totals, HIP_SYMBOL(g_spill_totals), sizeof(totals)) != hipSuccess) {
+        set_error("grid_encode_backward_binned_stats: reading the totals failed");
+        return SDFX_E_LAUNCH;
+    }
+    out[2] = totals[0];
+    out[3] = totals[1];
     return SDFX_OK;
 }
 

@@ -261,7 +261,7 @@ def _scatter_half(dev, x, gr, offsets, pls, chunk, table_init=None, layout=1):
     xt, grt = T(x, dev), T(gr, dev)
     S.call("sdfx_grid_encode_backward_binned", S.ptr(grt), S.ptr(xt), oh, S.ptr(gt), x.shape[0], 3, 2, 16, 16, S_, 16, 0, 0, 1,
            1, layout, S.ptr(scratch), scratch.numel(), S.stream())
-    stats = (C.c_uint32 * 2)()
+    stats = (C.c_uint32 * 4)()
     S.call("sdfx_grid_encode_backward_binned_stats", S.ptr(scratch), stats, S.stream())
     return gt, int(stats[0])
 

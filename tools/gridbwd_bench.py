@@ -34,7 +34,7 @@ for i in range(n + 1):
 e_.record(); torch.cuda.synchronize()
 print(f"grid bwd binned B={B} order={os.environ.get('STENCIL_ORDER', 'stencil')}: {s.elapsed_time(e_)/n*1e3:.1f} us/call")
 import ctypes, _sdfx
-_st = (ctypes.c_uint32 * 2)()
+_st = (ctypes.c_uint32 * 4)()
 _sdfx.call("sdfx_grid_encode_backward_binned_stats", _sdfx.ptr(_gridencoder._BINNED_SCRATCH[dev.index][-1]), _st, _sdfx.stream())
 print(f"  buckets that overflowed their list in the last launch: {_st[0]}")
 if os.environ.get("PER_LEVEL"):
