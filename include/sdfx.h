@@ -550,6 +550,8 @@ int sdfx_group_norm_forward(const void* x, const void* pre, const void* gamma, c
 int sdfx_group_norm_backward(const void* x, const void* pre, const void* dy, const void* gamma, const void* beta, const float* mean_rstd,
                              uint32_t N, uint32_t HW, uint32_t C, uint32_t G, int silu, void* dx, float* scratch, sdfx_stream_t stream);
 int sdfx_add_bias_residual(const void* a, const void* b, const void* bias, uint32_t N, uint32_t HW, uint32_t C, void* out, sdfx_stream_t stream);
+/* out[rows, n] = x[rows, :n] * gelu(x[rows, n:]) (exact erf GELU; the GEGLU of the UNet's feed-forward blocks), fp16, n % 8 == 0 */
+int sdfx_geglu(const void* x, uint64_t rows, uint32_t n, void* out, sdfx_stream_t stream);
 
 #ifdef __cplusplus
 }

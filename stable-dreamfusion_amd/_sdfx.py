@@ -104,6 +104,7 @@ _SIGNATURES = {
     "sdfx_group_norm_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _int, _ptr, _ptr, _ptr, _ptr],
     "sdfx_group_norm_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _int, _ptr, _ptr, _ptr],
     "sdfx_add_bias_residual": [_ptr, _ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
+    "sdfx_geglu": [_ptr, _u64, _u32, _ptr, _ptr],
     "sdfx_adan_ctl_words": [],
     "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],
     "sdfx_adan_prepare": [_ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _u32, _ptr],

@@ -354,6 +354,20 @@ __global__ __launch_bounds__(256) void k_add_bias_residual(const uint4* __restri
     }
 }
 
+// GEGLU: out[r, c] = x[r, c] * gelu(x[r, n + c]) (exact erf form), rows of 2 n halves -> n halves, 16-byte vectors
+__global__ __launch_bounds__(256) void k_geglu(const uint4* __restrict__ x, uint64_t rows, uint32_t nv, uint4* __restrict__ out) {
+    const uint64_t total = rows * nv;
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = v / nv, c = v - r * nv;
+        float a[8], g[8];
+        unpack8(x[r * 2 * nv + c], a);
+        unpack8(x[r * 2 * nv + nv + c], g);
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = a[i] * (0.5f * g[i] * (1.0f + erff(g[i] * 0.70710678118654752f)));
+        out[v] = pack8(a);
+    }
+}
+
 uint32_t stats_lds_bytes(const GnShape& s) { return 2u * s.ppi * s.C * (uint32_t)sizeof(float); }
 // the consumer kernels combine the partials themselves: few slabs, and at least two threads per (group, moment) to split them over
 bool inline_ok(const GnShape& s) { return s.slabs <= kInlineSlabs && s.threads >= 4 * s.G; }
@@ -434,6 +448,18 @@ int sdfx_add_bias_residual(const void* a, const void* b, const void* bias, uint3
     hipLaunchKernelGGL(k_add_bias_residual, dim3(blocks), dim3(256), 0, as_stream(stream), static_cast<const uint4*>(a), static_cast<const uint4*>(b),
                        static_cast<const __half*>(bias), nvec, C / 8, static_cast<uint4*>(out));
     return check_launch("add_bias_residual");
+}
+
+// out[rows, n] = x[rows, :n] * gelu(x[rows, n:]) (erf GELU), fp16, n % 8 == 0
+int sdfx_geglu(const void* x, uint64_t rows, uint32_t n, void* out, sdfx_stream_t stream) {
+    SDFX_REQUIRE(x && out, "geglu: null pointer");
+    SDFX_REQUIRE(n % 8 == 0 && n > 0, "geglu: n must be a positive multiple of 8 (got %u)", n);
+    SDFX_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) % 16) == 0, "geglu: misaligned pointer");
+    if (rows == 0) return SDFX_OK;
+    const uint64_t total = rows * (n / 8);
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_geglu, dim3(blocks), dim3(256), 0, as_stream(stream), static_cast<const uint4*>(x), rows, n / 8, static_cast<uint4*>(out));
+    return check_launch("geglu");
 }
 
 }  // extern "C"

@@ -82,6 +82,20 @@ def add_bias_residual(a, b, bias):
     return a + (b if bias is None else b + bias[None, :, None, None])
 
 
+def geglu(x):
+    """GEGLU of a feed-forward block: `a * gelu(gate)` for `a, gate = x.chunk(2, dim=-1)` (exact erf GELU) — one launch on a dense
+    fp16 CUDA tensor that needs no gradient (the frozen UNet), PyTorch's two otherwise."""
+    n = x.shape[-1] // 2
+    if (_FUSED and x.is_cuda and x.dtype == torch.float16 and not (x.requires_grad and torch.is_grad_enabled()) and x.is_contiguous()
+            and x.shape[-1] % 16 == 0 and x.data_ptr() % 16 == 0):
+        import _sdfx as S
+        out = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
+        S.call("sdfx_geglu", S.ptr(x), x.numel() // x.shape[-1], n, S.ptr(out), S.stream())
+        return out
+    a, gate = x.chunk(2, dim=-1)
+    return a * F.gelu(gate)
+
+
 def fused_ok(x, weight, bias, groups) -> bool:
     """The conditions under which csrc/groupnorm.hip takes the call (see the module docstring)."""
     if not (_FUSED and x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and weight is not None and bias is not None):

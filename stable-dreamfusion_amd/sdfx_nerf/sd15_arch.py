@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import guidance as G
-from .groupnorm import GroupNormAct, add_bias_residual, fused_ok
+from .groupnorm import GroupNormAct, add_bias_residual, fused_ok, geglu
 
 
 _BLOCK_FUSION = int(os.environ.get("SDFX_BLOCK_FUSION", "1"))   # A/B switch of ResBlock._forward_fused / the transformer's fused tail
@@ -43,16 +43,17 @@ class ResBlock(nn.Module):
         self.norm2, self.conv2 = _gn(cout, act=True), nn.Conv2d(cout, cout, 3, padding=1)
         self.skip = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
-    def forward(self, x, emb=None):
+    def forward(self, x, emb_act=None):
+        """`emb_act` = SiLU(time embedding): the activation is the same for every block, so the UNet applies it once."""
         if _BLOCK_FUSION and fused_ok(x, self.norm1.weight, self.norm1.bias, 32) and not self.conv1.bias.requires_grad:
-            return self._forward_fused(x, emb)
+            return self._forward_fused(x, emb_act)
         h = self.conv1(self.norm1(x))                       # norm1 / norm2 include the SiLU
         if self.temb is not None:
-            h = h + self.temb(F.silu(emb))[:, :, None, None]
+            h = h + self.temb(emb_act)[:, :, None, None]
         h = self.conv2(self.norm2(h))
         return (x if self.skip is None else self.skip(x)) + h
 
-    def _forward_fused(self, x, emb):
+    def _forward_fused(self, x, emb_act):
         """The same block on the channels-last fp16 path with three elementwise launches less: conv1's bias and the time-embedding
         projection are one [N, C] vector that norm2 adds while it reads its input (frozen weights: conv1's bias is folded into the
         projection's bias once), and conv2's bias joins the residual sum."""
@@ -63,7 +64,7 @@ class ResBlock(nn.Module):
             if getattr(self, "_folded_bias_of", None) != ver:        # (re)built when either parameter was replaced or written to
                 self._folded_bias, self._folded_bias_of = (self.temb.bias + self.conv1.bias).detach(), ver
             fb = self._folded_bias
-            pre = F.linear(F.silu(emb), self.temb.weight, fb)            # [N, C]
+            pre = F.linear(emb_act, self.temb.weight, fb)                # [N, C]
         else:
             pre = self.conv1.bias.detach()[None].expand(x.shape[0], -1).contiguous()
         h = conv(self.conv2, self.norm2(h, pre=pre))
@@ -110,15 +111,20 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x, ctx):
         B, C, H, W = x.shape
-        h = self.proj_in(self.norm(x)).flatten(2).transpose(1, 2)
+        fused = _BLOCK_FUSION and fused_ok(x, self.norm.weight, self.norm.bias, 32) and not self.proj_out.bias.requires_grad
+        if fused:
+            # channels-last memory IS [B, HW, C]: the two 1 x 1 convolutions are plain GEMMs on that view (hipBLASLt with the bias in
+            # its epilogue instead of MIOpen's implicit GEMM + zero fill + bias kernel), and no flatten / transpose copies exist
+            h = F.linear(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight.reshape(C, C), self.proj_in.bias)
+        else:
+            h = self.proj_in(self.norm(x)).flatten(2).transpose(1, 2)
         h = h + self.attn1(self.n1(h))
         h = h + self.attn2(self.n2(h), ctx)
-        a, gate = self.ff_in(self.n3(h)).chunk(2, dim=-1)
-        h = h + self.ff_out(a * F.gelu(gate))
-        h = h.transpose(1, 2).reshape(B, C, H, W)
-        if _BLOCK_FUSION and fused_ok(x, self.norm.weight, self.norm.bias, 32) and not self.proj_out.bias.requires_grad:
-            return add_bias_residual(x, F.conv2d(h, self.proj_out.weight, None), self.proj_out.bias)
-        return x + self.proj_out(h)
+        h = h + self.ff_out(geglu(self.ff_in(self.n3(h))))
+        if fused:
+            out = F.linear(h, self.proj_out.weight.reshape(C, C))                 # bias: in the residual sum
+            return add_bias_residual(x, out.view(B, H, W, C).permute(0, 3, 1, 2), self.proj_out.bias)
+        return x + self.proj_out(h.transpose(1, 2).reshape(B, C, H, W))
 
 
 class UNetSD15(nn.Module):
@@ -158,7 +164,7 @@ class UNetSD15(nn.Module):
         return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
     def forward(self, x, t, encoder_hidden_states):
-        emb = self.time(self.time_embedding(t).to(x.dtype))
+        emb = F.silu(self.time(self.time_embedding(t).to(x.dtype)))   # every ResNet block takes SiLU(emb): applied once here
         ctx = encoder_hidden_states.to(x.dtype)
         h = self.conv_in(x)
         hs = [h]

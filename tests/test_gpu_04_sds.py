@@ -222,3 +222,16 @@ def test_sd15_restatement_with_fused_norms_matches_stock_ops(dev):
             GN._FUSED = 1
     for a, b in zip(outs[1], outs[0]):
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-4, (float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_geglu_kernel_matches_torch(dev):
+    """a * gelu(gate) of the UNet's feed-forward blocks in one launch (csrc/groupnorm.hip k_geglu) against PyTorch's two ops."""
+    from sdfx_nerf.groupnorm import geglu
+    g = torch.Generator().manual_seed(9)
+    for shape in ((2, 4096, 2560), (2, 64, 10240), (3, 7, 32)):
+        x = (torch.randn(shape, generator=g) * 2).half().to(dev)
+        got = geglu(x)
+        a, gate = x.float().chunk(2, dim=-1)
+        want = a * torch.nn.functional.gelu(gate)
+        assert got.shape == want.shape and got.dtype == torch.float16
+        assert float((got.float() - want).abs().max()) <= 1e-3 * float(want.abs().max()) + 1e-4
