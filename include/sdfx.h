@@ -553,6 +553,24 @@ int sdfx_add_bias_residual(const void* a, const void* b, const void* bias, uint3
 /* out[rows, n] = x[rows, :n] * gelu(x[rows, n:]) (exact erf GELU; the GEGLU of the UNet's feed-forward blocks), fp16, n % 8 == 0 */
 int sdfx_geglu(const void* x, uint64_t rows, uint32_t n, void* out, sdfx_stream_t stream);
 
+/* ---------------------------------------------------------------- frozen prior: 3 x 3 convolutions on the matrix cores (extension) */
+
+/*
+ * Extension (no reference kernel: the reference gets these layers from diffusers, guidance/sd_utils.py:37-65) —
+ * y[N, Ho, Wo, Cout] = conv3x3(x[N, H, W, Cin], w[Cout, 3, 3, Cin], padding 1, stride 1 | 2) + bias[Cout] + residual[N, Ho, Wo, Cout]
+ * on fp16 CHANNELS-LAST maps (NHWC memory; the weight is a channels-last [Cout, Cin, 3, 3] tensor), float32 accumulation, forward
+ * only (frozen weights, no gradient): an implicit GEMM on v_mfma_f32_32x32x16_f16 (csrc/conv.hip). bias / residual may be NULL;
+ * y may alias residual. `upsample` != 0: the taps walk the nearest-neighbour 2 x upsampling of x ([N, 2H, 2W, Cin], never
+ * materialised). Needs Cin % 64 == 0, Cout % 64 == 0, maps below 2 GiB. Small maps split K over workgroups that write float32
+ * partials to `scratch` (sdfx_conv3x3_scratch_bytes(...) bytes, 0 = none needed), summed in a fixed order.
+ * splitk / tile_rows: 0 = chosen by shape (what callers pass); > 0 force the K split / 64- or 128-row tiles (measurements).
+ */
+uint64_t sdfx_conv3x3_scratch_bytes(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t upsample,
+                                    int splitk, int tile_rows);
+int sdfx_conv3x3_forward(const void* x, const void* w, const void* bias, const void* residual, uint32_t N, uint32_t H, uint32_t W,
+                         uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t upsample, int splitk, int tile_rows, void* y,
+                         float* scratch, sdfx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

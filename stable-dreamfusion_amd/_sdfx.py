@@ -105,6 +105,8 @@ _SIGNATURES = {
     "sdfx_group_norm_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _int, _ptr, _ptr, _ptr],
     "sdfx_add_bias_residual": [_ptr, _ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "sdfx_geglu": [_ptr, _u64, _u32, _ptr, _ptr],
+    "sdfx_conv3x3_scratch_bytes": [_u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _int],
+    "sdfx_conv3x3_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _int, _ptr, _ptr, _ptr],
     "sdfx_adan_ctl_words": [],
     "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],
     "sdfx_adan_prepare": [_ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _u32, _ptr],
@@ -120,6 +122,7 @@ _RESTYPES = {
     "sdfx_field_packed_words": _u32,
     "sdfx_field_backward_scratch_bytes": _u64,
     "sdfx_group_norm_scratch_bytes": _u64,
+    "sdfx_conv3x3_scratch_bytes": _u64,
     "sdfx_adan_ctl_words": _u32,
 }
 

@@ -1,0 +1,67 @@
+"""3 x 3 convolutions of the frozen prior on channels-last fp16 maps: csrc/conv.hip behind `conv3x3(...)`.
+
+`conv3x3(x, weight, bias, residual, stride, upsample)` ==
+`F.conv2d(F.interpolate(x, scale_factor=2) if upsample else x, weight, bias, stride, 1) + residual` for a frozen fp16 channels-last
+weight and input with Cin % 64 == 0, Cout % 64 == 0 on a CUDA device when no gradient is wanted (the UNet of the SDS step runs
+under `no_grad`); every other call goes through PyTorch's ops, so the function is a drop-in for them. SDFX_CONV=0 forces the
+PyTorch ops everywhere (A/B switch)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+_FUSED = int(os.environ.get("SDFX_CONV", "1"))
+_SCRATCH = {}   # device index -> float32 scratch for split-K partials, grown on demand (every call rewrites what it reads)
+
+
+def _scratch(device, nbytes):
+    buf = _SCRATCH.get(device.index)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _SCRATCH[device.index] = buf
+    return buf
+
+
+def conv_ok(x, weight, bias=None, residual=None, stride=1) -> bool:
+    """The conditions under which csrc/conv.hip takes the call (see the module docstring)."""
+    if not (_FUSED and x.is_cuda and x.dim() == 4 and weight.dim() == 4 and x.dtype == torch.float16 and weight.dtype == torch.float16):
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)
+                                    or (bias is not None and bias.requires_grad)):
+        return False
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or cin != x.shape[1] or cin % 64 or cout % 64 or stride not in (1, 2) or x.numel() == 0:
+        return False
+    if not (x.is_contiguous(memory_format=torch.channels_last) and weight.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    if x.numel() * 2 >= 2 ** 31 or weight.numel() * 2 >= 2 ** 31 or x.data_ptr() % 16 or weight.data_ptr() % 16:
+        return False
+    if bias is not None and (bias.dtype != torch.float16 or bias.shape != (cout,) or not bias.is_contiguous() or bias.data_ptr() % 16):
+        return False
+    if residual is not None and (residual.dtype != torch.float16 or residual.dim() != 4 or residual.data_ptr() % 16
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    return True
+
+
+def conv3x3(x, weight, bias=None, residual=None, stride=1, upsample=False, splitk=0, tile_rows=0):
+    """See the module docstring. `splitk` / `tile_rows`: 0 = chosen by shape; other values are for measurements (tools/conv_bench.py)."""
+    if conv_ok(x, weight, bias, residual, stride):
+        import _sdfx as S
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        Hu, Wu = (2 * H, 2 * W) if upsample else (H, W)
+        Ho, Wo = (Hu - 1) // stride + 1, (Wu - 1) // stride + 1
+        if residual is None or tuple(residual.shape) == (N, Cout, Ho, Wo):
+            y = torch.empty((N, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            nbytes = int(S.lib().sdfx_conv3x3_scratch_bytes(N, H, W, Cin, Cout, stride, int(bool(upsample)), int(splitk), int(tile_rows)))
+            scratch = _scratch(x.device, nbytes) if nbytes else None
+            S.call("sdfx_conv3x3_forward", S.ptr(x), S.ptr(weight), S.ptr(bias), S.ptr(residual), N, H, W, Cin, Cout, stride,
+                   int(bool(upsample)), int(splitk), int(tile_rows), S.ptr(y), S.ptr(scratch), S.stream())
+            return y
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(x, weight, bias, stride, 1)
+    return y if residual is None else y + residual

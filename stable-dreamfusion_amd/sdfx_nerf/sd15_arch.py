@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import guidance as G
+from .conv import conv3x3, conv_ok
 from .groupnorm import GroupNormAct, add_bias_residual, fused_ok, geglu
 
 
@@ -57,8 +58,8 @@ class ResBlock(nn.Module):
         """The same block on the channels-last fp16 path with three elementwise launches less: conv1's bias and the time-embedding
         projection are one [N, C] vector that norm2 adds while it reads its input (frozen weights: conv1's bias is folded into the
         projection's bias once), and conv2's bias joins the residual sum."""
-        conv = lambda c, t: F.conv2d(t, c.weight, None, c.stride, c.padding)
-        h = conv(self.conv1, self.norm1(x))
+        # (conv3x3: csrc/conv.hip when no gradient is wanted — the UNet of the SDS step — else F.conv2d)
+        h = conv3x3(self.norm1(x), self.conv1.weight)
         if self.temb is not None:
             ver = (self.temb.bias._version, self.conv1.bias._version, self.temb.bias.data_ptr(), self.conv1.bias.data_ptr())
             if getattr(self, "_folded_bias_of", None) != ver:        # (re)built when either parameter was replaced or written to
@@ -67,8 +68,15 @@ class ResBlock(nn.Module):
             pre = F.linear(emb_act, self.temb.weight, fb)                # [N, C]
         else:
             pre = self.conv1.bias.detach()[None].expand(x.shape[0], -1).contiguous()
-        h = conv(self.conv2, self.norm2(h, pre=pre))
-        return add_bias_residual(x if self.skip is None else self.skip(x), h, self.conv2.bias)
+        hn = self.norm2(h, pre=pre)
+        if self.skip is None:
+            skip = x
+        else:                                   # the 1 x 1 shortcut as a GEMM on the channels-last view (as the transformer's projections)
+            N, C, H, W = x.shape
+            skip = F.linear(x.permute(0, 2, 3, 1), self.skip.weight.reshape(self.skip.weight.shape[0], C), self.skip.bias).permute(0, 3, 1, 2)
+        if conv_ok(hn, self.conv2.weight, self.conv2.bias, skip):
+            return conv3x3(hn, self.conv2.weight, self.conv2.bias, skip)          # bias and shortcut in the convolution's epilogue
+        return add_bias_residual(skip, F.conv2d(hn, self.conv2.weight, None, 1, 1), self.conv2.bias)
 
 
 _WIDE_HEAD_MATMUL = int(os.environ.get("SDFX_WIDE_HEAD_MATMUL", "1"))   # A/B switch, see Attention.forward
@@ -174,7 +182,7 @@ class UNetSD15(nn.Module):
                 if attn is not None:
                     h = attn(h, ctx)
             else:
-                h = first(h)                                   # stride-2 downsample
+                h = conv3x3(h, first.weight, first.bias, None, 2)   # stride-2 downsample
             hs.append(h)
         h = self.mid[0](h, emb)
         h = self.mid[1](h, ctx)
@@ -183,8 +191,8 @@ class UNetSD15(nn.Module):
             h = res(torch.cat([h, hs.pop()], dim=1), emb)
             if attn is not None:
                 h = attn(h, ctx)
-            if upconv is not None:
-                h = upconv(F.interpolate(h, scale_factor=2.0, mode="nearest"))
+            if upconv is not None:                           # nearest 2 x upsample + convolution (the kernel reads through the upsample)
+                h = conv3x3(h, upconv.weight, upconv.bias, None, 1, upsample=True)
         return self.conv_out(self.norm_out(h))
 
 

@@ -1,0 +1,97 @@
+"""csrc/conv.hip (the frozen prior's 3 x 3 convolutions as MFMA implicit GEMMs) against PyTorch's float32 convolution of the same
+half inputs. The kernel accumulates in float32 and rounds once (twice with a residual): the tolerance is a few half ulps of the
+result's magnitude, far below what a wrong tap, channel chunk, fragment layout or tile boundary would produce."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_mod():
+    importlib.import_module("stable-dreamfusion_amd")
+    return importlib.import_module("sdfx_nerf.conv")
+
+
+def _inputs(dev, N, Cin, H, W, Cout, seed, residual_hw=None):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).half().to(dev).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, generator=g).half().to(dev)
+    r = None
+    if residual_hw is not None:
+        r = torch.randn(N, Cout, *residual_hw, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+    return x, w, b, r
+
+
+def _reference(x, w, b, r, stride, upsample):
+    xf = x.float()
+    if upsample:
+        xf = F.interpolate(xf, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(xf, w.float(), None if b is None else b.float(), stride, 1)
+    y = y.half().float()                                   # the kernel rounds conv + bias to half before the residual joins
+    return y if r is None else y + r.float()
+
+
+def _check(got, want):
+    assert got.dtype == torch.float16 and got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    err = float((got.float() - want).abs().max())
+    scale = float(want.abs().max())
+    assert err <= 3e-3 * scale + 1e-4, (err, scale)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,stride,upsample", [
+    (2, 64, 16, 16, 64, 1, False),        # one K chunk per tap, 4 tiles
+    (1, 128, 5, 7, 64, 1, False),         # 35 pixels: a ragged tile (rows beyond M), borders everywhere
+    (3, 64, 9, 6, 128, 2, False),         # stride 2 on odd / even sizes, three images in one tile
+    (2, 192, 6, 6, 64, 1, True),          # taps walk the 2 x upsampled map
+    (2, 320, 64, 64, 320, 1, False),      # the UNet's top level
+    (2, 1280, 8, 8, 1280, 1, False),      # the deepest level: one tile of pixels, K split
+    (2, 640, 32, 32, 640, 2, False),      # a downsampling layer
+    (2, 1280, 16, 16, 1280, 1, True),     # an upsampling layer
+])
+def test_conv3x3_matches_float32_convolution(dev, N, Cin, H, W, Cout, stride, upsample):
+    C = _conv_mod()
+    Hu, Wu = (2 * H, 2 * W) if upsample else (H, W)
+    Ho, Wo = (Hu - 1) // stride + 1, (Wu - 1) // stride + 1
+    x, w, b, r = _inputs(dev, N, Cin, H, W, Cout, seed=Cin + H, residual_hw=(Ho, Wo))
+    assert C.conv_ok(x, w, b, r, stride)
+    with torch.no_grad():
+        for bias, res in ((None, None), (b, None), (b, r)):
+            _check(C.conv3x3(x, w, bias, res, stride, upsample), _reference(x, w, bias, res, stride, upsample))
+
+
+@pytest.mark.parametrize("tile_rows", [64, 128])
+@pytest.mark.parametrize("splitk", [1, 2, 5, 64])
+def test_conv3x3_every_tiling_and_split_gives_the_same_map(dev, tile_rows, splitk):
+    """Forced tile heights and K splits (a split that does not divide the 27 steps, one slice per step at the extreme): all within
+    rounding of the float32 result, and each configuration bit-identical run to run (partials are summed in slice order)."""
+    C = _conv_mod()
+    x, w, b, r = _inputs(dev, 2, 192, 12, 10, 128, seed=11, residual_hw=(12, 10))
+    want = _reference(x, w, b, r, 1, False)
+    with torch.no_grad():
+        a = C.conv3x3(x, w, b, r, 1, False, splitk=splitk, tile_rows=tile_rows)
+        a2 = C.conv3x3(x, w, b, r, 1, False, splitk=splitk, tile_rows=tile_rows)
+    _check(a, want)
+    assert torch.equal(a, a2)
+
+
+def test_conv3x3_falls_back_to_pytorch_off_the_kernel_path(dev):
+    """Channel counts the kernel does not take (the UNet's first / last layer), float32, NCHW inputs and calls that want a gradient
+    go through F.conv2d with the same result as calling it directly."""
+    C = _conv_mod()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 8, 8, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 4, 3, 3, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+    assert not C.conv_ok(x, w)
+    with torch.no_grad():
+        assert torch.equal(C.conv3x3(x, w), F.conv2d(x, w, None, 1, 1))
+    x2, w2, b2, _ = _inputs(dev, 1, 64, 8, 8, 64, seed=2)
+    assert C.conv_ok(x2, w2, b2) and not C.conv_ok(x2.float(), w2.float()) and not C.conv_ok(x2.contiguous(), w2)
+    xg = x2.clone().requires_grad_(True)
+    assert not C.conv_ok(xg, w2)                      # a gradient is wanted: PyTorch's op (and its autograd) takes the call
+    y = C.conv3x3(xg, w2, b2)
+    y.float().sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad.float()).all()
