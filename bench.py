@@ -955,6 +955,9 @@ def main():
             "dtype": "fp16, outside autocast (UNet and VAE encoder)", "memory_format": "channels_last",
             "group_norm": "csrc/groupnorm.hip" if os.environ.get("SDFX_GROUPNORM", "1") != "0" else "torch.nn.functional.group_norm",
             "block_fusion": os.environ.get("SDFX_BLOCK_FUSION", "1") != "0" and os.environ.get("SDFX_GROUPNORM", "1") != "0",
+            "unet_conv3x3": "csrc/conv.hip" if os.environ.get("SDFX_CONV", "1") != "0" else "MIOpen",
+            "unet_attention": "csrc/attention.hip" if os.environ.get("SDFX_ATTENTION", "1") != "0" else "F.scaled_dot_product_attention",
+            "qkv_one_gemm": os.environ.get("SDFX_QKV_FUSION", "1") != "0",
             "miopen_find_mode": bool(torch.backends.cudnn.benchmark), "captured_in_hip_graph": job.train_mode == "graph"},
         "rays_per_iter": 512 * 512 if args.stage == "dmtet" else 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid, "phase": args.phase}
     try:   # the dispatch assumption behind the level-per-XCD plans (include/sdfx.h): 1 = workgroup b runs on XCD (b + c) mod 8

@@ -571,6 +571,20 @@ int sdfx_conv3x3_forward(const void* x, const void* w, const void* bias, const v
                          uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t upsample, int splitk, int tile_rows, void* y,
                          float* scratch, sdfx_stream_t stream);
 
+/* ---------------------------------------------------------------- frozen prior: attention on the matrix cores (extension) */
+
+/*
+ * Extension (no reference kernel: the reference gets these layers from diffusers, guidance/sd_utils.py:37-65) —
+ * o[B, Nq, H, D] (contiguous) = softmax(q k^T * scale) v per (batch, head), fp16 with float32 accumulation and statistics, forward
+ * only (the UNet of the SDS step takes no gradient): online softmax on v_mfma_f32_32x32x16_f16 (csrc/attention.hip).
+ * q[b, n, h, :] is read at q + b * q_strides[0] + n * q_strides[1] + h * q_strides[2] (elements; unit channel stride, every row
+ * 16-byte aligned), k / v likewise over Nk keys. D in {40, 80, 160} (the head widths of the SD-1.5 UNet at 8 heads).
+ * waves: 0 = workgroup size chosen by shape (what callers pass); 1 | 2 | 4 force it (measurements).
+ */
+int sdfx_attention_forward(const void* q, const void* k, const void* v, uint32_t B, uint32_t H, uint32_t Nq, uint32_t Nk, uint32_t D,
+                           const uint32_t* q_strides, const uint32_t* k_strides, const uint32_t* v_strides, float scale, int waves,
+                           void* o, sdfx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

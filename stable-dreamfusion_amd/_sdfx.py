@@ -105,6 +105,7 @@ _SIGNATURES = {
     "sdfx_group_norm_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _int, _ptr, _ptr, _ptr],
     "sdfx_add_bias_residual": [_ptr, _ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "sdfx_geglu": [_ptr, _u64, _u32, _ptr, _ptr],
+    "sdfx_attention_forward": [_ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _f32, _int, _ptr, _ptr],
     "sdfx_conv3x3_scratch_bytes": [_u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _int],
     "sdfx_conv3x3_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _int, _ptr, _ptr, _ptr],
     "sdfx_adan_ctl_words": [],

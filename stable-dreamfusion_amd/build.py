@@ -21,7 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB = os.path.join(CSRC, "libsdfx_hip.so")
 DEV_LIB = os.path.join(CSRC, "libsdfx_hip_dev.so")
-SOURCES = ["sdfx_core.hip", "raymarching.hip", "gridencoder.hip", "gridencoder_fwd.hip", "gridencoder_bwd_binned.hip", "encoders.hip", "field.hip", "optim.hip", "shade.hip", "render.hip", "occupancy.hip", "infer.hip", "head.hip", "sds.hip", "dmtet.hip", "raster.hip", "groupnorm.hip", "conv.hip"]
+SOURCES = ["sdfx_core.hip", "raymarching.hip", "gridencoder.hip", "gridencoder_fwd.hip", "gridencoder_bwd_binned.hip", "encoders.hip", "field.hip", "optim.hip", "shade.hip", "render.hip", "occupancy.hip", "infer.hip", "head.hip", "sds.hip", "dmtet.hip", "raster.hip", "groupnorm.hip", "conv.hip", "attention.hip"]
 ARCH = "gfx950"
 # -ffp-contract=off: the march / encode arithmetic must not gain FMAs the source does not spell
 # out (bit-exact ray counts and fp32 features against the CPU oracle).

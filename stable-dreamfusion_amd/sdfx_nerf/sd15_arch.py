@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import guidance as G
+from .attention import attention_bnc
 from .conv import conv3x3, conv_ok
 from .groupnorm import GroupNormAct, add_bias_residual, fused_ok, geglu
 
@@ -80,6 +81,7 @@ class ResBlock(nn.Module):
 
 
 _WIDE_HEAD_MATMUL = int(os.environ.get("SDFX_WIDE_HEAD_MATMUL", "1"))   # A/B switch, see Attention.forward
+_QKV_FUSION = int(os.environ.get("SDFX_QKV_FUSION", "1"))               # A/B switch: stacked projection weights, one GEMM
 
 
 class Attention(nn.Module):
@@ -91,9 +93,31 @@ class Attention(nn.Module):
         self.v = nn.Linear(ctx_dim or dim, dim, bias=False)
         self.o = nn.Linear(dim, dim)
 
+    def _fused_weight(self, names):
+        """The projections' weights stacked once (frozen parameters; rebuilt when one was replaced or written to): q / k / v of a
+        self-attention — or k / v of a cross-attention — are then ONE GEMM whose output the attention kernel reads through strides."""
+        ws = [getattr(self, n).weight for n in names]
+        ver = tuple((w._version, w.data_ptr()) for w in ws)
+        cache = self.__dict__.setdefault("_stacked", {})
+        if cache.get(names, (None, None))[0] != ver:
+            cache[names] = (ver, torch.cat([w.detach() for w in ws], dim=0))
+        return cache[names][1]
+
     def forward(self, x, ctx=None):
-        ctx = x if ctx is None else ctx
+        self_attn = ctx is None
+        ctx = x if self_attn else ctx
         B, N, C = x.shape
+        d = C // self.heads
+        frozen = not (self.q.weight.requires_grad or self.k.weight.requires_grad or self.v.weight.requires_grad)
+        if _QKV_FUSION and frozen and x.is_cuda and d <= 256:
+            heads = lambda t, i: t[..., i * C:(i + 1) * C].unflatten(-1, (self.heads, d)).transpose(1, 2)   # [B, H, n, d] view
+            if self_attn:
+                qkv = F.linear(x, self._fused_weight(("q", "k", "v")))
+                q, k, v = heads(qkv, 0), heads(qkv, 1), heads(qkv, 2)
+            else:
+                kv = F.linear(ctx, self._fused_weight(("k", "v")))
+                q, k, v = self.q(x).view(B, N, self.heads, d).transpose(1, 2), heads(kv, 0), heads(kv, 1)
+            return self.o(attention_bnc(q, k, v))
         split = lambda t: t.view(B, -1, self.heads, C // self.heads).transpose(1, 2)
         q, k, v = split(self.q(x)), split(self.k(ctx)), split(self.v(ctx))
         if _WIDE_HEAD_MATMUL and C // self.heads > 256 and q.is_cuda:
@@ -101,10 +125,12 @@ class Attention(nn.Module):
             # backward pair took 1.1 ms of an RGB iteration (profiles/r04_rgb_phase_kernel_stats.csv: bwd_kernel_dk_dv + bwd_kernel_dq)
             # for 85 GFLOP — while the three GEMMs of the explicit form run at hipBLASLt's rate and the 4096^2 score matrix is 32 MB.
             w = torch.softmax(torch.matmul(q * (1.0 / math.sqrt(q.shape[-1])), k.transpose(-1, -2)), dim=-1)
-            out = torch.matmul(w, v)
+            out = torch.matmul(w, v).transpose(1, 2).reshape(B, N, C)
         else:
-            out = F.scaled_dot_product_attention(q, k, v)
-        return self.o(out.transpose(1, 2).reshape(B, N, C))
+            # csrc/attention.hip when no gradient is wanted and the head is 40 / 80 / 160 wide (the UNet of the SDS step), else
+            # F.scaled_dot_product_attention; either way the result comes back as [B, N, C]
+            out = attention_bnc(q, k, v)
+        return self.o(out)
 
 
 class TransformerBlock(nn.Module):

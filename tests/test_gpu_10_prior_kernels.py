@@ -95,3 +95,74 @@ def test_conv3x3_falls_back_to_pytorch_off_the_kernel_path(dev):
     y = C.conv3x3(xg, w2, b2)
     y.float().sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad.float()).all()
+
+
+# ---- csrc/attention.hip -----------------------------------------------------------------------------------------------------------
+def _attn_mod():
+    importlib.import_module("stable-dreamfusion_amd")
+    return importlib.import_module("sdfx_nerf.attention")
+
+
+def _qkv(dev, B, H, Nq, Nk, d, seed, spread=1.0):
+    """q / k / v as the transformer blocks form them: [B, N, H d] projection outputs viewed as [B, H, N, d]."""
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda n, s: (torch.randn(B, n, H * d, generator=g) * s).half().to(dev).view(B, n, H, d).transpose(1, 2)
+    return mk(Nq, spread), mk(Nk, spread), mk(Nk, 1.0)
+
+
+def _attn_reference(q, k, v):
+    qf, kf, vf = q.float(), k.float(), v.float()
+    w = torch.softmax(torch.matmul(qf, kf.transpose(-1, -2)) * (q.shape[-1] ** -0.5), dim=-1)
+    return torch.matmul(w, vf).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,d", [
+    (2, 8, 4096, 4096, 40), (2, 8, 4096, 77, 40), (2, 8, 1024, 1024, 80), (2, 8, 1024, 77, 80),      # the UNet's calls
+    (2, 8, 256, 256, 160), (2, 8, 256, 77, 160), (2, 8, 64, 64, 160), (2, 8, 64, 77, 160),
+    (1, 3, 50, 77, 40),            # queries that do not fill a wave, keys that do not fill a tile
+    (1, 2, 33, 1, 80),             # one key: the softmax is 1 and the output is v
+    (2, 2, 100, 65, 160),          # one key in the second tile
+])
+def test_attention_matches_float32_softmax(dev, B, H, Nq, Nk, d):
+    """Against softmax(q k^T / sqrt(d)) v evaluated in float32 on the same half inputs. The kernel keeps float32 scores and
+    statistics and rounds the probabilities to half for the second product: a few half ulps of the values' magnitude."""
+    A = _attn_mod()
+    for spread in (1.0, 3.0):          # 3.0: peaked rows, the running maximum moves between tiles
+        q, k, v = _qkv(dev, B, H, Nq, Nk, d, seed=Nq + Nk + d, spread=spread)
+        assert A.attention_ok(q, k, v)
+        with torch.no_grad():
+            got = A.attention_bnc(q, k, v)
+        want = _attn_reference(q, k, v)
+        assert got.shape == want.shape and got.dtype == torch.float16 and got.is_contiguous()
+        err, scale = float((got.float() - want).abs().max()), float(want.abs().max())
+        assert err <= 3e-3 * scale + 1e-4, (spread, err, scale)
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4])
+def test_attention_workgroup_sizes_agree_and_a_late_peak_rescales(dev, waves):
+    """Forced workgroup sizes give the same numbers, bit for bit run to run; and a key planted in the LAST tile whose score towers
+    over everything before it exercises the rescaling of the accumulated output (the online softmax's correction path)."""
+    A = _attn_mod()
+    q, k, v = _qkv(dev, 2, 4, 300, 700, 40, seed=5)
+    k = k.contiguous()
+    k[:, :, 690] = (q[:, :, 7] * 6).to(k.dtype)          # query 7 (and its neighbours, less) meet a huge score at key 690
+    with torch.no_grad():
+        a, a2, base = A.attention_bnc(q, k, v, waves=waves), A.attention_bnc(q, k, v, waves=waves), A.attention_bnc(q, k, v)
+    want = _attn_reference(q, k, v)
+    assert torch.equal(a, a2) and torch.equal(a, base)
+    assert float((a.float() - want).abs().max()) <= 3e-3 * float(want.abs().max()) + 1e-4
+
+
+def test_attention_falls_back_to_pytorch_off_the_kernel_path(dev):
+    A = _attn_mod()
+    q, k, v = _qkv(dev, 1, 2, 64, 64, 64, seed=3)        # a head width the kernel is not built for
+    assert not A.attention_ok(q, k, v)
+    with torch.no_grad():
+        got = A.attention_bnc(q, k, v)
+    assert float((got.float() - _attn_reference(q, k, v)).abs().max()) <= 3e-3
+    q2, k2, v2 = _qkv(dev, 1, 2, 64, 64, 40, seed=4)
+    assert A.attention_ok(q2, k2, v2) and not A.attention_ok(q2.float(), k2.float(), v2.float())
+    qg = q2.detach().clone().requires_grad_(True)
+    assert not A.attention_ok(qg, k2, v2)
+    A.attention_bnc(qg, k2, v2).float().sum().backward()
+    assert qg.grad is not None
