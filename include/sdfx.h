@@ -570,6 +570,11 @@ uint64_t sdfx_conv3x3_scratch_bytes(uint32_t N, uint32_t H, uint32_t W, uint32_t
 int sdfx_conv3x3_forward(const void* x, const void* w, const void* bias, const void* residual, uint32_t N, uint32_t H, uint32_t W,
                          uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t upsample, int splitk, int tile_rows, void* y,
                          float* scratch, sdfx_stream_t stream);
+/* The same kernel with one tap: y[M, N] = x[M, K] . w[N, K]^T + bias[N] + residual[M, N] (bias / residual may be NULL; y may alias
+ * residual) — the small projections of the transformer blocks with their residual sums in the epilogue. K % 64 == 0, N % 64 == 0. */
+uint64_t sdfx_linear_scratch_bytes(uint32_t M, uint32_t K, uint32_t N, int splitk, int tile_rows);
+int sdfx_linear_forward(const void* x, const void* w, const void* bias, const void* residual, uint32_t M, uint32_t K, uint32_t N, int splitk,
+                        int tile_rows, void* y, float* scratch, sdfx_stream_t stream);
 
 /* ---------------------------------------------------------------- frozen prior: attention on the matrix cores (extension) */
 

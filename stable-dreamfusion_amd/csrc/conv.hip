@@ -35,7 +35,8 @@ struct ConvShape {
     uint32_t N, H, W, Cin;        // the map the taps walk (after the optional upsample): [N, H, W, Cin]
     uint32_t Hs, Ws;              // the STORED map: H >> up, W >> up
     uint32_t Ho, Wo, Cout;
-    uint32_t stride, up, pad;     // pad = 1
+    uint32_t stride, up, pad;     // pad = ks / 2
+    uint32_t ks, taps;            // kernel size 3 (taps 9) or 1 (a plain GEMM: taps 1)
     uint32_t M;                   // N Ho Wo
     uint32_t cpt;                 // 64-channel chunks per tap (Cin / 64)
     uint32_t steps;               // 9 cpt
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const _Float16* __restrict__
     const uint32_t t1 = min(t0 + s.steps_per_slice, s.steps);
 
     const __amdgpu_buffer_rsrc_t xb = rsrc(x, (uint64_t)s.N * s.Hs * s.Ws * s.Cin * 2);
-    const __amdgpu_buffer_rsrc_t wb = rsrc(w, (uint64_t)s.Cout * 9 * s.Cin * 2);
+    const __amdgpu_buffer_rsrc_t wb = rsrc(w, (uint64_t)s.Cout * s.taps * s.Cin * 2);
 
     // staging assignment: 8 threads per row (16 bytes each), rows tid / 8 + 32 i
     const uint32_t srow = tid >> 3, schunk = tid & 7u;
@@ -100,14 +101,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const _Float16* __restrict__
         ix0[i] = (int32_t)(ox * s.stride) - (int32_t)s.pad;
         nbase[i] = m < s.M ? n * s.Hs * s.Ws : kOob;
     }
-    const uint32_t wrow_bytes = 9u * s.Cin * 2u;
+    const uint32_t wrow_bytes = s.taps * s.Cin * 2u;
     const uint32_t lds_a_st = srow * kPitch + schunk * 16u;     // + 32 i kPitch
     const uint32_t lds_b_st = kATile + srow * kPitch + schunk * 16u;
 
     uint32_t tap = t0 / s.cpt, cc = t0 - tap * s.cpt;
     uint32_t aoff[RA];
     auto tap_offsets = [&](uint32_t tp) {
-        const int32_t ky = (int32_t)(tp / 3u), kx = (int32_t)(tp - 3u * (tp / 3u));
+        const int32_t ky = (int32_t)(tp / s.ks), kx = (int32_t)(tp - s.ks * (tp / s.ks));
 #pragma unroll
         for (uint32_t i = 0; i < RA; i++) {
             const int32_t iy = iy0[i] + ky, ix = ix0[i] + kx;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const _Float16* __restrict__
         if (++cc == s.cpt) {
             cc = 0;
             ++tap;
-            tap_offsets(tap < 9u ? tap : 8u);
+            tap_offsets(tap < s.taps ? tap : s.taps - 1u);
         }
         ++issued;
     };
@@ -295,17 +296,17 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const float* __restrict__ p
 
 // splitk_req: 0 = choose; > 0 = that many K slices (clamped). bm_req: 0 = choose; 64 | 128.
 bool make_shape(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t up, int splitk_req,
-                int bm_req, ConvShape& s) {
+                int bm_req, ConvShape& s, uint32_t ks = 3) {
     if (N == 0 || H == 0 || W == 0 || Cin == 0 || Cout == 0 || Cin % kKC || Cout % kBN || (stride != 1 && stride != 2) || up > 1)
         return false;
-    s.N = N; s.Hs = H; s.Ws = W; s.Cin = Cin; s.Cout = Cout; s.stride = stride; s.up = up; s.pad = 1;
+    s.N = N; s.Hs = H; s.Ws = W; s.Cin = Cin; s.Cout = Cout; s.stride = stride; s.up = up; s.ks = ks; s.taps = ks * ks; s.pad = ks / 2;
     s.H = H << up; s.W = W << up;
-    s.Ho = (s.H + 2 - 3) / stride + 1; s.Wo = (s.W + 2 - 3) / stride + 1;
+    s.Ho = (s.H + 2 * s.pad - ks) / stride + 1; s.Wo = (s.W + 2 * s.pad - ks) / stride + 1;
     const uint64_t M = (uint64_t)N * s.Ho * s.Wo;
-    if (M >= kOob || (uint64_t)N * H * W * Cin * 2 >= kOob || (uint64_t)Cout * 9 * Cin * 2 >= kOob) return false;
+    if (M >= kOob || (uint64_t)N * H * W * Cin * 2 >= kOob || (uint64_t)Cout * s.taps * Cin * 2 >= kOob) return false;
     if (bm_req != 0 && bm_req != 64 && bm_req != 128) return false;
     s.M = (uint32_t)M;
-    s.cpt = Cin / kKC; s.steps = 9 * s.cpt;
+    s.cpt = Cin / kKC; s.steps = s.taps * s.cpt;
     s.n_tiles = Cout / kBN;
     // Tiling and K split by shape, from the sweep of tools/conv_bench.py over the UNet's layers (profiles/r04_conv_bench.txt): a K step
     // takes ~0.8 us whatever the tile, so what matters is how evenly the workgroups fill the CUs. Maps with >= 512 64-row tiles and
@@ -315,11 +316,11 @@ bool make_shape(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout,
     const uint32_t t64 = ((s.M + 63) / 64) * s.n_tiles;
     uint32_t k = 1;
     if (bm_req) s.bm = (uint32_t)bm_req;
-    else s.bm = (t64 >= 512 && s.steps <= 96) ? 64u : 128u;
+    else s.bm = ((t64 >= 512 && s.steps <= 96) || (ks == 1 && t64 < 1024)) ? 64u : 128u;   // (GEMMs: a handful of K steps — more, smaller tiles)
     s.m_tiles = (s.M + s.bm - 1) / s.bm;
     const uint32_t tiles = s.m_tiles * s.n_tiles;
     if (splitk_req > 0) k = (uint32_t)splitk_req;
-    else if (s.bm == 128) {
+    else if (s.bm == 128 || tiles < 256) {
         const uint32_t target = tiles <= 40 ? 256u : tiles <= 256 ? 512u : 1280u;
         k = tiles <= 256 ? target / tiles : (target + tiles / 2) / tiles;
         const uint32_t most = s.steps / 6 ? s.steps / 6 : 1;   // >= 6 K steps per slice
@@ -333,31 +334,9 @@ bool make_shape(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout,
     return true;
 }
 
-}  // namespace
-
-extern "C" {
-
-// float32 scratch for the split-K partials of one call (0 when the shape runs unsplit or is not taken)
-uint64_t sdfx_conv3x3_scratch_bytes(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t upsample,
-                                    int splitk, int tile_rows) {
-    ConvShape s;
-    if (!make_shape(N, H, W, Cin, Cout, stride, upsample, splitk, tile_rows, s)) return 0;
-    return s.splitk > 1 ? (uint64_t)s.splitk * s.M * Cout * sizeof(float) : 0;
-}
-
-// y[N, Ho, Wo, Cout] = conv3x3(x[N, H, W, Cin] (read through a nearest 2x upsample when `upsample`), w[Cout, 3, 3, Cin], padding 1,
-// stride 1 | 2) + bias[Cout] (or NULL) + residual[N, Ho, Wo, Cout] (or NULL); fp16, float32 accumulation. y may alias residual.
-int sdfx_conv3x3_forward(const void* x, const void* w, const void* bias, const void* residual, uint32_t N, uint32_t H, uint32_t W,
-                         uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t upsample, int splitk, int tile_rows, void* y,
-                         float* scratch, sdfx_stream_t stream) {
-    SDFX_REQUIRE(x && w && y, "conv3x3_forward: null pointer");
-    ConvShape s;
-    SDFX_REQUIRE(make_shape(N, H, W, Cin, Cout, stride, upsample, splitk, tile_rows, s),
-                 "conv3x3_forward: needs Cin %% 64 == 0, Cout %% 64 == 0, stride 1 or 2, maps below 2 GiB (got N=%u H=%u W=%u Cin=%u Cout=%u stride=%u)",
-                 N, H, W, Cin, Cout, stride);
-    SDFX_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y) |
-                   reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 16) == 0, "conv3x3_forward: misaligned pointer");
-    SDFX_REQUIRE(s.splitk == 1 || scratch, "conv3x3_forward: this shape splits K %u ways and needs sdfx_conv3x3_scratch_bytes() of scratch", s.splitk);
+int run(const ConvShape& s, const void* x, const void* w, const void* bias, const void* residual, void* y, float* scratch,
+        sdfx_stream_t stream, const char* what) {
+    const uint32_t Cout = s.Cout;
     hipStream_t st = as_stream(stream);
     const _Float16* xp = static_cast<const _Float16*>(x);
     const _Float16* wp = static_cast<const _Float16*>(w);
@@ -393,7 +372,56 @@ int sdfx_conv3x3_forward(const void* x, const void* w, const void* bias, const v
         const uint64_t vecs = (uint64_t)s.M * Cout / 8;
         hipLaunchKernelGGL(k_conv_reduce, dim3(div_up(vecs, 256)), dim3(256), 0, st, scratch, bp, rp, yp, s.M, Cout, s.splitk);
     }
-    return check_launch("conv3x3_forward");
+    return check_launch(what);
+}
+
+}  // namespace
+
+extern "C" {
+
+// float32 scratch for the split-K partials of one call (0 when the shape runs unsplit or is not taken)
+uint64_t sdfx_conv3x3_scratch_bytes(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t upsample,
+                                    int splitk, int tile_rows) {
+    ConvShape s;
+    if (!make_shape(N, H, W, Cin, Cout, stride, upsample, splitk, tile_rows, s)) return 0;
+    return s.splitk > 1 ? (uint64_t)s.splitk * s.M * Cout * sizeof(float) : 0;
+}
+
+// y[N, Ho, Wo, Cout] = conv3x3(x[N, H, W, Cin] (read through a nearest 2x upsample when `upsample`), w[Cout, 3, 3, Cin], padding 1,
+// stride 1 | 2) + bias[Cout] (or NULL) + residual[N, Ho, Wo, Cout] (or NULL); fp16, float32 accumulation. y may alias residual.
+int sdfx_conv3x3_forward(const void* x, const void* w, const void* bias, const void* residual, uint32_t N, uint32_t H, uint32_t W,
+                         uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t upsample, int splitk, int tile_rows, void* y,
+                         float* scratch, sdfx_stream_t stream) {
+    SDFX_REQUIRE(x && w && y, "conv3x3_forward: null pointer");
+    ConvShape s;
+    SDFX_REQUIRE(make_shape(N, H, W, Cin, Cout, stride, upsample, splitk, tile_rows, s),
+                 "conv3x3_forward: needs Cin %% 64 == 0, Cout %% 64 == 0, stride 1 or 2, maps below 2 GiB (got N=%u H=%u W=%u Cin=%u Cout=%u stride=%u)",
+                 N, H, W, Cin, Cout, stride);
+    SDFX_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y) |
+                   reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 16) == 0, "conv3x3_forward: misaligned pointer");
+    SDFX_REQUIRE(s.splitk == 1 || scratch, "conv3x3_forward: this shape splits K %u ways and needs sdfx_conv3x3_scratch_bytes() of scratch", s.splitk);
+    return run(s, x, w, bias, residual, y, scratch, stream, "conv3x3_forward");
+}
+
+// float32 scratch for sdfx_linear_forward's split-K partials (0 = none)
+uint64_t sdfx_linear_scratch_bytes(uint32_t M, uint32_t K, uint32_t N, int splitk, int tile_rows) {
+    ConvShape s;
+    if (!make_shape(1, 1, M, K, N, 1, 0, splitk, tile_rows, s, 1)) return 0;
+    return s.splitk > 1 ? (uint64_t)s.splitk * s.M * N * sizeof(float) : 0;
+}
+
+// y[M, N] = x[M, K] . w[N, K]^T + bias[N] (or NULL) + residual[M, N] (or NULL): the same kernel with one tap — the transformer blocks'
+// small projections, whose residual sums then need no launch of their own. fp16, float32 accumulation; K % 64 == 0, N % 64 == 0.
+int sdfx_linear_forward(const void* x, const void* w, const void* bias, const void* residual, uint32_t M, uint32_t K, uint32_t N, int splitk,
+                        int tile_rows, void* y, float* scratch, sdfx_stream_t stream) {
+    SDFX_REQUIRE(x && w && y, "linear_forward: null pointer");
+    ConvShape s;
+    SDFX_REQUIRE(make_shape(1, 1, M, K, N, 1, 0, splitk, tile_rows, s, 1), "linear_forward: needs K %% 64 == 0, N %% 64 == 0, operands below 2 GiB (got M=%u K=%u N=%u)",
+                 M, K, N);
+    SDFX_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y) |
+                   reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 16) == 0, "linear_forward: misaligned pointer");
+    SDFX_REQUIRE(s.splitk == 1 || scratch, "linear_forward: this shape splits K %u ways and needs sdfx_linear_scratch_bytes() of scratch", s.splitk);
+    return run(s, x, w, bias, residual, y, scratch, stream, "linear_forward");
 }
 
 }  // extern "C"

@@ -22,6 +22,8 @@ def _scratch(device, nbytes):
     buf = _SCRATCH.get(device.index)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            return buf          # memory of the graph being captured: it lives and dies with that graph, so it is not kept for later calls
         _SCRATCH[device.index] = buf
     return buf
 

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from . import guidance as G
 from .attention import attention_bnc
-from .conv import conv3x3, conv_ok
+from .conv import conv3x3, conv_ok, linear_auto
 from .groupnorm import GroupNormAct, add_bias_residual, fused_ok, geglu
 
 
@@ -74,7 +74,7 @@ class ResBlock(nn.Module):
             skip = x
         else:                                   # the 1 x 1 shortcut as a GEMM on the channels-last view (as the transformer's projections)
             N, C, H, W = x.shape
-            skip = F.linear(x.permute(0, 2, 3, 1), self.skip.weight.reshape(self.skip.weight.shape[0], C), self.skip.bias).permute(0, 3, 1, 2)
+            skip = linear_auto(x.permute(0, 2, 3, 1), self.skip.weight.reshape(self.skip.weight.shape[0], C), self.skip.bias).permute(0, 3, 1, 2)
         if conv_ok(hn, self.conv2.weight, self.conv2.bias, skip):
             return conv3x3(hn, self.conv2.weight, self.conv2.bias, skip)          # bias and shortcut in the convolution's epilogue
         return add_bias_residual(skip, F.conv2d(hn, self.conv2.weight, None, 1, 1), self.conv2.bias)
@@ -103,7 +103,8 @@ class Attention(nn.Module):
             cache[names] = (ver, torch.cat([w.detach() for w in ws], dim=0))
         return cache[names][1]
 
-    def forward(self, x, ctx=None):
+    def forward(self, x, ctx=None, residual=None):
+        """attention(x, ctx) [+ residual]: the sum rides in the output projection's epilogue where csrc/conv.hip runs it."""
         self_attn = ctx is None
         ctx = x if self_attn else ctx
         B, N, C = x.shape
@@ -112,12 +113,12 @@ class Attention(nn.Module):
         if _QKV_FUSION and frozen and x.is_cuda and d <= 256:
             heads = lambda t, i: t[..., i * C:(i + 1) * C].unflatten(-1, (self.heads, d)).transpose(1, 2)   # [B, H, n, d] view
             if self_attn:
-                qkv = F.linear(x, self._fused_weight(("q", "k", "v")))
+                qkv = linear_auto(x, self._fused_weight(("q", "k", "v")))
                 q, k, v = heads(qkv, 0), heads(qkv, 1), heads(qkv, 2)
             else:
                 kv = F.linear(ctx, self._fused_weight(("k", "v")))
                 q, k, v = self.q(x).view(B, N, self.heads, d).transpose(1, 2), heads(kv, 0), heads(kv, 1)
-            return self.o(attention_bnc(q, k, v))
+            return linear_auto(attention_bnc(q, k, v), self.o.weight, self.o.bias, residual)
         split = lambda t: t.view(B, -1, self.heads, C // self.heads).transpose(1, 2)
         q, k, v = split(self.q(x)), split(self.k(ctx)), split(self.v(ctx))
         if _WIDE_HEAD_MATMUL and C // self.heads > 256 and q.is_cuda:
@@ -130,7 +131,8 @@ class Attention(nn.Module):
             # csrc/attention.hip when no gradient is wanted and the head is 40 / 80 / 160 wide (the UNet of the SDS step), else
             # F.scaled_dot_product_attention; either way the result comes back as [B, N, C]
             out = attention_bnc(q, k, v)
-        return self.o(out)
+        out = self.o(out)
+        return out if residual is None else out + residual
 
 
 class TransformerBlock(nn.Module):
@@ -149,15 +151,16 @@ class TransformerBlock(nn.Module):
         if fused:
             # channels-last memory IS [B, HW, C]: the two 1 x 1 convolutions are plain GEMMs on that view (hipBLASLt with the bias in
             # its epilogue instead of MIOpen's implicit GEMM + zero fill + bias kernel), and no flatten / transpose copies exist
-            h = F.linear(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight.reshape(C, C), self.proj_in.bias)
+            h = linear_auto(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight.reshape(C, C), self.proj_in.bias)
         else:
             h = self.proj_in(self.norm(x)).flatten(2).transpose(1, 2)
-        h = h + self.attn1(self.n1(h))
-        h = h + self.attn2(self.n2(h), ctx)
-        h = h + self.ff_out(geglu(self.ff_in(self.n3(h))))
+        h = self.attn1(self.n1(h), None, h)                    # (+ h: in the output projection)
+        h = self.attn2(self.n2(h), ctx, h)
+        h = linear_auto(geglu(self.ff_in(self.n3(h))), self.ff_out.weight, self.ff_out.bias, h)
         if fused:
-            out = F.linear(h, self.proj_out.weight.reshape(C, C))                 # bias: in the residual sum
-            return add_bias_residual(x, out.view(B, H, W, C).permute(0, 3, 1, 2), self.proj_out.bias)
+            xr = x.permute(0, 2, 3, 1).reshape(B, H * W, C)       # channels-last memory IS [B, HW, C]
+            out = linear_auto(h, self.proj_out.weight.reshape(C, C), self.proj_out.bias, xr)   # bias and residual in the epilogue
+            return out.view(B, H, W, C).permute(0, 3, 1, 2)
         return x + self.proj_out(h.transpose(1, 2).reshape(B, C, H, W))
 
 

@@ -166,3 +166,34 @@ def test_attention_falls_back_to_pytorch_off_the_kernel_path(dev):
     assert not A.attention_ok(qg, k2, v2)
     A.attention_bnc(qg, k2, v2).float().sum().backward()
     assert qg.grad is not None
+
+
+# ---- csrc/conv.hip with one tap: GEMM + bias + residual --------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N", [(8192, 320, 320), (2048, 640, 1920), (512, 5120, 1280), (128, 2560, 1280), (154, 768, 640), (77, 64, 64), (1, 64, 128)])
+def test_linear_matches_float32_gemm(dev, M, K, N):
+    C = _conv_mod()
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).half().to(dev)
+    if M % 2 == 0:
+        x = x.view(2, M // 2, K)                       # leading dimensions are flattened
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+    b = torch.randn(N, generator=g).half().to(dev)
+    r = torch.randn(*x.shape[:-1], N, generator=g).half().to(dev)
+    assert C.linear_ok(x, w, b, r)
+    with torch.no_grad():
+        for bias, res in ((None, None), (b, None), (b, r)):
+            got = C.linear(x, w, bias, res)
+            want = F.linear(x.float(), w.float(), None if bias is None else bias.float()).half().float()
+            want = want if res is None else want + res.float()
+            assert got.shape == want.shape and got.dtype == torch.float16
+            err, scale = float((got.float() - want).abs().max()), float(want.abs().max())
+            assert err <= 3e-3 * scale + 1e-4, (err, scale)
+        for tile_rows, splitk in ((64, 1), (128, 1), (128, 2)):
+            a = C.linear(x, w, b, r, splitk=splitk, tile_rows=tile_rows)
+            assert torch.equal(a, C.linear(x, w, b, r, splitk=splitk, tile_rows=tile_rows))
+            assert float((a.float() - want).abs().max()) <= 3e-3 * scale + 1e-4
+    assert not C.linear_ok(x.float(), w.float()) and not C.linear_ok(x[..., :K - 1], w[:, :K - 1].contiguous())
+    xg = x.clone().requires_grad_(True)
+    assert not C.linear_ok(xg, w)
+    C.linear(xg, w, b, r).float().sum().backward()
+    assert xg.grad is not None

@@ -8,6 +8,9 @@ import torch
 importlib.import_module("stable-dreamfusion_amd")
 from sdfx_nerf import sd15_arch as A, conv as C, attention as AT
 torch.backends.cudnn.benchmark = True
+if os.environ.get("UNET_BLAS"):            # "cublas" = rocBLAS, "cublaslt" = hipBLASLt
+    torch.backends.cuda.preferred_blas_library(os.environ["UNET_BLAS"])
+    print("preferred BLAS library:", torch.backends.cuda.preferred_blas_library(), flush=True)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 unet = A.UNetSD15().to(dev, torch.half).eval().requires_grad_(False).to(memory_format=torch.channels_last)
