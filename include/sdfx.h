@@ -570,6 +570,15 @@ uint64_t sdfx_conv3x3_scratch_bytes(uint32_t N, uint32_t H, uint32_t W, uint32_t
 int sdfx_conv3x3_forward(const void* x, const void* w, const void* bias, const void* residual, uint32_t N, uint32_t H, uint32_t W,
                          uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t upsample, int splitk, int tile_rows, void* y,
                          float* scratch, sdfx_stream_t stream);
+/* The halo form for stride 1 and (upsampled) rows of 16 / 32 / 64 pixels with H W % 128 == 0 (sdfx_conv3x3_packed_ok): a tile's halo of
+ * one 64-channel chunk is staged once for all 9 taps, and the weights — packed once per frozen tensor by sdfx_conv3x3_pack_weights into
+ * MFMA fragment order, Cout * 9 * Cin halves — go from memory straight into operand registers. Same arguments and result (up to the
+ * summation order) as sdfx_conv3x3_forward with stride 1. */
+int sdfx_conv3x3_packed_ok(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t upsample);
+uint64_t sdfx_conv3x3_packed_scratch_bytes(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t upsample, int splitk);
+int sdfx_conv3x3_pack_weights(const void* w, uint32_t Cin, uint32_t Cout, void* packed, sdfx_stream_t stream);
+int sdfx_conv3x3_packed_forward(const void* x, const void* packed, const void* bias, const void* residual, uint32_t N, uint32_t H, uint32_t W,
+                                uint32_t Cin, uint32_t Cout, uint32_t upsample, int splitk, void* y, float* scratch, sdfx_stream_t stream);
 /* The same kernel with one tap: y[M, N] = x[M, K] . w[N, K]^T + bias[N] + residual[M, N] (bias / residual may be NULL; y may alias
  * residual) — the small projections of the transformer blocks with their residual sums in the epilogue. K % 64 == 0, N % 64 == 0. */
 uint64_t sdfx_linear_scratch_bytes(uint32_t M, uint32_t K, uint32_t N, int splitk, int tile_rows);

@@ -106,6 +106,10 @@ _SIGNATURES = {
     "sdfx_add_bias_residual": [_ptr, _ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "sdfx_geglu": [_ptr, _u64, _u32, _ptr, _ptr],
     "sdfx_attention_forward": [_ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _f32, _int, _ptr, _ptr],
+    "sdfx_conv3x3_packed_ok": [_u32, _u32, _u32, _u32, _u32, _u32],
+    "sdfx_conv3x3_packed_scratch_bytes": [_u32, _u32, _u32, _u32, _u32, _u32, _int],
+    "sdfx_conv3x3_pack_weights": [_ptr, _u32, _u32, _ptr, _ptr],
+    "sdfx_conv3x3_packed_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _u32, _int, _ptr, _ptr, _ptr],
     "sdfx_linear_scratch_bytes": [_u32, _u32, _u32, _int, _int],
     "sdfx_linear_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _int, _int, _ptr, _ptr, _ptr],
     "sdfx_conv3x3_scratch_bytes": [_u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _int],
@@ -127,6 +131,7 @@ _RESTYPES = {
     "sdfx_group_norm_scratch_bytes": _u64,
     "sdfx_conv3x3_scratch_bytes": _u64,
     "sdfx_linear_scratch_bytes": _u64,
+    "sdfx_conv3x3_packed_scratch_bytes": _u64,
     "sdfx_adan_ctl_words": _u32,
 }
 

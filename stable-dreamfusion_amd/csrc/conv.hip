@@ -261,6 +261,216 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const _Float16* __restrict__
     }
 }
 
+// =========================================================================================
+// Second form (stride 1, maps whose rows divide 128 pixels: the UNet's 64^2, 32^2 and 16^2 levels and its upsampling layers):
+// HALO tile + weights in fragment order. The ablation of the kernel above (profiles/r04_conv_ablation.txt) puts a third of its
+// time in the VGPR -> LDS write path (24 KB per K step: the activation tile is re-staged for each of the 9 taps, the weight tile
+// every step), a quarter in fragment reads and a fifth in exposed global loads; the MFMAs are 4 %. Here
+//   * a tile is 128 / W whole image rows; its (R + 2) x (W + 2) halo of ONE 64-channel chunk is staged once and serves all 9 taps
+//     (a tap is a constant offset into the halo): 2.9 KB of LDS writes per step instead of 16 KB; double-buffered, one barrier
+//     per chunk instead of one per step;
+//   * the weights never pass through LDS: sdfx_conv3x3_pack_weights lays them out as the B operands themselves
+//     ([32-channel block][chunk][tap][K step][lane][8 halves]), so a wave's four fragments of a step are 4 KB of contiguous,
+//     coalesced 16-byte loads straight into the registers the MFMAs read; the sets of the next two taps are in flight during a tap.
+// Every tap issues one halo piece of the NEXT chunk before its weight loads (vmcnt counts in order: a load older than the
+// weights a tap waits for would have to land with them).
+// =========================================================================================
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+constexpr uint32_t kHaloMaxPix = 264;                   // (2 + 2) x (64 + 2): the widest halo (W = 64, 128: 3 x 130 would be 390 — not taken)
+constexpr uint32_t kHaloBuf = kHaloMaxPix * kPitch;     // 38016
+constexpr int kHaloPieces = 9;                          // 16-byte pieces per thread and chunk: ceil(264 * 8 / 256)
+
+struct HaloShape {
+    uint32_t N, H, W, Cin;        // the map the taps walk (after the optional upsample)
+    uint32_t Hs, Ws, up;          // the stored map
+    uint32_t Cout, M;             // M = N H W (stride 1)
+    uint32_t HW2, HP;             // halo row length W + 2, halo pixels (128 / W + 2) (W + 2)
+    uint32_t cpt;                 // 64-channel chunks
+    uint32_t splitk, chunks_per_slice;
+    uint32_t m_tiles, n_tiles;
+};
+
+__device__ __forceinline__ u4v buf_load16v(__amdgpu_buffer_rsrc_t b, uint32_t voff) {
+    return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, 0, 0));
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const _Float16* __restrict__ x, const _Float16* __restrict__ wpk,
+                                                          const _Float16* __restrict__ bias, const _Float16* __restrict__ residual,
+                                                          _Float16* __restrict__ y, float* __restrict__ partial, HaloShape s) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kHaloBuf + 256 * 16];   // + one dump slot per thread (see write_halo)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t wm = wave >> 1, wn = wave & 1u;
+    const uint32_t tiles = s.m_tiles * s.n_tiles;
+    const uint32_t lid = xcd_contiguous(blockIdx.x, tiles * s.splitk);
+    const uint32_t slice = lid / tiles, tile = lid - slice * tiles;
+    const uint32_t mt = tile / s.n_tiles, nt = tile - mt * s.n_tiles;
+    const uint32_t m0 = mt * 128u, n0 = nt * kBN;
+    const uint32_t c0 = slice * s.chunks_per_slice;
+    const uint32_t c1 = min(c0 + s.chunks_per_slice, s.cpt);
+
+    const __amdgpu_buffer_rsrc_t xb = rsrc(x, (uint64_t)s.N * s.Hs * s.Ws * s.Cin * 2);
+    const __amdgpu_buffer_rsrc_t wb = rsrc(wpk, (uint64_t)s.Cout * 9 * s.Cin * 2);
+
+    // the tile: image n, rows y0 .. y0 + 128 / W - 1, all columns; halo origin (y0 - 1, -1)
+    const uint32_t img = m0 / (s.H * s.W), y0 = (m0 - img * s.H * s.W) / s.W;
+    uint32_t hoff[kHaloPieces];       // source byte offset of this thread's piece i (channel chunk 0), kOob outside the map / the halo
+#pragma unroll
+    for (int i = 0; i < kHaloPieces; i++) {
+        const uint32_t q = tid + 256u * i, hp = q >> 3, hy = hp / s.HW2, hx = hp - hy * s.HW2;
+        const int32_t iy = (int32_t)(y0 + hy) - 1, ix = (int32_t)hx - 1;
+        const bool ok = hp < s.HP && iy >= 0 && ix >= 0 && iy < (int32_t)s.H && ix < (int32_t)s.W;
+        hoff[i] = ok ? (((img * s.Hs + ((uint32_t)iy >> s.up)) * s.Ws + ((uint32_t)ix >> s.up)) * s.Cin + (q & 7u) * 8u) * 2u : kOob;
+    }
+    u4v hreg[kHaloPieces];
+    auto halo_piece = [&](int i, uint32_t c) { hreg[i] = buf_load16v(xb, hoff[i] == kOob ? kOob : hoff[i] + c * (kKC * 2u)); };
+    // Pieces beyond the halo (the tail of the last 256) go to the thread's dump slot, unconditionally: a conditional store lets the
+    // compiler sink the LOAD into the condition — to the end of the chunk, its latency exposed.
+    auto write_halo = [&](uint32_t buf) {
+#pragma unroll
+        for (int i = 0; i < kHaloPieces; i++) {
+            const uint32_t q = tid + 256u * i;
+            const uint32_t at = q < s.HP * 8u ? buf * kHaloBuf + (q >> 3) * kPitch + (q & 7u) * 16u : 2u * kHaloBuf + tid * 16u;
+            *reinterpret_cast<u4v*>(lds + at) = hreg[i];
+        }
+    };
+
+    // weight fragments: block (32 output channels) nblk, chunk c, tap t, K step kk: 1 KB at ((((nblk cpt + c) 9 + t) 4 + kk) 64 + lane) 16
+    const uint32_t nblk = (n0 >> 5) + wn;
+    u4v bq[3][4];
+    auto weights = [&](int set, uint32_t c, uint32_t t) {
+        const uint32_t o = ((((nblk * s.cpt + c) * 9u + t) * 4u) * 64u + lane) * 16u;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) bq[set][kk] = buf_load16v(wb, o + kk * 1024u);
+    };
+
+    // this lane's two pixels (one per 32-row block of the wave's 64 rows) in halo coordinates, tap (0, 0)
+    uint32_t pixoff[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++) {
+        const uint32_t p = 64u * wm + 32u * mi + (lane & 31u), ty = p / s.W, tx = p - ty * s.W;
+        pixoff[mi] = (ty * s.HW2 + tx) * kPitch + (lane >> 5) * 16u;
+    }
+    f32x16 acc[2] = {zero16(), zero16()};
+    auto multiply = [&](uint32_t buf, uint32_t t, int set) {
+        const uint32_t ky = t / 3u, kx = t - 3u * ky;
+        const uint8_t* base = lds + buf * kHaloBuf + (ky * s.HW2 + kx) * kPitch;
+#pragma unroll
+        for (uint32_t kk = 0; kk < 4; kk++) {
+            const h8 b = __builtin_bit_cast(h8, bq[set][kk]);
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) {
+                const h8 a = *reinterpret_cast<const h8*>(base + pixoff[mi] + kk * 32u);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi], 0, 0, 0);
+            }
+        }
+    };
+
+    // prologue: the first chunk's halo, the first two taps' weights
+#pragma unroll
+    for (int i = 0; i < kHaloPieces; i++) halo_piece(i, c0);
+    weights(0, c0, 0);
+    weights(1, c0, 1);
+    write_halo(0);
+    __syncthreads();
+    // a chunk: 9 taps; tap t multiplies with weight set t % 3 while the sets of taps t + 1 and t + 2 (the next chunk's past tap 8:
+    // 9 = 3 x 3, the rotation carries over) and one halo piece of the next chunk are in flight
+    uint32_t buf = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t cn = c + 1 < c1 ? c + 1 : c;                 // (past the last chunk: reloads that are never used)
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            halo_piece(t, cn);
+            if (t + 2 < 9) weights((t + 2) % 3, c, t + 2);
+            else weights((t + 2) % 3, cn, t + 2 - 9);
+            __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks each load to two MFMAs before its use)
+            multiply(buf, t, t % 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        write_halo(buf ^ 1u);                       // (after the last chunk: a copy nobody reads)
+        __syncthreads();
+        buf ^= 1u;
+    }
+
+    // ---- epilogue: as above (the halo buffers are free after the last barrier)
+    const uint32_t col = 32u * wn + (lane & 31u);
+    if (SPLIT) {
+        float* p = partial + (size_t)slice * s.M * s.Cout;
+#pragma unroll
+        for (uint32_t b = 0; b < 2; b++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t m = m0 + 64u * wm + 32u * b + (r & 3) + 8u * (r >> 2) + 4u * (lane >> 5);
+                p[(size_t)m * s.Cout + n0 + col] = acc[b][r];
+            }
+        }
+        return;
+    }
+    const float bv = bias ? (float)bias[n0 + col] : 0.f;
+    _Float16* tile_h = reinterpret_cast<_Float16*>(lds);
+#pragma unroll
+    for (uint32_t b = 0; b < 2; b++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t row = 64u * wm + 32u * b + (r & 3) + 8u * (r >> 2) + 4u * (lane >> 5);
+            tile_h[row * (kPitch / 2) + col] = (_Float16)(acc[b][r] + bv);
+        }
+    }
+    __syncthreads();
+    const uint32_t srow = tid >> 3, schunk = tid & 7u;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t row = srow + 32u * i, m = m0 + row;
+        h8 v = *reinterpret_cast<const h8*>(lds + row * kPitch + schunk * 16u);
+        const size_t o = (size_t)m * s.Cout + n0 + schunk * 8u;
+        if (residual) {
+            const h8 rv = *reinterpret_cast<const h8*>(residual + o);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (_Float16)((float)v[j] + (float)rv[j]);
+        }
+        *reinterpret_cast<h8*>(y + o) = v;
+    }
+}
+
+// w[Cout, 3, 3, Cin] -> the B operands of k_conv3x3_halo: piece ((((nblk cpt + c) 9 + t) 4 + kk) 64 + lane) = the 8 halves
+// w[32 nblk + (lane & 31)][t][64 c + 16 kk + 8 (lane >> 5) .. + 7]
+__global__ __launch_bounds__(256) void k_conv_pack_weights(const uint4* __restrict__ w, uint4* __restrict__ out, uint32_t Cin, uint32_t Cout) {
+    const uint32_t cpt = Cin / 64u, pieces = Cout * 9u * Cin / 8u;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= pieces) return;
+    const uint32_t lane = i & 63u, kk = (i >> 6) & 3u, r = i >> 8, t = r % 9u, r2 = r / 9u, c = r2 % cpt, nblk = r2 / cpt;
+    const uint32_t co = 32u * nblk + (lane & 31u), ci = 64u * c + 16u * kk + 8u * (lane >> 5);
+    out[i] = w[((size_t)(co * 9u + t) * Cin + ci) / 8u];
+}
+
+bool make_halo_shape(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t up, int splitk_req, HaloShape& s) {
+    if (N == 0 || H == 0 || W == 0 || Cin % kKC || Cout % kBN || up > 1) return false;
+    s.N = N; s.Hs = H; s.Ws = W; s.up = up; s.H = H << up; s.W = W << up; s.Cin = Cin; s.Cout = Cout;
+    if (s.W != 16 && s.W != 32 && s.W != 64) return false;
+    if ((s.H * s.W) % 128u) return false;
+    const uint64_t M = (uint64_t)N * s.H * s.W;
+    if (M >= kOob || (uint64_t)N * H * W * Cin * 2 >= kOob || (uint64_t)Cout * 9 * Cin * 2 >= kOob) return false;
+    s.M = (uint32_t)M;
+    s.HW2 = s.W + 2; s.HP = (128u / s.W + 2u) * s.HW2;
+    s.cpt = Cin / kKC;
+    s.m_tiles = s.M / 128u; s.n_tiles = Cout / kBN;
+    const uint32_t tiles = s.m_tiles * s.n_tiles;
+    uint32_t k = 1;
+    // K split from the sweep of tools/conv_bench.py (profiles/r04_conv_bench_halo.txt): up to 512 workgroups (2 per CU resident),
+    // a slice keeps >= 3 chunks (27 taps); maps with >= 300 tiles run unsplit
+    if (splitk_req > 0) k = (uint32_t)splitk_req;
+    else {
+        k = 512u / tiles;
+        const uint32_t most = s.cpt / 3 ? s.cpt / 3 : 1;
+        if (k > most) k = most;
+        if (k < 1) k = 1;
+    }
+    if (k > s.cpt) k = s.cpt;
+    s.chunks_per_slice = (s.cpt + k - 1) / k;
+    s.splitk = (s.cpt + s.chunks_per_slice - 1) / s.chunks_per_slice;
+    return true;
+}
+
 // y[m, c] = fp16(fp16(sum_s partial[s, m, c] + bias[c]) + residual[m, c]); 8 channels per thread
 __global__ __launch_bounds__(256) void k_conv_reduce(const float* __restrict__ partial, const _Float16* __restrict__ bias,
                                                     const _Float16* __restrict__ residual, _Float16* __restrict__ y, uint32_t M,
@@ -401,6 +611,54 @@ int sdfx_conv3x3_forward(const void* x, const void* w, const void* bias, const v
                    reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 16) == 0, "conv3x3_forward: misaligned pointer");
     SDFX_REQUIRE(s.splitk == 1 || scratch, "conv3x3_forward: this shape splits K %u ways and needs sdfx_conv3x3_scratch_bytes() of scratch", s.splitk);
     return run(s, x, w, bias, residual, y, scratch, stream, "conv3x3_forward");
+}
+
+// ---- the halo form (packed weights) ---------------------------------------------------------------------------------------------
+// 1 when sdfx_conv3x3_packed_forward takes the shape: stride 1, (upsampled) rows of 16 / 32 / 64 pixels, whole 128-pixel tiles
+int sdfx_conv3x3_packed_ok(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t upsample) {
+    HaloShape s;
+    return make_halo_shape(N, H, W, Cin, Cout, upsample, 0, s) ? 1 : 0;
+}
+uint64_t sdfx_conv3x3_packed_scratch_bytes(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t upsample, int splitk) {
+    HaloShape s;
+    if (!make_halo_shape(N, H, W, Cin, Cout, upsample, splitk, s)) return 0;
+    return s.splitk > 1 ? (uint64_t)s.splitk * s.M * Cout * sizeof(float) : 0;
+}
+// packed[Cout * 9 * Cin] <- w[Cout, 3, 3, Cin] in the fragment order k_conv3x3_halo loads (once per frozen weight)
+int sdfx_conv3x3_pack_weights(const void* w, uint32_t Cin, uint32_t Cout, void* packed, sdfx_stream_t stream) {
+    SDFX_REQUIRE(w && packed, "conv3x3_pack_weights: null pointer");
+    SDFX_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0 && Cin && Cout && (uint64_t)Cout * 9 * Cin * 2 < kOob, "conv3x3_pack_weights: needs Cin %% 64 == 0, Cout %% 64 == 0 (got %u, %u)", Cin, Cout);
+    SDFX_REQUIRE(((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(packed)) % 16) == 0, "conv3x3_pack_weights: misaligned pointer");
+    const uint32_t pieces = Cout * 9u * Cin / 8u;
+    hipLaunchKernelGGL(k_conv_pack_weights, dim3(div_up(pieces, 256)), dim3(256), 0, as_stream(stream), static_cast<const uint4*>(w),
+                       static_cast<uint4*>(packed), Cin, Cout);
+    return check_launch("conv3x3_pack_weights");
+}
+// sdfx_conv3x3_forward for stride 1 with the weights packed by sdfx_conv3x3_pack_weights (same result up to summation order)
+int sdfx_conv3x3_packed_forward(const void* x, const void* packed, const void* bias, const void* residual, uint32_t N, uint32_t H, uint32_t W,
+                                uint32_t Cin, uint32_t Cout, uint32_t upsample, int splitk, void* y, float* scratch, sdfx_stream_t stream) {
+    SDFX_REQUIRE(x && packed && y, "conv3x3_packed_forward: null pointer");
+    HaloShape s;
+    SDFX_REQUIRE(make_halo_shape(N, H, W, Cin, Cout, upsample, splitk, s),
+                 "conv3x3_packed_forward: needs rows of 16 / 32 / 64 pixels, H W %% 128 == 0, Cin %% 64 == 0, Cout %% 64 == 0 (got N=%u H=%u W=%u Cin=%u Cout=%u up=%u)",
+                 N, H, W, Cin, Cout, upsample);
+    SDFX_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(y) |
+                   reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 16) == 0, "conv3x3_packed_forward: misaligned pointer");
+    SDFX_REQUIRE(s.splitk == 1 || scratch, "conv3x3_packed_forward: this shape splits K %u ways and needs scratch", s.splitk);
+    hipStream_t st = as_stream(stream);
+    const _Float16* xp = static_cast<const _Float16*>(x);
+    const _Float16* wp = static_cast<const _Float16*>(packed);
+    const _Float16* bp = static_cast<const _Float16*>(bias);
+    const _Float16* rp = static_cast<const _Float16*>(residual);
+    _Float16* yp = static_cast<_Float16*>(y);
+    const uint32_t grid = s.m_tiles * s.n_tiles * s.splitk;
+    if (s.splitk == 1) {
+        hipLaunchKernelGGL((k_conv3x3_halo<false>), dim3(grid), dim3(256), 0, st, xp, wp, bp, rp, yp, (float*)nullptr, s);
+    } else {
+        hipLaunchKernelGGL((k_conv3x3_halo<true>), dim3(grid), dim3(256), 0, st, xp, wp, bp, rp, yp, scratch, s);
+        hipLaunchKernelGGL(k_conv_reduce, dim3(div_up((uint64_t)s.M * Cout / 8, 256)), dim3(256), 0, st, scratch, bp, rp, yp, s.M, Cout, s.splitk);
+    }
+    return check_launch("conv3x3_packed_forward");
 }
 
 // float32 scratch for sdfx_linear_forward's split-K partials (0 = none)

@@ -34,10 +34,15 @@ def attention_ok(q, k, v) -> bool:
     return True
 
 
-def attention_bnc(q, k, v, waves=0):
-    """See the module docstring. `waves`: 0 = chosen by shape; 1 / 2 / 4 waves per workgroup are for measurements."""
+_AUTO_MAX_D = int(os.environ.get("SDFX_ATTENTION_MAX_D", "80"))   # wider heads: only when asked for (see attention_bnc)
+
+
+def attention_bnc(q, k, v, waves=0, force=False):
+    """See the module docstring. `waves`: 0 = chosen by shape; 1 / 2 / 4 waves per workgroup are for measurements. The 160-wide heads
+    (256 and 64 tokens: 0.7 GFLOP, 32 workgroups) are left to PyTorch's op unless `force`: in the replayed UNet the kernel took 26 us
+    per call there against ~12 us (profiles/r04_unet_kernel_stats_own_conv_attention.csv)."""
     B, H, Nq, d = q.shape
-    if attention_ok(q, k, v):
+    if (force or waves or d <= _AUTO_MAX_D) and attention_ok(q, k, v):
         import _sdfx as S
         out = torch.empty(B, Nq, H * d, dtype=q.dtype, device=q.device)
         st = lambda t: _U3(t.stride(0), t.stride(2), t.stride(1))           # batch, token, head (elements)

@@ -48,20 +48,49 @@ def conv_ok(x, weight, bias=None, residual=None, stride=1) -> bool:
     return True
 
 
-def conv3x3(x, weight, bias=None, residual=None, stride=1, upsample=False, splitk=0, tile_rows=0):
-    """See the module docstring. `splitk` / `tile_rows`: 0 = chosen by shape; other values are for measurements (tools/conv_bench.py)."""
+_PACKED = {}    # (data_ptr, version, shape) of a frozen weight -> its copy in MFMA fragment order (csrc/conv.hip, halo form)
+
+
+def packed_weight(weight):
+    """`weight` [Cout, Cin, 3, 3] (channels-last, frozen) in the fragment order of the halo kernel; built once per weight (rebuilt when
+    the parameter was replaced or written to) — the price of weights that go from memory straight into MFMA operand registers."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _PACKED.get(id(weight))
+    if hit is None or hit[0] != key:
+        import _sdfx as S
+        out = torch.empty(weight.numel(), dtype=weight.dtype, device=weight.device)
+        S.call("sdfx_conv3x3_pack_weights", S.ptr(weight), weight.shape[1], weight.shape[0], S.ptr(out), S.stream())
+        hit = (key, out)
+        _PACKED[id(weight)] = hit
+    return hit[1]
+
+
+def conv3x3(x, weight, bias=None, residual=None, stride=1, upsample=False, splitk=0, tile_rows=0, form="auto"):
+    """See the module docstring. `form`: "halo" (stride 1, rows of 16 / 32 / 64 pixels: halo tiles + packed weights), "tiles" (the general
+    kernel) or "auto" (halo where it applies). `splitk` / `tile_rows`: 0 = chosen by shape; other values are for measurements
+    (tools/conv_bench.py; `tile_rows` implies the general kernel)."""
     if conv_ok(x, weight, bias, residual, stride):
         import _sdfx as S
         N, Cin, H, W = x.shape
         Cout = weight.shape[0]
+        up = int(bool(upsample))
         Hu, Wu = (2 * H, 2 * W) if upsample else (H, W)
         Ho, Wo = (Hu - 1) // stride + 1, (Wu - 1) // stride + 1
         if residual is None or tuple(residual.shape) == (N, Cout, Ho, Wo):
             y = torch.empty((N, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-            nbytes = int(S.lib().sdfx_conv3x3_scratch_bytes(N, H, W, Cin, Cout, stride, int(bool(upsample)), int(splitk), int(tile_rows)))
+            halo = form != "tiles" and not tile_rows and stride == 1 and bool(S.lib().sdfx_conv3x3_packed_ok(N, H, W, Cin, Cout, up))
+            if form == "halo" and not halo:
+                raise RuntimeError(f"conv3x3: the halo form does not take this shape {tuple(x.shape)} stride {stride}")
+            if halo:
+                nbytes = int(S.lib().sdfx_conv3x3_packed_scratch_bytes(N, H, W, Cin, Cout, up, int(splitk)))
+                scratch = _scratch(x.device, nbytes) if nbytes else None
+                S.call("sdfx_conv3x3_packed_forward", S.ptr(x), S.ptr(packed_weight(weight)), S.ptr(bias), S.ptr(residual), N, H, W, Cin, Cout, up,
+                       int(splitk), S.ptr(y), S.ptr(scratch), S.stream())
+                return y
+            nbytes = int(S.lib().sdfx_conv3x3_scratch_bytes(N, H, W, Cin, Cout, stride, up, int(splitk), int(tile_rows)))
             scratch = _scratch(x.device, nbytes) if nbytes else None
             S.call("sdfx_conv3x3_forward", S.ptr(x), S.ptr(weight), S.ptr(bias), S.ptr(residual), N, H, W, Cin, Cout, stride,
-                   int(bool(upsample)), int(splitk), int(tile_rows), S.ptr(y), S.ptr(scratch), S.stream())
+                   up, int(splitk), int(tile_rows), S.ptr(y), S.ptr(scratch), S.stream())
             return y
     if upsample:
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")

@@ -47,6 +47,8 @@ def _check(got, want):
     (1, 128, 5, 7, 64, 1, False),         # 35 pixels: a ragged tile (rows beyond M), borders everywhere
     (3, 64, 9, 6, 128, 2, False),         # stride 2 on odd / even sizes, three images in one tile
     (2, 192, 6, 6, 64, 1, True),          # taps walk the 2 x upsampled map
+    (1, 64, 8, 16, 128, 1, False),        # the smallest map of the halo form: one 128-pixel tile
+    (3, 128, 16, 32, 64, 1, False),       # rows of 32 pixels, 4 per tile, three images
     (2, 320, 64, 64, 320, 1, False),      # the UNet's top level
     (2, 1280, 8, 8, 1280, 1, False),      # the deepest level: one tile of pixels, K split
     (2, 640, 32, 32, 640, 2, False),      # a downsampling layer
@@ -58,9 +60,14 @@ def test_conv3x3_matches_float32_convolution(dev, N, Cin, H, W, Cout, stride, up
     Ho, Wo = (Hu - 1) // stride + 1, (Wu - 1) // stride + 1
     x, w, b, r = _inputs(dev, N, Cin, H, W, Cout, seed=Cin + H, residual_hw=(Ho, Wo))
     assert C.conv_ok(x, w, b, r, stride)
+    import _sdfx as S
+    halo_ok = stride == 1 and bool(S.lib().sdfx_conv3x3_packed_ok(N, H, W, Cin, Cout, int(upsample)))
+    assert halo_ok == (stride == 1 and Wo in (16, 32, 64) and (Ho * Wo) % 128 == 0)
     with torch.no_grad():
-        for bias, res in ((None, None), (b, None), (b, r)):
-            _check(C.conv3x3(x, w, bias, res, stride, upsample), _reference(x, w, bias, res, stride, upsample))
+        for form in ("tiles", "halo") if halo_ok else ("tiles",):        # both kernels on the shapes both take
+            for bias, res in ((None, None), (b, None), (b, r)):
+                _check(C.conv3x3(x, w, bias, res, stride, upsample, form=form), _reference(x, w, bias, res, stride, upsample))
+        _check(C.conv3x3(x, w, b, r, stride, upsample), _reference(x, w, b, r, stride, upsample))     # and whichever "auto" picks
 
 
 @pytest.mark.parametrize("tile_rows", [64, 128])
@@ -72,10 +79,28 @@ def test_conv3x3_every_tiling_and_split_gives_the_same_map(dev, tile_rows, split
     x, w, b, r = _inputs(dev, 2, 192, 12, 10, 128, seed=11, residual_hw=(12, 10))
     want = _reference(x, w, b, r, 1, False)
     with torch.no_grad():
-        a = C.conv3x3(x, w, b, r, 1, False, splitk=splitk, tile_rows=tile_rows)
-        a2 = C.conv3x3(x, w, b, r, 1, False, splitk=splitk, tile_rows=tile_rows)
+        a = C.conv3x3(x, w, b, r, 1, False, splitk=splitk, tile_rows=tile_rows, form="tiles")
+        a2 = C.conv3x3(x, w, b, r, 1, False, splitk=splitk, tile_rows=tile_rows, form="tiles")
     _check(a, want)
     assert torch.equal(a, a2)
+
+
+@pytest.mark.parametrize("splitk", [1, 2, 3, 20])
+def test_conv3x3_halo_form_split_over_chunks(dev, splitk):
+    """The halo kernel with its K range split over 64-channel chunks (3 chunks: one, two-and-one, one each; 20 is clamped to 3),
+    bit-identical run to run, and a weight written to in place is packed again."""
+    C = _conv_mod()
+    x, w, b, r = _inputs(dev, 2, 192, 16, 16, 128, seed=13, residual_hw=(16, 16))
+    want = _reference(x, w, b, r, 1, False)
+    with torch.no_grad():
+        a = C.conv3x3(x, w, b, r, 1, False, splitk=splitk, form="halo")
+        a2 = C.conv3x3(x, w, b, r, 1, False, splitk=splitk, form="halo")
+        _check(a, want)
+        assert torch.equal(a, a2)
+        w.mul_(0.5)                                    # in place: same storage, new version
+        _check(C.conv3x3(x, w, b, r, 1, False, form="halo"), _reference(x, w, b, r, 1, False))
+    with pytest.raises(RuntimeError):
+        C.conv3x3(x[:, :, :5, :7].contiguous(memory_format=torch.channels_last), w, form="halo")
 
 
 def test_conv3x3_falls_back_to_pytorch_off_the_kernel_path(dev):
@@ -131,7 +156,7 @@ def test_attention_matches_float32_softmax(dev, B, H, Nq, Nk, d):
         q, k, v = _qkv(dev, B, H, Nq, Nk, d, seed=Nq + Nk + d, spread=spread)
         assert A.attention_ok(q, k, v)
         with torch.no_grad():
-            got = A.attention_bnc(q, k, v)
+            got = A.attention_bnc(q, k, v, force=True)
         want = _attn_reference(q, k, v)
         assert got.shape == want.shape and got.dtype == torch.float16 and got.is_contiguous()
         err, scale = float((got.float() - want).abs().max()), float(want.abs().max())

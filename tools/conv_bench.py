@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""csrc/conv.hip against MIOpen on every 3 x 3 convolution shape of one SD-1.5 UNet evaluation (batch 2, 64 x 64 latents): us per
-call on the GPU clock for F.conv2d (find mode on) and for sdfx_conv3x3_forward with its own choice of tiling / K split and with
-forced ones, max error against the float32 convolution, and the UNet total.  python tools/conv_bench.py [--sweep]"""
+"""csrc/conv.hip against MIOpen on every 3 x 3 convolution shape of one SD-1.5 UNet evaluation (batch 2, 64 x 64 latents): GPU us per call (replayed HIP graphs) for F.conv2d (find mode on), the general kernel, the kernel conv3x3 chooses, and — with --sweep —
+the halo form at forced K splits, max error against the float32 convolution, and the UNet total.  python tools/conv_bench.py [--sweep]"""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,17 +18,24 @@ SHAPES = [(2, 320, 64, 64, 320, 1, 0, 7), (2, 320, 64, 64, 320, 2, 0, 1), (2, 32
           (2, 960, 32, 32, 640, 1, 0, 1), (2, 640, 32, 32, 640, 1, 1, 1), (2, 960, 64, 64, 320, 1, 0, 1), (2, 640, 64, 64, 320, 1, 0, 2)]
 
 
-def timed(f, n=20):
-    for _ in range(3): f()
+def timed(f, n=10, reps=5):
+    """us per call inside a replayed HIP graph of n calls: GPU time, no host launch cost"""
+    for _ in range(2): f()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n): f()
+    g.replay(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); a.record()
-    for _ in range(n): f()
+    a.record()
+    for _ in range(reps): g.replay()
     b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / n * 1e3
+    return a.elapsed_time(b) / (n * reps) * 1e3
 
 
-tot_ref = tot_own = 0.0
-print("N Cin   H   W  Cout s up calls | MIOpen us  TF/s | own us  TF/s  err/scale | forced (tile_rows, splitk): us ...")
+import _sdfx as S
+tot_ref = tot_tiles = tot_own = 0.0
+print("N Cin   H   W  Cout s up calls | MIOpen us TF/s | tiles us | auto us TF/s  err/scale | halo form by K split: us ...")
 with torch.no_grad():
     for N, Cin, H, W, Cout, s, up, calls in SHAPES:
         g = torch.Generator().manual_seed(Cin + H)
@@ -43,16 +49,13 @@ with torch.no_grad():
         err = float((own().float() - want).abs().max()) / float(want.abs().max())
         Ho, Wo = want.shape[2], want.shape[3]
         gf = 2.0 * N * Ho * Wo * Cout * Cin * 9 / 1e9
-        tr, to = timed(ref), timed(own)
-        tot_ref += tr * calls; tot_own += to * calls
-        line = f"{N} {Cin:4d} {H:3d} {W:3d} {Cout:5d} {s} {up} {calls:5d} | {tr:8.1f} {gf / tr:6.0f} | {to:7.1f} {gf / to:6.0f} {err:9.2e} |"
-        if SWEEP:
-            steps = 9 * Cin // 64
-            for tile_rows in (64, 128):
-                for k in (1, 2, 3, 4, 6, 8, 12, 16, 24):
-                    tiles = ((N * Ho * Wo + tile_rows - 1) // tile_rows) * (Cout // 64)
-                    if k > steps or tiles * k > 4096 or tiles * k < 96: continue
-                    t = timed(lambda: C.conv3x3(x, w, b, None, s, bool(up), splitk=k, tile_rows=tile_rows), 10)
-                    line += f" ({tile_rows},{k}):{t:.1f}"
+        tr, tt, to = timed(ref), timed(lambda: C.conv3x3(x, w, b, None, s, bool(up), form="tiles")), timed(own)
+        tot_ref += tr * calls; tot_tiles += tt * calls; tot_own += to * calls
+        line = f"{N} {Cin:4d} {H:3d} {W:3d} {Cout:5d} {s} {up} {calls:5d} | {tr:8.1f} {gf / tr * 1e-3 * 1e3:5.0f} | {tt:7.1f} | {to:7.1f} {gf / to * 1e-3 * 1e3:5.0f} {err:9.2e} |"
+        if SWEEP and s == 1 and S.lib().sdfx_conv3x3_packed_ok(N, H, W, Cin, Cout, up):
+            for k in (1, 2, 3, 4, 5, 6, 8, 10):
+                if k > Cin // 64: continue
+                t = timed(lambda: C.conv3x3(x, w, b, None, s, bool(up), splitk=k, form="halo"), 10, 3)
+                line += f" {k}:{t:.1f}"
         print(line, flush=True)
-print(f"all 3 x 3 convolutions of one UNet evaluation: MIOpen {tot_ref / 1e3:.2f} ms, csrc/conv.hip {tot_own / 1e3:.2f} ms")
+print(f"all 3 x 3 convolutions of one UNet evaluation: MIOpen {tot_ref / 1e3:.2f} ms, csrc/conv.hip tiles form {tot_tiles / 1e3:.2f} ms, as chosen {tot_own / 1e3:.2f} ms")
