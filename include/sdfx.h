@@ -570,7 +570,7 @@ uint64_t sdfx_conv3x3_scratch_bytes(uint32_t N, uint32_t H, uint32_t W, uint32_t
 int sdfx_conv3x3_forward(const void* x, const void* w, const void* bias, const void* residual, uint32_t N, uint32_t H, uint32_t W,
                          uint32_t Cin, uint32_t Cout, uint32_t stride, uint32_t upsample, int splitk, int tile_rows, void* y,
                          float* scratch, sdfx_stream_t stream);
-/* The halo form for stride 1 and (upsampled) rows of 16 / 32 / 64 pixels with H W % 128 == 0 (sdfx_conv3x3_packed_ok): a tile's halo of
+/* The halo form for stride 1 and (upsampled) rows of 8 / 16 / 32 / 64 pixels in whole 128-pixel tiles (sdfx_conv3x3_packed_ok): a tile's halo of
  * one 64-channel chunk is staged once for all 9 taps, and the weights — packed once per frozen tensor by sdfx_conv3x3_pack_weights into
  * MFMA fragment order, Cout * 9 * Cin halves — go from memory straight into operand registers. Same arguments and result (up to the
  * summation order) as sdfx_conv3x3_forward with stride 1. */

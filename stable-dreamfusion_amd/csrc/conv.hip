@@ -262,11 +262,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const _Float16* __restrict__
 }
 
 // =========================================================================================
-// Second form (stride 1, maps whose rows divide 128 pixels: the UNet's 64^2, 32^2 and 16^2 levels and its upsampling layers):
+// Second form (stride 1, rows of 8 / 16 / 32 / 64 pixels in whole 128-pixel tiles: every level of the UNet and its upsampling layers):
 // HALO tile + weights in fragment order. The ablation of the kernel above (profiles/r04_conv_ablation.txt) puts a third of its
 // time in the VGPR -> LDS write path (24 KB per K step: the activation tile is re-staged for each of the 9 taps, the weight tile
 // every step), a quarter in fragment reads and a fifth in exposed global loads; the MFMAs are 4 %. Here
-//   * a tile is 128 / W whole image rows; its (R + 2) x (W + 2) halo of ONE 64-channel chunk is staged once and serves all 9 taps
+//   * a tile is 128 / W whole image rows (two whole 8 x 8 images at the deepest level); its halo — (R + 2) x (W + 2) pixels per
+//     segment — of ONE 64-channel chunk is staged once and serves all 9 taps
 //     (a tap is a constant offset into the halo): 2.9 KB of LDS writes per step instead of 16 KB; double-buffered, one barrier
 //     per chunk instead of one per step;
 //   * the weights never pass through LDS: sdfx_conv3x3_pack_weights lays them out as the B operands themselves
@@ -284,7 +285,9 @@ struct HaloShape {
     uint32_t N, H, W, Cin;        // the map the taps walk (after the optional upsample)
     uint32_t Hs, Ws, up;          // the stored map
     uint32_t Cout, M;             // M = N H W (stride 1)
-    uint32_t HW2, HP;             // halo row length W + 2, halo pixels (128 / W + 2) (W + 2)
+    uint32_t HW2, HP;             // halo row length W + 2, halo pixels of a tile: segs * segsz
+    uint32_t RH, segs, segsz;     // a tile = `segs` segments of RH whole rows: one segment of 128 / W rows of an image, or (maps below 128
+                                  // pixels) 128 / (H W) whole images; halo pixels per segment (RH + 2) (W + 2)
     uint32_t cpt;                 // 64-channel chunks
     uint32_t splitk, chunks_per_slice;
     uint32_t m_tiles, n_tiles;
@@ -312,15 +315,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const _Float16* __restr
     const __amdgpu_buffer_rsrc_t xb = rsrc(x, (uint64_t)s.N * s.Hs * s.Ws * s.Cin * 2);
     const __amdgpu_buffer_rsrc_t wb = rsrc(wpk, (uint64_t)s.Cout * 9 * s.Cin * 2);
 
-    // the tile: image n, rows y0 .. y0 + 128 / W - 1, all columns; halo origin (y0 - 1, -1)
+    // the tile: segment g = rows y0 .. y0 + RH - 1 of image img + g, all columns; a segment's halo origin is (y0 - 1, -1)
     const uint32_t img = m0 / (s.H * s.W), y0 = (m0 - img * s.H * s.W) / s.W;
     uint32_t hoff[kHaloPieces];       // source byte offset of this thread's piece i (channel chunk 0), kOob outside the map / the halo
 #pragma unroll
     for (int i = 0; i < kHaloPieces; i++) {
-        const uint32_t q = tid + 256u * i, hp = q >> 3, hy = hp / s.HW2, hx = hp - hy * s.HW2;
+        const uint32_t q = tid + 256u * i, hp = q >> 3, seg = hp / s.segsz, r = hp - seg * s.segsz, hy = r / s.HW2, hx = r - hy * s.HW2;
         const int32_t iy = (int32_t)(y0 + hy) - 1, ix = (int32_t)hx - 1;
         const bool ok = hp < s.HP && iy >= 0 && ix >= 0 && iy < (int32_t)s.H && ix < (int32_t)s.W;
-        hoff[i] = ok ? (((img * s.Hs + ((uint32_t)iy >> s.up)) * s.Ws + ((uint32_t)ix >> s.up)) * s.Cin + (q & 7u) * 8u) * 2u : kOob;
+        hoff[i] = ok ? ((((img + seg) * s.Hs + ((uint32_t)iy >> s.up)) * s.Ws + ((uint32_t)ix >> s.up)) * s.Cin + (q & 7u) * 8u) * 2u : kOob;
     }
     u4v hreg[kHaloPieces];
     auto halo_piece = [&](int i, uint32_t c) { hreg[i] = buf_load16v(xb, hoff[i] == kOob ? kOob : hoff[i] + c * (kKC * 2u)); };
@@ -348,8 +351,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const _Float16* __restr
     uint32_t pixoff[2];
 #pragma unroll
     for (int mi = 0; mi < 2; mi++) {
-        const uint32_t p = 64u * wm + 32u * mi + (lane & 31u), ty = p / s.W, tx = p - ty * s.W;
-        pixoff[mi] = (ty * s.HW2 + tx) * kPitch + (lane >> 5) * 16u;
+        const uint32_t p = 64u * wm + 32u * mi + (lane & 31u), seg = p / (s.RH * s.W), r = p - seg * s.RH * s.W, ty = r / s.W, tx = r - ty * s.W;
+        pixoff[mi] = (seg * s.segsz + ty * s.HW2 + tx) * kPitch + (lane >> 5) * 16u;
     }
     f32x16 acc[2] = {zero16(), zero16()};
     auto multiply = [&](uint32_t buf, uint32_t t, int set) {
@@ -446,12 +449,18 @@ __global__ __launch_bounds__(256) void k_conv_pack_weights(const uint4* __restri
 bool make_halo_shape(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t up, int splitk_req, HaloShape& s) {
     if (N == 0 || H == 0 || W == 0 || Cin % kKC || Cout % kBN || up > 1) return false;
     s.N = N; s.Hs = H; s.Ws = W; s.up = up; s.H = H << up; s.W = W << up; s.Cin = Cin; s.Cout = Cout;
-    if (s.W != 16 && s.W != 32 && s.W != 64) return false;
-    if ((s.H * s.W) % 128u) return false;
+    if (s.W != 8 && s.W != 16 && s.W != 32 && s.W != 64) return false;
+    if (s.H * s.W >= 128u ? (s.H * s.W) % 128u != 0 : 128u % (s.H * s.W) != 0) return false;    // tiles of whole rows, or of whole images
     const uint64_t M = (uint64_t)N * s.H * s.W;
     if (M >= kOob || (uint64_t)N * H * W * Cin * 2 >= kOob || (uint64_t)Cout * 9 * Cin * 2 >= kOob) return false;
     s.M = (uint32_t)M;
-    s.HW2 = s.W + 2; s.HP = (128u / s.W + 2u) * s.HW2;
+    if (M % 128u) return false;
+    s.HW2 = s.W + 2;
+    s.RH = s.H * s.W >= 128u ? 128u / s.W : s.H;
+    s.segs = 128u / (s.RH * s.W);
+    s.segsz = (s.RH + 2u) * s.HW2;
+    s.HP = s.segs * s.segsz;
+    if (s.HP > kHaloMaxPix) return false;
     s.cpt = Cin / kKC;
     s.m_tiles = s.M / 128u; s.n_tiles = Cout / kBN;
     const uint32_t tiles = s.m_tiles * s.n_tiles;
@@ -461,7 +470,8 @@ bool make_halo_shape(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t 
     if (splitk_req > 0) k = (uint32_t)splitk_req;
     else {
         k = 512u / tiles;
-        const uint32_t most = s.cpt / 3 ? s.cpt / 3 : 1;
+        const uint32_t keep = tiles <= 40 ? 2u : 3u;            // (the smallest maps stream their weights: more, shorter slices)
+        const uint32_t most = s.cpt / keep ? s.cpt / keep : 1;
         if (k > most) k = most;
         if (k < 1) k = 1;
     }
@@ -614,7 +624,7 @@ int sdfx_conv3x3_forward(const void* x, const void* w, const void* bias, const v
 }
 
 // ---- the halo form (packed weights) ---------------------------------------------------------------------------------------------
-// 1 when sdfx_conv3x3_packed_forward takes the shape: stride 1, (upsampled) rows of 16 / 32 / 64 pixels, whole 128-pixel tiles
+// 1 when sdfx_conv3x3_packed_forward takes the shape: stride 1, (upsampled) rows of 8 / 16 / 32 / 64 pixels, whole 128-pixel tiles
 int sdfx_conv3x3_packed_ok(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t Cout, uint32_t upsample) {
     HaloShape s;
     return make_halo_shape(N, H, W, Cin, Cout, upsample, 0, s) ? 1 : 0;
@@ -640,7 +650,7 @@ int sdfx_conv3x3_packed_forward(const void* x, const void* packed, const void* b
     SDFX_REQUIRE(x && packed && y, "conv3x3_packed_forward: null pointer");
     HaloShape s;
     SDFX_REQUIRE(make_halo_shape(N, H, W, Cin, Cout, upsample, splitk, s),
-                 "conv3x3_packed_forward: needs rows of 16 / 32 / 64 pixels, H W %% 128 == 0, Cin %% 64 == 0, Cout %% 64 == 0 (got N=%u H=%u W=%u Cin=%u Cout=%u up=%u)",
+                 "conv3x3_packed_forward: needs rows of 8 / 16 / 32 / 64 pixels in whole 128-pixel tiles, Cin %% 64 == 0, Cout %% 64 == 0 (got N=%u H=%u W=%u Cin=%u Cout=%u up=%u)",
                  N, H, W, Cin, Cout, upsample);
     SDFX_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(y) |
                    reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 16) == 0, "conv3x3_packed_forward: misaligned pointer");

@@ -121,13 +121,21 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_stats(const __half* __restri
         const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
         const uint4* base = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
         uint32_t np = 0;
-#pragma unroll 2
-        for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
-            float f[8];
-            unpack8(base[(size_t)p * s.cvs], f);
+        // four pixels per trip, their loads issued together (a slab is a handful of trips: one load in flight per trip left the
+        // kernel waiting on memory latency, 6-8 us on maps of a few MB); same order of accumulation
+        for (uint32_t p = slab * s.P + pp; p < p1; p += 4 * s.ppi) {
+            uint4 v[4];
 #pragma unroll
-            for (int i = 0; i < 8; i++) { sum[i] += f[i]; sq[i] += f[i] * f[i]; }
-            np++;
+            for (uint32_t u = 0; u < 4; u++) v[u] = base[(size_t)min(p + u * s.ppi, p1 - 1) * s.cvs];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                if (p + u * s.ppi >= p1) break;
+                float f[8];
+                unpack8(v[u], f);
+#pragma unroll
+                for (int i = 0; i < 8; i++) { sum[i] += f[i]; sq[i] += f[i] * f[i]; }
+                np++;
+            }
         }
         if (pre) {   // moments of x + e from those of x: e is constant over this thread's pixels
             float e[8];
@@ -182,7 +190,14 @@ __device__ __forceinline__ void moments_inline(const GnShape& s, const float* __
     if (j < J) {
         const float* p = partial + (size_t)n * s.slabs * K + k;
         double a = 0.0;
-        for (uint32_t w = j; w < s.slabs; w += J) a += (double)p[(size_t)w * K];
+        for (uint32_t w = j; w < s.slabs; w += 8 * J) {                 // eight partials per trip, loaded together; same order of addition
+            float v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) v[u] = p[(size_t)min(w + u * J, s.slabs - 1) * K];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++)
+                if (w + u * J < s.slabs) a += (double)v[u];
+        }
         scr[j * K + k] = a;
     }
     __syncthreads();
@@ -230,16 +245,145 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_apply(const __half* __restri
     const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
     const uint4* src = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
     uint4* dst = reinterpret_cast<uint4*>(y + (size_t)n * s.HW * s.C) + cv;
-#pragma unroll 2
-    for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
-        float f[8];
-        unpack8(src[(size_t)p * s.cvs], f);
+    for (uint32_t p = slab * s.P + pp; p < p1; p += 4 * s.ppi) {       // four pixels per trip, loads first (see k_gn_stats)
+        uint4 v[4];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float z = f[i] * a[i] + b[i];
-            f[i] = ACT ? z * sigmoid_(z) : z;
+        for (uint32_t u = 0; u < 4; u++) v[u] = src[(size_t)min(p + u * s.ppi, p1 - 1) * s.cvs];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            if (p + u * s.ppi >= p1) break;
+            float f[8];
+            unpack8(v[u], f);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float z = f[i] * a[i] + b[i];
+                f[i] = ACT ? z * sigmoid_(z) : z;
+            }
+            dst[(size_t)(p + u * s.ppi) * s.cvs] = pack8(f);
         }
-        dst[(size_t)p * s.cvs] = pack8(f);
+    }
+}
+
+// ---- small maps in one launch ----------------------------------------------------------------------------------------------------
+// The two-kernel form above costs ~13 us per norm however small the map (two launches, partials through memory, a dependent
+// combination in every workgroup): 29 of the UNet's 61 norms are 16 x 16 and 8 x 8 maps of 0.2-2 MB (20 vectors per thread — the 32 x 32 maps too — was slower: 32 workgroups each waiting on 80 KB). Here a workgroup owns a block
+// of GB whole groups (GB cpg channels, a multiple of 8) of one sample over ALL its pixels — at most kSmallVecs 16-byte vectors per
+// thread, loaded at once and kept in registers: statistics (float per thread, a fixed tree over the workgroup, mean / rstd in
+// double), then the normalised, activated values straight from the registers. One read, one write, no partials.
+constexpr uint32_t kSmallVecs = 12;
+struct GnSmall {
+    uint32_t N, HW, C, G, cpg;
+    uint32_t GB, VB;             // groups per workgroup, 16-byte vectors per pixel of its channel block (GB cpg / 8)
+    uint32_t blocks;             // G / GB workgroups per sample
+    uint32_t vecs;               // HW VB
+};
+bool make_small(uint32_t N, uint32_t HW, uint32_t C, uint32_t G, GnSmall& s) {
+    if (N == 0 || HW == 0 || C == 0 || G == 0 || C % G || C % 8 || C / G < 8) return false;
+    s.N = N; s.HW = HW; s.C = C; s.G = G; s.cpg = C / G;
+    for (uint32_t gb = 1; gb <= 4 && gb <= G; gb++) {
+        if (G % gb || (gb * s.cpg) % 8) continue;
+        s.GB = gb; s.VB = gb * s.cpg / 8; s.blocks = G / gb; s.vecs = HW * s.VB;
+        return s.vecs <= 256 * kSmallVecs && s.vecs >= 64;
+    }
+    return false;
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(256) void k_gn_small(const __half* __restrict__ x, const __half* __restrict__ pre, const __half* __restrict__ gamma,
+                                                 const __half* __restrict__ beta, GnSmall s, float eps, __half* __restrict__ y,
+                                                 float* __restrict__ mean_rstd) {
+    __shared__ float red[4][4][2];        // [wave][group of the block][sum, sum of squares]
+    __shared__ float mom[4][2];           // [group of the block][mean, rstd]
+    const uint32_t n = blockIdx.x / s.blocks, blk = blockIdx.x - n * s.blocks;
+    const uint32_t c0 = blk * s.GB * s.cpg, tid = threadIdx.x;
+    const uint4* src = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C + c0);
+    uint4* dst = reinterpret_cast<uint4*>(y + (size_t)n * s.HW * s.C + c0);
+    const uint32_t cvs = s.C / 8;
+    uint4 v[kSmallVecs];                 // the block's map, packed as it was read (unpacked twice: 80 registers instead of 240)
+#pragma unroll
+    for (uint32_t i = 0; i < kSmallVecs; i++) {
+        const uint32_t q = min(tid + 256u * i, s.vecs - 1), px = q / s.VB, vb = q - px * s.VB;
+        v[i] = src[(size_t)px * cvs + vb];
+    }
+    const uint4* pre4 = pre ? reinterpret_cast<const uint4*>(pre + (size_t)n * s.C + c0) : nullptr;
+    float sum[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t i = 0; i < kSmallVecs; i++) {
+        const uint32_t q = tid + 256u * i;
+        if (q >= s.vecs) break;
+        const uint32_t px = q / s.VB, vb = q - px * s.VB;
+        float f[8];
+        unpack8(v[i], f);
+        if (pre4) {
+            float e[8];
+            unpack8(pre4[vb], e);
+#pragma unroll
+            for (int j = 0; j < 8; j++) f[j] += e[j];
+        }
+        // a vector of 8 channels lies in one group or straddles two (cpg >= 8): elements below `cut` belong to group glo
+        const uint32_t glo = (vb * 8) / s.cpg, cut = (glo + 1) * s.cpg - vb * 8;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const float t = f[j];
+            if (j < cut) { s0 += t; q0 += t * t; } else { s1 += t; q1 += t * t; }
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++) {
+            if (g == glo) { sum[g] += s0; sq[g] += q0; }
+            if (g == glo + 1) { sum[g] += s1; sq[g] += q1; }
+        }
+    }
+    // workgroup sums: butterfly within the wave (the same tree in every run), then the four waves in order
+#pragma unroll
+    for (uint32_t g = 0; g < 4; g++) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { sum[g] += __shfl_xor(sum[g], o, 64); sq[g] += __shfl_xor(sq[g], o, 64); }
+    }
+    if ((tid & 63u) == 0) {
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++) { red[tid >> 6][g][0] = sum[g]; red[tid >> 6][g][1] = sq[g]; }
+    }
+    __syncthreads();
+    if (tid < s.GB) {
+        const double cnt = (double)s.HW * s.cpg;
+        double e0 = ((double)red[0][tid][0] + (double)red[1][tid][0]) + ((double)red[2][tid][0] + (double)red[3][tid][0]);
+        double e1 = ((double)red[0][tid][1] + (double)red[1][tid][1]) + ((double)red[2][tid][1] + (double)red[3][tid][1]);
+        e0 /= cnt; e1 /= cnt;
+        double var = e1 - e0 * e0;
+        var = var > 0.0 ? var : 0.0;
+        const float mean = (float)e0, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        mom[tid][0] = mean; mom[tid][1] = rstd;
+        if (mean_rstd) {          // (of x + pre, as the two-kernel form reports it)
+            float* o = mean_rstd + ((size_t)n * s.G + blk * s.GB + tid) * 2;
+            o[0] = mean; o[1] = rstd;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kSmallVecs; i++) {
+        const uint32_t q = tid + 256u * i;
+        if (q >= s.vecs) break;
+        const uint32_t px = q / s.VB, vb = q - px * s.VB;
+        float ga[8], be[8], f[8];
+        unpack8(reinterpret_cast<const uint4*>(gamma + c0)[vb], ga);
+        unpack8(reinterpret_cast<const uint4*>(beta + c0)[vb], be);
+        unpack8(v[i], f);
+        if (pre4) {
+            float e[8];
+            unpack8(pre4[vb], e);
+#pragma unroll
+            for (int j = 0; j < 8; j++) f[j] += e[j];
+        }
+        const uint32_t glo = (vb * 8) / s.cpg, cut = (glo + 1) * s.cpg - vb * 8, ghi = min(glo + 1, s.GB - 1);
+        const float m0 = mom[glo][0], r0 = mom[glo][1], m1 = mom[ghi][0], r1 = mom[ghi][1];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const float mean = j < cut ? m0 : m1, a = (j < cut ? r0 : r1) * ga[j];
+            const float z = (f[j] - mean) * a + be[j];
+            f[j] = ACT ? z * sigmoid_(z) : z;
+        }
+        dst[(size_t)px * cvs + vb] = pack8(f);
     }
 }
 
@@ -278,16 +422,25 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_stats(const __half* __re
         const uint32_t p1 = (slab + 1) * s.P < s.HW ? (slab + 1) * s.P : s.HW;
         const uint4* xs = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
         const uint4* ds = reinterpret_cast<const uint4*>(dy + (size_t)n * s.HW * s.C) + cv;
-#pragma unroll 2
-        for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
-            float fx[8], fd[8];
-            unpack8(xs[(size_t)p * s.cvs], fx);
-            unpack8(ds[(size_t)p * s.cvs], fd);
+        for (uint32_t p = slab * s.P + pp; p < p1; p += 4 * s.ppi) {       // four pixels per trip, loads first (see k_gn_stats)
+            uint4 vx[4], vd[4];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                float xh, dxh;
-                elem_bwd<ACT>(fx[i], fd[i], mean[i], rstd[i], ga[i], be[i], xh, dxh);
-                s1[i] += dxh; s2[i] += dxh * xh;
+            for (uint32_t u = 0; u < 4; u++) {
+                const size_t at = (size_t)min(p + u * s.ppi, p1 - 1) * s.cvs;
+                vx[u] = xs[at]; vd[u] = ds[at];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                if (p + u * s.ppi >= p1) break;
+                float fx[8], fd[8];
+                unpack8(vx[u], fx);
+                unpack8(vd[u], fd);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float xh, dxh;
+                    elem_bwd<ACT>(fx[i], fd[i], mean[i], rstd[i], ga[i], be[i], xh, dxh);
+                    s1[i] += dxh; s2[i] += dxh * xh;
+                }
             }
         }
     }
@@ -325,18 +478,27 @@ __global__ __launch_bounds__(kMaxThreads) void k_gn_bwd_apply(const __half* __re
     const uint4* xs = reinterpret_cast<const uint4*>(x + (size_t)n * s.HW * s.C) + cv;
     const uint4* ds = reinterpret_cast<const uint4*>(dy + (size_t)n * s.HW * s.C) + cv;
     uint4* dst = reinterpret_cast<uint4*>(dx + (size_t)n * s.HW * s.C) + cv;
-#pragma unroll 2
-    for (uint32_t p = slab * s.P + pp; p < p1; p += s.ppi) {
-        float fx[8], fd[8];
-        unpack8(xs[(size_t)p * s.cvs], fx);
-        unpack8(ds[(size_t)p * s.cvs], fd);
+    for (uint32_t p = slab * s.P + pp; p < p1; p += 4 * s.ppi) {           // four pixels per trip, loads first (see k_gn_stats)
+        uint4 vx[4], vd[4];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            float xh, dxh;
-            elem_bwd<ACT>(fx[i], fd[i], mean[i], rstd[i], ga[i], be[i], xh, dxh);
-            fx[i] = rstd[i] * (dxh - m1[i] - xh * m2[i]);
+        for (uint32_t u = 0; u < 4; u++) {
+            const size_t at = (size_t)min(p + u * s.ppi, p1 - 1) * s.cvs;
+            vx[u] = xs[at]; vd[u] = ds[at];
         }
-        dst[(size_t)p * s.cvs] = pack8(fx);
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            if (p + u * s.ppi >= p1) break;
+            float fx[8], fd[8];
+            unpack8(vx[u], fx);
+            unpack8(vd[u], fd);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float xh, dxh;
+                elem_bwd<ACT>(fx[i], fd[i], mean[i], rstd[i], ga[i], be[i], xh, dxh);
+                fx[i] = rstd[i] * (dxh - m1[i] - xh * m2[i]);
+            }
+            dst[(size_t)(p + u * s.ppi) * s.cvs] = pack8(fx);
+        }
     }
 }
 
@@ -396,6 +558,16 @@ int sdfx_group_norm_forward(const void* x, const void* pre, const void* gamma, c
     hipStream_t st = as_stream(stream);
     const __half* xp = static_cast<const __half*>(x);
     const __half* pp_ = static_cast<const __half*>(pre);
+    GnSmall sm;
+    if (dev_switch("SDFX_GN_SMALL", 1) && make_small(N, HW, C, G, sm)) {      // small maps: one launch, the map held in registers
+        if (silu)
+            hipLaunchKernelGGL(k_gn_small<true>, dim3(N * sm.blocks), dim3(256), 0, st, xp, pp_, static_cast<const __half*>(gamma),
+                               static_cast<const __half*>(beta), sm, eps, static_cast<__half*>(y), mean_rstd);
+        else
+            hipLaunchKernelGGL(k_gn_small<false>, dim3(N * sm.blocks), dim3(256), 0, st, xp, pp_, static_cast<const __half*>(gamma),
+                               static_cast<const __half*>(beta), sm, eps, static_cast<__half*>(y), mean_rstd);
+        return check_launch("group_norm_forward");
+    }
     const int inl = inline_ok(s) ? 1 : 0;
     float* mr = (mean_rstd || inl) ? mean_rstd : scratch + (size_t)N * s.slabs * G * 2;
     hipLaunchKernelGGL(k_gn_stats, dim3(N * s.slabs), dim3(s.threads), stats_lds_bytes(s), st, xp, pp_, s, scratch);

@@ -66,7 +66,7 @@ def packed_weight(weight):
 
 
 def conv3x3(x, weight, bias=None, residual=None, stride=1, upsample=False, splitk=0, tile_rows=0, form="auto"):
-    """See the module docstring. `form`: "halo" (stride 1, rows of 16 / 32 / 64 pixels: halo tiles + packed weights), "tiles" (the general
+    """See the module docstring. `form`: "halo" (stride 1, rows of 8 / 16 / 32 / 64 pixels in whole 128-pixel tiles: halo tiles + packed weights), "tiles" (the general
     kernel) or "auto" (halo where it applies). `splitk` / `tile_rows`: 0 = chosen by shape; other values are for measurements
     (tools/conv_bench.py; `tile_rows` implies the general kernel)."""
     if conv_ok(x, weight, bias, residual, stride):

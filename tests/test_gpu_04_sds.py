@@ -141,7 +141,11 @@ def test_if_step_matches_the_tensor_expressions(dev, hw):
 # ---- GroupNorm + SiLU of the frozen prior (csrc/groupnorm.hip; no reference kernel: the oracle is PyTorch's op in float32) ----
 @pytest.mark.parametrize("shape,act", [((2, 320, 64, 64), True), ((2, 1920, 16, 16), True), ((2, 2560, 8, 8), True),
                                        ((2, 960, 32, 32), False), ((1, 128, 256, 256), True), ((1, 512, 64, 64), False),
-                                       ((3, 64, 5, 7), True), ((1, 640, 1, 1), True)])
+                                       ((3, 64, 5, 7), True), ((1, 640, 1, 1), True),
+                                       # maps the one-launch kernel takes (k_gn_small: <= 3072 vectors per block of groups): one group per
+                                       # workgroup, two, four with vectors that straddle groups, a ragged last round of vectors
+                                       ((2, 1280, 16, 16), True), ((2, 640, 16, 16), True), ((2, 1280, 8, 8), False), ((2, 960, 8, 8), True),
+                                       ((2, 320, 16, 16), True), ((3, 2560, 5, 7), True)])
 def test_group_norm_kernels_match_torch_float32(dev, shape, act):
     """y = act(GroupNorm_32(x) gamma + beta) and dx on channels-last fp16 maps — every channel count of the SD-1.5 UNet / VAE
     restatement (channels per group 2 ... 80, vectors that straddle two groups), odd sizes, a 1 x 1 map — against

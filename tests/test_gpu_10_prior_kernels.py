@@ -47,7 +47,9 @@ def _check(got, want):
     (1, 128, 5, 7, 64, 1, False),         # 35 pixels: a ragged tile (rows beyond M), borders everywhere
     (3, 64, 9, 6, 128, 2, False),         # stride 2 on odd / even sizes, three images in one tile
     (2, 192, 6, 6, 64, 1, True),          # taps walk the 2 x upsampled map
-    (1, 64, 8, 16, 128, 1, False),        # the smallest map of the halo form: one 128-pixel tile
+    (1, 64, 8, 16, 128, 1, False),        # a map that is one 128-pixel tile
+    (4, 128, 4, 8, 64, 1, False),         # four whole images per tile
+    (3, 64, 8, 8, 64, 1, False),          # 192 pixels: not whole tiles, the general kernel
     (3, 128, 16, 32, 64, 1, False),       # rows of 32 pixels, 4 per tile, three images
     (2, 320, 64, 64, 320, 1, False),      # the UNet's top level
     (2, 1280, 8, 8, 1280, 1, False),      # the deepest level: one tile of pixels, K split
@@ -62,7 +64,8 @@ def test_conv3x3_matches_float32_convolution(dev, N, Cin, H, W, Cout, stride, up
     assert C.conv_ok(x, w, b, r, stride)
     import _sdfx as S
     halo_ok = stride == 1 and bool(S.lib().sdfx_conv3x3_packed_ok(N, H, W, Cin, Cout, int(upsample)))
-    assert halo_ok == (stride == 1 and Wo in (16, 32, 64) and (Ho * Wo) % 128 == 0)
+    whole = (Ho * Wo) % 128 == 0 if Ho * Wo >= 128 else 128 % (Ho * Wo) == 0
+    assert halo_ok == (stride == 1 and Wo in (8, 16, 32, 64) and whole and (N * Ho * Wo) % 128 == 0)
     with torch.no_grad():
         for form in ("tiles", "halo") if halo_ok else ("tiles",):        # both kernels on the shapes both take
             for bias, res in ((None, None), (b, None), (b, r)):
