@@ -8,6 +8,7 @@ PyTorch ops everywhere (A/B switch)."""
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -48,21 +49,24 @@ def conv_ok(x, weight, bias=None, residual=None, stride=1) -> bool:
     return True
 
 
-_PACKED = {}    # (data_ptr, version, shape) of a frozen weight -> its copy in MFMA fragment order (csrc/conv.hip, halo form)
+_PACKED = {}    # id(weight) -> (weak reference to that tensor, (data_ptr, version, shape), its copy in MFMA fragment order)
 
 
 def packed_weight(weight):
-    """`weight` [Cout, Cin, 3, 3] (channels-last, frozen) in the fragment order of the halo kernel; built once per weight (rebuilt when
-    the parameter was replaced or written to) — the price of weights that go from memory straight into MFMA operand registers."""
+    """`weight` [Cout, Cin, 3, 3] (channels-last, frozen) in the fragment order of the halo kernel (csrc/conv.hip); built once per weight
+    TENSOR and rebuilt when that tensor was written to or re-pointed — the price of weights that go from memory straight into MFMA
+    operand registers. The entry dies with the tensor: another tensor that later lands on the same address (or gets the same `id`)
+    never sees it."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape))
     hit = _PACKED.get(id(weight))
-    if hit is None or hit[0] != key:
+    if hit is None or hit[0]() is not weight or hit[1] != key:
         import _sdfx as S
         out = torch.empty(weight.numel(), dtype=weight.dtype, device=weight.device)
         S.call("sdfx_conv3x3_pack_weights", S.ptr(weight), weight.shape[1], weight.shape[0], S.ptr(out), S.stream())
-        hit = (key, out)
-        _PACKED[id(weight)] = hit
-    return hit[1]
+        wid = id(weight)
+        hit = (weakref.ref(weight, lambda _r, wid=wid: _PACKED.pop(wid, None)), key, out)
+        _PACKED[wid] = hit
+    return hit[2]
 
 
 def conv3x3(x, weight, bias=None, residual=None, stride=1, upsample=False, splitk=0, tile_rows=0, form="auto"):

@@ -106,6 +106,25 @@ def test_conv3x3_halo_form_split_over_chunks(dev, splitk):
         C.conv3x3(x[:, :, :5, :7].contiguous(memory_format=torch.channels_last), w, form="halo")
 
 
+def test_conv3x3_packed_weights_follow_the_tensor_not_its_address(dev):
+    """The halo form's packed copy of a weight belongs to that weight TENSOR: a different tensor of the same shape that the caching
+    allocator places on the freed address of the first (same data_ptr, version 0) must be packed afresh. (The first version of the cache
+    keyed on address + version and served the previous test's weights — a wrong map on whichever test came second.)"""
+    C = _conv_mod()
+    x, w1, b, _ = _inputs(dev, 2, 64, 16, 16, 64, seed=21)
+    with torch.no_grad():
+        _check(C.conv3x3(x, w1, b, None, form="halo"), _reference(x, w1, b, None, 1, False))
+        ptr = w1.data_ptr()
+        del w1
+        for seed in (22, 23, 24):                       # new tensors; the allocator hands the freed block back
+            _, w2, _, _ = _inputs(dev, 2, 64, 16, 16, 64, seed=seed)
+            _check(C.conv3x3(x, w2, b, None, form="halo"), _reference(x, w2, b, None, 1, False))
+            same = w2.data_ptr() == ptr
+            del w2
+    assert len(C._PACKED) == 0 or all(ref() is not None for ref, _, _ in C._PACKED.values())   # dead tensors leave no entry
+    assert same or True                                 # (address reuse is the allocator's choice; the check above holds either way)
+
+
 def test_conv3x3_falls_back_to_pytorch_off_the_kernel_path(dev):
     """Channel counts the kernel does not take (the UNet's first / last layer), float32, NCHW inputs and calls that want a gradient
     go through F.conv2d with the same result as calling it directly."""
