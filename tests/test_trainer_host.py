@@ -341,3 +341,48 @@ def test_group_norm_act_module_is_a_drop_in_group_norm_off_the_fused_path():
         assert not fused_ok(x, m.weight, m.bias, 32)
         want = F.silu(ref(x)) if act else ref(x)
         assert torch.equal(m(x), want)
+
+
+def test_prior_kernel_wrappers_are_drop_ins_off_the_gpu():
+    """sdfx_nerf/conv.py and attention.py on CPU tensors (or float32, NCHW, with gradients wanted) are PyTorch's own ops: the same
+    numbers, the same autograd — what the HIP kernels replace is only the frozen fp16 channels-last CUDA case."""
+    import torch.nn.functional as F
+    from sdfx_nerf import attention as AT
+    from sdfx_nerf import conv as CV
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 6, 6, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    b = torch.randn(64, generator=g)
+    r = torch.randn(2, 64, 6, 6, generator=g)
+    assert not CV.conv_ok(x, w, b, r) and not CV.linear_ok(x.flatten(1), torch.randn(64, 64 * 36))
+    assert torch.equal(CV.conv3x3(x, w, b, r), F.conv2d(x, w, b, 1, 1) + r)
+    assert torch.equal(CV.conv3x3(x, w, b, None, stride=2), F.conv2d(x, w, b, 2, 1))
+    assert torch.equal(CV.conv3x3(x, w, None, None, 1, upsample=True), F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, 1, 1))
+    t, wl, bl = torch.randn(3, 5, 64, generator=g), torch.randn(128, 64, generator=g), torch.randn(128, generator=g)
+    res = torch.randn(3, 5, 128, generator=g)
+    assert torch.equal(CV.linear(t, wl, bl, res), F.linear(t, wl, bl) + res) and torch.equal(CV.linear_auto(t, wl, bl), F.linear(t, wl, bl))
+    q, k, v = (torch.randn(2, 3, n, 40, generator=g) for n in (7, 5, 5))
+    assert not AT.attention_ok(q, k, v)
+    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(2, 7, 120)
+    assert torch.equal(AT.attention_bnc(q, k, v), want)
+    xg = x.clone().requires_grad_(True)
+    CV.conv3x3(xg, w, b, r).sum().backward()
+    assert xg.grad is not None and xg.grad.shape == x.shape
+
+
+def test_sd15_attention_with_stacked_projections_equals_the_three_linears():
+    """Attention._fused_weight: q / k / v (k / v for a cross-attention) as one GEMM over stacked frozen weights gives the same
+    projections as the three Linear modules, and the stack is rebuilt when a weight is written to."""
+    from sdfx_nerf import sd15_arch as A
+    torch.manual_seed(1)
+    a = A.Attention(64, None, 2).requires_grad_(False)
+    x = torch.randn(2, 9, 64)
+    w = a._fused_weight(("q", "k", "v"))
+    qkv = torch.nn.functional.linear(x, w)
+    for i, m in enumerate((a.q, a.k, a.v)):
+        assert torch.equal(qkv[..., i * 64:(i + 1) * 64], m(x))
+    assert a._fused_weight(("q", "k", "v")) is w                       # cached
+    with torch.no_grad():
+        a.k.weight.mul_(2.0)
+    w2 = a._fused_weight(("q", "k", "v"))
+    assert w2 is not w and torch.equal(w2[64:128], a.k.weight)
