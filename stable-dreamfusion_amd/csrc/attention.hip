@@ -45,10 +45,6 @@ struct AttnShape {
     float c;                              // softmax scale * log2(e)
 };
 
-__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t bid, uint32_t total) {
-    const uint32_t per = total >> 3, rem = total & 7u, xcd = bid & 7u, q = bid >> 3;
-    return xcd < rem ? xcd * (per + 1) + q : rem * (per + 1) + (xcd - rem) * per + q;
-}
 // max over lanes l and l ^ 32
 __device__ __forceinline__ float max_halves(float x) {
     const uint32_t u = __float_as_uint(x);

@@ -1,22 +1,25 @@
-// conv.hip — the 3 x 3 convolutions of the frozen prior as implicit GEMMs on the matrix cores (gfx950), forward only.
+// conv.hip — the 3 x 3 convolutions (and small GEMMs) of the frozen prior as implicit GEMMs on the matrix cores (gfx950), forward only.
 //
 // What it replaces: `F.conv2d(x, w, padding=1)` on channels-last fp16 activations inside the SD-1.5 UNet restatement
 // (sdfx_nerf/sd15_arch.py; the reference gets these layers from diffusers, guidance/sd_utils.py:37-65). MIOpen's NHWC implicit-GEMM
 // kernels run the UNet's 61 such layers at 280 TFLOP/s on average (tools/unet_conv_shapes.py: 15.1 GFLOP in 45 us at every level,
 // 3.8 GFLOP in 43 us at the 8 x 8 level), a ninth of the dense fp16 rate: 3.0 ms of a 12.8 ms iteration.
+// Two kernels:
+//   k_conv3x3       the GENERAL form, below: any map size, stride 1 | 2, read-through 2 x upsample, 1 or 9 taps (with one tap it is
+//                   sdfx_linear_forward: GEMM + bias + residual for the transformer blocks' small projections)
+//   k_conv3x3_halo  stride 1, rows of 8 / 16 / 32 / 64 pixels: a tile's halo staged once for all 9 taps, weights pre-packed into MFMA
+//                   fragment order and loaded straight into operand registers — what the UNet's layers run on (further down)
 //
 // The GEMM: D[m, co] = sum_{tap, ci} X[pixel(m) + tap, ci] * W[co, tap, ci], m = (n, oy, ox) flattened (the NHWC row index),
-// K = 9 Cin walked as (tap, 64-channel chunk) steps. A workgroup (4 waves, 2 x 2) owns a 128-pixel x 64-channel tile of D; a K
-// step stages the 128 x 64 activation tile of ONE tap (rows shifted by the tap, zero outside the map: buffer loads with the
-// offset pushed out of range) and the 64 x 64 weight tile into LDS, double-buffered: the loads of step t + 1 are in flight while
-// the MFMAs of step t run. Rows are pitched 144 bytes: the 16 lanes of a ds_read_b128 group address 16 different rows whose
-// starts 36 r mod 64 dwords are 16 different multiples of 4 — conflict-free. Each wave accumulates 64 x 32 of the tile with
-// v_mfma_f32_32x32x16_f16 (2 A fragments + 1 B fragment per two MFMAs).
-// Small maps (32 x 32 and below: fewer tiles than CUs) split K over `splitk` workgroups that write float32 partials;
+// K = 9 Cin walked as (tap, 64-channel chunk) steps. A workgroup (4 waves, 2 x 2) owns a 128- or 64-pixel x 64-channel tile of D; a K
+// step stages the activation tile of ONE tap (rows shifted by the tap, zero outside the map: buffer loads with the
+// offset pushed out of range) and the 64 x 64 weight tile into LDS, double-buffered, with the loads of steps t + 1 and t + 2 in
+// flight (two register sets) while the MFMAs of step t run. Rows are pitched 144 bytes: the 16 lanes of a ds_read_b128 group address
+// 16 different rows whose starts 36 r mod 64 dwords are 16 different multiples of 4 — conflict-free. Each wave accumulates 64 x 32
+// (32 x 32 with 64-row tiles) of the tile with v_mfma_f32_32x32x16_f16.
+// Small maps (fewer tiles than CUs) split K over `splitk` workgroups that write float32 partials;
 // k_conv_reduce sums them in slice order (bit-reproducible, no atomics) and applies the epilogue. The epilogue — bias, residual
 // map, fp16 rounding — otherwise runs on the tile passed through LDS so that every thread stores 16 contiguous bytes.
-// Options: stride 2 (the UNet's downsampling layers), input read through a nearest-neighbour 2 x upsample (the UNet's upsampling
-// layers: `conv(F.interpolate(h, 2))` without the 4 x larger intermediate map).
 #include "sdfx_common.h"
 
 using namespace sdfx;
@@ -59,12 +62,6 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
-// Consecutive workgroup ids go round the 8 XCDs: give every XCD a contiguous range of tiles (its n tiles of one m tile share the
-// activation tile in that XCD's L2).
-__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t bid, uint32_t total) {
-    const uint32_t per = total >> 3, rem = total & 7u, xcd = bid & 7u, q = bid >> 3;
-    return xcd < rem ? xcd * (per + 1) + q : rem * (per + 1) + (xcd - rem) * per + q;
-}
 
 // ABL (devtools builds only, SDFX_CONV_ABLATE): parts of the K step left out to see what bounds it — 1: no global loads (the registers
 // keep what they hold), 2: no MFMAs (fragments still read), 4: no LDS writes, 8: no fragment reads and no MFMAs. Results are garbage.

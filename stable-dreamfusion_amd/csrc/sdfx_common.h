@@ -70,6 +70,13 @@ StencilSrc stencil_src();   // the calling thread's current setting
 __global__ __launch_bounds__(256) static void k_zero_words(uint32_t* __restrict__ p, uint64_t words) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (uint64_t)gridDim.x * 256) p[i] = 0u;
 }
+// Consecutive workgroup ids go round the 8 XCDs (sdfx_xcd_round_robin checks it): logical id for workgroup `bid` of `total` such that
+// every XCD works on a CONTIGUOUS range of logical ids — neighbours in that order (the column tiles of one row tile of a GEMM, the
+// query tiles of one head) then share their operands in that XCD's L2. Results never depend on it.
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t bid, uint32_t total) {
+    const uint32_t per = total >> 3, rem = total & 7u, xcd = bid & 7u, q = bid >> 3;
+    return xcd < rem ? xcd * (per + 1) + q : rem * (per + 1) + (xcd - rem) * per + q;
+}
 static inline void zero_device(void* p, uint64_t bytes, hipStream_t st) {
     const uint64_t words = bytes / 4;
     if (words == 0) return;

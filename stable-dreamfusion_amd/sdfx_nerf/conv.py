@@ -63,6 +63,8 @@ def packed_weight(weight):
         import _sdfx as S
         out = torch.empty(weight.numel(), dtype=weight.dtype, device=weight.device)
         S.call("sdfx_conv3x3_pack_weights", S.ptr(weight), weight.shape[1], weight.shape[0], S.ptr(out), S.stream())
+        if torch.cuda.is_current_stream_capturing():
+            return out          # packed inside the graph being captured (memory of that graph's pool): not kept beyond it
         wid = id(weight)
         hit = (weakref.ref(weight, lambda _r, wid=wid: _PACKED.pop(wid, None)), key, out)
         _PACKED[wid] = hit

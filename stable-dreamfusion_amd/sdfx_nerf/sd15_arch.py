@@ -64,8 +64,11 @@ class ResBlock(nn.Module):
         if self.temb is not None:
             ver = (self.temb.bias._version, self.conv1.bias._version, self.temb.bias.data_ptr(), self.conv1.bias.data_ptr())
             if getattr(self, "_folded_bias_of", None) != ver:        # (re)built when either parameter was replaced or written to
-                self._folded_bias, self._folded_bias_of = (self.temb.bias + self.conv1.bias).detach(), ver
-            fb = self._folded_bias
+                fb = (self.temb.bias + self.conv1.bias).detach()
+                if not (fb.is_cuda and torch.cuda.is_current_stream_capturing()):   # (a capture's memory is not kept beyond it)
+                    self._folded_bias, self._folded_bias_of = fb, ver
+            else:
+                fb = self._folded_bias
             pre = F.linear(emb_act, self.temb.weight, fb)                # [N, C]
         else:
             pre = self.conv1.bias.detach()[None].expand(x.shape[0], -1).contiguous()
@@ -100,7 +103,10 @@ class Attention(nn.Module):
         ver = tuple((w._version, w.data_ptr()) for w in ws)
         cache = self.__dict__.setdefault("_stacked", {})
         if cache.get(names, (None, None))[0] != ver:
-            cache[names] = (ver, torch.cat([w.detach() for w in ws], dim=0))
+            stacked = torch.cat([w.detach() for w in ws], dim=0)
+            if stacked.is_cuda and torch.cuda.is_current_stream_capturing():
+                return stacked      # built inside a graph capture (that graph's memory pool): not kept beyond it
+            cache[names] = (ver, stacked)
         return cache[names][1]
 
     def forward(self, x, ctx=None, residual=None):

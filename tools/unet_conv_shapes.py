@@ -2,6 +2,7 @@
 """Every convolution the SD-1.5 UNet restatement runs (batch 2, 64 x 64 latents), timed alone on the GPU clock: shape, FLOPs, us,
 TFLOP/s — the size of the opportunity a hand-written MFMA implicit GEMM would have."""
 import importlib, os, sys, collections
+os.environ["SDFX_CONV"] = "0"      # every convolution through F.conv2d (what this tool times); csrc/conv.hip has tools/conv_bench.py
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, torch.nn.functional as F
@@ -25,11 +26,14 @@ def counted(x, w, b=None, stride=1, padding=0, *a, **k):
     shapes[key] = shapes.get(key, 0) + 1
     return orig(x, w, b, stride, padding, *a, **k)
 A.F.conv2d = counted
+import sdfx_nerf.conv as _CV
+_CV.F.conv2d = counted          # (the fused blocks reach F.conv2d through sdfx_nerf/conv.py's fallback)
 x = torch.randn(2, 4, 64, 64, device=dev).half().contiguous(memory_format=torch.channels_last)
 t = torch.tensor([20, 700], device=dev); ctx = torch.randn(2, 77, 768, device=dev).half()
 with torch.no_grad():
     unet(x, t, ctx)
 A.F.conv2d = orig
+_CV.F.conv2d = orig
 for h in hs: h.remove()
 tot_us = tot_fl = 0.0
 print("input [N,C,H,W]        Cout k s  calls   us/call  GFLOP  TFLOP/s")
