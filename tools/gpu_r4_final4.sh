@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 4, after the packed-weight cache fix: the whole GPU suite, smoke, the default bench (same kernels as tools/gpu_r4_final2.sh's run)
-OUT=gpurun_out/r4final3
+# round 4, on the final commit (capture-safe caches, shared xcd_contiguous): the whole GPU suite, smoke, the default bench (same kernels as tools/gpu_r4_final2.sh's run)
+OUT=gpurun_out/r4final4
 mkdir -p $OUT
 echo "== $(date)" | tee $OUT/summary.txt
 timeout 900 python -m pytest tests -m gpu -q -rA --durations=5 --timeout 600 -p no:cacheprovider > $OUT/pytest.txt 2>&1
