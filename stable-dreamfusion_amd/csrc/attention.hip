@@ -236,9 +236,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_fwd(const _Float16* __restr
     }
 }
 
+#ifdef SDFX_DEVTOOLS
+#include "attention_pipe.inc.h"
+#endif
+
 template <int D, int NW>
 void launch(const _Float16* q, const _Float16* k, const _Float16* v, _Float16* o, AttnShape s, hipStream_t st) {
     s.q_tiles = (s.Nq + 32 * NW - 1) / (32 * NW);
+#ifdef SDFX_DEVTOOLS
+    if (D <= 80 && dev_switch("SDFX_ATTN_PIPE", 0)) {      // measurement variant, see attention_pipe.inc.h
+        hipLaunchKernelGGL((k_attn_fwd_pipe<(D <= 80 ? D : 40), NW>), dim3(s.q_tiles * s.B * s.H), dim3(64 * NW), 0, st, q, k, v, o, s);
+        return;
+    }
+#endif
     hipLaunchKernelGGL((k_attn_fwd<D, NW>), dim3(s.q_tiles * s.B * s.H), dim3(64 * NW), 0, st, q, k, v, o, s);
 }
 template <int D>

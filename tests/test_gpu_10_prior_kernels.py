@@ -244,3 +244,19 @@ def test_linear_matches_float32_gemm(dev, M, K, N):
     assert not C.linear_ok(xg, w)
     C.linear(xg, w, b, r).float().sum().backward()
     assert xg.grad is not None
+
+
+def test_attention_pipelined_variant_is_bit_identical(dev):
+    """csrc/attention_pipe.inc.h (devtools library, SDFX_ATTN_PIPE=1): the next tile's scores issued before this tile's softmax. Same
+    arithmetic in the same order per tile, so the same bits as k_attn_fwd — on full tiles, a ragged last tile, one tile, two tiles."""
+    import _sdfx as S
+    if not S.is_devtools():
+        pytest.skip("implementation switches exist only in libsdfx_hip_dev.so (SDFX_LIB)")
+    A = _attn_mod()
+    with torch.no_grad():
+        for B, H, Nq, Nk, d in ((2, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (1, 3, 50, 77, 40), (1, 2, 33, 1, 80), (2, 2, 100, 129, 40)):
+            q, k, v = _qkv(dev, B, H, Nq, Nk, d, seed=Nq + Nk, spread=2.0)
+            base = A.attention_bnc(q, k, v, force=True)
+            with S.dev_switch(SDFX_ATTN_PIPE=1):
+                pipe = A.attention_bnc(q, k, v, force=True)
+            assert torch.equal(base, pipe), (B, H, Nq, Nk, d, float((base.float() - pipe.float()).abs().max()))
