@@ -244,8 +244,9 @@ template <int D, int NW>
 void launch(const _Float16* q, const _Float16* k, const _Float16* v, _Float16* o, AttnShape s, hipStream_t st) {
     s.q_tiles = (s.Nq + 32 * NW - 1) / (32 * NW);
 #ifdef SDFX_DEVTOOLS
-    if (D <= 80 && dev_switch("SDFX_ATTN_PIPE", 0)) {      // measurement variant, see attention_pipe.inc.h
-        hipLaunchKernelGGL((k_attn_fwd_pipe<(D <= 80 ? D : 40), NW>), dim3(s.q_tiles * s.B * s.H), dim3(64 * NW), 0, st, q, k, v, o, s);
+    if (const int pipe = D <= 80 ? dev_switch("SDFX_ATTN_PIPE", 0) : 0) {      // measurement variants, see attention_pipe.inc.h
+        if (pipe == 2) hipLaunchKernelGGL((k_attn_fwd_pipe<(D <= 80 ? D : 40), NW, true>), dim3(s.q_tiles * s.B * s.H), dim3(64 * NW), 0, st, q, k, v, o, s);
+        else hipLaunchKernelGGL((k_attn_fwd_pipe<(D <= 80 ? D : 40), NW, false>), dim3(s.q_tiles * s.B * s.H), dim3(64 * NW), 0, st, q, k, v, o, s);
         return;
     }
 #endif

@@ -2,11 +2,12 @@
 // matrix cores before the current tile's softmax, so that the 6 S^T MFMAs run under the ~950 VALU cycles of the exponentials instead of
 // in front of them (K staged one tile further ahead: three K buffers). Written at the end of round 4 WITHOUT a GPU run (the round's GPU
 // minutes were spent): same arithmetic in the same order per tile as k_attn_fwd, so the results must be bit-identical to it — the first
+// (SDFX_ATTN_PIPE=2 adds SWZ: V^T's 8-slot groups permuted per channel chunk against the bank conflicts of the transposing stores.)
 // thing to check (tests/test_gpu_10_prior_kernels.py::test_attention_pipelined_variant_is_bit_identical, skipped on the product
 // library), then tools/attn_bench.py under SDFX_LIB=…_dev.so SDFX_ATTN_PIPE=1. Included inside attention.hip's anonymous namespace.
 #pragma once
 
-template <int D, int NW>
+template <int D, int NW, bool SWZ>
 __global__ __launch_bounds__(64 * NW, 2) void k_attn_fwd_pipe(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                        const _Float16* __restrict__ v, _Float16* __restrict__ o, AttnShape s) {
     constexpr int DP = (D + 15) / 16 * 16;            // channels padded to whole MFMA K steps (48 / 80 / 160)
@@ -87,7 +88,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_fwd_pipe(const _Float16* __
             const uint32_t c = tid + (uint32_t)i * T;
             if (PT * T == NCH || c < (uint32_t)NCH) {
                 const uint32_t row = c / CH, ch = c - row * CH;
-                const uint32_t slot = (row & ~12u) | ((row & 4u) << 1) | ((row & 8u) >> 1);     // (the key order of k_attn_fwd)
+                uint32_t slot = (row & ~12u) | ((row & 4u) << 1) | ((row & 8u) >> 1);     // (the key order of k_attn_fwd)
+                // SWZ: the 8-slot groups of a V^T row are permuted by the row's channel chunk (slot ^= (ch & 7) << 3). A row pitch that
+                // keeps 16-byte reads aligned is a multiple of 8 halves, so the 8 channel rows one thread writes — and the same key's
+                // rows of EVERY other chunk — start on the same bank: ~9-way conflicts on each of the 16 ds_write_b16 per thread and tile.
+                if (SWZ) slot ^= (ch & 7u) << 3;
                 uint16_t* col = vd + (ch * 8u) * (kVtPitch / 2) + slot;
                 const u4v w = rv[i];
                 col[0 * (kVtPitch / 2)] = (uint16_t)(w.x & 0xffffu); col[1 * (kVtPitch / 2)] = (uint16_t)(w.x >> 16);
@@ -174,9 +179,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_fwd_pipe(const _Float16* __
             for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
 #pragma unroll
         for (int ks2 = 0; ks2 < 4; ks2++) {
-            const uint32_t koff = (16u * ks2 + 8u * hi) * 2u;
 #pragma unroll
             for (int dt = 0; dt < DT; dt++) {
+                const uint32_t grp = (2u * ks2 + hi) ^ (SWZ ? ((32u * dt + ql) >> 3) & 7u : 0u);      // 8-slot group of this channel row
+                const uint32_t koff = grp * 16u;
                 const h8 a = *reinterpret_cast<const h8*>(vt + (32u * dt + ql) * kVtPitch + koff);
                 oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[ks2], oacc[dt], 0, 0, 0);
             }

@@ -257,6 +257,7 @@ def test_attention_pipelined_variant_is_bit_identical(dev):
         for B, H, Nq, Nk, d in ((2, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (1, 3, 50, 77, 40), (1, 2, 33, 1, 80), (2, 2, 100, 129, 40)):
             q, k, v = _qkv(dev, B, H, Nq, Nk, d, seed=Nq + Nk, spread=2.0)
             base = A.attention_bnc(q, k, v, force=True)
-            with S.dev_switch(SDFX_ATTN_PIPE=1):
-                pipe = A.attention_bnc(q, k, v, force=True)
-            assert torch.equal(base, pipe), (B, H, Nq, Nk, d, float((base.float() - pipe.float()).abs().max()))
+            for mode in (1, 2):                      # 2: + V^T's slot groups permuted per channel chunk (a layout change only)
+                with S.dev_switch(SDFX_ATTN_PIPE=mode):
+                    pipe = A.attention_bnc(q, k, v, force=True)
+                assert torch.equal(base, pipe), (mode, B, H, Nq, Nk, d, float((base.float() - pipe.float()).abs().max()))
