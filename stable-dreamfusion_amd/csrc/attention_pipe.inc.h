@@ -1,10 +1,13 @@
-// attention_pipe.inc.h — DEVTOOLS ONLY (SDFX_ATTN_PIPE=1 on libsdfx_hip_dev.so): k_attn_fwd with the NEXT tile's scores issued to the
-// matrix cores before the current tile's softmax, so that the 6 S^T MFMAs run under the ~950 VALU cycles of the exponentials instead of
-// in front of them (K staged one tile further ahead: three K buffers). Written at the end of round 4 WITHOUT a GPU run (the round's GPU
-// minutes were spent): same arithmetic in the same order per tile as k_attn_fwd, so the results must be bit-identical to it — the first
-// (SDFX_ATTN_PIPE=2 adds SWZ: V^T's 8-slot groups permuted per channel chunk against the bank conflicts of the transposing stores.)
-// thing to check (tests/test_gpu_10_prior_kernels.py::test_attention_pipelined_variant_is_bit_identical, skipped on the product
-// library), then tools/attn_bench.py under SDFX_LIB=…_dev.so SDFX_ATTN_PIPE=1. Included inside attention.hip's anonymous namespace.
+// attention_pipe.inc.h — DEVTOOLS ONLY (libsdfx_hip_dev.so, SDFX_ATTN_PIPE): two measurement variants of k_attn_fwd.
+//   SDFX_ATTN_PIPE=1   the NEXT tile's scores are issued to the matrix cores before the current tile's softmax, so that the 6 S^T MFMAs
+//                      run under the ~950 VALU cycles of the exponentials instead of in front of them (K staged one tile further
+//                      ahead: three K buffers)
+//   SDFX_ATTN_PIPE=2   the same + SWZ: V^T's 8-slot groups permuted per channel chunk against the bank conflicts of the transposing
+//                      2-byte stores
+// Same arithmetic in the same order per tile as k_attn_fwd: bit-identical results (tests/test_gpu_10_prior_kernels.py::
+// test_attention_pipelined_variant_is_bit_identical, skipped on the product library; passed on the GPU at the end of round 4). Measured
+// then (profiles/r04_attn_variants.txt): 4096 x 4096 x 40 107 -> 109 / 109 us, 1024 x 1024 x 80 32.1 -> 35.8 / 29.2 us — neither is what
+// bounds the 40-wide case. Included inside attention.hip's anonymous namespace.
 #pragma once
 
 template <int D, int NW, bool SWZ>
