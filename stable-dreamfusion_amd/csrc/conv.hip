@@ -294,11 +294,14 @@ __device__ __forceinline__ u4v buf_load16v(__amdgpu_buffer_rsrc_t b, uint32_t vo
     return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, 0, 0));
 }
 
-template <bool SPLIT>
+// DBUF = false (devtools library, SDFX_CONV_HALO_SINGLE=1: a measurement variant): ONE halo buffer — 42 KB of LDS instead of 80, three
+// workgroups per CU instead of two — at the price of a second barrier per chunk (nobody may still read the halo that is overwritten).
+template <bool SPLIT, bool DBUF = true>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const _Float16* __restrict__ x, const _Float16* __restrict__ wpk,
                                                           const _Float16* __restrict__ bias, const _Float16* __restrict__ residual,
                                                           _Float16* __restrict__ y, float* __restrict__ partial, HaloShape s) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kHaloBuf + 256 * 16];   // + one dump slot per thread (see write_halo)
+    constexpr uint32_t kDump = (DBUF ? 2u : 1u) * kHaloBuf;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kDump + 256 * 16];   // + one dump slot per thread (see write_halo)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t wm = wave >> 1, wn = wave & 1u;
     const uint32_t tiles = s.m_tiles * s.n_tiles;
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const _Float16* __restr
 #pragma unroll
         for (int i = 0; i < kHaloPieces; i++) {
             const uint32_t q = tid + 256u * i;
-            const uint32_t at = q < s.HP * 8u ? buf * kHaloBuf + (q >> 3) * kPitch + (q & 7u) * 16u : 2u * kHaloBuf + tid * 16u;
+            const uint32_t at = q < s.HP * 8u ? buf * kHaloBuf + (q >> 3) * kPitch + (q & 7u) * 16u : kDump + tid * 16u;
             *reinterpret_cast<u4v*>(lds + at) = hreg[i];
         }
     };
@@ -387,9 +390,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const _Float16* __restr
             multiply(buf, t, t % 3);
             __builtin_amdgcn_sched_barrier(0);
         }
-        write_halo(buf ^ 1u);                       // (after the last chunk: a copy nobody reads)
-        __syncthreads();
-        buf ^= 1u;
+        if (DBUF) {
+            write_halo(buf ^ 1u);                   // (after the last chunk: a copy nobody reads)
+            __syncthreads();
+            buf ^= 1u;
+        } else {
+            __syncthreads();                        // every wave is done with this chunk's halo
+            write_halo(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: as above (the halo buffers are free after the last barrier)
@@ -466,7 +475,7 @@ bool make_halo_shape(uint32_t N, uint32_t H, uint32_t W, uint32_t Cin, uint32_t 
     // a slice keeps >= 3 chunks (27 taps); maps with >= 300 tiles run unsplit
     if (splitk_req > 0) k = (uint32_t)splitk_req;
     else {
-        k = 512u / tiles;
+        k = (uint32_t)dev_switch("SDFX_CONV_HALO_TARGET", 512) / tiles;   // (devtools: 768 with three workgroups per CU)
         const uint32_t keep = tiles <= 40 ? 2u : 3u;            // (the smallest maps stream their weights: more, shorter slices)
         const uint32_t most = s.cpt / keep ? s.cpt / keep : 1;
         if (k > most) k = most;
@@ -659,6 +668,16 @@ int sdfx_conv3x3_packed_forward(const void* x, const void* packed, const void* b
     const _Float16* rp = static_cast<const _Float16*>(residual);
     _Float16* yp = static_cast<_Float16*>(y);
     const uint32_t grid = s.m_tiles * s.n_tiles * s.splitk;
+#ifdef SDFX_DEVTOOLS
+    if (dev_switch("SDFX_CONV_HALO_SINGLE", 0)) {       // measurement variant: one halo buffer, three workgroups per CU
+        if (s.splitk == 1) hipLaunchKernelGGL((k_conv3x3_halo<false, false>), dim3(grid), dim3(256), 0, st, xp, wp, bp, rp, yp, (float*)nullptr, s);
+        else {
+            hipLaunchKernelGGL((k_conv3x3_halo<true, false>), dim3(grid), dim3(256), 0, st, xp, wp, bp, rp, yp, scratch, s);
+            hipLaunchKernelGGL(k_conv_reduce, dim3(div_up((uint64_t)s.M * Cout / 8, 256)), dim3(256), 0, st, scratch, bp, rp, yp, s.M, Cout, s.splitk);
+        }
+        return check_launch("conv3x3_packed_forward (single halo buffer)");
+    }
+#endif
     if (s.splitk == 1) {
         hipLaunchKernelGGL((k_conv3x3_halo<false>), dim3(grid), dim3(256), 0, st, xp, wp, bp, rp, yp, (float*)nullptr, s);
     } else {

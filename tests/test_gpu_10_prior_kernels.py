@@ -125,6 +125,26 @@ def test_conv3x3_packed_weights_follow_the_tensor_not_its_address(dev):
     assert same or True                                 # (address reuse is the allocator's choice; the check above holds either way)
 
 
+def test_conv3x3_halo_single_buffer_variant_is_bit_identical(dev):
+    """SDFX_CONV_HALO_SINGLE=1 (devtools library): the halo kernel with one halo buffer and two barriers per chunk — 42 KB of LDS, three
+    workgroups per CU. A staging change only: the same sums in the same order as the product kernel, hence the same bits (unsplit and
+    split over chunks). Written at the end of round 4 after the counters showed the kernel's waves parked 58 % of their cycles; not
+    yet timed (tools/conv_bench.py under SDFX_LIB=..._dev.so SDFX_CONV_HALO_SINGLE=1 [SDFX_CONV_HALO_TARGET=768])."""
+    import _sdfx as S
+    if not S.is_devtools():
+        pytest.skip("implementation switches exist only in libsdfx_hip_dev.so (SDFX_LIB)")
+    C = _conv_mod()
+    with torch.no_grad():
+        for N, Cin, H, W, Cout, up in ((2, 320, 64, 64, 320, False), (2, 1280, 16, 16, 1280, False), (2, 1280, 8, 8, 1280, False), (2, 192, 8, 8, 64, True)):
+            Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+            x, w, b, r = _inputs(dev, N, Cin, H, W, Cout, seed=Cin + W, residual_hw=(Ho, Wo))
+            base = C.conv3x3(x, w, b, r, 1, up, form="halo")
+            with S.dev_switch(SDFX_CONV_HALO_SINGLE=1):
+                one = C.conv3x3(x, w, b, r, 1, up, form="halo")
+            assert torch.equal(base, one), (N, Cin, H, W, Cout, up)
+            _check(one, _reference(x, w, b, r, 1, up))
+
+
 def test_conv3x3_falls_back_to_pytorch_off_the_kernel_path(dev):
     """Channel counts the kernel does not take (the UNet's first / last layer), float32, NCHW inputs and calls that want a gradient
     go through F.conv2d with the same result as calling it directly."""
