@@ -128,8 +128,8 @@ def test_conv3x3_packed_weights_follow_the_tensor_not_its_address(dev):
 def test_conv3x3_halo_single_buffer_variant_is_bit_identical(dev):
     """SDFX_CONV_HALO_SINGLE=1 (devtools library): the halo kernel with one halo buffer and two barriers per chunk — 42 KB of LDS, three
     workgroups per CU. A staging change only: the same sums in the same order as the product kernel, hence the same bits (unsplit and
-    split over chunks). Written at the end of round 4 after the counters showed the kernel's waves parked 58 % of their cycles; not
-    yet timed (tools/conv_bench.py under SDFX_LIB=..._dev.so SDFX_CONV_HALO_SINGLE=1 [SDFX_CONV_HALO_TARGET=768])."""
+    split over chunks). Written at the end of round 4 after the counters showed the kernel's waves parked 58 % of their cycles;
+    timed then and no faster (profiles/r04_conv_halo_single_buffer.txt): kept as a measurement variant."""
     import _sdfx as S
     if not S.is_devtools():
         pytest.skip("implementation switches exist only in libsdfx_hip_dev.so (SDFX_LIB)")
