@@ -542,6 +542,9 @@ class GpuJob:
         self.dmtet = args.stage == "dmtet"
         if self.dmtet:
             from sdfx_nerf.options import dmtet_preset
+            from sdfx_nerf.renderer import NeRFRenderer
+            import dmtet_caller                      # tests/dmtet_caller.py: the reference's run_dmtet + mesh regularisers (caller code the
+            dmtet_caller.install(NeRFRenderer)       # package does not ship; /root/reference is absent on the GPU box)
             dmtet_preset(self.opt)                   # main.py:253-260: 512 x 512, t_range [0.02, 0.50]
         self.model = NeRFNetwork(self.opt).to(dev)
         if self.dmtet:

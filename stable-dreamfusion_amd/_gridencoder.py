@@ -3,11 +3,11 @@ gridencoder/grid.py:10-13 tries `import _gridencoder as _backend` first)."""
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 
 import _sdfx as S
+import _devswitch
 
 _FLOATS = (torch.float32, torch.float16)
 
@@ -55,10 +55,10 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C_, L, max_l
 
 
 # ---- binned scatter (D = 3, C = 2): persistent scratch per device -----------------------------------
-_BINNED = int(os.environ.get("SDFX_GRID_BWD_BINNED", "1"))
+_BINNED = _devswitch.get("SDFX_GRID_BWD_BINNED", 1)
 # largest batch scattered in ONE pass of the three kernels (bigger batches are chunked): 2^23 points = one 7-point stencil batch
 # of 1.2 M samples. The scratch is sized for the batch actually seen (next step of a 1.5x ladder), not for this maximum.
-_BINNED_CHUNK_POINTS = int(os.environ.get("SDFX_GRID_BWD_CHUNK", str(1 << 23)))
+_BINNED_CHUNK_POINTS = _devswitch.get("SDFX_GRID_BWD_CHUNK", 1 << 23)
 _BINNED_SCRATCH = {}   # device index -> list of buffers, the last one is the current (largest) one
 _BINNED_BYTES = {}     # (level layout, ..., chunk points) -> scratch bytes
 

@@ -19,6 +19,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
+# superseded / measurement-only kernels that only the devtools library compiles in (field_dot2.inc.h, attention_pipe.inc.h): they
+# live outside the product source tree
+DEVTOOLS_KERNELS = os.path.normpath(os.path.join(HERE, "..", "tools", "devtools_kernels"))
 LIB = os.path.join(CSRC, "libsdfx_hip.so")
 DEV_LIB = os.path.join(CSRC, "libsdfx_hip_dev.so")
 SOURCES = ["sdfx_core.hip", "raymarching.hip", "gridencoder.hip", "gridencoder_fwd.hip", "gridencoder_bwd_binned.hip", "encoders.hip", "field.hip", "optim.hip", "shade.hip", "render.hip", "occupancy.hip", "infer.hip", "head.hip", "sds.hip", "dmtet.hip", "raster.hip", "groupnorm.hip", "conv.hip", "attention.hip"]
@@ -36,8 +39,10 @@ def hipcc() -> str:
     return exe
 
 
-def _deps_mtime() -> float:
+def _deps_mtime(devtools: bool = False) -> float:
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "sdfx.h")]
+    if devtools and os.path.isdir(DEVTOOLS_KERNELS):
+        hdrs += [os.path.join(DEVTOOLS_KERNELS, f) for f in os.listdir(DEVTOOLS_KERNELS) if f.endswith(".h")]
     return max(os.path.getmtime(h) for h in hdrs)
 
 
@@ -45,9 +50,9 @@ def _compile(src: str, force: bool, verbose: bool, devtools: bool = False) -> st
     path = os.path.join(CSRC, src)
     obj = os.path.join(CSRC, "build_dev" if devtools else "build", src.replace(".hip", ".o"))
     os.makedirs(os.path.dirname(obj), exist_ok=True)
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime()):
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime(devtools)):
         return obj
-    cmd = [hipcc()] + FLAGS + (["-DSDFX_DEVTOOLS"] if devtools else []) + ["-c", path, "-o", obj]
+    cmd = [hipcc()] + FLAGS + (["-DSDFX_DEVTOOLS", "-I", DEVTOOLS_KERNELS] if devtools else []) + ["-c", path, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

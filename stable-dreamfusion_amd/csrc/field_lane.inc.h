@@ -1,7 +1,8 @@
-// field_lane.inc.h — part of field.hip (included inside its anonymous namespace): the "lane owns a sample" matrix-core kernels
-// k_field_forward_mma / k_field_backward_mma and the LDS staging helpers of their weight-gradient contraction. They serve the
-// feature layout the native-layout kernels of field.hip do not take ([B, 32], the reference's own layout) and batches of
-// 2^25 rows and more.
+// field_lane.inc.h — PRODUCT code, part of field.hip (included inside its anonymous namespace): the "lane owns a sample" matrix-core
+// kernels k_field_forward_mma / k_field_backward_mma and the LDS staging helpers of their weight-gradient contraction. They are
+// what sdfx_field_forward / _backward launch for the feature layout the native-layout kernels of field.hip do not take — [B, 32],
+// the reference's own layout at the module boundary (enc_layout = 1) — and for batches of 2^25 rows and more; not a devtools
+// variant (those live in tools/devtools_kernels/).
 #pragma once
 
 // =========================================================================================

@@ -29,11 +29,14 @@
 // contribution AND every partial sum to half, gridencoder.cu:334-340) — and K1's hot path carries no overflow code.
 // Float tables fall back to float atomics, which is what the reference does for every contribution.
 #include "grid_point.h"
+#include "dev_stamps.h"
 
 using namespace sdfx;
 using namespace sdfx::grid;
 
 namespace {
+
+SDFX_DEV_CTL_DEFINE   // devtools build: per-workgroup timestamps, ablation bits (dev_stamps.h); nothing in the product build
 
 #ifndef SDFX_BUCKET_LOG2
 #define SDFX_BUCKET_LOG2 11   // measurement aid: -DSDFX_BUCKET_LOG2=12 builds the 4096-row variant (64 KiB of accumulators in K2)
@@ -299,7 +302,7 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
     uint32_t my_cnt = 0;
     if (threadIdx.x < nb) {
         my_cnt = hist[threadIdx.x];
-        gbase[threadIdx.x] = my_cnt ? atomicAdd(&cursors[bucket0 + threadIdx.x], my_cnt) : 0u;
+        gbase[threadIdx.x] = (my_cnt && !SDFX_ABLATE(4u)) ? atomicAdd(&cursors[bucket0 + threadIdx.x], my_cnt) : 0u;
     }
     {   // nb <= kMaxBucketsPerLevel = kBinThreads: thread b scans bucket b (wave scan + per-wave totals)
         const uint32_t incl = wave_incl_sum_u32(my_cnt, lane);
@@ -320,7 +323,7 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
     // (exact); float tables add with the reference's float atomics.
     const uint32_t cap = bin.cap[level];
     Item<HALF>* level_items = items + (size_t)bin.item_first[level] * 1024u;
-    if (emit) {
+    if (emit && !SDFX_ABLATE(2u)) {
 #pragma unroll
         for (uint32_t i = 0; i < NIT; i++) {
             if constexpr (HALF) {
@@ -338,7 +341,7 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
     }
     __syncthreads();
 
-    const uint32_t total = *block_total;
+    const uint32_t total = SDFX_ABLATE(3u) ? 0u : *block_total;
     for (uint32_t k = threadIdx.x; k < total; k += kBinThreads) {
         const Item<HALF> it = stage[k];
         const uint32_t bucket = it.bucket();
@@ -374,6 +377,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename 
     if (!plan_item(plan, blockIdx.x, level, tile)) return;   // wave-uniform (depends on blockIdx only)
     // a tile of padding rows (sdfx_set_row_limit) has nothing to scatter
     if (rows_dead(rl, b0 + tile * kBinThreads, kBinThreads)) return;
+    SDFX_STAMP_BEGIN
     const LevelConst lc = lv.lv[level];
     if ((bin.merge_mask >> level) & 1u)   // workgroup-uniform; all lanes take part in the DPP exchanges
         bin_tile<HALF, INTERP, ALIGN, HASHGRID, true>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors,
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename 
     else
         bin_tile<HALF, INTERP, ALIGN, HASHGRID, false>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors,
                                                        items, rl, src, hist, gbase, boff, wave_tot, &block_total, stage);
+    SDFX_STAMP_END(2u, level, tile)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -526,6 +531,7 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
     __shared__ unsigned long long acc[kBucketRows * 2];  // 32 KiB
     ReduceJob j;
     if (!reduce_job<true>(bin, cursors, j)) return;
+    SDFX_STAMP_BEGIN
     for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) acc[i] = 0ull;
     __syncthreads();
 
@@ -578,6 +584,7 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
             // |sum| < 2^63 * 2^-24; the double is exact up to 2^53, the float conversion rounds once
             flush_row<true>(grad_table + ((size_t)row0 + row) * 2, fixed_to_float(ia), fixed_to_float(ib));
         }
+        SDFX_STAMP_END(3u, j.level, j.bucket)
         return;
     }
     // Several workgroups share this bucket (a level of few buckets): they add their exact partial sums into a 64-bit
@@ -590,6 +597,7 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
         if (spill) v += spill[i];
         if (v) atomicAdd(&gacc[i], v);
     }
+    SDFX_STAMP_END(3u, j.level, j.bucket | (j.split << 16))
 }
 
 // K3: one workgroup per bucket of the levels of few buckets; buckets that were reduced by a single workgroup are done already
@@ -937,6 +945,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
             chunk = ((chunk / 2 + gran - 1) / gran) * gran;
         }
     }
+    dev_ctl_sync();
     char* const base = static_cast<char*>(scratch);
     uint32_t* cursors = static_cast<uint32_t*>(scratch);
     unsigned long long* shared_acc = reinterpret_cast<unsigned long long*>(base + kSharedAccOffset);

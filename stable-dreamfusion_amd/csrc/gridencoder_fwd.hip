@@ -28,6 +28,7 @@
 //     round-after-every-operation, see Acc2), and all gathers of a lane issued before the first result is touched
 //     (more points per thread were measured slower: 2 -> -2 %, 4 -> -10 %).
 #include "grid_point.h"
+#include "dev_stamps.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -38,6 +39,8 @@ using namespace sdfx;
 using namespace sdfx::grid;
 
 namespace {
+
+SDFX_DEV_CTL_DEFINE   // devtools build: per-workgroup timestamps (dev_stamps.h); nothing in the product build
 
 constexpr uint32_t kMaxSegs = 6;       // per XCD
 constexpr uint32_t kGroup = 7;         // points per stencil
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
     constexpr uint32_t P_TILE = P * kTile;
     uint32_t level, tile0, seg_end;
     if (!fwd_item(plan, level, tile0, seg_end)) return;
+    SDFX_STAMP_BEGIN
     // padding rows of a fixed-capacity batch (sdfx_set_row_limit): samples >= row_total[0] are neither read nor written, and a
     // tile of nothing else ends here. (Stencil batches: the sample is the row within the slab; otherwise the row itself.)
     const uint32_t n_rows = plan.slabs == kGroup ? plan.slab_points : B;
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
         }
     }
     }   // tiles of this workgroup
+    SDFX_STAMP_END(1u, level, tile0)
 }
 
 // ---- host: the plan -------------------------------------------------------------------------------------------------
@@ -398,6 +403,7 @@ void launch(const float* inputs, const void* table, void* outputs, uint32_t B, u
     const uint32_t axis = plan.slabs == kGroup ? plan.slab_points : B;
     const int32_t* row_total = (rl.total && (rl.period == axis || (rl.period == 0 && plan.slabs != kGroup))) ? rl.total : nullptr;
     const StencilSrc src = stencil_src();   // validated by the caller: src.M * 7 == B when set
+    dev_ctl_sync();
 #define SDFX_FWD(INTERP_, ALIGN_, HASH_)                                                                               \
     do {                                                                                                               \
         if (plan.lds_mask)                                                                                             \

@@ -1,5 +1,6 @@
 // sdfx_core.hip — error reporting and build info for libsdfx_hip.so.
 #include "sdfx_common.h"
+#include "dev_stamps.h"
 
 #include <stdarg.h>
 #include <stdlib.h>
@@ -49,6 +50,21 @@ int dev_switch(const char* name, int dflt) {
     return v == INT32_MIN ? dflt : v;
 }
 const char* dev_string(const char* name) { return getenv(name); }
+// per-workgroup timestamps and ablation bits of the instrumented kernels (dev_stamps.h)
+namespace {
+unsigned long long* g_stamp_buf = nullptr;
+uint32_t g_stamp_cap = 0;
+}
+DevCtl dev_ctl_host() {
+    DevCtl c;
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        c.stamps = g_stamp_buf;
+        c.cap = g_stamp_cap;
+    }
+    c.ablate = (uint32_t)dev_switch("SDFX_DEV_ABLATE", 0);
+    return c;
+}
 #endif
 
 // ---- XCD probe ------------------------------------------------------------------------------
@@ -94,6 +110,12 @@ void sdfx_dev_set(const char* name, int value) {
     if (!name) return;
     std::lock_guard<std::mutex> lock(sdfx::g_dev_mutex);
     sdfx::g_dev_values[name] = value;
+}
+// `buf`: device memory of (2 + 4 * cap) 64-bit words, zeroed by the caller; nullptr switches the stamps off
+void sdfx_dev_stamps(void* buf, uint32_t cap) {
+    std::lock_guard<std::mutex> lock(sdfx::g_dev_mutex);
+    sdfx::g_stamp_buf = static_cast<unsigned long long*>(buf);
+    sdfx::g_stamp_cap = buf ? cap : 0u;
 }
 void sdfx_dev_unset(const char* name) {   // back to the environment / the default
     if (!name) return;

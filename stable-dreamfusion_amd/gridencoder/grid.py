@@ -6,7 +6,6 @@ grad_total_variation, grad_weight_decay, buffer and parameter names) over libsdf
 from __future__ import annotations
 
 import math
-import os
 
 import numpy as np
 import torch
@@ -15,13 +14,14 @@ from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
 import _gridencoder as _backend
+import _devswitch
 
 _gridtype_to_id = {"hash": 0, "tiled": 1}
 _interp_to_id = {"linear": 0, "smoothstep": 1}
 
 # 0: kernels read/write the reference's level-major [L, B, C] layout and torch permutes;
 # 1: the permute is folded into the kernels' own loads/stores ([B, L*C] directly).
-_FUSED_LAYOUT = int(os.environ.get("SDFX_GRID_FUSED_LAYOUT", "0"))
+_FUSED_LAYOUT = _devswitch.get("SDFX_GRID_FUSED_LAYOUT", 0)
 
 
 class _grid_encode(Function):

@@ -7,12 +7,12 @@ step runs under `no_grad`); every other call goes through PyTorch's op. SDFX_ATT
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 import torch.nn.functional as F
+import _devswitch
 
-_FUSED = int(os.environ.get("SDFX_ATTENTION", "1"))
+_FUSED = _devswitch.get("SDFX_ATTENTION", 1)
 _U3 = C.c_uint32 * 3
 
 
@@ -34,7 +34,7 @@ def attention_ok(q, k, v) -> bool:
     return True
 
 
-_AUTO_MAX_D = int(os.environ.get("SDFX_ATTENTION_MAX_D", "80"))   # wider heads: only when asked for (see attention_bnc)
+_AUTO_MAX_D = _devswitch.get("SDFX_ATTENTION_MAX_D", 80)   # wider heads: only when asked for (see attention_bnc)
 
 
 def attention_bnc(q, k, v, waves=0, force=False):

@@ -7,13 +7,13 @@ under `no_grad`); every other call goes through PyTorch's ops, so the function i
 PyTorch ops everywhere (A/B switch)."""
 from __future__ import annotations
 
-import os
 import weakref
 
 import torch
 import torch.nn.functional as F
+import _devswitch
 
-_FUSED = int(os.environ.get("SDFX_CONV", "1"))
+_FUSED = _devswitch.get("SDFX_CONV", 1)
 _SCRATCH = {}   # device index -> float32 scratch for split-K partials, grown on demand (every call rewrites what it reads)
 
 

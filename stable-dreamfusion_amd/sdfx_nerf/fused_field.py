@@ -14,14 +14,14 @@ import torch
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
-import os
 
 import _field
 import _gridencoder
 import _sdfx
+import _devswitch
 
 # the [7, M, 3] finite-difference stencil batch formed inside the kernels (sdfx_set_stencil_source) instead of by k_stencil_points
-_STENCIL_SOURCE = int(os.environ.get("SDFX_STENCIL_SOURCE", "1"))
+_STENCIL_SOURCE = _devswitch.get("SDFX_STENCIL_SOURCE", 1)
 
 
 class _fused_field(Function):

@@ -8,13 +8,12 @@ PyTorch's own ops, so the module is a drop-in `nn.GroupNorm` (same parameters, s
 SDFX_GROUPNORM=0 forces the PyTorch ops everywhere (A/B switch)."""
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+import _devswitch
 
-_FUSED = int(os.environ.get("SDFX_GROUPNORM", "1"))
+_FUSED = _devswitch.get("SDFX_GROUPNORM", 1)
 _SCRATCH = {}   # device index -> float32 scratch, grown on demand (partials of ONE call; every call rewrites what it reads)
 
 

@@ -17,11 +17,11 @@ The frozen 2D prior itself (UNet / VAE / text encoder) is third-party code the r
 from __future__ import annotations
 
 import hashlib
-import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+import _devswitch
 
 
 def ddim_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
@@ -176,11 +176,11 @@ class SDSGuidance(nn.Module):
         return 0.5 * F.mse_loss(latents.float(), targets, reduction="sum") / latents.shape[0]
 
 
-_FUSED_SDS = int(os.environ.get("SDFX_FUSED_SDS", "1"))
-_VAE_AUTOCAST = int(os.environ.get("SDFX_VAE_AUTOCAST", "0"))
+_FUSED_SDS = _devswitch.get("SDFX_FUSED_SDS", 1)
+_VAE_AUTOCAST = _devswitch.get("SDFX_VAE_AUTOCAST", 0)
 # channels-last VAE: slower with stock GroupNorm (every norm converts to NCHW and back: 29.3 -> 25.8 it/s in the RGB phase),
 # the faster layout once the norms are csrc/groupnorm.hip's NHWC kernels — so it follows that switch unless set explicitly
-_VAE_CL = int(os.environ.get("SDFX_VAE_CL", os.environ.get("SDFX_GROUPNORM", "1")))
+_VAE_CL = _devswitch.get("SDFX_VAE_CL", _devswitch.get("SDFX_GROUPNORM", 1))
 
 
 class _UpsampleToVAE(torch.autograd.Function):

@@ -2,8 +2,6 @@
 density blob, finite-difference normals, Lambertian shading, frequency-encoded background MLP."""
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -16,26 +14,27 @@ from gridencoder import GridEncoder
 from . import fused_field as _ff
 from . import fused_shade as _fs
 from .renderer import NeRFRenderer, safe_normalize
+import _devswitch
 
 # fused encode -> MLP -> activation kernels for the fp16-autocast path (SDFX_FUSED_FIELD=0 keeps the
 # reference's module-by-module evaluation: GridEncoder -> nn.Linear stack -> torch activations)
-_FUSED = int(os.environ.get("SDFX_FUSED_FIELD", "1"))
+_FUSED = _devswitch.get("SDFX_FUSED_FIELD", 1)
 # evaluate the sample and its six finite-difference neighbours in ONE field call (the field is point-wise, so the
 # values are those of the reference's seven separate common_forward calls, network_grid.py:81-96, 108-115)
-_BATCH_STENCIL = int(os.environ.get("SDFX_BATCH_STENCIL", "1"))
-_ROW_LIMIT = int(os.environ.get("SDFX_ROW_LIMIT", "1"))   # skip the padding rows of fixed-capacity buffers in the field kernels
-_STENCIL_KERNEL = int(os.environ.get("SDFX_STENCIL_KERNEL", "1"))   # the [7, M, 3] stencil batch from one kernel (csrc/field.hip)
+_BATCH_STENCIL = _devswitch.get("SDFX_BATCH_STENCIL", 1)
+_ROW_LIMIT = _devswitch.get("SDFX_ROW_LIMIT", 1)   # skip the padding rows of fixed-capacity buffers in the field kernels
+_STENCIL_KERNEL = _devswitch.get("SDFX_STENCIL_KERNEL", 1)   # the [7, M, 3] stencil batch from one kernel (csrc/field.hip)
 # normal / shading / orientation glue between the field and the compositor in one HIP kernel each way
-_FUSED_SHADE = int(os.environ.get("SDFX_FUSED_SHADE", "1"))
+_FUSED_SHADE = _devswitch.get("SDFX_FUSED_SHADE", 1)
 # ... and the compositor and the entropy / orientation sums in the same kernel (csrc/render.hip)
-_FUSED_RENDER = int(os.environ.get("SDFX_FUSED_RENDER", "1"))
+_FUSED_RENDER = _devswitch.get("SDFX_FUSED_RENDER", 1)
 # test-time frames: march + field + compositing + compaction of nerf/renderer.py:759-794 in one persistent kernel (csrc/infer.hip)
-_FUSED_INFER = int(os.environ.get("SDFX_FUSED_INFER", "1"))
+_FUSED_INFER = _devswitch.get("SDFX_FUSED_INFER", 1)
 # The background MLP (4096 rays x 1.4 k MACs) is evaluated in float32 even under autocast: its gradient is the image
 # gradient times the loss scale, un-attenuated by compositing weights, and is what overflows fp16 first — in half it
 # caps the loss scale ~64x lower (field gradients underflow) and costs a GradScaler skip every ~12 iterations.
 # SDFX_BG_FP32=0 restores the reference's autocast behaviour (nn.Linear in half, nerf/network_grid.py:132-139).
-_BG_FP32 = int(os.environ.get("SDFX_BG_FP32", "1"))
+_BG_FP32 = _devswitch.get("SDFX_BG_FP32", 1)
 
 
 class _trunc_exp(Function):

@@ -16,7 +16,6 @@ prediction, damped, to the consistent stand-in of `guidance.SyntheticUNet`; see 
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -26,9 +25,10 @@ from . import guidance as G
 from .attention import attention_bnc
 from .conv import conv3x3, conv_ok, linear_auto
 from .groupnorm import GroupNormAct, add_bias_residual, fused_ok, geglu
+import _devswitch
 
 
-_BLOCK_FUSION = int(os.environ.get("SDFX_BLOCK_FUSION", "1"))   # A/B switch of ResBlock._forward_fused / the transformer's fused tail
+_BLOCK_FUSION = _devswitch.get("SDFX_BLOCK_FUSION", 1)   # A/B switch of ResBlock._forward_fused / the transformer's fused tail
 
 
 def _gn(c, act=False):
@@ -83,8 +83,8 @@ class ResBlock(nn.Module):
         return add_bias_residual(skip, F.conv2d(hn, self.conv2.weight, None, 1, 1), self.conv2.bias)
 
 
-_WIDE_HEAD_MATMUL = int(os.environ.get("SDFX_WIDE_HEAD_MATMUL", "1"))   # A/B switch, see Attention.forward
-_QKV_FUSION = int(os.environ.get("SDFX_QKV_FUSION", "1"))               # A/B switch: stacked projection weights, one GEMM
+_WIDE_HEAD_MATMUL = _devswitch.get("SDFX_WIDE_HEAD_MATMUL", 1)   # A/B switch, see Attention.forward
+_QKV_FUSION = _devswitch.get("SDFX_QKV_FUSION", 1)               # A/B switch: stacked projection weights, one GEMM
 
 
 class Attention(nn.Module):

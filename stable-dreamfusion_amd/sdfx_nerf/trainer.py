@@ -23,7 +23,6 @@ Three ways of driving the same arithmetic (`mode`, default from SDFX_TRAIN_MODE,
 from __future__ import annotations
 
 import collections
-import os
 import random
 import time
 import warnings
@@ -36,14 +35,15 @@ from .fused_shade import MODES as _SHADE_MODES
 from .fused_shade import image_head, weights_entropy_sum
 from .guidance import fused_text_mix_available, text_mix
 from .optim import Adan, DeviceAdan
+import _devswitch
 
-_FUSED_ENTROPY = int(os.environ.get("SDFX_FUSED_ENTROPY", "1"))
+_FUSED_ENTROPY = _devswitch.get("SDFX_FUSED_ENTROPY", 1)
 # background network + background mix + [1, C, H, W] layout + the three regulariser terms in one kernel each way (csrc/head.hip)
-_COUNT_WAIT = os.environ.get("SDFX_COUNT_WAIT", "event")   # how the host waits for the sample total: event | query | poll
-_FUSED_STAGE = int(os.environ.get("SDFX_FUSED_STAGE", "1"))
-_FUSED_HEAD = int(os.environ.get("SDFX_FUSED_HEAD", "1"))
-_PREFETCH = int(os.environ.get("SDFX_PREFETCH", "1"))      # counting pass of the next iteration on a second stream
-_STEP_SYNC = int(os.environ.get("SDFX_STEP_SYNC", "0"))    # debugging aid: device-wide synchronisation after every step
+_COUNT_WAIT = _devswitch.get("SDFX_COUNT_WAIT", "event")   # how the host waits for the sample total: event | query | poll
+_FUSED_STAGE = _devswitch.get("SDFX_FUSED_STAGE", 1)
+_FUSED_HEAD = _devswitch.get("SDFX_FUSED_HEAD", 1)
+_PREFETCH = _devswitch.get("SDFX_PREFETCH", 1)      # counting pass of the next iteration on a second stream
+_STEP_SYNC = _devswitch.get("SDFX_STEP_SYNC", 0)    # debugging aid: device-wide synchronisation after every step
 
 # layout of the per-iteration scalar block
 _SC_AMBIENT, _SC_BG, _SC_WF, _SC_WS, _SC_WB, _SC_ENTROPY, _SC_MODE, _SC_WORDS = 0, 1, 4, 5, 6, 7, 8, 12
@@ -52,7 +52,7 @@ _SC_AMBIENT, _SC_BG, _SC_WF, _SC_WS, _SC_WB, _SC_ENTROPY, _SC_MODE, _SC_WORDS = 
 class TrainStep:
     def __init__(self, opt, model, guidance, device, seed=0, mode=None):
         self.opt, self.model, self.guidance, self.device = opt, model, guidance, device
-        self.mode = mode or os.environ.get("SDFX_TRAIN_MODE", "graph")
+        self.mode = mode or _devswitch.get("SDFX_TRAIN_MODE", "graph")
         assert self.mode in ("reference", "device", "graph")
         self.global_step = 0
         self.rng = random.Random(seed)
@@ -99,10 +99,10 @@ class TrainStep:
         self.n_valid = torch.ones((), dtype=torch.float32, device=device)
         self._num_samples = 0
         self.hw = (opt.h, opt.w)
-        self.graph_bucket = int(os.environ.get("SDFX_GRAPH_BUCKET", "32768"))
-        self.graph_ratio = float(os.environ.get("SDFX_GRAPH_RATIO", "1.1"))   # capacity ladder: <= 10 % padding
+        self.graph_bucket = _devswitch.get("SDFX_GRAPH_BUCKET", 32768)
+        self.graph_ratio = _devswitch.get("SDFX_GRAPH_RATIO", 1.1)   # capacity ladder: <= 10 % padding
         self.graph_prime_span = 1.5      # on a miss, capture every ladder step within this factor of the need
-        self.max_graphs = int(os.environ.get("SDFX_MAX_GRAPHS", "64"))
+        self.max_graphs = _devswitch.get("SDFX_MAX_GRAPHS", 64)
         self._warm = set()               # kinds that have run eagerly once
         self._priming = set()            # keys captured by the _prime call in progress
         self.graphs = {}                 # (capacity, shading class, as_latent, bg_kind, H, W, lr signature) -> captured stages

@@ -176,7 +176,7 @@ def test_product_library_has_no_switches_and_the_devtools_library_declares_its_o
     assert "set_impl" not in header and "sdfx_dev_" not in header
     dev_header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sdfx_devtools.h")).read(), flags=re.S)
     dev_syms = sorted(set(re.findall(r"\b(sdfx_[a-zA-Z0-9_]+)\s*\(", dev_header)))
-    assert dev_syms == ["sdfx_dev_set", "sdfx_dev_unset"]
+    assert dev_syms == ["sdfx_dev_set", "sdfx_dev_stamps", "sdfx_dev_unset"]
     nm = lambda path: subprocess.run(["nm", "-D", path], capture_output=True, text=True, check=True).stdout
     prod, dev = nm(product), nm(_sdfx.DEV_LIB_PATH)
     assert " U getenv" not in prod, "the product library must not read the environment"

@@ -65,6 +65,35 @@ def test_grid_other_dims_fp32(oracle, dev, D, C):
     assert np.allclose(N_(gi), gi_ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("D,C", [(2, 4), (3, 8), (4, 2)])
+def test_grid_other_dims_fp16(oracle, dev, D, C):
+    """Half tables for D / C other than the hot path's (3, 2): the reference dispatches `at::Half` for every even C
+    (gridencoder.cu:403-411). Forward features (fp16 accumulation in the reference's corner order) bit for bit against the oracle;
+    the table gradient — packed-half atomics, whose sums depend on the order of arrival — against the float32-accumulated truth
+    within the half-accumulating oracle's own distance from it."""
+    import _gridencoder as B
+    offsets, pls = oracle.grid_offsets(input_dim=D, num_levels=6, level_dim=C, log2_hashmap_size=14, desired_resolution=256)
+    table = synth.s_table(int(offsets[-1]), C, "trained")
+    th = table.astype(np.float16)
+    n = 3001
+    x = synth.s_points_uniform(n, D, seed=40 + D)
+    out_ref, lbc_ref, _ = oracle.grid_encode_forward(x, th, offsets, pls, 16, False, 0, False, 0)
+    assert lbc_ref.dtype == np.float16
+    out = torch.empty(6, n, C, device=dev, dtype=torch.float16)
+    B.grid_encode_forward(T(x, dev), T(th, dev), T(offsets, dev), out, n, D, C, 6, 6, np.log2(pls), 16, None, 0, False, 0)
+    assert np.array_equal(N_(out).view(np.uint16), lbc_ref.view(np.uint16))
+    gr = (np.random.default_rng(2).normal(size=(n, 6 * C)) * 0.01).astype(np.float16)
+    _, gt_half = oracle.grid_encode_backward(gr, x, th, offsets, pls, 16, None, 0, False, 0)
+    _, gt32 = oracle.grid_encode_backward(gr.astype(np.float32), x, th.astype(np.float32), offsets, pls, 16, None, 0, False, 0)
+    gt = torch.zeros_like(T(th, dev))
+    B.grid_encode_backward(T(gr, dev), T(x, dev), T(th, dev), T(offsets, dev), gt, n, D, C, 6, 6, np.log2(pls), 16, None, None, 0,
+                           False, 0, 1)
+    g, scale = N_(gt).astype(np.float32), np.abs(gt32).max()
+    assert np.array_equal(g != 0, gt32 != 0) or np.abs(g - gt32)[(g != 0) != (gt32 != 0)].max() < 1e-3 * scale
+    assert np.abs(g - gt32).max() < 2e-2 * scale
+    assert np.abs(g - gt32).mean() < 3.0 * np.abs(gt_half.astype(np.float32) - gt32).mean() + 1e-5 * scale
+
+
 def test_grid_max_level_and_errors(oracle, dev):
     from gridencoder import GridEncoder
     import _gridencoder as B

@@ -1,4 +1,4 @@
-// attention_pipe.inc.h — DEVTOOLS ONLY (libsdfx_hip_dev.so, SDFX_ATTN_PIPE): two measurement variants of k_attn_fwd.
+// attention_pipe.inc.h (tools/devtools_kernels/) — DEVTOOLS ONLY (libsdfx_hip_dev.so, SDFX_ATTN_PIPE): two measurement variants of k_attn_fwd.
 //   SDFX_ATTN_PIPE=1   the NEXT tile's scores are issued to the matrix cores before the current tile's softmax, so that the 6 S^T MFMAs
 //                      run under the ~950 VALU cycles of the exponentials instead of in front of them (K staged one tile further
 //                      ahead: three K buffers)

@@ -1,4 +1,4 @@
-// field_dot2.inc.h — part of field.hip, DEVTOOLS BUILD ONLY (-DSDFX_DEVTOOLS; included inside its anonymous namespace after
+// field_dot2.inc.h (tools/devtools_kernels/) — part of field.hip in the DEVTOOLS BUILD ONLY (-DSDFX_DEVTOOLS; included inside its anonymous namespace after
 // field_lane.inc.h): the round-1 per-thread v_dot2 kernels. The product library does not contain them. They are the arithmetic
 // csrc/infer.hip inlines, so the devtools library keeps them selectable (SDFX_FIELD_IMPL=1) for the exact A/B of
 // tests/test_gpu_07_infer.py and for tools/field_bench.py.
