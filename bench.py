@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--no-kernel-bench", action="store_true")
     ap.add_argument("--no-nerf-only", action="store_true", help="skip the secondary timed passes (without the frozen UNet; with the "
                                                                 "synthetic prior = this repository's kernels only)")
+    ap.add_argument("--no-stock-prior", action="store_true", help="skip the pass with the frozen prior on stock PyTorch-ROCm ops")
+    ap.add_argument("--no-children", action="store_true", help="skip the child runs of BASELINE configs[3] (--prior if) and configs[4] "
+                                                               "(--stage dmtet) that the default N = 1 line carries")
     ap.add_argument("--phase", default="mix", choices=["mix", "latent", "rgb"],
                     help="mix (default): 20 %% of the timed steps in the latent phase, 80 %% in the RGB phase, as in a default run; "
                          "latent / rgb: that phase only")
@@ -177,6 +180,87 @@ def event_time_ms(fn, iters=20, warmup=3):
     e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
+
+
+def graph_time_us(fn, launches=50, replays=5):
+    """GPU-clock time of one launch of `fn` inside a REPLAYED HIP graph (`launches` back-to-back copies, event-timed over `replays`
+    replays): what the kernel costs in the captured training iteration — its duration plus one kernel boundary (~1.5 us), without the
+    host's launch gap that HIP events around eager launches include."""
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            fn()
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for _ in range(launches):
+                fn()
+        g.replay()
+        stream.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(stream)
+        for _ in range(replays):
+            g.replay()
+        e.record(stream)
+        stream.synchronize()
+    return s.elapsed_time(e) / (launches * replays) * 1e3
+
+
+def render_fixed_marginal(dev):
+    """The fused shading + compositing kernels (csrc/render.hip) at 4096 rays against the SAMPLE COUNT, on the GPU clock (graph
+    replay): the rays of one view through the fully occupied grid with every ray cut to a fraction f of its samples (thin medium, no
+    early termination). Least squares t = fixed + marginal * samples: the fixed part — one workgroup per ray, the dependent loads
+    rays[n] -> first chunk, the cross-wave product exchange, the ray reduction, and the kernel boundary — is what keeps the
+    kernel from its byte roofline at 4096 rays; the marginal rate is the streaming rate."""
+    import _render
+    import raymarching
+    import synth
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    o, d = synth.s_rays(0)
+    od, dd = to(o), to(d)
+    nears, fars = raymarching.near_far_from_aabb(od, dd, to(np.array([-1, -1, -1, 1, 1, 1], np.float32)))
+    _, dirs, ts, rays = raymarching.march_rays_train(od, dd, 1.0, to(synth.s_grid_full()), 1, 128, nears, fars, True, 0, 1024, False,
+                                                     to(synth.s_noises(4096)))
+    rays_h, dirs_h, ts_h = rays.cpu().numpy(), dirs.cpu().numpy(), ts.cpu().numpy()
+    N, f32 = 4096, dict(dtype=torch.float32, device=dev)
+    g = torch.Generator().manual_seed(1)
+    rows = []
+    for frac in (0.1, 0.25, 0.5, 1.0):
+        cnt = np.ceil(rays_h[:, 1] * frac).astype(np.int32)
+        keep = np.concatenate([np.arange(o_, o_ + c_) for o_, c_ in zip(rays_h[:, 0], cnt)])
+        M = int(cnt.sum())
+        rays_f = to(np.stack([np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32), cnt], 1))
+        dirs_f, ts_f = to(dirs_h[keep]), to(ts_h[keep])
+        s7 = (torch.rand(7, M, generator=g) * 0.6).to(dev).view(-1)
+        alb = torch.rand(M, 3, generator=g).to(dev)
+        light, ratio = torch.randn(3, generator=g).to(dev), torch.tensor(0.3, device=dev)
+        total = torch.tensor([M], dtype=torch.int32, device=dev)
+        w, ws, dep, img, sums = torch.empty(M, **f32), torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, 3, **f32), torch.empty(N, 2, **f32)
+        gws, gimg, gsum = torch.randn(N, **f32), torch.randn(N, 3, **f32), torch.randn(N, 2, **f32) * 0.01
+        ds7, dalb = torch.empty(7 * M, **f32), torch.empty(M, 3, **f32)
+        fwd = lambda: _render.train_forward(s7, alb, dirs_f, ts_f, rays_f, od, light, ratio, None, 1, 1e-2, 1e-4, total, w, ws, dep, img, sums)
+        bwd = lambda: _render.train_backward(s7, alb, dirs_f, ts_f, rays_f, od, light, ratio, None, 1, 1e-2, 1e-4, total, ws, dep, img,
+                                             gws, None, gimg, gsum, ds7, dalb)
+        fwd()
+        rows.append((M, graph_time_us(fwd), graph_time_us(bwd)))
+    Ms = np.array([r[0] for r in rows], np.float64) / 1e6
+    A = np.stack([np.ones_like(Ms), Ms], 1)
+    out = {"rays": N, "samples": [r[0] for r in rows], "clock": "GPU (replayed HIP graph of 50 launches; includes one kernel boundary)"}
+    for tag, col, per_sample, per_ray, survey in (("forward", 1, RENDER_FWD_BYTES[0], RENDER_FWD_BYTES[1], COMPOSITE_FWD_BYTES),
+                                                  ("backward", 2, RENDER_BWD_BYTES[0], RENDER_BWD_BYTES[1], COMPOSITE_BWD_BYTES)):
+        t = np.array([r[col] for r in rows], np.float64)
+        (fixed, marg), *_ = np.linalg.lstsq(A, t, rcond=None)
+        # sample count at which the kernel would reach 40 % of the HBM peak by each byte count (inf: the fixed part alone forbids it)
+        def need(bytes_per_sample, bytes_per_ray):
+            # (M b + N r) / (fixed + marg M) = 0.4 peak  ->  M = (0.4 peak fixed - N r) / (b - 0.4 peak marg)
+            rate = 0.4 * HBM_PEAK_GBPS * 1e3          # bytes per us
+            den = bytes_per_sample - rate * marg / 1e6
+            return float((rate * fixed - N * bytes_per_ray) / den) if den > 0 else float("inf")
+        out[tag] = {"us": [round(float(x), 2) for x in t], "fixed_us": round(float(fixed), 2), "us_per_million_samples": round(float(marg), 2),
+                    "marginal_GBps_fused_bytes": round(per_sample / marg * 1e3, 1) if marg > 0 else None,
+                    "samples_for_0.40_of_peak_by_fused_bytes": need(per_sample, per_ray),
+                    "samples_for_0.40_of_peak_by_survey_bytes": need(survey[0], survey[1])}
+    return out
 
 
 def kernel_microbench(dev):
@@ -674,6 +758,72 @@ class GpuJob:
                 break
 
 
+class stock_prior_ops:
+    """`with stock_prior_ops(prior): ...` — the frozen prior on stock PyTorch-ROCm ops: this repository's kernels for its 3 x 3
+    convolutions / small GEMMs, attention and GroupNorm switched off (what `SDFX_DEV=1 SDFX_CONV=0 SDFX_ATTENTION=0 SDFX_GROUPNORM=0`
+    selects at import), the VAE back in NCHW (channels-last only pays with the NHWC GroupNorm kernels: sdfx_nerf/guidance.py)."""
+
+    def __init__(self, prior):
+        self.prior = prior
+
+    def __enter__(self):
+        from sdfx_nerf import attention, conv, groupnorm
+        self.mods = (conv, attention, groupnorm)
+        self.saved = [m._FUSED for m in self.mods]
+        for m in self.mods:
+            m._FUSED = 0
+        vae = getattr(self.prior, "vae", None)
+        self.vae_cl = bool(getattr(vae, "channels_last_input", False))
+        if self.vae_cl:
+            vae.to(memory_format=torch.contiguous_format)
+            vae.channels_last_input = False
+        return self
+
+    def __exit__(self, *exc):
+        for m, v in zip(self.mods, self.saved):
+            m._FUSED = v
+        if self.vae_cl:
+            self.prior.vae.to(memory_format=torch.channels_last)
+            self.prior.vae.channels_last_input = True
+        return False
+
+
+def stock_prior_pass(job, step, plan, timed_pass):
+    """iters/s of the same timed region with the frozen prior on stock PyTorch-ROCm ops (north_star: "the SD UNet forward for the
+    SDS gradient runs on PyTorch-ROCm"); the graphs captured with this repository's prior kernels are dropped before and after."""
+    def drop_graphs():
+        step.graphs.clear(); step.graph_uses.clear(); step._warm.clear()
+    try:
+        with stock_prior_ops(job.prior):
+            drop_graphs()
+            for name, _ in plan:
+                job.prime(name)
+            return timed_pass()
+    finally:
+        drop_graphs()
+
+
+def child_bench(extra, steps, timeout_s=420):
+    """One more configuration of BASELINE.json as a CHILD run of this file (its own process: own model, prior and graphs): returns
+    (the child's JSON line as a dict | None, seconds, error text)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "4", "--no-cpu-baseline",
+           "--no-kernel-bench", "--no-nerf-only", "--no-reference-flow", "--no-children"] + list(extra)
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s,
+                             env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    except subprocess.TimeoutExpired:
+        return None, time.perf_counter() - t0, f"timed out after {timeout_s} s"
+    line = next((l for l in reversed(out.stdout.decode("utf-8", "replace").splitlines()) if l.startswith("{")), None)
+    if line is None:
+        return None, time.perf_counter() - t0, "no JSON line; stderr tail: " + out.stderr.decode("utf-8", "replace")[-300:]
+    try:
+        return json.loads(line), time.perf_counter() - t0, None
+    except ValueError as exc:
+        return None, time.perf_counter() - t0, f"bad JSON: {exc}"
+
+
 def main():
     args = parse()
     if args.cpu_probe:
@@ -834,15 +984,16 @@ def main():
         if dist is not None:
             dist.barrier()
         t1 = time.perf_counter()
-        j = args.warmup
+        j, n_samples = args.warmup, 0
         for name, k in plan:
             job.set_phase(name)
             for _ in range(k):
-                job.step(j)
+                n_samples += job.step(j)
                 j += 1
         job.sync()
         if dist is not None:
             dist.barrier()
+        timed_pass.samples_per_iter = n_samples / max(args.steps, 1)
         return job_throughput(world, args.steps, job_elapsed(time.perf_counter() - t1, dist, dev))
 
     # second figure, same run: the iteration without the frozen prior's UNet (the RGB phase still runs the SD-1.5 VAE encoder)
@@ -856,6 +1007,12 @@ def main():
         without_unet = timed_pass()
         job.prior.unet.skip_unet = False
         step.graphs.clear(); step.graph_uses.clear(); step._warm.clear()
+    # the north_star configuration of the headline: the frozen UNet / VAE on STOCK PyTorch-ROCm ops (MIOpen convolutions, PyTorch's
+    # GroupNorm and scaled_dot_product_attention; none of csrc/conv.hip, attention.hip, groupnorm.hip) — same scene, same mix
+    stock_prior = None
+    if job.guidance_kind == "sd15_random" and not args.no_nerf_only and not args.no_stock_prior:
+        stock_prior = stock_prior_pass(job, step, plan, timed_pass)
+        stage("stock-prior pass done")
     # third figure: the reference's host flow (torch.amp.GradScaler + foreach Adan, no device-side tail, no graph replay,
     # nerf/utils.py:1032-1072) on the same kernels — what an unchanged main.py gets from the drop-in operators
     ref_flow = None
@@ -878,19 +1035,25 @@ def main():
             for name, _ in plan:
                 job.prime(name)
             nerf_only = timed_pass()
-            nerf_only_samples = job.step_obj.last.get("num_samples")
+            nerf_only_samples = timed_pass.samples_per_iter
             job.step_obj, job.prior, job.guidance_kind = graph_step, big_prior, big_kind
         else:
             nerf_only = job_throughput(world, args.steps, elapsed)      # the headline run already used the stand-in
+            nerf_only_samples = samples / max(args.steps, 1)
         nerf_only_ms = 1e3 * world / nerf_only
     stage("secondary passes done")
     result["iters_per_sec_without_unet"] = without_unet
+    # the configuration north_star defines (frozen prior on stock PyTorch-ROCm ops) beside `value` (prior on this repository's
+    # conv / attention / GroupNorm kernels, which are outside SURVEY section 8 and claim no row of it)
+    result["iters_per_sec_stock_prior"] = stock_prior
     result["iters_per_sec_reference_flow"] = ref_flow
     result["iters_per_sec_nerf_only"] = nerf_only
     result["ms_nerf_only"] = nerf_only_ms
+    # comparable across rounds and scenes: the iteration's cost is proportional to the samples the march emits
+    result["ms_nerf_only_per_million_samples"] = (nerf_only_ms / (nerf_only_samples / 1e6)) if (nerf_only_ms and nerf_only_samples) else None
     # the scene this pass runs on is the one the headline pass trained (denser than a fresh scene: the iteration's cost is
     # proportional to the samples the march emits), so the sample count of its last iteration is printed beside it
-    result["samples_last_iter_nerf_only"] = nerf_only_samples
+    result["samples_per_iter_nerf_only"] = nerf_only_samples
     result["seconds_to_first_barrier_per_rank"] = first_barrier_s
 
     if rank != 0:
@@ -905,7 +1068,7 @@ def main():
     # requests at 64 B, MI355X_MICROARCH.md "HBM"). The file stores, per kernel, the counters AND the work of the launches they
     # were averaged over (`points_per_launch`); traffic is scaled per point to the launch size this run reports, so that
     # `traffic`, `algorithmic_bytes_per_launch` and `avg_launch_us` describe the same launch. null when the file is absent.
-    traffic_file = next((f for f in ("profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
+    traffic_file = next((f for f in ("profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
                          if os.path.exists(os.path.join(ROOT, f))), None)
     pmc = {}
     if traffic_file:
@@ -949,6 +1112,7 @@ def main():
                     f"{m.indices.shape[0]} tetrahedra; Kuhn n = 64, the reference's tets/128_tets.npz is a missing blob), mesh rasterised / "
                     f"interpolated / antialiased at 512 x 512, albedo from the 16-level hash-grid field at the visible surface points, "
                     f"SDS at 512^2, normal-consistency + Laplacian regularisers, AMP backward, Adan (sdf, deform, field)")
+    prior_mods = {n: importlib.import_module("sdfx_nerf." + n) for n in ("groupnorm", "conv", "attention", "sd15_arch")}
     result["config"] = {
         "workload": workload + "; timed steps = " + " + ".join(f"{k} {n}" for n, k in plan), "stage": args.stage,
         "guidance": job.guidance_kind + prior_txt, "prior": args.prior,
@@ -956,11 +1120,13 @@ def main():
         # autocast, channels-last, GroupNorm(+SiLU) / bias + residual sums as this repository's NHWC kernels, MIOpen find mode
         "prior_execution": {
             "dtype": "fp16, outside autocast (UNet and VAE encoder)", "memory_format": "channels_last",
-            "group_norm": "csrc/groupnorm.hip" if os.environ.get("SDFX_GROUPNORM", "1") != "0" else "torch.nn.functional.group_norm",
-            "block_fusion": os.environ.get("SDFX_BLOCK_FUSION", "1") != "0" and os.environ.get("SDFX_GROUPNORM", "1") != "0",
-            "unet_conv3x3": "csrc/conv.hip" if os.environ.get("SDFX_CONV", "1") != "0" else "MIOpen",
-            "unet_attention": "csrc/attention.hip" if os.environ.get("SDFX_ATTENTION", "1") != "0" else "F.scaled_dot_product_attention",
-            "qkv_one_gemm": os.environ.get("SDFX_QKV_FUSION", "1") != "0",
+            "group_norm": "csrc/groupnorm.hip" if prior_mods["groupnorm"]._FUSED else "torch.nn.functional.group_norm",
+            "block_fusion": bool(prior_mods["sd15_arch"]._BLOCK_FUSION and prior_mods["groupnorm"]._FUSED),
+            "unet_conv3x3": "csrc/conv.hip" if prior_mods["conv"]._FUSED else "MIOpen",
+            "unet_attention": "csrc/attention.hip" if prior_mods["attention"]._FUSED else "F.scaled_dot_product_attention",
+            "qkv_one_gemm": bool(prior_mods["sd15_arch"]._QKV_FUSION),
+            "note": "`value` runs the frozen prior on this repository's kernels (outside SURVEY section 8); iters_per_sec_stock_prior is the "
+                    "same region with stock PyTorch-ROCm ops, north_star's configuration",
             "miopen_find_mode": bool(torch.backends.cudnn.benchmark), "captured_in_hip_graph": job.train_mode == "graph"},
         "rays_per_iter": 512 * 512 if args.stage == "dmtet" else 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid, "phase": args.phase}
     try:   # the dispatch assumption behind the level-per-XCD plans (include/sdfx.h): 1 = workgroup b runs on XCD (b + c) mod 8
@@ -1038,7 +1204,27 @@ def main():
                                         bytes_fused_per_sample_fwd_bwd=[RENDER_FWD_BYTES[0], RENDER_BWD_BYTES[0]])
     result["kernels_in_step"] = {k: {"GBps": round(v["GBps"], 1), "avg_us": round(v["avg_us"], 1), "launches": v["launches"]}
                                  for k, v in ksum.items()}
+    result["kernels_in_step"]["_clock"] = ("HIP events around EAGER launches of the pass named in roofline.measured_in: each figure includes the "
+                                           "host's launch gap (~8 us; a third of the sub-50-us kernels' figures). GPU-clock durations: "
+                                           "roofline_composite.fit (graph replay) and the rocprofv3 kernel stats under profiles/")
     if not args.no_kernel_bench:
+        try:
+            # the compositor's bound at 4096 rays, measured here: fixed + marginal fit on the GPU clock
+            fit = render_fixed_marginal(dev)
+            rc = result["roofline_composite"]
+            rc["fit"] = fit
+            rc["bound"] = "launch-latency"
+            rc["bound_note"] = (f"at 4096 rays the fused render kernels are bound by a FIXED per-launch cost, not by bytes: forward "
+                                f"{fit['forward']['fixed_us']} us + {fit['forward']['us_per_million_samples']} us per million samples, backward "
+                                f"{fit['backward']['fixed_us']} us + {fit['backward']['us_per_million_samples']} us per million samples (GPU clock, "
+                                f"least squares over {fit['samples']} samples); the marginal rates are "
+                                f"{fit['forward']['marginal_GBps_fused_bytes']} / {fit['backward']['marginal_GBps_fused_bytes']} GB/s of the kernels' own "
+                                f"bytes. 0.40 of the HBM peak by SURVEY section 8(d)'s compositor bytes (28 / 44 B per sample) would need "
+                                f"{fit['forward']['samples_for_0.40_of_peak_by_survey_bytes']:.3g} / {fit['backward']['samples_for_0.40_of_peak_by_survey_bytes']:.3g} "
+                                f"samples per launch (inf = unreachable at any size for a separate launch); by the fused kernels' bytes "
+                                f"{fit['forward']['samples_for_0.40_of_peak_by_fused_bytes']:.3g} / {fit['backward']['samples_for_0.40_of_peak_by_fused_bytes']:.3g}")
+        except Exception as exc:  # noqa: BLE001
+            result["roofline_composite"]["fit"] = {"error": f"{type(exc).__name__}: {exc}"}
         try:
             kb = kernel_microbench(dev)
             kb.update(inference_bench(job.model, dev))
@@ -1046,6 +1232,19 @@ def main():
                                             for k, v in kb.items()}
         except Exception as exc:  # noqa: BLE001
             result["kernels_standalone"] = {"error": f"{type(exc).__name__}: {exc}"}
+    # BASELINE configs[3] (`--IF`) and configs[4] (DMTet stage) in the same driver-visible line: two short CHILD runs of this file
+    # (own process each: own model, prior, graphs), one after the other on this GPU — while THIS process, whose GPU work is done,
+    # times the CPU baseline on the host cores (the children keep one host thread busy each)
+    children, child_thread = {}, None
+    if world == 1 and not args.no_children and args.prior == "sd" and args.stage == "nerf":
+        import threading
+
+        def run_children():
+            for key, extra, steps in (("if", ["--prior", "if"], 20), ("dmtet", ["--stage", "dmtet"], 10)):
+                children[key] = child_bench(extra, steps)
+        torch.cuda.empty_cache()
+        child_thread = threading.Thread(target=run_children, daemon=True)
+        child_thread.start()
     if world == 1 and not args.no_cpu_baseline:
         try:
             cb = cpu_baseline()
@@ -1066,6 +1265,16 @@ def main():
         except Exception as exc:  # noqa: BLE001
             result["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "restated (-O2 port, golden-pinned)",
                                       "sample": f"failed: {type(exc).__name__}: {exc}"}
+    if child_thread is not None:
+        child_thread.join()
+        for key, name in (("if", "iters_per_sec_if"), ("dmtet", "iters_per_sec_dmtet")):
+            line, secs, err = children.get(key, (None, 0.0, "not run"))
+            result[name] = line["value"] if line else None
+            result[name + "_config"] = ({"workload": line["config"]["workload"], "guidance": line["config"]["guidance"], "steps": line["steps"],
+                                         "ms_per_step": line["ms_per_step"], "train_mode": line.get("train_mode"),
+                                         "samples_per_iter": line.get("samples_per_iter"), "child_run_seconds": round(secs, 1),
+                                         "ran": "child process of this run, alone on the GPU while the parent timed the CPU baseline"}
+                                        if line else {"error": err, "child_run_seconds": round(secs, 1)})
     print(json.dumps(result))
     if dist is not None:
         dist.barrier()

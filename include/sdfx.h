@@ -70,7 +70,8 @@ const char* sdfx_build_info(void);
 
 /* Whether the dispatcher deals the workgroups of a launch to the eight XCDs round-robin (workgroup b -> XCD (b + c) mod 8), which
  * is what the level-per-XCD work plans of the encoder kernels assume for L2 residency of the tables. One probe launch on the
- * current device at the first call (reads HW_REG_XCC_ID per workgroup), cached: 1 = holds, 0 = does not, -1 = probe failed.
+ * current device at the first call FOR THAT DEVICE (reads HW_REG_XCC_ID per workgroup; allocates and launches on the null stream:
+ * call it once outside any stream capture), cached per device: 1 = holds, 0 = does not, -1 = probe failed.
  * Results never depend on it; bench.py reports it and tests/test_gpu_02_parity.py asserts it on the hardware under test. */
 int sdfx_xcd_round_robin(void);
 

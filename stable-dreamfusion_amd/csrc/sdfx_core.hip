@@ -101,7 +101,17 @@ int probe_xcd_round_robin() {
 extern "C" {
 
 int sdfx_xcd_round_robin(void) {
-    static const int v = sdfx::probe_xcd_round_robin();
+    // one answer per device (a process may drive several); the probe allocates and launches on the null stream, so the first call
+    // for a device must be made outside a stream capture
+    static std::mutex m;
+    static std::map<int, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lock(m);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    const int v = sdfx::probe_xcd_round_robin();
+    cache[dev] = v;
     return v;
 }
 

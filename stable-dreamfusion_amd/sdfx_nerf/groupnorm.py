@@ -14,17 +14,21 @@ import torch.nn.functional as F
 import _devswitch
 
 _FUSED = _devswitch.get("SDFX_GROUPNORM", 1)
-_SCRATCH = {}   # device index -> float32 scratch, grown on demand (partials of ONE call; every call rewrites what it reads)
+_SCRATCH = {}   # (device index, stream) -> [float32 scratch buffers, the last one current]:, grown on demand (partials of ONE call; every call rewrites what it reads)
 
 
 def _scratch(device, nbytes):
-    buf = _SCRATCH.get(device.index)
-    if buf is None or buf.numel() * 4 < nbytes:
+    """Per (device, stream) scratch. An outgrown buffer is kept alive beside its replacement (as _gridencoder._BINNED_SCRATCH does): a
+    HIP graph captured while it was current has its address baked in and may be replayed later; streams get their own buffer because
+    nothing orders two streams' calls against each other."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    bufs = _SCRATCH.setdefault(key, [])
+    if not bufs or bufs[-1].numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
         if torch.cuda.is_current_stream_capturing():
             return buf          # memory of the graph being captured: it lives and dies with that graph, so it is not kept for later calls
-        _SCRATCH[device.index] = buf
-    return buf
+        bufs.append(buf)
+    return bufs[-1]
 
 
 class _GroupNormActFn(torch.autograd.Function):

@@ -47,13 +47,24 @@ class ResBlock(nn.Module):
 
     def forward(self, x, emb_act=None):
         """`emb_act` = SiLU(time embedding): the activation is the same for every block, so the UNet applies it once."""
-        if _BLOCK_FUSION and fused_ok(x, self.norm1.weight, self.norm1.bias, 32) and not self.conv1.bias.requires_grad:
+        if _BLOCK_FUSION and fused_ok(x, self.norm1.weight, self.norm1.bias, 32) and self._frozen() and not (
+                emb_act is not None and emb_act.requires_grad):
             return self._forward_fused(x, emb_act)
         h = self.conv1(self.norm1(x))                       # norm1 / norm2 include the SiLU
         if self.temb is not None:
             h = h + self.temb(emb_act)[:, :, None, None]
         h = self.conv2(self.norm2(h))
         return (x if self.skip is None else self.skip(x)) + h
+
+    def _frozen(self):
+        """The fused form folds / detaches conv1's and conv2's biases, the time-embedding projection and the shortcut: only when none
+        of them trains (the frozen prior; a LoRA / fine-tuned block takes the plain form above)."""
+        ps = [self.conv1.bias, self.conv2.bias, self.conv1.weight, self.conv2.weight]
+        if self.temb is not None:
+            ps += [self.temb.weight, self.temb.bias]
+        if self.skip is not None:
+            ps += [self.skip.weight, self.skip.bias]
+        return not any(p.requires_grad for p in ps)
 
     def _forward_fused(self, x, emb_act):
         """The same block on the channels-last fp16 path with three elementwise launches less: conv1's bias and the time-embedding
@@ -88,12 +99,14 @@ _QKV_FUSION = _devswitch.get("SDFX_QKV_FUSION", 1)               # A/B switch: s
 
 
 class Attention(nn.Module):
-    def __init__(self, dim, ctx_dim=None, heads=8):
+    def __init__(self, dim, ctx_dim=None, heads=8, qkv_bias=False):
+        """`qkv_bias`: the UNet's attention layers project without bias (`to_q` / `to_k` / `to_v`), the VAE's single-head mid-block
+        attention with one (sd15_manifest.py: the published key -> shape layout both are pinned to)."""
         super().__init__()
         self.heads = heads
-        self.q = nn.Linear(dim, dim, bias=False)
-        self.k = nn.Linear(ctx_dim or dim, dim, bias=False)
-        self.v = nn.Linear(ctx_dim or dim, dim, bias=False)
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.k = nn.Linear(ctx_dim or dim, dim, bias=qkv_bias)
+        self.v = nn.Linear(ctx_dim or dim, dim, bias=qkv_bias)
         self.o = nn.Linear(dim, dim)
 
     def _fused_weight(self, names):
@@ -115,8 +128,9 @@ class Attention(nn.Module):
         ctx = x if self_attn else ctx
         B, N, C = x.shape
         d = C // self.heads
-        frozen = not (self.q.weight.requires_grad or self.k.weight.requires_grad or self.v.weight.requires_grad)
-        if _QKV_FUSION and frozen and x.is_cuda and d <= 256:
+        frozen = not (self.q.weight.requires_grad or self.k.weight.requires_grad or self.v.weight.requires_grad
+                      or self.o.weight.requires_grad or self.o.bias.requires_grad)
+        if _QKV_FUSION and frozen and x.is_cuda and d <= 256 and self.q.bias is None:
             heads = lambda t, i: t[..., i * C:(i + 1) * C].unflatten(-1, (self.heads, d)).transpose(1, 2)   # [B, H, n, d] view
             if self_attn:
                 qkv = linear_auto(x, self._fused_weight(("q", "k", "v")))
@@ -247,7 +261,7 @@ class VAEEncoderSD15(nn.Module):
             if lvl < len(mult) - 1:
                 blocks.append(nn.Conv2d(c, c, 3, stride=2, padding=0))   # asymmetric pad (0, 1, 0, 1) applied in forward
         self.blocks = nn.ModuleList(blocks)
-        self.mid1, self.mid_norm, self.mid_attn, self.mid2 = ResBlock(c, c), _gn(c), Attention(c, None, heads=1), ResBlock(c, c)
+        self.mid1, self.mid_norm, self.mid_attn, self.mid2 = ResBlock(c, c), _gn(c), Attention(c, None, heads=1, qkv_bias=True), ResBlock(c, c)
         self.norm_out, self.conv_out, self.quant = _gn(c, act=True), nn.Conv2d(c, 2 * z, 3, padding=1), nn.Conv2d(2 * z, 2 * z, 1)
         self.z = z
 
