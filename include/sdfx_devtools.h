@@ -20,7 +20,8 @@
  *   SDFX_GRIDBWD_MERGE_RES / _COARSE_SPLIT / _BALANCE / _LEVEL_COST (string)                   gridencoder_bwd_binned.hip
  *   SDFX_FIELD_IMPL        0 (default) matrix-core kernels, 1 per-thread v_dot2 kernels        field.hip
  *   SDFX_FIELD_FWD_NAT / _FWD_BLOCKS / _BWD_NAT / _BWD_NB / _BWD_LDSFRAG                      field.hip
- *   SDFX_DEV_ABLATE        bits: parts of k_grid_bwd_bin left out (1 list stores, 2 staging, 4 reservations)   gridencoder_bwd_binned.hip
+ *   SDFX_DEV_ABLATE        bits: parts of k_grid_bwd_bin left out (1 list stores, 2 staging, 4 reservations,   gridencoder_bwd_binned.hip
+ *                          8 histogram atomics, 16 gradient load, 32 coordinate loads)
  *   SDFX_RENDER_WAVES, SDFX_INFER_WAVES                                                        render.hip, infer.hip
  */
 #ifndef SDFX_DEVTOOLS_H
@@ -33,7 +34,8 @@ extern "C" {
 void sdfx_dev_set(const char* name, int value);
 void sdfx_dev_unset(const char* name);
 /* Per-workgroup timestamps of the instrumented kernels (csrc/dev_stamps.h: k_grid_fwd = 1, k_grid_bwd_bin = 2,
- * k_grid_bwd_reduce_fixed = 3): `buf` = device memory of (2 + 4 * cap) 64-bit words zeroed by the caller, NULL = off.
+ * k_grid_bwd_reduce_fixed = 3): `buf` = device memory of (2 + 3 * 4 * cap) 64-bit words zeroed by the caller (cap = workgroups of the largest
+ * launch), NULL = off.
  * tools/xcd_timeline.py reduces the records to a per-XCD busy timeline. */
 void sdfx_dev_stamps(void* buf, uint32_t cap);
 

@@ -5,7 +5,9 @@
 // SDFX_STAMP_BEGIN / SDFX_STAMP_END(kernel, level, tile). One record per workgroup:
 //   [0] t0, [1] t1   s_memrealtime (100 MHz, one counter for the whole device: comparable across XCDs)
 //   [2] kernel | level << 8 | XCC_ID << 16 | HW_ID << 32     [3] tile | blockIdx.x << 32
-// buf[0] counts the records asked for (the first `cap` are kept), records start at buf[2].
+// The record of workgroup b of kernel k (1..3) is slot (k - 1) * cap + b — NO shared counter: a first version reserved slots with one
+// atomicAdd, and 100 000 workgroups queueing on one word (~88 returning atomics per microsecond) doubled the span of the kernels it
+// was meant to observe. A slot whose t1 is 0 was not written; records start at buf[2].
 // In the product build every macro below is empty and nothing of this exists: the product kernels' ISA does not change.
 #pragma once
 
@@ -16,7 +18,7 @@ namespace sdfx {
 
 struct DevCtl {
     unsigned long long* stamps;   // nullptr: off
-    uint32_t cap;                 // records
+    uint32_t cap;                 // records per kernel id
     uint32_t ablate;              // kernel-specific bits (SDFX_K1_ABLATE ...)
 };
 DevCtl dev_ctl_host();            // sdfx_core.hip: what sdfx_dev_stamps / sdfx_dev_set("SDFX_K1_ABLATE") asked for
@@ -39,9 +41,8 @@ __device__ __forceinline__ void stamp_end(const DevCtl& c, unsigned long long t0
     uint32_t xcc, hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    const unsigned long long i = atomicAdd(&c.stamps[0], 1ull);
-    if (i >= c.cap) return;
-    unsigned long long* r = c.stamps + 2 + i * 4;
+    if (blockIdx.x >= c.cap || kernel < 1u || kernel > 3u) return;
+    unsigned long long* r = c.stamps + 2 + ((unsigned long long)(kernel - 1u) * c.cap + blockIdx.x) * 4;
     r[0] = t0; r[1] = t1;
     r[2] = (unsigned long long)(kernel | (level << 8) | ((xcc & 15u) << 16)) | ((unsigned long long)hwid << 32);
     r[3] = (unsigned long long)tile | ((unsigned long long)blockIdx.x << 32);

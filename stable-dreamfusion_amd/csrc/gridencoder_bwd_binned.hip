@@ -45,6 +45,8 @@ constexpr uint32_t kBucketRowsLog2 = SDFX_BUCKET_LOG2;
 constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;  // rows per bucket (16 KiB of float2 accumulators)
 constexpr uint32_t kMaxBucketsPerLevel = 512;            // levels up to 2^20 rows
 constexpr uint32_t kBinThreads = 512;
+constexpr uint32_t kBinWaves = 6;                 // K1: waves per SIMD its registers are allocated for (see k_grid_bwd_bin)
+constexpr uint32_t kCusPerXcd = 32;
 constexpr uint32_t kPointsPerThread = 1;
 static_assert(kMaxBucketsPerLevel <= kBinThreads, "K1 scans the bucket histogram with one thread per bucket");
 constexpr uint32_t kReduceThreads = 256;
@@ -202,40 +204,74 @@ struct Contrib {
     bool emit;
 };
 
-template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
-__device__ __forceinline__ void tile_contributions(const typename Elem<HALF>::type* __restrict__ grad, const float* __restrict__ inputs,
-                                                   uint32_t B, uint32_t L, uint32_t b0, uint32_t b1, uint32_t level, uint32_t tile,
-                                                   const LevelConst& lc, int grad_layout, const RowLimit& rl, const StencilSrc& src,
-                                                   Contrib& c) {
+// The inputs of one (level, tile) item for this thread: ISSUED here as loads and consumed by tile_compute — in K1's tile loop the
+// next item's loads are in flight while the current item is processed, so nothing of them sits on a workgroup's critical path
+// (the one-tile-per-workgroup form paid three dependent round trips — row limit, coordinates, then the gradient, which was only
+// loaded for in-range points — in front of every tile: profiles/r05_xcd_timeline.txt, K1 with parts left out).
+struct TileIn {
+    float x[3];      // inputs[b] (unit cube), or with a stencil source the base sample xyzs[b % M] (world)
+    uint32_t g[2];   // the gradient row: one half2 word (half tables) or two floats
+    bool ok;         // the row b = b0 + tile * kBinThreads + threadIdx.x is < b1 and not a padding row; nothing was loaded otherwise
+};
+
+template <bool HALF>
+__device__ __forceinline__ void tile_load(const typename Elem<HALF>::type* __restrict__ grad, const float* __restrict__ inputs, uint32_t B,
+                                          uint32_t L, uint32_t b0, uint32_t b1, uint32_t level, uint32_t tile, int grad_layout,
+                                          const RowLimitNow& rl, const StencilSrc& src, TileIn& t) {
     using T = typename Elem<HALF>::type;
-    constexpr uint32_t C = 2, NCORN = 8;
-    const int lane = lane_id();
-    // ---- the sample: coordinates, gradient row, cell, weights, the 8 table rows ----
     const uint32_t b = b0 + tile * kBinThreads + threadIdx.x;
-    bool valid = b < b1 && row_live(rl, b);
-    float in[3] = {0.f, 0.f, 0.f};
-    if (valid) {
-        if (src.xyzs) stencil_unit_row(src, b, in);   // sdfx_set_stencil_source: the [7, M, 3] batch formed here
+    t.ok = b < b1 && row_live(rl, b);
+    t.x[0] = t.x[1] = t.x[2] = 0.f;
+    t.g[0] = t.g[1] = 0u;
+    if (!t.ok) return;
+    if (SDFX_ABLATE(32u)) {   // measurement: coordinates from the row number instead of from memory
+        t.x[0] = (float)(b & 1023u) * (1.f / 1024.f); t.x[1] = (float)((b >> 10) & 1023u) * (1.f / 1024.f); t.x[2] = (float)(b >> 20) * (1.f / 16.f);
+    } else {
+        const float* xp = src.xyzs ? src.xyzs + (size_t)(b - stencil_slab(b, src.M) * src.M) * 3 : inputs + (size_t)b * 3;
+        t.x[0] = xp[0]; t.x[1] = xp[1]; t.x[2] = xp[2];
+    }
+    // the gradient row is loaded whether or not the point turns out to lie in the unit cube (the row exists either way): the load
+    // does not wait for the coordinates
+    const T* gp = grad_layout == 0 ? grad + ((size_t)level * B + b) * 2 : grad + ((size_t)b * L + level) * 2;
+    if (SDFX_ABLATE(16u)) {   // measurement: no gradient load
+        t.g[0] = HALF ? 0xA51F211Fu : __float_as_uint(0.01f); t.g[1] = __float_as_uint(-0.02f);
+    } else if constexpr (HALF) {
+        t.g[0] = *reinterpret_cast<const uint32_t*>(gp);
+    } else {
+        const uint2 f = *reinterpret_cast<const uint2*>(gp);
+        t.g[0] = f.x; t.g[1] = f.y;
+    }
+}
+
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
+__device__ __forceinline__ void tile_compute(const TileIn& t, uint32_t b0, uint32_t tile, const LevelConst& lc, const StencilSrc& src,
+                                             Contrib& c) {
+    constexpr uint32_t NCORN = 8;
+    const int lane = lane_id();
+    const uint32_t b = b0 + tile * kBinThreads + threadIdx.x;
+    // ---- the sample: coordinates, gradient row, cell, weights, the 8 table rows ----
+    bool valid = t.ok;
+    float in[3] = {t.x[0], t.x[1], t.x[2]};
+    if (src.xyzs && !SDFX_ABLATE(32u)) {   // sdfx_set_stencil_source: row b of the [7, M, 3] batch formed here (stencil_unit_row's arithmetic)
+        float p[3];
+        stencil_world(src, stencil_slab(valid ? b : 0u, src.M), t.x, p);
 #pragma unroll
-        for (uint32_t d = 0; d < 3; d++) {
-            if (!src.xyzs) in[d] = inputs[(size_t)b * 3 + d];
-            if (in[d] < 0 || in[d] > 1) valid = false;  // gridencoder.cu:279-284
-        }
+        for (uint32_t d = 0; d < 3; d++) in[d] = (p[d] + src.bound) * src.inv;
     }
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++)
+        if (in[d] < 0 || in[d] > 1) valid = false;  // gridencoder.cu:279-284
     float2_t g = {0.f, 0.f};
-    if (valid) {
-        const T* gp = grad_layout == 0 ? grad + ((size_t)level * B + b) * C : grad + ((size_t)b * L + level) * C;
-        if constexpr (HALF) {
-            const half2_t h = *reinterpret_cast<const half2_t*>(gp);
-            g.x = (float)h.x; g.y = (float)h.y;
-        } else {
-            const float2 f = *reinterpret_cast<const float2*>(gp);
-            g.x = f.x; g.y = f.y;
-        }
-        // nothing to scatter: samples behind a ray's early-termination cut, and the zero-gradient padding rows of
-        // fixed-capacity sample buffers (which all sit in ONE cell and would overflow its bucket)
-        if (g.x == 0.f && g.y == 0.f) valid = false;
+    if constexpr (HALF) {
+        const half2_t h = __builtin_bit_cast(half2_t, t.g[0]);
+        g.x = (float)h.x; g.y = (float)h.y;
+    } else {
+        g.x = __uint_as_float(t.g[0]); g.y = __uint_as_float(t.g[1]);
     }
+    // nothing to scatter: samples behind a ray's early-termination cut, and the zero-gradient padding rows of
+    // fixed-capacity sample buffers (which all sit in ONE cell and would overflow its bucket)
+    if (g.x == 0.f && g.y == 0.f) valid = false;
+    if (!valid) { g.x = 0.f; g.y = 0.f; }
     const float xs[3] = {valid ? in[0] : 0.f, valid ? in[1] : 0.f, valid ? in[2] : 0.f};
     LevelPoint p;
     level_prepare<INTERP, ALIGN, HASHGRID>(lc, xs, p);
@@ -258,23 +294,32 @@ __device__ __forceinline__ void tile_contributions(const typename Elem<HALF>::ty
     }
 }
 
+// load + compute in one go (the spill kernel)
 template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
-__device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __restrict__ grad, const float* __restrict__ inputs,
-                                         typename Elem<HALF>::type* __restrict__ grad_table, uint32_t B, uint32_t L, uint32_t b0,
-                                         uint32_t b1, uint32_t level, uint32_t tile, const LevelConst& lc, const BinPlan& bin,
-                                         int grad_layout, uint32_t* __restrict__ cursors, Item<HALF>* __restrict__ items,
-                                         const RowLimit& rl, const StencilSrc& src, uint32_t* hist, uint32_t* gbase, uint32_t* boff,
-                                         uint32_t* wave_tot, uint32_t* block_total, Item<HALF>* stage) {
+__device__ __forceinline__ void tile_contributions(const typename Elem<HALF>::type* __restrict__ grad, const float* __restrict__ inputs,
+                                                   uint32_t B, uint32_t L, uint32_t b0, uint32_t b1, uint32_t level, uint32_t tile,
+                                                   const LevelConst& lc, int grad_layout, const RowLimitNow& rl, const StencilSrc& src,
+                                                   Contrib& c) {
+    TileIn t;
+    tile_load<HALF>(grad, inputs, B, L, b0, b1, level, tile, grad_layout, rl, src, t);
+    tile_compute<HALF, INTERP, ALIGN, HASHGRID, MERGE>(t, b0, tile, lc, src, c);
+}
+
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
+__device__ __forceinline__ void bin_tile(const TileIn& in, TileIn& next, typename Elem<HALF>::type* __restrict__ grad_table, uint32_t b0,
+                                         uint32_t level, uint32_t tile, const LevelConst& lc, const BinPlan& bin, uint32_t* __restrict__ cursors,
+                                         Item<HALF>* __restrict__ items, const StencilSrc& src, uint32_t* hist, uint32_t* gbase,
+                                         uint32_t* boff, uint32_t* wave_tot, uint32_t* block_total, Item<HALF>* stage) {
     using T = typename Elem<HALF>::type;
     constexpr uint32_t C = 2, NCORN = 8;
     const int lane = lane_id();
     const uint32_t bucket0 = bin.bucket_first[level];
     const uint32_t nb = bin.bucket_first[level + 1] - bucket0;
     for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) hist[i] = 0;
-    __syncthreads();
+    __syncthreads();   // (also: the previous tile's write-out has read stage / gbase / boff)
 
     Contrib c;
-    tile_contributions<HALF, INTERP, ALIGN, HASHGRID, MERGE>(grad, inputs, B, L, b0, b1, level, tile, lc, grad_layout, rl, src, c);
+    tile_compute<HALF, INTERP, ALIGN, HASHGRID, MERGE>(in, b0, tile, lc, src, c);
     const uint32_t (&rows)[NCORN] = c.rows;
     const float2_t (&v)[NCORN] = c.v;
     const bool emit = c.emit;
@@ -294,15 +339,17 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
     }
     if (emit) {
 #pragma unroll
-        for (uint32_t i = 0; i < NIT; i++) rank[i] = atomicAdd(&hist[ibucket[i]], 1u);  // LDS
+        for (uint32_t i = 0; i < NIT; i++) rank[i] = SDFX_ABLATE(8u) ? 0u : atomicAdd(&hist[ibucket[i]], 1u);  // LDS
     }
     __syncthreads();
-    // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's list; and an exclusive
-    // prefix sum of the histogram = where each bucket's items go in the workgroup's LDS staging area
-    uint32_t my_cnt = 0;
+    // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's list. Its result is not needed before the
+    // write-out: it stays in a register while the histogram is scanned and the items are staged (the round trip of a returning
+    // device-scope atomic is a microsecond or two). And an exclusive prefix sum of the histogram = where each bucket's items go in
+    // the workgroup's LDS staging area
+    uint32_t my_cnt = 0, my_base = 0;
     if (threadIdx.x < nb) {
         my_cnt = hist[threadIdx.x];
-        gbase[threadIdx.x] = (my_cnt && !SDFX_ABLATE(4u)) ? atomicAdd(&cursors[bucket0 + threadIdx.x], my_cnt) : 0u;
+        if (my_cnt && !SDFX_ABLATE(4u)) my_base = atomicAdd(&cursors[bucket0 + threadIdx.x], my_cnt);
     }
     {   // nb <= kMaxBucketsPerLevel = kBinThreads: thread b scans bucket b (wave scan + per-wave totals)
         const uint32_t incl = wave_incl_sum_u32(my_cnt, lane);
@@ -339,6 +386,11 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
             }
         }
     }
+    if (threadIdx.x < nb) gbase[threadIdx.x] = my_base;   // (the reservation's result is first touched here)
+    // The NEXT tile's inputs (loads issued before this tile was processed) are taken into registers HERE, in front of this tile's
+    // list stores: waiting for them at the top of the next tile would wait for those stores as well (one counter orders a wave's
+    // vector-memory operations), and they have been in flight for the whole tile already. The empty asm is the "use".
+    asm volatile("" : "+v"(next.x[0]), "+v"(next.x[1]), "+v"(next.x[2]), "+v"(next.g[0]), "+v"(next.g[1]));
     __syncthreads();
 
     const uint32_t total = SDFX_ABLATE(3u) ? 0u : *block_total;
@@ -356,16 +408,21 @@ __device__ __forceinline__ void bin_tile(const typename Elem<HALF>::type* __rest
     }
 }
 
-// (second bound = waves per SIMD: 8, i.e. 4 workgroups per CU, which the 38 KB of LDS allow: the kernel waits on memory and barriers most of the time —
-// PMC: 61 % of its wave cycles — so residency matters more than registers; without the bound the compiler took 72 VGPRs = 3 workgroups)
-template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
-__global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,
+// K1 is a loop: the launch has `stride` workgroups per XCD (as many as are resident at once), workgroup w of an XCD takes items w,
+// w + stride, ... of that XCD's range of (level, tile) items — whole levels, see make_plan — and the loads of its next item are
+// issued before the current one is processed. One tile per workgroup (rounds 1-4) spent most of a workgroup's 8 us on dependent
+// round trips that nothing overlapped: with the input loads, the reservation atomics and the list stores each left out in turn the
+// kernel lost 21-25 % of its time, with all of them 55 % (profiles/r05_xcd_timeline.txt).
+// WAVES = waves per SIMD the register allocation aims at: 8 / 6 / 4 = 4 / 3 / 2 resident workgroups per CU at 64 / 80 / 128 registers
+// (the 30 KB of LDS allow 5). The product library instantiates kBinWaves only; the devtools library all three (SDFX_GRIDBWD_K1_WAVES).
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, uint32_t WAVES>
+__global__ __launch_bounds__(kBinThreads, WAVES) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,
                                                                const float* __restrict__ inputs,
                                                                typename Elem<HALF>::type* __restrict__ grad_table,
                                                                uint32_t B, uint32_t L, uint32_t b0, uint32_t b1,
                                                                GridPlan plan, BinPlan bin, BinLevels lv, int grad_layout,
                                                                uint32_t* __restrict__ cursors,
-                                                               Item<HALF>* __restrict__ items, RowLimit rl, StencilSrc src) {
+                                                               Item<HALF>* __restrict__ items, RowLimit rl, StencilSrc src, uint32_t stride) {
     __shared__ uint32_t hist[kMaxBucketsPerLevel];
     __shared__ uint32_t gbase[kMaxBucketsPerLevel];
     __shared__ uint32_t boff[kMaxBucketsPerLevel];
@@ -373,19 +430,48 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename 
     __shared__ uint32_t block_total;
     __shared__ Item<HALF> stage[kBinThreads * (HALF ? 4 : 8)];   // 24 KiB (half: 4 pair items per sample) / 48 KiB (float items)
 
-    uint32_t level, tile;
-    if (!plan_item(plan, blockIdx.x, level, tile)) return;   // wave-uniform (depends on blockIdx only)
-    // a tile of padding rows (sdfx_set_row_limit) has nothing to scatter
-    if (rows_dead(rl, b0 + tile * kBinThreads, kBinThreads)) return;
+    // this XCD's range of items (workgroups are dealt to the XCDs round-robin: plan_item)
+    const uint32_t xcd = blockIdx.x % kXcds;
+    const uint32_t first = plan.start[xcd], n_items = plan.end[xcd] - first;
+    const RowLimitNow rln = row_limit_now(rl);
+    auto item_at = [&](uint32_t it, uint32_t& level, uint32_t& tile) {
+        const uint32_t item = first + it, virt = item / plan.tiles;
+        level = plan.order[virt];
+        tile = item - virt * plan.tiles;
+    };
+    // the next item at or after `it` (in steps of `stride`) that is not a tile of padding rows (sdfx_set_row_limit); workgroup-uniform
+    auto next_live = [&](uint32_t it, uint32_t& level, uint32_t& tile) {
+        for (; it < n_items; it += stride) {
+            item_at(it, level, tile);
+            if (!rows_dead(rln, b0 + tile * kBinThreads, kBinThreads)) break;
+        }
+        return it;
+    };
+    uint32_t level = 0, tile = 0;
+    uint32_t it = next_live(blockIdx.x / kXcds, level, tile);
+    if (it >= n_items) return;
     SDFX_STAMP_BEGIN
-    const LevelConst lc = lv.lv[level];
-    if ((bin.merge_mask >> level) & 1u)   // workgroup-uniform; all lanes take part in the DPP exchanges
-        bin_tile<HALF, INTERP, ALIGN, HASHGRID, true>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors,
-                                                      items, rl, src, hist, gbase, boff, wave_tot, &block_total, stage);
-    else
-        bin_tile<HALF, INTERP, ALIGN, HASHGRID, false>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors,
-                                                       items, rl, src, hist, gbase, boff, wave_tot, &block_total, stage);
-    SDFX_STAMP_END(2u, level, tile)
+    TileIn cur;
+    tile_load<HALF>(grad, inputs, B, L, b0, b1, level, tile, grad_layout, rln, src, cur);
+    uint32_t n_done = 0;
+    for (;;) {
+        uint32_t nlevel = 0, ntile = 0;
+        const uint32_t nit = next_live(it + stride, nlevel, ntile);
+        TileIn nxt;
+        nxt.x[0] = nxt.x[1] = nxt.x[2] = 0.f; nxt.g[0] = nxt.g[1] = 0u; nxt.ok = false;
+        if (nit < n_items) tile_load<HALF>(grad, inputs, B, L, b0, b1, nlevel, ntile, grad_layout, rln, src, nxt);
+        const LevelConst lc = lv.lv[level];
+        if ((bin.merge_mask >> level) & 1u)   // workgroup-uniform; all lanes take part in the DPP exchanges
+            bin_tile<HALF, INTERP, ALIGN, HASHGRID, true>(cur, nxt, grad_table, b0, level, tile, lc, bin, cursors, items, src, hist, gbase, boff, wave_tot,
+                                                          &block_total, stage);
+        else
+            bin_tile<HALF, INTERP, ALIGN, HASHGRID, false>(cur, nxt, grad_table, b0, level, tile, lc, bin, cursors, items, src, hist, gbase, boff, wave_tot,
+                                                           &block_total, stage);
+        n_done++;
+        if (nit >= n_items) break;
+        cur = nxt; it = nit; level = nlevel; tile = ntile;
+    }
+    SDFX_STAMP_END(2u, level, n_done)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,7 +502,7 @@ template <uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
 __device__ __forceinline__ void spill_tile(const __half* __restrict__ grad, const float* __restrict__ inputs, __half* __restrict__ grad_table,
                                            uint32_t B, uint32_t L, uint32_t b0, uint32_t b1, uint32_t level, uint32_t tile,
                                            const LevelConst& lc, const BinPlan& bin, int grad_layout, const uint32_t* __restrict__ cursors,
-                                           const RowLimit& rl, const StencilSrc& src, unsigned long long* __restrict__ spill_acc) {
+                                           const RowLimitNow& rl, const StencilSrc& src, unsigned long long* __restrict__ spill_acc) {
     Contrib c;
     tile_contributions<true, INTERP, ALIGN, HASHGRID, MERGE>(grad, inputs, B, L, b0, b1, level, tile, lc, grad_layout, rl, src, c);
     if (!c.emit) return;
@@ -438,16 +524,17 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_spill(const __half* __
                                                                 const uint32_t* __restrict__ diag, uint32_t k1_grid) {
     if (diag[0] == 0u) return;   // no bucket overflowed: nearly every launch of the training loop ends here
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_spill_totals[1], 1u);
+    const RowLimitNow rln = row_limit_now(rl);
     for (uint32_t i = 0; i < kSpillTilesPerGroup; i++) {
         const uint32_t vblock = blockIdx.x * kSpillTilesPerGroup + i;
         uint32_t level, tile;
         if (vblock >= k1_grid || !plan_item(plan, vblock, level, tile)) continue;   // workgroup-uniform
-        if (rows_dead(rl, b0 + tile * kBinThreads, kBinThreads)) continue;
+        if (rows_dead(rln, b0 + tile * kBinThreads, kBinThreads)) continue;
         const LevelConst lc = lv.lv[level];
         if ((bin.merge_mask >> level) & 1u)
-            spill_tile<INTERP, ALIGN, HASHGRID, true>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors, rl, src, spill_acc);
+            spill_tile<INTERP, ALIGN, HASHGRID, true>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors, rln, src, spill_acc);
         else
-            spill_tile<INTERP, ALIGN, HASHGRID, false>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors, rl, src, spill_acc);
+            spill_tile<INTERP, ALIGN, HASHGRID, false>(grad, inputs, grad_table, B, L, b0, b1, level, tile, lc, bin, grad_layout, cursors, rln, src, spill_acc);
     }
 }
 
@@ -974,11 +1061,29 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         memset(&lv, 0, sizeof(lv));
         for (uint32_t l = 0; l < max_level; l++) lv.lv[l] = make_level_const(offsets_host, l, S, H);
         const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
-#define SDFX_BIN(HALF_, INTERP_, ALIGN_, HASH_)                                                                                   \
-    hipLaunchKernelGGL((k_grid_bwd_bin<HALF_, INTERP_, ALIGN_, HASH_>), dim3(grid1), dim3(kBinThreads), 0, st,                    \
+        // K1's launch: `k1_stride` workgroups per XCD — as many as are resident at once — walk that XCD's items (see k_grid_bwd_bin);
+        // never more than the items there are
+        const uint32_t k1_waves = [] { const int v = dev_switch("SDFX_GRIDBWD_K1_WAVES", (int)kBinWaves); return v == 8 || v == 4 ? (uint32_t)v : 6u; }();
+        const uint32_t k1_stride = [&] {
+            const uint32_t want = (uint32_t)dev_switch("SDFX_GRIDBWD_K1_STRIDE", (int)(kCusPerXcd * k1_waves / 2u));
+            const uint32_t longest = grid1 / kXcds;
+            return want < 1u ? 1u : (want < longest ? want : longest);
+        }();
+#define SDFX_BIN_W(HALF_, INTERP_, ALIGN_, HASH_, WAVES_)                                                                         \
+    hipLaunchKernelGGL((k_grid_bwd_bin<HALF_, INTERP_, ALIGN_, HASH_, WAVES_>), dim3(k1_stride * kXcds), dim3(kBinThreads), 0, st, \
                        static_cast<const typename Elem<HALF_>::type*>(grad), inputs,                                              \
                        static_cast<typename Elem<HALF_>::type*>(grad_embeddings), B, L, b0, b1, plan, bin, lv, grad_layout,        \
-                       cursors, static_cast<Item<HALF_>*>(items), row_limit(), stencil_src())
+                       cursors, static_cast<Item<HALF_>*>(items), row_limit(), stencil_src(), k1_stride)
+#ifdef SDFX_DEVTOOLS
+#define SDFX_BIN(HALF_, INTERP_, ALIGN_, HASH_)                                                                                   \
+    do {                                                                                                                          \
+        if (k1_waves == 8) SDFX_BIN_W(HALF_, INTERP_, ALIGN_, HASH_, 8u);                                                         \
+        else if (k1_waves == 4) SDFX_BIN_W(HALF_, INTERP_, ALIGN_, HASH_, 4u);                                                    \
+        else SDFX_BIN_W(HALF_, INTERP_, ALIGN_, HASH_, 6u);                                                                       \
+    } while (0)
+#else
+#define SDFX_BIN(HALF_, INTERP_, ALIGN_, HASH_) SDFX_BIN_W(HALF_, INTERP_, ALIGN_, HASH_, kBinWaves)
+#endif
 #define SDFX_BIN_SEL(HALF_)                                                                                                       \
     switch (sel) {                                                                                                                \
         case 0: SDFX_BIN(HALF_, 0u, false, false); break;                                                                         \
@@ -1023,6 +1128,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         }
 #undef SDFX_BIN_SEL
 #undef SDFX_BIN
+#undef SDFX_BIN_W
     }
     return check_launch("grid_encode_backward_binned");
 }

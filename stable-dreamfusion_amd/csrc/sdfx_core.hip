@@ -121,7 +121,7 @@ void sdfx_dev_set(const char* name, int value) {
     std::lock_guard<std::mutex> lock(sdfx::g_dev_mutex);
     sdfx::g_dev_values[name] = value;
 }
-// `buf`: device memory of (2 + 4 * cap) 64-bit words, zeroed by the caller; nullptr switches the stamps off
+// `buf`: device memory of (2 + 3 * 4 * cap) 64-bit words, zeroed by the caller; nullptr switches the stamps off
 void sdfx_dev_stamps(void* buf, uint32_t cap) {
     std::lock_guard<std::mutex> lock(sdfx::g_dev_mutex);
     sdfx::g_stamp_buf = static_cast<unsigned long long*>(buf);

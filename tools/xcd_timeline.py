@@ -37,8 +37,8 @@ out = torch.empty(16, B, 2, device=dev, dtype=torch.half)
 grad = (torch.randn(16, B, 2, device=dev) * 0.01).half()
 gt = torch.zeros_like(table)
 STEP = 1.0 / 591.0
-CAP = 1 << 19
-stamps = torch.zeros(2 + 4 * CAP, dtype=torch.int64, device=dev)
+CAP = 1 << 18    # workgroups of the largest launch (records are indexed by workgroup id: no shared counter, see csrc/dev_stamps.h)
+stamps = torch.zeros(2 + 3 * 4 * CAP, dtype=torch.int64, device=dev)
 KERNELS = {1: "k_grid_fwd", 2: "k_grid_bwd_bin", 3: "k_grid_bwd_reduce_fixed"}
 
 
@@ -69,9 +69,8 @@ def stamped(fn):
     fn(); torch.cuda.synchronize()
     _sdfx.lib().sdfx_dev_stamps(None, 0)
     h = stamps.cpu().numpy()
-    n = int(h[0])
-    assert n <= CAP, f"{n} records, buffer holds {CAP}"
-    r = h[2:2 + 4 * n].reshape(n, 4).astype(np.uint64)
+    r = h[2:].reshape(3 * CAP, 4)
+    r = r[r[:, 1] != 0].astype(np.uint64)        # slots that were written
     return dict(t0=r[:, 0].astype(np.int64), t1=r[:, 1].astype(np.int64), kernel=(r[:, 2] & 0xFF).astype(int),
                 level=((r[:, 2] >> 8) & 0xFF).astype(int), xcc=((r[:, 2] >> 16) & 0xF).astype(int),
                 hwid=(r[:, 2] >> 32).astype(np.int64), tile=(r[:, 3] & 0xFFFFFFFF).astype(np.int64))
@@ -106,19 +105,31 @@ def report(rec, kid, title):
 
 
 print(f"samples M = {M} ({views} views), stencil batch B = {B}")
-print(f"encode forward  {timed(fwd):8.1f} us/launch (events, 5 launches)  = {B * 588 / timed(fwd) / 1e6 / 8000:.3f} of 8 TB/s at 588 B/point")
+print(f"encode forward  {timed(fwd):8.1f} us/launch (events, 5 launches)  = {B * 588 / timed(fwd) / 1e3 / 8000:.3f} of 8 TB/s at 588 B/point")
 print(f"scatter (K1+K2+K3+zeroing) {timed(bwd):8.1f} us/launch")
 report(stamped(fwd), 1, "encode forward")
 rec = stamped(bwd)
 report(rec, 2, "scatter K1")
 report(rec, 3, "scatter K2")
+print("== K1 by register target (SDFX_GRIDBWD_K1_WAVES: waves per SIMD) and workgroups per XCD (SDFX_GRIDBWD_K1_STRIDE)")
+for waves, strides in ((8, (128, 160)), (6, (96, 128)), (4, (64, 96))):
+    for stride in strides:
+        with _sdfx.dev_switch(SDFX_GRIDBWD_K1_WAVES=waves, SDFX_GRIDBWD_K1_STRIDE=stride):
+            r = stamped(bwd)
+            whole = timed(bwd)
+        m = r["kernel"] == 2
+        span = (r["t1"][m].max() - r["t0"][m].min()) / 100.0
+        per_x = [round((r["t1"][m & (r["xcc"] == x)].max() - r["t0"][m].min()) / 100.0) for x in sorted(set(r["xcc"][m]))]
+        print(f"   waves {waves} stride {stride:3d}: K1 span {span:7.1f} us  K1+K2+K3+zeroing {whole:7.1f} us  workgroups {m.sum()}  per-XCD finish {per_x}")
 if do_ablate:
     print("== K1 with parts left out (SDFX_DEV_ABLATE; wrong results by construction, K2 then sees short or empty lists)")
     for bits, what in ((0, "whole kernel"), (1, "no list stores"), (3, "no staging, no list stores"), (4, "no reservation atomics"),
-                       (7, "contributions + histogram only")):
+                       (7, "contributions + histogram only"), (15, "contributions only (no LDS histogram)"), (16, "no gradient load"),
+                       (32, "no coordinate loads"), (48, "no input loads at all"), (63, "arithmetic only")):
         with _sdfx.dev_switch(SDFX_DEV_ABLATE=bits):
             r = stamped(bwd)
         m = r["kernel"] == 2
         span = (r["t1"][m].max() - r["t0"][m].min()) / 100.0
         per_x = [round((r["t1"][m & (r["xcc"] == x)].max() - r["t0"][m].min()) / 100.0) for x in sorted(set(r["xcc"][m]))]
-        print(f"   ablate={bits} ({what:32s}): K1 span {span:7.1f} us   per-XCD finish {per_x}")
+        dur = (r["t1"][m] - r["t0"][m]) / 100.0
+        print(f"   ablate={bits:2d} ({what:38s}): K1 span {span:7.1f} us  mean workgroup {dur.mean():5.2f} us  per-XCD finish {per_x}")
