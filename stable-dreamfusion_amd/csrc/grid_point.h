@@ -9,7 +9,7 @@ namespace sdfx {
 namespace grid {
 
 struct LevelConst {   // 32 bytes, one s_load_dwordx8
-    uint32_t res, row0, size, m1, m2, flags, pad0, pad1;   // flags: 1 = hashed, 2 = size is a power of two
+    uint32_t res, row0, size, m1, m2, flags, pad0, pad1;   // flags: 1 = hashed, 2 = size is a power of two, 4 = 24-bit multiplies give the rows
 };
 
 // per-level constants from the host copy of `offsets` (gridencoder.cu:61-79, 133)
@@ -24,6 +24,11 @@ inline LevelConst make_level_const(const int32_t* offsets_host, uint32_t level, 
     if (stride <= c.size) { c.m1 = (uint32_t)stride; stride *= c.res; }
     if (stride <= c.size) { c.m2 = (uint32_t)stride; stride *= c.res; }
     c.flags = (stride > c.size ? 1u : 0u) | ((c.size & (c.size - 1u)) == 0u ? 2u : 0u);
+    // level_prepare_uniform: full-rate v_mul_u32_u24 instead of the quarter-rate 32-bit multiply. Dense rows need the exact products
+    // (coordinate < res and strides < 2^24, product < size < 2^32); hashed rows only the product's bits below log2(size), which a
+    // 24 x 24-bit product has right when the size is a power of two of at most 2^24 (the primes are taken modulo 2^24)
+    const bool small = c.res < (1u << 24) && c.m1 < (1u << 24) && c.m2 < (1u << 24);
+    if ((c.flags & 1u) ? ((c.flags & 2u) && c.size <= (1u << 24) && c.res < (1u << 24)) : small) c.flags |= 4u;
     return c;
 }
 
@@ -118,6 +123,49 @@ __device__ __forceinline__ void level_prepare(const LevelConst& lc, const float 
         // three axes fit: x + y res + z res^2 < res^3 <= size) never exceeds its size; what is left — a level that is hashed, or
         // tiled with a truncated stride, AND whose size is no power of two — is a property of the level, decided on the scalar unit
         if (need_mod) { i0 %= lc.size; i1 %= lc.size; }
+        p.r0[k] = i0; p.r1[k] = i1;
+    }
+}
+
+// The same rows and weights with the level's KIND decided by (wave-uniform) control flow — for kernels that handle one level per
+// workgroup (the binned scatter): no second set of products, and 24-bit multiplies where the level allows (flags & 4).
+template <uint32_t INTERP, bool ALIGN, bool HASHGRID>
+__device__ __forceinline__ void level_prepare_uniform(const LevelConst& lc, const float x[3], LevelPoint& p) {
+    const bool hashed = HASHGRID && (lc.flags & 1u);
+    const bool pow2 = (lc.flags & 2u) != 0u, mul24 = (lc.flags & 4u) != 0u;
+    float pos[3], deriv;
+    uint32_t pg[3], pn[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        grid_locate_axis(x[d], lc.res, ALIGN, INTERP, pos[d], deriv, pg[d]);
+        pg[d] = min(pg[d], lc.res - 1u);
+        pn[d] = min(pg[d] + 1u, lc.res - 1u);
+    }
+    (void)deriv;
+    p.ax1 = pos[0]; p.ay1 = pos[1]; p.az1 = pos[2];
+    p.cx = pg[0]; p.cy = pg[1]; p.cz = pg[2];
+    const bool need_mod = (lc.flags & 3u) == 1u;
+    const uint32_t wm = pow2 ? lc.size - 1u : 0xffffffffu;
+    uint32_t ty[2], tz[2];   // the y and z terms of the row
+    const uint32_t fy = hashed ? 2654435761u : lc.m1, fz = hashed ? 805459861u : lc.m2;
+    if (mul24) {
+        ty[0] = __umul24(pg[1], fy & 0xFFFFFFu); ty[1] = __umul24(pn[1], fy & 0xFFFFFFu);
+        tz[0] = __umul24(pg[2], fz & 0xFFFFFFu); tz[1] = __umul24(pn[2], fz & 0xFFFFFFu);
+    } else {
+        ty[0] = pg[1] * fy; ty[1] = pn[1] * fy;
+        tz[0] = pg[2] * fz; tz[1] = pn[2] * fz;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t i0, i1;
+        if (hashed) {
+            const uint32_t yz = ty[k & 1] ^ tz[k >> 1];
+            i0 = (pg[0] ^ yz) & wm; i1 = (pn[0] ^ yz) & wm;
+        } else {
+            const uint32_t yz = ty[k & 1] + tz[k >> 1];
+            i0 = (pg[0] + yz) & wm; i1 = (pn[0] + yz) & wm;
+        }
+        if (need_mod) { i0 %= lc.size; i1 %= lc.size; }   // (see level_prepare)
         p.r0[k] = i0; p.r1[k] = i1;
     }
 }

@@ -45,8 +45,6 @@ constexpr uint32_t kBucketRowsLog2 = SDFX_BUCKET_LOG2;
 constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;  // rows per bucket (16 KiB of float2 accumulators)
 constexpr uint32_t kMaxBucketsPerLevel = 512;            // levels up to 2^20 rows
 constexpr uint32_t kBinThreads = 512;
-constexpr uint32_t kBinWaves = 6;                 // K1: waves per SIMD its registers are allocated for (see k_grid_bwd_bin)
-constexpr uint32_t kCusPerXcd = 32;
 constexpr uint32_t kPointsPerThread = 1;
 static_assert(kMaxBucketsPerLevel <= kBinThreads, "K1 scans the bucket histogram with one thread per bucket");
 constexpr uint32_t kReduceThreads = 256;
@@ -156,15 +154,15 @@ __device__ __forceinline__ void fold_runs(const RunScan& r, float2_t& v) {
     { const float2_t u = {masked_shr<8>(v.x, r.take8), masked_shr<8>(v.y, r.take8)}; v = v + u; }
 }
 
-struct BinLevels {
-    LevelConst lv[kMaxLevels];   // per-level constants of the forward (grid_point.h): one 32-byte scalar load per workgroup
-};
-
 __device__ __forceinline__ uint32_t round_half2(float2_t v) {   // both channels rounded to half (nearest even) by one instruction
     half2_t h;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(v.x), "v"(v.y));
     return __builtin_bit_cast(uint32_t, h);
 }
+struct BinLevels {
+    LevelConst lv[kMaxLevels];   // per-level constants of the forward (grid_point.h): one 32-byte scalar load per workgroup
+};
+
 __device__ __forceinline__ Item<true> make_pair_item(uint32_t row0, uint32_t row1, uint32_t val0, uint32_t val1) {
     Item<true> it;
     it.rows = row0 | ((row0 ^ row1) << 20);
@@ -198,36 +196,52 @@ __device__ __forceinline__ void spill_add(unsigned long long* __restrict__ spill
 // folding is a workgroup-uniform template branch and nothing about a corner is decided by control flow.
 // the contributions of this lane's sample at one level: 8 table rows, 8 float2 values (folded over the lane run that ends here
 // when MERGE), and whether this lane emits them. Shared by K1 and by the spill kernel, which must reproduce K1's values bit for bit.
-struct Contrib {
+template <bool HALF> struct Contrib;
+template <> struct Contrib<true> {     // half tables: the value is rounded to half2 (the reference's half(g * w)) as soon as it is final —
+    uint32_t rows[8];                  // 8 registers instead of 16 live across the histogram, the scan and two barriers
+    uint32_t h[8];
+    bool emit;
+    __device__ __forceinline__ void set(uint32_t idx, float2_t v) { h[idx] = round_half2(v); }
+};
+template <> struct Contrib<false> {
     uint32_t rows[8];
     float2_t v[8];
     bool emit;
+    __device__ __forceinline__ void set(uint32_t idx, float2_t v_) { v[idx] = v_; }
 };
 
-// The inputs of one (level, tile) item for this thread: ISSUED here as loads and consumed by tile_compute — in K1's tile loop the
-// next item's loads are in flight while the current item is processed, so nothing of them sits on a workgroup's critical path
-// (the one-tile-per-workgroup form paid three dependent round trips — row limit, coordinates, then the gradient, which was only
-// loaded for in-range points — in front of every tile: profiles/r05_xcd_timeline.txt, K1 with parts left out).
+// The inputs of one (level, tile) item for this thread: all ISSUED by tile_load — coordinates and gradient row together, the row
+// limit read once into a scalar register before — and consumed by tile_compute. Rounds 1-4 paid three DEPENDENT round trips in front
+// of every tile (row limit, then the coordinates, then the gradient, which was only loaded for in-range points): with the
+// gradient load left out the kernel lost 21 % of its time (profiles/r05_xcd_timeline_one_tile_per_workgroup.txt).
 struct TileIn {
     float x[3];      // inputs[b] (unit cube), or with a stencil source the base sample xyzs[b % M] (world)
     uint32_t g[2];   // the gradient row: one half2 word (half tables) or two floats
     bool ok;         // the row b = b0 + tile * kBinThreads + threadIdx.x is < b1 and not a padding row; nothing was loaded otherwise
 };
 
+// slab of row b of a [7, M, ...] stencil batch when b lies in the tile of kBinThreads rows starting at the (uniform) row `first`:
+// the tile's first slab, decided on uniform values, unless the tile straddles a slab boundary
+__device__ __forceinline__ uint32_t tile_slab(uint32_t first, uint32_t b, uint32_t M) {
+    const uint32_t k0 = stencil_slab(__builtin_amdgcn_readfirstlane(first), M);
+    if (__builtin_amdgcn_readfirstlane(first) + kBinThreads <= (k0 + 1u) * M || k0 == 6u) return k0;   // (uniform branch)
+    return stencil_slab(b, M);
+}
+
 template <bool HALF>
 __device__ __forceinline__ void tile_load(const typename Elem<HALF>::type* __restrict__ grad, const float* __restrict__ inputs, uint32_t B,
                                           uint32_t L, uint32_t b0, uint32_t b1, uint32_t level, uint32_t tile, int grad_layout,
                                           const RowLimitNow& rl, const StencilSrc& src, TileIn& t) {
     using T = typename Elem<HALF>::type;
-    const uint32_t b = b0 + tile * kBinThreads + threadIdx.x;
-    t.ok = b < b1 && row_live(rl, b);
+    const uint32_t first = b0 + tile * kBinThreads, b = first + threadIdx.x;
+    t.ok = b < b1 && row_live_tile(rl, first, threadIdx.x, kBinThreads);
     t.x[0] = t.x[1] = t.x[2] = 0.f;
     t.g[0] = t.g[1] = 0u;
     if (!t.ok) return;
     if (SDFX_ABLATE(32u)) {   // measurement: coordinates from the row number instead of from memory
         t.x[0] = (float)(b & 1023u) * (1.f / 1024.f); t.x[1] = (float)((b >> 10) & 1023u) * (1.f / 1024.f); t.x[2] = (float)(b >> 20) * (1.f / 16.f);
     } else {
-        const float* xp = src.xyzs ? src.xyzs + (size_t)(b - stencil_slab(b, src.M) * src.M) * 3 : inputs + (size_t)b * 3;
+        const float* xp = src.xyzs ? src.xyzs + (size_t)(b - tile_slab(first, b, src.M) * src.M) * 3 : inputs + (size_t)b * 3;
         t.x[0] = xp[0]; t.x[1] = xp[1]; t.x[2] = xp[2];
     }
     // the gradient row is loaded whether or not the point turns out to lie in the unit cube (the row exists either way): the load
@@ -245,16 +259,16 @@ __device__ __forceinline__ void tile_load(const typename Elem<HALF>::type* __res
 
 template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
 __device__ __forceinline__ void tile_compute(const TileIn& t, uint32_t b0, uint32_t tile, const LevelConst& lc, const StencilSrc& src,
-                                             Contrib& c) {
+                                             Contrib<HALF>& c) {
     constexpr uint32_t NCORN = 8;
     const int lane = lane_id();
-    const uint32_t b = b0 + tile * kBinThreads + threadIdx.x;
+    const uint32_t first = b0 + tile * kBinThreads, b = first + threadIdx.x;
     // ---- the sample: coordinates, gradient row, cell, weights, the 8 table rows ----
     bool valid = t.ok;
     float in[3] = {t.x[0], t.x[1], t.x[2]};
     if (src.xyzs && !SDFX_ABLATE(32u)) {   // sdfx_set_stencil_source: row b of the [7, M, 3] batch formed here (stencil_unit_row's arithmetic)
         float p[3];
-        stencil_world(src, stencil_slab(valid ? b : 0u, src.M), t.x, p);
+        stencil_world(src, valid ? tile_slab(first, b, src.M) : 0u, t.x, p);
 #pragma unroll
         for (uint32_t d = 0; d < 3; d++) in[d] = (p[d] + src.bound) * src.inv;
     }
@@ -274,24 +288,27 @@ __device__ __forceinline__ void tile_compute(const TileIn& t, uint32_t b0, uint3
     if (!valid) { g.x = 0.f; g.y = 0.f; }
     const float xs[3] = {valid ? in[0] : 0.f, valid ? in[1] : 0.f, valid ? in[2] : 0.f};
     LevelPoint p;
-    level_prepare<INTERP, ALIGN, HASHGRID>(lc, xs, p);
+    level_prepare_uniform<INTERP, ALIGN, HASHGRID>(lc, xs, p);   // (one level per workgroup: the level's kind is control flow)
     // corner idx = xbit + 2 ybit + 4 zbit (gridencoder.cu:171-184); weight ((1 * a_x) * a_y) * a_z in that order
     const float ax[2] = {1 - p.ax1, p.ax1}, ay[2] = {1 - p.ay1, p.ay1}, az[2] = {1 - p.az1, p.az1};
+    float2_t v[NCORN];
 #pragma unroll
     for (uint32_t idx = 0; idx < NCORN; idx++) {
         const uint32_t k = idx >> 1;
         c.rows[idx] = (idx & 1u) ? p.r1[k] : p.r0[k];
         const float w = ((1 * ax[idx & 1u]) * ay[k & 1u]) * az[k >> 1];
-        c.v[idx] = g * w;
+        v[idx] = g * w;
     }
     c.emit = valid;
     if constexpr (MERGE) {
         // merged levels have res <= 640, so a cell id fits 10 bits per axis
         const RunScan runs = scan_cell_runs(p.cx | (p.cy << 10) | (p.cz << 20), valid, lane);
 #pragma unroll
-        for (uint32_t idx = 0; idx < NCORN; idx++) fold_runs(runs, c.v[idx]);
+        for (uint32_t idx = 0; idx < NCORN; idx++) fold_runs(runs, v[idx]);
         c.emit = runs.tail;
     }
+#pragma unroll
+    for (uint32_t idx = 0; idx < NCORN; idx++) c.set(idx, v[idx]);
 }
 
 // load + compute in one go (the spill kernel)
@@ -299,14 +316,14 @@ template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
 __device__ __forceinline__ void tile_contributions(const typename Elem<HALF>::type* __restrict__ grad, const float* __restrict__ inputs,
                                                    uint32_t B, uint32_t L, uint32_t b0, uint32_t b1, uint32_t level, uint32_t tile,
                                                    const LevelConst& lc, int grad_layout, const RowLimitNow& rl, const StencilSrc& src,
-                                                   Contrib& c) {
+                                                   Contrib<HALF>& c) {
     TileIn t;
     tile_load<HALF>(grad, inputs, B, L, b0, b1, level, tile, grad_layout, rl, src, t);
     tile_compute<HALF, INTERP, ALIGN, HASHGRID, MERGE>(t, b0, tile, lc, src, c);
 }
 
 template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
-__device__ __forceinline__ void bin_tile(const TileIn& in, TileIn& next, typename Elem<HALF>::type* __restrict__ grad_table, uint32_t b0,
+__device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::type* __restrict__ grad_table, uint32_t b0,
                                          uint32_t level, uint32_t tile, const LevelConst& lc, const BinPlan& bin, uint32_t* __restrict__ cursors,
                                          Item<HALF>* __restrict__ items, const StencilSrc& src, uint32_t* hist, uint32_t* gbase,
                                          uint32_t* boff, uint32_t* wave_tot, uint32_t* block_total, Item<HALF>* stage) {
@@ -316,12 +333,11 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, TileIn& next, typenam
     const uint32_t bucket0 = bin.bucket_first[level];
     const uint32_t nb = bin.bucket_first[level + 1] - bucket0;
     for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) hist[i] = 0;
-    __syncthreads();   // (also: the previous tile's write-out has read stage / gbase / boff)
+    __syncthreads();
 
-    Contrib c;
+    Contrib<HALF> c;
     tile_compute<HALF, INTERP, ALIGN, HASHGRID, MERGE>(in, b0, tile, lc, src, c);
     const uint32_t (&rows)[NCORN] = c.rows;
-    const float2_t (&v)[NCORN] = c.v;
     const bool emit = c.emit;
     // items of this lane: one per corner (float tables) or one per x-pair of corners (half tables, see Item<true>)
     constexpr uint32_t NIT = HALF ? NCORN / 2 : NCORN;
@@ -374,7 +390,7 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, TileIn& next, typenam
 #pragma unroll
         for (uint32_t i = 0; i < NIT; i++) {
             if constexpr (HALF) {
-                const uint32_t v0 = round_half2(v[2 * i]), v1 = round_half2(v[2 * i + 1]);
+                const uint32_t v0 = c.h[2 * i], v1 = c.h[2 * i + 1];
                 stage[boff[ibucket[i]] + rank[i]] = make_pair_item(rows[2 * i], split[i] ? rows[2 * i] : rows[2 * i + 1], v0, split[i] ? 0u : v1);
                 if (split[i]) {   // the second corner goes to its own bucket's list by a one-slot reservation of this lane
                     const uint32_t b1 = rows[2 * i + 1] >> kBucketRowsLog2;
@@ -382,15 +398,11 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, TileIn& next, typenam
                     if (slot < cap) level_items[(size_t)b1 * cap + slot] = make_pair_item(rows[2 * i + 1], rows[2 * i + 1], v1, 0u);
                 }
             } else {
-                stage[boff[ibucket[i]] + rank[i]] = Item<false>::make(rows[i], v[i].x, v[i].y);
+                stage[boff[ibucket[i]] + rank[i]] = Item<false>::make(rows[i], c.v[i].x, c.v[i].y);
             }
         }
     }
     if (threadIdx.x < nb) gbase[threadIdx.x] = my_base;   // (the reservation's result is first touched here)
-    // The NEXT tile's inputs (loads issued before this tile was processed) are taken into registers HERE, in front of this tile's
-    // list stores: waiting for them at the top of the next tile would wait for those stores as well (one counter orders a wave's
-    // vector-memory operations), and they have been in flight for the whole tile already. The empty asm is the "use".
-    asm volatile("" : "+v"(next.x[0]), "+v"(next.x[1]), "+v"(next.x[2]), "+v"(next.g[0]), "+v"(next.g[1]));
     __syncthreads();
 
     const uint32_t total = SDFX_ABLATE(3u) ? 0u : *block_total;
@@ -408,21 +420,21 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, TileIn& next, typenam
     }
 }
 
-// K1 is a loop: the launch has `stride` workgroups per XCD (as many as are resident at once), workgroup w of an XCD takes items w,
-// w + stride, ... of that XCD's range of (level, tile) items — whole levels, see make_plan — and the loads of its next item are
-// issued before the current one is processed. One tile per workgroup (rounds 1-4) spent most of a workgroup's 8 us on dependent
-// round trips that nothing overlapped: with the input loads, the reservation atomics and the list stores each left out in turn the
-// kernel lost 21-25 % of its time, with all of them 55 % (profiles/r05_xcd_timeline.txt).
-// WAVES = waves per SIMD the register allocation aims at: 8 / 6 / 4 = 4 / 3 / 2 resident workgroups per CU at 64 / 80 / 128 registers
-// (the 30 KB of LDS allow 5). The product library instantiates kBinWaves only; the devtools library all three (SDFX_GRIDBWD_K1_WAVES).
-template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, uint32_t WAVES>
-__global__ __launch_bounds__(kBinThreads, WAVES) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,
+// One (level, tile) item per workgroup; every XCD walks its own range of whole levels (make_plan). A workgroup's time is a chain of
+// memory round trips around ~3 us of arithmetic, so the chain is kept short: inputs issued together (tile_load), the reservation's
+// result not waited for before the write-out (bin_tile). A LOOP form — `stride` workgroups per XCD walking their XCD's items with the
+// next item's loads in flight — was measured this round and is slower: it needs 87 registers, i.e. 6 waves per SIMD instead of 8
+// (1083 us against 1034 us at B = 3.26 M; at 64 registers it spills 24 words: 2158 us), and this kernel's waves are latency-bound
+// streams (LDS round trips, five barriers): its throughput follows the resident waves (profiles/r05_xcd_timeline_k1_tile_loop_variant.txt).
+// (second bound = waves per SIMD: 8, i.e. 4 workgroups per CU, which the 30 KB of LDS allow)
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
+__global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,
                                                                const float* __restrict__ inputs,
                                                                typename Elem<HALF>::type* __restrict__ grad_table,
                                                                uint32_t B, uint32_t L, uint32_t b0, uint32_t b1,
                                                                GridPlan plan, BinPlan bin, BinLevels lv, int grad_layout,
                                                                uint32_t* __restrict__ cursors,
-                                                               Item<HALF>* __restrict__ items, RowLimit rl, StencilSrc src, uint32_t stride) {
+                                                               Item<HALF>* __restrict__ items, RowLimit rl, StencilSrc src) {
     __shared__ uint32_t hist[kMaxBucketsPerLevel];
     __shared__ uint32_t gbase[kMaxBucketsPerLevel];
     __shared__ uint32_t boff[kMaxBucketsPerLevel];
@@ -430,48 +442,22 @@ __global__ __launch_bounds__(kBinThreads, WAVES) void k_grid_bwd_bin(const typen
     __shared__ uint32_t block_total;
     __shared__ Item<HALF> stage[kBinThreads * (HALF ? 4 : 8)];   // 24 KiB (half: 4 pair items per sample) / 48 KiB (float items)
 
-    // this XCD's range of items (workgroups are dealt to the XCDs round-robin: plan_item)
-    const uint32_t xcd = blockIdx.x % kXcds;
-    const uint32_t first = plan.start[xcd], n_items = plan.end[xcd] - first;
+    uint32_t level, tile;
+    if (!plan_item(plan, blockIdx.x, level, tile)) return;   // wave-uniform (depends on blockIdx only)
+    // a tile of padding rows (sdfx_set_row_limit) has nothing to scatter
     const RowLimitNow rln = row_limit_now(rl);
-    auto item_at = [&](uint32_t it, uint32_t& level, uint32_t& tile) {
-        const uint32_t item = first + it, virt = item / plan.tiles;
-        level = plan.order[virt];
-        tile = item - virt * plan.tiles;
-    };
-    // the next item at or after `it` (in steps of `stride`) that is not a tile of padding rows (sdfx_set_row_limit); workgroup-uniform
-    auto next_live = [&](uint32_t it, uint32_t& level, uint32_t& tile) {
-        for (; it < n_items; it += stride) {
-            item_at(it, level, tile);
-            if (!rows_dead(rln, b0 + tile * kBinThreads, kBinThreads)) break;
-        }
-        return it;
-    };
-    uint32_t level = 0, tile = 0;
-    uint32_t it = next_live(blockIdx.x / kXcds, level, tile);
-    if (it >= n_items) return;
+    if (rows_dead(rln, b0 + tile * kBinThreads, kBinThreads)) return;
     SDFX_STAMP_BEGIN
-    TileIn cur;
-    tile_load<HALF>(grad, inputs, B, L, b0, b1, level, tile, grad_layout, rln, src, cur);
-    uint32_t n_done = 0;
-    for (;;) {
-        uint32_t nlevel = 0, ntile = 0;
-        const uint32_t nit = next_live(it + stride, nlevel, ntile);
-        TileIn nxt;
-        nxt.x[0] = nxt.x[1] = nxt.x[2] = 0.f; nxt.g[0] = nxt.g[1] = 0u; nxt.ok = false;
-        if (nit < n_items) tile_load<HALF>(grad, inputs, B, L, b0, b1, nlevel, ntile, grad_layout, rln, src, nxt);
-        const LevelConst lc = lv.lv[level];
-        if ((bin.merge_mask >> level) & 1u)   // workgroup-uniform; all lanes take part in the DPP exchanges
-            bin_tile<HALF, INTERP, ALIGN, HASHGRID, true>(cur, nxt, grad_table, b0, level, tile, lc, bin, cursors, items, src, hist, gbase, boff, wave_tot,
-                                                          &block_total, stage);
-        else
-            bin_tile<HALF, INTERP, ALIGN, HASHGRID, false>(cur, nxt, grad_table, b0, level, tile, lc, bin, cursors, items, src, hist, gbase, boff, wave_tot,
-                                                           &block_total, stage);
-        n_done++;
-        if (nit >= n_items) break;
-        cur = nxt; it = nit; level = nlevel; tile = ntile;
-    }
-    SDFX_STAMP_END(2u, level, n_done)
+    TileIn in;
+    tile_load<HALF>(grad, inputs, B, L, b0, b1, level, tile, grad_layout, rln, src, in);
+    const LevelConst lc = lv.lv[level];
+    if ((bin.merge_mask >> level) & 1u)   // workgroup-uniform; all lanes take part in the DPP exchanges
+        bin_tile<HALF, INTERP, ALIGN, HASHGRID, true>(in, grad_table, b0, level, tile, lc, bin, cursors, items, src, hist, gbase, boff, wave_tot,
+                                                      &block_total, stage);
+    else
+        bin_tile<HALF, INTERP, ALIGN, HASHGRID, false>(in, grad_table, b0, level, tile, lc, bin, cursors, items, src, hist, gbase, boff, wave_tot,
+                                                       &block_total, stage);
+    SDFX_STAMP_END(2u, level, tile)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -503,7 +489,7 @@ __device__ __forceinline__ void spill_tile(const __half* __restrict__ grad, cons
                                            uint32_t B, uint32_t L, uint32_t b0, uint32_t b1, uint32_t level, uint32_t tile,
                                            const LevelConst& lc, const BinPlan& bin, int grad_layout, const uint32_t* __restrict__ cursors,
                                            const RowLimitNow& rl, const StencilSrc& src, unsigned long long* __restrict__ spill_acc) {
-    Contrib c;
+    Contrib<true> c;
     tile_contributions<true, INTERP, ALIGN, HASHGRID, MERGE>(grad, inputs, B, L, b0, b1, level, tile, lc, grad_layout, rl, src, c);
     if (!c.emit) return;
     const uint32_t bucket0 = bin.bucket_first[level], cap = bin.cap[level];
@@ -511,7 +497,7 @@ __device__ __forceinline__ void spill_tile(const __half* __restrict__ grad, cons
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; idx++) {
         const uint32_t gb = bucket0 + (c.rows[idx] >> kBucketRowsLog2);
-        if (cursors[gb] > cap) spill_add(spill_acc, gtab, gb, c.rows[idx], round_half2(c.v[idx]));
+        if (cursors[gb] > cap) spill_add(spill_acc, gtab, gb, c.rows[idx], c.h[idx]);
     }
 }
 
@@ -1061,29 +1047,11 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         memset(&lv, 0, sizeof(lv));
         for (uint32_t l = 0; l < max_level; l++) lv.lv[l] = make_level_const(offsets_host, l, S, H);
         const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
-        // K1's launch: `k1_stride` workgroups per XCD — as many as are resident at once — walk that XCD's items (see k_grid_bwd_bin);
-        // never more than the items there are
-        const uint32_t k1_waves = [] { const int v = dev_switch("SDFX_GRIDBWD_K1_WAVES", (int)kBinWaves); return v == 8 || v == 4 ? (uint32_t)v : 6u; }();
-        const uint32_t k1_stride = [&] {
-            const uint32_t want = (uint32_t)dev_switch("SDFX_GRIDBWD_K1_STRIDE", (int)(kCusPerXcd * k1_waves / 2u));
-            const uint32_t longest = grid1 / kXcds;
-            return want < 1u ? 1u : (want < longest ? want : longest);
-        }();
-#define SDFX_BIN_W(HALF_, INTERP_, ALIGN_, HASH_, WAVES_)                                                                         \
-    hipLaunchKernelGGL((k_grid_bwd_bin<HALF_, INTERP_, ALIGN_, HASH_, WAVES_>), dim3(k1_stride * kXcds), dim3(kBinThreads), 0, st, \
+#define SDFX_BIN(HALF_, INTERP_, ALIGN_, HASH_)                                                                                   \
+    hipLaunchKernelGGL((k_grid_bwd_bin<HALF_, INTERP_, ALIGN_, HASH_>), dim3(grid1), dim3(kBinThreads), 0, st,                    \
                        static_cast<const typename Elem<HALF_>::type*>(grad), inputs,                                              \
                        static_cast<typename Elem<HALF_>::type*>(grad_embeddings), B, L, b0, b1, plan, bin, lv, grad_layout,        \
-                       cursors, static_cast<Item<HALF_>*>(items), row_limit(), stencil_src(), k1_stride)
-#ifdef SDFX_DEVTOOLS
-#define SDFX_BIN(HALF_, INTERP_, ALIGN_, HASH_)                                                                                   \
-    do {                                                                                                                          \
-        if (k1_waves == 8) SDFX_BIN_W(HALF_, INTERP_, ALIGN_, HASH_, 8u);                                                         \
-        else if (k1_waves == 4) SDFX_BIN_W(HALF_, INTERP_, ALIGN_, HASH_, 4u);                                                    \
-        else SDFX_BIN_W(HALF_, INTERP_, ALIGN_, HASH_, 6u);                                                                       \
-    } while (0)
-#else
-#define SDFX_BIN(HALF_, INTERP_, ALIGN_, HASH_) SDFX_BIN_W(HALF_, INTERP_, ALIGN_, HASH_, kBinWaves)
-#endif
+                       cursors, static_cast<Item<HALF_>*>(items), row_limit(), stencil_src())
 #define SDFX_BIN_SEL(HALF_)                                                                                                       \
     switch (sel) {                                                                                                                \
         case 0: SDFX_BIN(HALF_, 0u, false, false); break;                                                                         \
@@ -1128,7 +1096,6 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         }
 #undef SDFX_BIN_SEL
 #undef SDFX_BIN
-#undef SDFX_BIN_W
     }
     return check_launch("grid_encode_backward_binned");
 }

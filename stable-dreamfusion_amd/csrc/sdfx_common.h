@@ -115,6 +115,16 @@ __device__ __forceinline__ bool row_live(const RowLimitNow& v, uint32_t r) {
     const uint32_t j = v.period ? r % v.period : r;
     return j < v.total;
 }
+// row_live for row first + i of a tile of n <= period consecutive rows starting at the (workgroup-uniform) row `first`: the modulo
+// is taken once per tile on uniform values, a lane adds its offset and wraps at most once
+__device__ __forceinline__ bool row_live_tile(const RowLimitNow& v, uint32_t first, uint32_t i, uint32_t n) {
+    if (v.period == 0) return first + i < v.total;
+    if (n > v.period) return row_live(v, first + i);
+    const uint32_t j0 = __builtin_amdgcn_readfirstlane(first) % v.period;
+    uint32_t j = j0 + i;
+    if (j >= v.period) j -= v.period;
+    return j < v.total;
+}
 __device__ __forceinline__ bool rows_dead(const RowLimitNow& v, uint32_t r0, uint32_t n) {
     const uint32_t j0 = v.period ? r0 % v.period : r0;
     return j0 >= v.total && (v.period == 0 || j0 + n <= v.period);

@@ -111,16 +111,6 @@ report(stamped(fwd), 1, "encode forward")
 rec = stamped(bwd)
 report(rec, 2, "scatter K1")
 report(rec, 3, "scatter K2")
-print("== K1 by register target (SDFX_GRIDBWD_K1_WAVES: waves per SIMD) and workgroups per XCD (SDFX_GRIDBWD_K1_STRIDE)")
-for waves, strides in ((8, (128, 160)), (6, (96, 128)), (4, (64, 96))):
-    for stride in strides:
-        with _sdfx.dev_switch(SDFX_GRIDBWD_K1_WAVES=waves, SDFX_GRIDBWD_K1_STRIDE=stride):
-            r = stamped(bwd)
-            whole = timed(bwd)
-        m = r["kernel"] == 2
-        span = (r["t1"][m].max() - r["t0"][m].min()) / 100.0
-        per_x = [round((r["t1"][m & (r["xcc"] == x)].max() - r["t0"][m].min()) / 100.0) for x in sorted(set(r["xcc"][m]))]
-        print(f"   waves {waves} stride {stride:3d}: K1 span {span:7.1f} us  K1+K2+K3+zeroing {whole:7.1f} us  workgroups {m.sum()}  per-XCD finish {per_x}")
 if do_ablate:
     print("== K1 with parts left out (SDFX_DEV_ABLATE; wrong results by construction, K2 then sees short or empty lists)")
     for bits, what in ((0, "whole kernel"), (1, "no list stores"), (3, "no staging, no list stores"), (4, "no reservation atomics"),
