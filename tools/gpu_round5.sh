@@ -8,6 +8,7 @@
 #   bench      default bench.py line (N = 1)
 #   stats      rocprofv3 --kernel-trace --stats of a short default bench -> kernel_stats csv (top rows)
 #   pmc        tools/gpu_profile_round.sh-style FETCH_SIZE / WRITE_SIZE passes (synthetic prior) -> pmc_traffic.json
+#   variants   A/B libraries under ab/ (tools/build_variant.py): scatter timeline + scatter tests on each
 #   scatter    tools/gridbwd_bench.py 20 (standalone loop of K1 + K2 + K3) on the product library [and on ab/libsdfx_hip_base.so]
 TAG=${1:-r5}; shift
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
@@ -41,6 +42,13 @@ for STEP in "$@"; do
     scatter)
       timeout 300 python tools/gridbwd_bench.py 20 2>&1 | grep -v "amdgpu.ids" | tee $OUT/gridbwd_bench.txt | tee -a $OUT/summary.txt
       if [ -f ab/libsdfx_hip_base.so ]; then SDFX_LIB=$REPO/ab/libsdfx_hip_base.so timeout 300 python tools/gridbwd_bench.py 20 2>&1 | grep -v "amdgpu.ids" | sed 's/^/BASE: /' | tee -a $OUT/gridbwd_bench.txt | tee -a $OUT/summary.txt; fi ;;
+    variants)   # every ab/libsdfx_hip_<name>.so built by tools/build_variant.py (VARIANTS="name ..." picks some): timeline without ablations + scatter tests
+      for lib in ${VARIANTS:-$(ls ab/libsdfx_hip_*.so | sed 's#ab/libsdfx_hip_##; s#\.so##' | grep -v '^base$')}; do
+        echo "== variant $lib" | tee -a $OUT/summary.txt
+        SDFX_LIB=$REPO/ab/libsdfx_hip_$lib.so timeout 300 python tools/xcd_timeline.py ${VIEWS:-2} 0 2>&1 | grep -v "amdgpu.ids" > $OUT/xcd_timeline_$lib.txt
+        grep -E "^encode|^scatter|^== scatter|XCD finish" $OUT/xcd_timeline_$lib.txt | cut -c1-200 | tee -a $OUT/summary.txt
+        SDFX_LIB=$REPO/ab/libsdfx_hip_$lib.so timeout 600 python -m pytest tests/test_gpu_02_parity.py tests/test_gpu_zz_stress.py tests/test_gpu_00_vs_reference_kernels.py -m gpu -q -p no:cacheprovider -k "grid or scatter or stencil or binned" 2>&1 | tail -3 | cut -c1-300 | tee -a $OUT/summary.txt
+      done ;;
     *) echo "unknown step $STEP" | tee -a $OUT/summary.txt ;;
   esac
 done

@@ -111,6 +111,15 @@ report(stamped(fwd), 1, "encode forward")
 rec = stamped(bwd)
 report(rec, 2, "scatter K1")
 report(rec, 3, "scatter K2")
+if os.environ.get("K1_STRIDES"):
+    print("== K1 by workgroups per XCD (SDFX_GRIDBWD_K1_STRIDE)")
+    for stride in [int(v) for v in os.environ["K1_STRIDES"].split(",")]:
+        with _sdfx.dev_switch(SDFX_GRIDBWD_K1_STRIDE=stride):
+            r = stamped(bwd)
+            whole = timed(bwd)
+        m = r["kernel"] == 2
+        span = (r["t1"][m].max() - r["t0"][m].min()) / 100.0
+        print(f"   stride {stride:3d}: K1 span {span:7.1f} us  K1+K2+K3+zeroing {whole:7.1f} us  workgroups {m.sum()}")
 if do_ablate:
     print("== K1 with parts left out (SDFX_DEV_ABLATE; wrong results by construction, K2 then sees short or empty lists)")
     for bits, what in ((0, "whole kernel"), (1, "no list stores"), (3, "no staging, no list stores"), (4, "no reservation atomics"),
