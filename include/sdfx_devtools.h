@@ -16,12 +16,15 @@
  *   SDFX_GRID_LDS          0: largest level table (bytes) gathered from LDS (slower)           gridencoder_fwd.hip
  *   SDFX_GRID_PLAN         (string, environment only) "sample_major" (slower)                  gridencoder_fwd.hip
  *   SDFX_GRID_PLAN_DEBUG   print the per-XCD segments                                          gridencoder_fwd.hip
+ *   SDFX_GRID_ONLY_LEVEL   l: the hinted forward evaluates level l alone on all eight XCDs     gridencoder_fwd.hip
+ *   SDFX_GRID_LEVEL_COST   (string, environment only) "c0,c1,...": cost per tile by level      gridencoder_fwd.hip
  *   SDFX_GRID_NOVEC16      1: one gather per corner in the generic kernels                     gridencoder.hip
  *   SDFX_GRIDBWD_MERGE_RES / _COARSE_SPLIT / _BALANCE / _LEVEL_COST (string)                   gridencoder_bwd_binned.hip
  *   SDFX_FIELD_IMPL        0 (default) matrix-core kernels, 1 per-thread v_dot2 kernels        field.hip
  *   SDFX_FIELD_FWD_NAT / _FWD_BLOCKS / _BWD_NAT / _BWD_NB / _BWD_LDSFRAG                      field.hip
  *   SDFX_DEV_ABLATE        bits: parts of k_grid_bwd_bin left out (1 list stores, 2 staging, 4 reservations,   gridencoder_bwd_binned.hip
- *                          8 histogram atomics, 16 gradient load, 32 coordinate loads)
+ *                          8 histogram atomics, 16 gradient load, 32 coordinate loads); 64: k_grid_bwd_reduce_fixed adds
+ *                          every lane of a wave to a different row (prices same-row LDS atomics)
  *   SDFX_RENDER_WAVES, SDFX_INFER_WAVES                                                        render.hip, infer.hip
  */
 #ifndef SDFX_DEVTOOLS_H

@@ -48,7 +48,6 @@ constexpr uint32_t kMaxBucketsPerLevel = 512;            // levels up to 2^20 ro
 #define SDFX_BIN_THREADS 512   // measurement aid: -DSDFX_BIN_THREADS=1024 builds K1 with 1024-sample tiles (half as many reservations per item)
 #endif
 constexpr uint32_t kBinThreads = SDFX_BIN_THREADS;
-constexpr uint32_t kBinWorkgroupsPerXcd = 32u * (2048u / kBinThreads);   // K1's launch: 32 CUs x the workgroups resident per CU (8 waves per SIMD)
 constexpr uint32_t kPointsPerThread = 1;
 static_assert(kMaxBucketsPerLevel <= kBinThreads, "K1 scans the bucket histogram with one thread per bucket");
 constexpr uint32_t kReduceThreads = SDFX_BUCKET_LOG2 >= 12 ? 128 : 256;   // (float tables: per-wave private accumulators must fit the LDS)
@@ -326,20 +325,121 @@ __device__ __forceinline__ void tile_contributions(const typename Elem<HALF>::ty
     tile_compute<HALF, INTERP, ALIGN, HASHGRID, MERGE>(t, b0, tile, lc, src, c);
 }
 
-// K1 is a software-pipelined loop. The launch has `stride` workgroups per XCD (what is resident at once: four per CU), workgroup w of an
-// XCD takes items w, w + stride, ... of that XCD's range of (level, tile) items (whole levels, make_plan). One tile per workgroup
-// (rounds 1-4) spent more than half of a workgroup's 8 us on memory round trips that nothing overlapped — with the input loads,
-// the reservation atomics and the list stores each left out in turn the kernel lost 17-25 % of its time, with all of them 55 %
-// (profiles/r05_xcd_timeline_one_tile_per_workgroup.txt) — and neither fewer reservations (4096-row buckets, 1024-sample tiles:
-// profiles/r05_scatter_bucket_tile_variants.txt) nor fewer instructions moved it: it is a chain, at the hardware's 8 waves per SIMD.
-// So every round trip gets a whole tile's arithmetic to complete in. Per iteration (tile t; tile t - 1 is staged in LDS):
-//   A  issue the loads of tile t + 1 (coordinates, gradient row)
-//   B  contributions of tile t (registers) and their ranks in the bucket histogram (LDS atomics)
-//      then the ONE wait of the iteration: reservation results of tile t - 1 (issued in F of the previous iteration), loads of A
-//   D  write tile t - 1's staged items to the bucket lists (stores: nobody waits for them before the next iteration's wait)
-//   F  reserve list slices for tile t (one returning atomic per non-empty bucket, result left in a register), scan the histogram
-//   H  stage tile t's items in LDS, grouped by bucket
-// with three barriers (after B, D, F's scan) + the scan's own. 56 registers: 8 waves per SIMD as before.
+template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool MERGE>
+__device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::type* __restrict__ grad_table, uint32_t b0,
+                                         uint32_t level, uint32_t tile, const LevelConst& lc, const BinPlan& bin, uint32_t* __restrict__ cursors,
+                                         Item<HALF>* __restrict__ items, const StencilSrc& src, uint32_t* hist, uint32_t* gbase,
+                                         uint32_t* boff, uint32_t* wave_tot, uint32_t* block_total, Item<HALF>* stage) {
+    using T = typename Elem<HALF>::type;
+    constexpr uint32_t C = 2, NCORN = 8;
+    const int lane = lane_id();
+    const uint32_t bucket0 = bin.bucket_first[level];
+    const uint32_t nb = bin.bucket_first[level + 1] - bucket0;
+    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) hist[i] = 0;
+    __syncthreads();
+
+    Contrib<HALF> c;
+    tile_compute<HALF, INTERP, ALIGN, HASHGRID, MERGE>(in, b0, tile, lc, src, c);
+    const uint32_t (&rows)[NCORN] = c.rows;
+    const bool emit = c.emit;
+    // items of this lane: one per corner (float tables) or one per x-pair of corners (half tables, see Item<true>)
+    constexpr uint32_t NIT = HALF ? NCORN / 2 : NCORN;
+    uint32_t ibucket[NIT], rank[NIT];
+    bool split[NIT];
+#pragma unroll
+    for (uint32_t i = 0; i < NIT; i++) {
+        if constexpr (HALF) {
+            ibucket[i] = rows[2 * i] >> kBucketRowsLog2;
+            split[i] = (rows[2 * i + 1] >> kBucketRowsLog2) != ibucket[i];   // the pair straddles two buckets (dense levels, rarely)
+        } else {
+            ibucket[i] = rows[i] >> kBucketRowsLog2;
+            split[i] = false;
+        }
+    }
+    if (emit) {
+#pragma unroll
+        for (uint32_t i = 0; i < NIT; i++) rank[i] = SDFX_ABLATE(8u) ? 0u : atomicAdd(&hist[ibucket[i]], 1u);  // LDS
+    }
+    __syncthreads();
+    // one global atomic per (workgroup, non-empty bucket): reserve a slice of the bucket's list. Its result is not needed before the
+    // write-out: it stays in a register while the histogram is scanned and the items are staged (the round trip of a returning
+    // device-scope atomic is a microsecond or two). And an exclusive prefix sum of the histogram = where each bucket's items go in
+    // the workgroup's LDS staging area
+    uint32_t my_cnt = 0, my_base = 0;
+    if (threadIdx.x < nb) {
+        my_cnt = hist[threadIdx.x];
+        if (my_cnt && !SDFX_ABLATE(4u)) my_base = atomicAdd(&cursors[bucket0 + threadIdx.x], my_cnt);
+    }
+    {   // nb <= kMaxBucketsPerLevel = kBinThreads: thread b scans bucket b (wave scan + per-wave totals)
+        const uint32_t incl = wave_incl_sum_u32(my_cnt, lane);
+        if (lane == (int)kWave - 1) wave_tot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) woff += wave_tot[w];
+        if (threadIdx.x < nb) boff[threadIdx.x] = woff + incl - my_cnt;
+        if (threadIdx.x == kBinThreads - 1) *block_total = woff + incl;
+    }
+    __syncthreads();
+
+    // Stage the items in LDS grouped by bucket, then stream them out: consecutive staging slots of one bucket go to
+    // consecutive slots of its list, so a wave store covers a few contiguous runs instead of 64 unrelated 8-byte
+    // writes (the scattered version was bound by L2 write transactions: one per item).
+    // A slot at or beyond the list's capacity: half tables drop the item — the cursor keeps counting, cursor > cap tells K2 to
+    // take the bucket's sum from its spill accumulator, which k_grid_bwd_spill fills with ALL of the bucket's contributions
+    // (exact); float tables add with the reference's float atomics.
+    const uint32_t cap = bin.cap[level];
+    Item<HALF>* level_items = items + (size_t)bin.item_first[level] * 1024u;
+    if (emit && !SDFX_ABLATE(2u)) {
+#pragma unroll
+        for (uint32_t i = 0; i < NIT; i++) {
+            if constexpr (HALF) {
+                const uint32_t v0 = c.h[2 * i], v1 = c.h[2 * i + 1];
+                stage[boff[ibucket[i]] + rank[i]] = make_pair_item(rows[2 * i], split[i] ? rows[2 * i] : rows[2 * i + 1], v0, split[i] ? 0u : v1);
+                if (split[i]) {   // the second corner goes to its own bucket's list by a one-slot reservation of this lane
+                    const uint32_t b1 = rows[2 * i + 1] >> kBucketRowsLog2;
+                    const uint32_t slot = atomicAdd(&cursors[bucket0 + b1], 1u);
+                    if (slot < cap) level_items[(size_t)b1 * cap + slot] = make_pair_item(rows[2 * i + 1], rows[2 * i + 1], v1, 0u);
+                }
+            } else {
+                stage[boff[ibucket[i]] + rank[i]] = Item<false>::make(rows[i], c.v[i].x, c.v[i].y);
+            }
+        }
+    }
+    if (threadIdx.x < nb) gbase[threadIdx.x] = my_base;   // (the reservation's result is first touched here)
+    __syncthreads();
+
+    const uint32_t total = SDFX_ABLATE(3u) ? 0u : *block_total;
+    for (uint32_t k = threadIdx.x; k < total; k += kBinThreads) {
+        const Item<HALF> it = stage[k];
+        const uint32_t bucket = it.bucket();
+        const uint32_t slot = gbase[bucket] + (k - boff[bucket]);
+        if (slot < cap) {
+            level_items[(size_t)bucket * cap + slot] = it;
+        } else if constexpr (!HALF) {
+            T* dst = grad_table + ((size_t)lc.row0 + it.row) * C;
+            unsafeAtomicAdd(dst, it.a);
+            unsafeAtomicAdd(dst + 1, it.b);
+        }
+    }
+}
+
+// One (level, tile) item per workgroup; every XCD walks its own range of whole levels (make_plan). A workgroup's time is a chain of
+// memory round trips around ~3.5 us of arithmetic (with the input loads, the reservation atomics and the list stores each left out
+// in turn the round-4 kernel lost 21-25 % of its time, with all of them 55 %: profiles/r05_xcd_timeline_one_tile_per_workgroup.txt),
+// so the chain is kept short: inputs issued together (tile_load), the reservation's result not waited for before the write-out
+// (bin_tile), 48 registers without spills (Contrib<true>). Measured this round and NOT adopted, all bit-identical in their results:
+//   * a tile LOOP with the next tile's loads in flight (commit 71d704a): 87 registers = 6 waves per SIMD, 1083 us against 1034 us at
+//     B = 3.26 M (at 64 registers it spilled 24 words: 2158 us) — profiles/r05_xcd_timeline_k1_tile_loop_variant.txt;
+//   * the same loop software-pipelined at 64 registers without spills (commit 6b153e7: previous tile's write-out and reservation
+//     results one tile behind, one memory wait per iteration): 984-1056 us against this kernel's 898-926 us — the loop's own
+//     overhead (item bookkeeping, 108 scalar-register spill moves, a higher arithmetic-only floor: 616 against 535 us) eats what the
+//     overlap gains, and the list stores still cost 13 % with nobody waiting for them: they are throughput, not latency
+//     (profiles/r05_xcd_timeline_k1_pipelined_loop_variant.txt);
+//   * fewer, longer reservations — 4096-row buckets and / or 1024-sample tiles (half as many atomics, 192-byte runs): K1 unchanged
+//     (907 us) or slower (978-1020 us), K2 twice as slow with 64 KB of accumulators (profiles/r05_scatter_bucket_tile_variants.txt);
+//     tools/ubench/write_streams.hip says why the runs do not help yet: 96-byte and 192-byte runs write at 2.2-2.4 TB/s, the jump
+//     to 4.8-5.4 TB/s comes at 384 bytes (profiles/r05_write_streams_ubench.txt).
+// (second bound = waves per SIMD: 8, i.e. 4 workgroups per CU, which the 30 KB of LDS allow)
 template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
 __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,
                                                                const float* __restrict__ inputs,
@@ -347,151 +447,30 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename 
                                                                uint32_t B, uint32_t L, uint32_t b0, uint32_t b1,
                                                                GridPlan plan, BinPlan bin, BinLevels lv, int grad_layout,
                                                                uint32_t* __restrict__ cursors,
-                                                               Item<HALF>* __restrict__ items, RowLimit rl, StencilSrc src, uint32_t stride) {
-    using T = typename Elem<HALF>::type;
-    constexpr uint32_t C = 2, NCORN = 8;
-    constexpr uint32_t NIT = HALF ? NCORN / 2 : NCORN;   // items of a lane: one per corner (float tables) or per x-pair of corners (half tables)
+                                                               Item<HALF>* __restrict__ items, RowLimit rl, StencilSrc src) {
     __shared__ uint32_t hist[kMaxBucketsPerLevel];
     __shared__ uint32_t gbase[kMaxBucketsPerLevel];
     __shared__ uint32_t boff[kMaxBucketsPerLevel];
     __shared__ uint32_t wave_tot[kBinThreads / 64];
     __shared__ uint32_t block_total;
     __shared__ Item<HALF> stage[kBinThreads * (HALF ? 4 : 8)];   // 24 KiB (half: 4 pair items per sample) / 48 KiB (float items)
-    const int lane = lane_id();
 
-    // this XCD's range of items (workgroups are dealt to the XCDs round-robin: plan_item)
-    const uint32_t xcd = blockIdx.x % kXcds;
-    const uint32_t first = plan.start[xcd], n_items = plan.end[xcd] - first;
+    uint32_t level, tile;
+    if (!plan_item(plan, blockIdx.x, level, tile)) return;   // wave-uniform (depends on blockIdx only)
+    // a tile of padding rows (sdfx_set_row_limit) has nothing to scatter
     const RowLimitNow rln = row_limit_now(rl);
-    auto item_at = [&](uint32_t it, uint32_t& level, uint32_t& tile) {
-        const uint32_t item = first + it, virt = item / plan.tiles;
-        level = plan.order[virt];
-        tile = item - virt * plan.tiles;
-    };
-    // the next item at or after `it` (in steps of `stride`) that is not a tile of padding rows (sdfx_set_row_limit); workgroup-uniform
-    auto next_live = [&](uint32_t it, uint32_t& level, uint32_t& tile) {
-        for (; it < n_items; it += stride) {
-            item_at(it, level, tile);
-            if (!rows_dead(rln, b0 + tile * kBinThreads, kBinThreads)) break;
-        }
-        return it;
-    };
-    // D: the staged items of a tile of level `lvl` go to their lists
-    auto write_out = [&](uint32_t lvl) {
-        const uint32_t cap = bin.cap[lvl];
-        Item<HALF>* level_items = items + (size_t)bin.item_first[lvl] * 1024u;
-        const uint32_t total = SDFX_ABLATE(3u) ? 0u : block_total;
-        for (uint32_t k = threadIdx.x; k < total; k += kBinThreads) {
-            const Item<HALF> it = stage[k];
-            const uint32_t bucket = it.bucket();
-            const uint32_t slot = gbase[bucket] + (k - boff[bucket]);
-            // A slot at or beyond the list's capacity: half tables drop the item — the cursor keeps counting, cursor > cap tells K2 to
-            // take the bucket's sum from its spill accumulator, which k_grid_bwd_spill fills with ALL of the bucket's contributions
-            // (exact); float tables add with the reference's float atomics.
-            if (slot < cap) {
-                level_items[(size_t)bucket * cap + slot] = it;
-            } else if constexpr (!HALF) {
-                T* dst = grad_table + ((size_t)lv.lv[lvl].row0 + it.row) * C;
-                unsafeAtomicAdd(dst, it.a);
-                unsafeAtomicAdd(dst + 1, it.b);
-            }
-        }
-    };
-
-    uint32_t level = 0, tile = 0;
-    uint32_t it = next_live(blockIdx.x / kXcds, level, tile);
-    if (it >= n_items) return;
+    if (rows_dead(rln, b0 + tile * kBinThreads, kBinThreads)) return;
     SDFX_STAMP_BEGIN
-    for (uint32_t i = threadIdx.x; i < kMaxBucketsPerLevel; i += kBinThreads) hist[i] = 0;
-    TileIn cur;
-    tile_load<HALF>(grad, inputs, B, L, b0, b1, level, tile, grad_layout, rln, src, cur);
-    // (the first tile's loads are waited for HERE: left pending into the loop, their wait would sit at the top of every iteration —
-    // in front of the arithmetic that is there to cover the previous tile's reservations and stores)
-    asm volatile("" : "+v"(cur.x[0]), "+v"(cur.x[1]), "+v"(cur.x[2]), "+v"(cur.g[0]), "+v"(cur.g[1]));
-    bool have_prev = false;
-    uint32_t plevel = 0, pnb = 0, my_base = 0, n_done = 0;
-    __syncthreads();
-    for (;;) {
-        // ---- A: the next tile's inputs
-        uint32_t nlevel = 0, ntile = 0;
-        const uint32_t nit = next_live(it + stride, nlevel, ntile);
-        TileIn nxt;
-        nxt.x[0] = nxt.x[1] = nxt.x[2] = 0.f; nxt.g[0] = nxt.g[1] = 0u; nxt.ok = false;
-        if (nit < n_items) tile_load<HALF>(grad, inputs, B, L, b0, b1, nlevel, ntile, grad_layout, rln, src, nxt);
-        // ---- B: this tile's contributions and their ranks in the histogram
-        const LevelConst lc = lv.lv[level];
-        Contrib<HALF> c;
-        if ((bin.merge_mask >> level) & 1u)   // workgroup-uniform; all lanes take part in the DPP exchanges
-            tile_compute<HALF, INTERP, ALIGN, HASHGRID, true>(cur, b0, tile, lc, src, c);
-        else
-            tile_compute<HALF, INTERP, ALIGN, HASHGRID, false>(cur, b0, tile, lc, src, c);
-        // bucket of item i of this lane, and whether the pair straddles two buckets (dense levels, rarely): cheap, so formed where they
-        // are used (B and H) instead of being carried in registers across D and F
-        auto bucket_of = [&](uint32_t i) { return (HALF ? c.rows[2 * i] : c.rows[i]) >> kBucketRowsLog2; };
-        uint32_t rank[NIT];
-        if (c.emit) {
-#pragma unroll
-            for (uint32_t i = 0; i < NIT; i++) rank[i] = SDFX_ABLATE(8u) ? 0u : atomicAdd(&hist[bucket_of(i)], 1u);  // LDS
-        }
-        // the iteration's one wait on memory: the previous tile's reservations (issued a whole tile ago) and the loads of A
-        if (have_prev && threadIdx.x < pnb) gbase[threadIdx.x] = my_base;
-        asm volatile("" : "+v"(nxt.x[0]), "+v"(nxt.x[1]), "+v"(nxt.x[2]), "+v"(nxt.g[0]), "+v"(nxt.g[1]));
-        __syncthreads();
-        // ---- D: the previous tile's items to their lists
-        if (have_prev) write_out(plevel);
-        __syncthreads();
-        // ---- F: one global atomic per non-empty bucket reserves a slice of the bucket's list (its result is needed in the NEXT
-        // iteration); an exclusive prefix sum of the histogram = where each bucket's items go in the staging area; histogram cleared
-        const uint32_t bucket0 = bin.bucket_first[level];
-        const uint32_t nb = bin.bucket_first[level + 1] - bucket0;
-        uint32_t my_cnt = 0;
-        my_base = 0;
-        if (threadIdx.x < nb) {
-            my_cnt = hist[threadIdx.x];
-            hist[threadIdx.x] = 0;
-            if (my_cnt && !SDFX_ABLATE(4u)) my_base = atomicAdd(&cursors[bucket0 + threadIdx.x], my_cnt);
-        }
-        {   // nb <= kMaxBucketsPerLevel <= kBinThreads: thread b scans bucket b (wave scan + per-wave totals)
-            const uint32_t incl = wave_incl_sum_u32(my_cnt, lane);
-            if (lane == (int)kWave - 1) wave_tot[threadIdx.x >> 6] = incl;
-            __syncthreads();
-            uint32_t woff = 0;
-            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) woff += wave_tot[w];
-            if (threadIdx.x < nb) boff[threadIdx.x] = woff + incl - my_cnt;
-            if (threadIdx.x == kBinThreads - 1) block_total = woff + incl;
-        }
-        __syncthreads();
-        // ---- H: stage the items in LDS grouped by bucket: consecutive staging slots of one bucket go to consecutive slots of its
-        // list, so a wave store of D covers a few contiguous runs instead of 64 unrelated writes
-        if (c.emit && !SDFX_ABLATE(2u)) {
-            const uint32_t cap = bin.cap[level];
-#pragma unroll
-            for (uint32_t i = 0; i < NIT; i++) {
-                const uint32_t ib = bucket_of(i);
-                if constexpr (HALF) {
-                    const uint32_t v0 = c.h[2 * i], v1 = c.h[2 * i + 1];
-                    const uint32_t bb = c.rows[2 * i + 1] >> kBucketRowsLog2;
-                    const bool split = bb != ib;
-                    stage[boff[ib] + rank[i]] = make_pair_item(c.rows[2 * i], split ? c.rows[2 * i] : c.rows[2 * i + 1], v0, split ? 0u : v1);
-                    if (split) {   // the second corner goes to its own bucket's list by a one-slot reservation of this lane
-                        const uint32_t slot = atomicAdd(&cursors[bucket0 + bb], 1u);
-                        if (slot < cap) (items + (size_t)bin.item_first[level] * 1024u)[(size_t)bb * cap + slot] = make_pair_item(c.rows[2 * i + 1], c.rows[2 * i + 1], v1, 0u);
-                    }
-                } else {
-                    stage[boff[ib] + rank[i]] = Item<false>::make(c.rows[i], c.v[i].x, c.v[i].y);
-                }
-            }
-        }
-        have_prev = true; plevel = level; pnb = nb;
-        n_done++;
-        if (nit >= n_items) break;
-        cur = nxt; it = nit; level = nlevel; tile = ntile;
-    }
-    // the last tile
-    if (threadIdx.x < pnb) gbase[threadIdx.x] = my_base;
-    __syncthreads();
-    write_out(plevel);
-    SDFX_STAMP_END(2u, plevel, n_done)
+    TileIn in;
+    tile_load<HALF>(grad, inputs, B, L, b0, b1, level, tile, grad_layout, rln, src, in);
+    const LevelConst lc = lv.lv[level];
+    if ((bin.merge_mask >> level) & 1u)   // workgroup-uniform; all lanes take part in the DPP exchanges
+        bin_tile<HALF, INTERP, ALIGN, HASHGRID, true>(in, grad_table, b0, level, tile, lc, bin, cursors, items, src, hist, gbase, boff, wave_tot,
+                                                      &block_total, stage);
+    else
+        bin_tile<HALF, INTERP, ALIGN, HASHGRID, false>(in, grad_table, b0, level, tile, lc, bin, cursors, items, src, hist, gbase, boff, wave_tot,
+                                                       &block_total, stage);
+    SDFX_STAMP_END(2u, level, tile)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -590,6 +569,10 @@ struct ReduceJob {
 // workgroup -> (level, bucket, split) and its slice of the bucket's item list; false if there is nothing to do
 template <bool HALF>
 __device__ __forceinline__ bool reduce_job(const BinPlan& bin, const uint32_t* __restrict__ cursors, ReduceJob& j) {
+    // (K2's workgroups are launched level by level, coarse to fine. Launching the longest-running ones — the finest levels, 4 items
+    // per point — first, so that the short ones fill the tail, was measured this round and is 5 % SLOWER: K2 streams its lists at
+    // the HBM read rate — 1.34 GB in 340 us — and the fine levels' workgroups all running at once slow each other, 95 -> 150-170 us
+    // apiece: profiles/r05_scatter_k2_per_level.txt)
     uint32_t level = 0;
     while (level + 1 < bin.levels && blockIdx.x >= bin.split_first[level + 1]) level++;
     const uint32_t splits = bin.splits[level];
@@ -667,7 +650,8 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
             // channel-major accumulators (acc[ch * kBucketRows + row]): a 64-bit slot covers two banks, so with the two channels of
             // a row side by side only rows 0..7 (mod 8) are distinct bank groups — 64 random rows collide 8 ways on average; with
             // one array per channel it is rows mod 16
-            const uint32_t r = row & (kBucketRows - 1);
+            uint32_t r = row & (kBucketRows - 1);
+            if (SDFX_ABLATE(64u)) r = (r ^ (threadIdx.x * 37u)) & (kBucketRows - 1);   // measurement: no two lanes of a wave on one row
             if (lo & 0x7FFFu) atomicAdd(&acc[r], (unsigned long long)half_to_fixed(lo));      // ds_add_u64
             if (hi & 0x7FFFu) atomicAdd(&acc[kBucketRows + r], (unsigned long long)half_to_fixed(hi));
         };
@@ -1084,18 +1068,11 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         memset(&lv, 0, sizeof(lv));
         for (uint32_t l = 0; l < max_level; l++) lv.lv[l] = make_level_const(offsets_host, l, S, H);
         const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
-        // K1's launch: `k1_stride` workgroups per XCD — what is resident at once, 4 per CU — walk that XCD's items (k_grid_bwd_bin);
-        // never more than the items there are (SDFX_GRIDBWD_K1_STRIDE: measurement aid)
-        const uint32_t k1_stride = [&] {
-            const uint32_t want = (uint32_t)dev_switch("SDFX_GRIDBWD_K1_STRIDE", (int)kBinWorkgroupsPerXcd);
-            const uint32_t longest = grid1 / kXcds;
-            return want < 1u ? 1u : (want < longest ? want : longest);
-        }();
 #define SDFX_BIN(HALF_, INTERP_, ALIGN_, HASH_)                                                                                   \
-    hipLaunchKernelGGL((k_grid_bwd_bin<HALF_, INTERP_, ALIGN_, HASH_>), dim3(k1_stride * kXcds), dim3(kBinThreads), 0, st,       \
+    hipLaunchKernelGGL((k_grid_bwd_bin<HALF_, INTERP_, ALIGN_, HASH_>), dim3(grid1), dim3(kBinThreads), 0, st,                    \
                        static_cast<const typename Elem<HALF_>::type*>(grad), inputs,                                              \
                        static_cast<typename Elem<HALF_>::type*>(grad_embeddings), B, L, b0, b1, plan, bin, lv, grad_layout,        \
-                       cursors, static_cast<Item<HALF_>*>(items), row_limit(), stencil_src(), k1_stride)
+                       cursors, static_cast<Item<HALF_>*>(items), row_limit(), stencil_src())
 #define SDFX_BIN_SEL(HALF_)                                                                                                       \
     switch (sel) {                                                                                                                \
         case 0: SDFX_BIN(HALF_, 0u, false, false); break;                                                                         \

@@ -355,6 +355,26 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
         for (uint32_t l = levels; l-- > 0;) units[nu++] = {l, lines[l] > valu_lines ? lines[l] : valu_lines};
     }
 
+    // measurement aids (devtools build): SDFX_GRID_ONLY_LEVEL = l: the launch evaluates level l alone, spread over all eight XCDs (what
+    // a tile of that level costs with the whole GPU on it: tools/xcd_timeline.py); SDFX_GRID_LEVEL_COST = "c0,c1,...": cost per tile by level
+    {
+        const int only = dev_switch("SDFX_GRID_ONLY_LEVEL", -1);
+        if (only >= 0 && (uint32_t)only < levels) { units[0] = {(uint32_t)only, 1.0}; nu = 1; }
+        if (const char* e = dev_string("SDFX_GRID_LEVEL_COST")) {
+            double c[kMaxLevels];
+            uint32_t n = 0;
+            while (*e && n < kMaxLevels) {
+                char* end = nullptr;
+                const double v = strtod(e, &end);
+                if (end == e) break;
+                c[n++] = v;
+                e = (*end == ',') ? end + 1 : end;
+            }
+            for (uint32_t u = 0; u < nu; u++)
+                if (units[u].level < n && c[units[u].level] > 0) units[u].cost = c[units[u].level];
+        }
+    }
+
     // ---- cut the sequence into 8 ranges of equal cost ----
     double total = 0;
     for (uint32_t u = 0; u < nu; u++) total += units[u].cost * T;

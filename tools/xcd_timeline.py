@@ -108,9 +108,42 @@ print(f"samples M = {M} ({views} views), stencil batch B = {B}")
 print(f"encode forward  {timed(fwd):8.1f} us/launch (events, 5 launches)  = {B * 588 / timed(fwd) / 1e3 / 8000:.3f} of 8 TB/s at 588 B/point")
 print(f"scatter (K1+K2+K3+zeroing) {timed(bwd):8.1f} us/launch")
 report(stamped(fwd), 1, "encode forward")
+if os.environ.get("FWD_LEVELS", "1") == "1":
+    print("== encode forward, ONE level per launch on the whole GPU (SDFX_GRID_ONLY_LEVEL): us per launch, ns per 256-thread tile, relative to level 0")
+    iso = []
+    for l in range(16):
+        with _sdfx.dev_switch(SDFX_GRID_ONLY_LEVEL=l):
+            iso.append(timed(fwd, 10))
+    tiles = -(-(-(-M // 9) * 64) // 256)
+    for l in range(16):
+        print(f"   level {l:2d}: {iso[l]:7.1f} us  {1e3 * iso[l] / tiles:6.2f} ns/tile  x{iso[l] / iso[0]:.2f}")
+    print(f"   sum over the levels {sum(iso):.1f} us = {sum(iso) / 8:.1f} us per XCD if split perfectly; all levels in one launch: {timed(fwd, 10):.1f} us")
+    print("   as SDFX_GRID_LEVEL_COST: " + ",".join(f"{v / iso[0] * 100:.0f}" for v in iso))
+    os.environ["SDFX_GRID_LEVEL_COST"] = ",".join(f"{v / iso[0] * 100:.0f}" for v in iso)
+    print(f"   with the split cut by these measured costs: {timed(fwd, 10):.1f} us per launch")
+    report(stamped(fwd), 1, "encode forward, split by the measured per-level costs")
+    del os.environ["SDFX_GRID_LEVEL_COST"]
 rec = stamped(bwd)
 report(rec, 2, "scatter K1")
 report(rec, 3, "scatter K2")
+# items per level (the bucket cursors at the head of the scratch: one uint32 per bucket, levels in order, 2048 rows per bucket) against
+# K2's workgroup time per level: where K2's time goes per item
+cur = _gridencoder._BINNED_SCRATCH[dev.index][-1][:65536].view(torch.int32).cpu().numpy()
+m3 = rec["kernel"] == 3
+dur3 = (rec["t1"][m3] - rec["t0"][m3]) / 100.0
+print("== K2 per level: pair items in the lists, summed workgroup time, ns of workgroup time per item")
+b_first = 0
+for l in range(16):
+    nb = -(-int(offsets_np[l + 1] - offsets_np[l]) // 2048)
+    n_items = int(cur[b_first:b_first + nb].sum()); b_first += nb
+    t = float(dur3[rec["level"][m3] == l].sum())
+    print(f"   level {l:2d}: buckets {nb:4d}  items {n_items:10d} ({n_items / B:5.2f} per point)  K2 workgroup time {t:9.1f} us  {1e3 * t / max(n_items, 1):6.2f} ns/item")
+with _sdfx.dev_switch(SDFX_DEV_ABLATE=64):
+    r64 = stamped(bwd)
+m = r64["kernel"] == 3
+d64 = (r64["t1"][m] - r64["t0"][m]) / 100.0
+print(f"== K2 with every lane of a wave on a different row (SDFX_DEV_ABLATE=64; wrong sums): span {(r64['t1'][m].max() - r64['t0'][m].min()) / 100.0:.1f} us; "
+      "workgroup time per level " + " ".join(f"{l}:{d64[r64['level'][m] == l].sum() / 1e3:.1f}ms" for l in range(16)))
 if os.environ.get("K1_STRIDES"):
     print("== K1 by workgroups per XCD (SDFX_GRIDBWD_K1_STRIDE)")
     for stride in [int(v) for v in os.environ["K1_STRIDES"].split(",")]:
