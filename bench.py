@@ -772,6 +772,16 @@ class stock_prior_ops:
         self.saved = [m._FUSED for m in self.mods]
         for m in self.mods:
             m._FUSED = 0
+        # the UNet's convolutions go to MIOpen in its immediate mode — PyTorch's own default (cudnn.benchmark = False); the VAE keeps
+        # the solvers found for it at start-up. A find-mode search over the UNet's ~40 convolution shapes would add two minutes to
+        # this pass for nothing: round 4 measured the latent phase the same in both modes
+        unet = self.prior.unet
+        self.unet_forward = unet.forward
+
+        def forward_immediate(*a, **k):
+            with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+                return self.unet_forward(*a, **k)
+        unet.forward = forward_immediate
         vae = getattr(self.prior, "vae", None)
         self.vae_cl = bool(getattr(vae, "channels_last_input", False))
         if self.vae_cl:
@@ -782,6 +792,7 @@ class stock_prior_ops:
     def __exit__(self, *exc):
         for m, v in zip(self.mods, self.saved):
             m._FUSED = v
+        self.prior.unet.forward = self.unet_forward
         if self.vae_cl:
             self.prior.vae.to(memory_format=torch.channels_last)
             self.prior.vae.channels_last_input = True

@@ -174,10 +174,17 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
         }
     }
 
-    auto wrap = [&](uint32_t idx) -> uint32_t {   // index % hashmap_size (gridencoder.cu:78)
-        if (pow2) return idx & (lc.size - 1u);
-        return idx < lc.size ? idx : idx % lc.size;
+    // index % hashmap_size (gridencoder.cu:78): a mask for a power-of-two size; nothing for a fully dense level (strides of all three
+    // axes fit: x + y res + z res^2 < res^3 <= size); a real modulo only for a level that is hashed, or tiled with a truncated
+    // stride, AND whose size is no power of two — a property of the level, decided on the scalar unit (make_level_const: flags)
+    const bool need_mod = (lc.flags & 3u) == 1u;
+    const uint32_t wmask = pow2 ? lc.size - 1u : 0xffffffffu;
+    auto wrap = [&](uint32_t idx) -> uint32_t {
+        idx &= wmask;
+        if (need_mod) idx %= lc.size;
+        return idx;
     };
+    const bool mul24 = (lc.flags & 4u) != 0u;   // 24-bit multiplies give the rows (full rate; the 32-bit multiply is quarter rate)
 
     // Phase 1: cell, weights and the row indices of the 4 x-pairs of every point (no memory access)
     float ax[P][2], ay[P][2], az[P][2];
@@ -200,16 +207,18 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
         ay[j][0] = 1 - pos[1]; ay[j][1] = pos[1];
         az[j][0] = 1 - pos[2]; az[j][1] = pos[2];
         uint32_t yz[4];   // (y, z) part of the row index for the four (y, z) corners (gridencoder.cu:45-79)
-        if (hashed) {
-            const uint32_t hy[2] = {pg[1] * 2654435761u, pn[1] * 2654435761u};
-            const uint32_t hz[2] = {pg[2] * 805459861u, pn[2] * 805459861u};
+        {
+            const uint32_t fy = hashed ? 2654435761u : lc.m1, fz = hashed ? 805459861u : lc.m2;
+            uint32_t ty[2], tz[2];
+            if (mul24) {
+                ty[0] = __umul24(pg[1], fy & 0xFFFFFFu); ty[1] = __umul24(pn[1], fy & 0xFFFFFFu);
+                tz[0] = __umul24(pg[2], fz & 0xFFFFFFu); tz[1] = __umul24(pn[2], fz & 0xFFFFFFu);
+            } else {
+                ty[0] = pg[1] * fy; ty[1] = pn[1] * fy;
+                tz[0] = pg[2] * fz; tz[1] = pn[2] * fz;
+            }
 #pragma unroll
-            for (int k = 0; k < 4; k++) yz[k] = hy[k & 1] ^ hz[k >> 1];
-        } else {
-            const uint32_t sy[2] = {pg[1] * lc.m1, pn[1] * lc.m1};
-            const uint32_t sz[2] = {pg[2] * lc.m2, pn[2] * lc.m2};
-#pragma unroll
-            for (int k = 0; k < 4; k++) yz[k] = sy[k & 1] + sz[k >> 1];
+            for (int k = 0; k < 4; k++) yz[k] = hashed ? (ty[k & 1] ^ tz[k >> 1]) : (ty[k & 1] + tz[k >> 1]);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
