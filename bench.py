@@ -493,7 +493,9 @@ def cpu_baseline(budget_s=30.0, probe_timeout_s=25.0):
     t_begin = time.perf_counter()
     probe, probe_txt, best = {}, {}, None
     for n in sorted({min(c, ncpu) for c in (32, 64, 128, ncpu)}):
-        sec, txt = _probe_threads(n, probe_timeout_s)
+        # (the large counts are known to be slower by an order of magnitude on this path: they get time to show one iteration that
+        # beats the small counts' ~1.5 s, not to finish three slow ones)
+        sec, txt = _probe_threads(n, probe_timeout_s if n <= 64 else min(probe_timeout_s, 12.0))
         probe_txt[str(n)] = txt
         if sec is not None:
             probe[n] = sec
