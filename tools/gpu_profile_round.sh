@@ -6,7 +6,7 @@ TAG=${1:-round}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
-CMD="python $REPO/bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-kernel-bench --no-reference-flow --no-nerf-only"
+CMD="python $REPO/bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-kernel-bench --no-reference-flow --no-nerf-only --no-children"
 # The counter passes serialise every kernel: with the 860 M-parameter UNet of the default prior (thousands of stock
 # PyTorch kernels per iteration, plus MIOpen's one-off solver search) one pass takes > 10 minutes. The kernels of this
 # repository are the same with the synthetic prior, so the PMC passes run that.
