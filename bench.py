@@ -816,6 +816,17 @@ def stock_prior_pass(job, step, plan, timed_pass):
         drop_graphs()
 
 
+CHILD_CORES = 16   # host cores set aside for the child runs while the parent times the CPU baseline on the others
+
+
+def _pin_child():
+    """The child runs (host-paced launches: the DMTet stage runs the reference's host flow) keep cores [0, CHILD_CORES) to themselves."""
+    try:
+        os.sched_setaffinity(0, set(range(min(CHILD_CORES, os.cpu_count() or 1))))
+    except (AttributeError, OSError):
+        pass
+
+
 def child_bench(extra, steps, timeout_s=420):
     """One more configuration of BASELINE.json as a CHILD run of this file (its own process: own model, prior and graphs): returns
     (the child's JSON line as a dict | None, seconds, error text)."""
@@ -825,7 +836,8 @@ def child_bench(extra, steps, timeout_s=420):
     t0 = time.perf_counter()
     try:
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s,
-                             env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+                             env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")},
+                             preexec_fn=_pin_child)
     except subprocess.TimeoutExpired:
         return None, time.perf_counter() - t0, f"timed out after {timeout_s} s"
     line = next((l for l in reversed(out.stdout.decode("utf-8", "replace").splitlines()) if l.startswith("{")), None)
@@ -1258,6 +1270,12 @@ def main():
         torch.cuda.empty_cache()
         child_thread = threading.Thread(target=run_children, daemon=True)
         child_thread.start()
+        try:     # ... and the CPU baseline (this process and its thread-probe children) keeps off the children's cores
+            ncpu = os.cpu_count() or 1
+            if ncpu > 2 * CHILD_CORES:
+                os.sched_setaffinity(0, set(range(CHILD_CORES, ncpu)))
+        except (AttributeError, OSError):
+            pass
     if world == 1 and not args.no_cpu_baseline:
         try:
             cb = cpu_baseline()
@@ -1286,7 +1304,7 @@ def main():
             result[name + "_config"] = ({"workload": line["config"]["workload"], "guidance": line["config"]["guidance"], "steps": line["steps"],
                                          "ms_per_step": line["ms_per_step"], "train_mode": line.get("train_mode"),
                                          "samples_per_iter": line.get("samples_per_iter"), "child_run_seconds": round(secs, 1),
-                                         "ran": "child process of this run, alone on the GPU while the parent timed the CPU baseline"}
+                                         "ran": f"child process of this run, alone on the GPU (host cores 0-{CHILD_CORES - 1}) while the parent timed the CPU baseline on the other cores"}
                                         if line else {"error": err, "child_run_seconds": round(secs, 1)})
     print(json.dumps(result))
     if dist is not None:
