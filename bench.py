@@ -866,6 +866,10 @@ def main():
         # convolution is timed once at its first call, +30-60 s before the first barrier) unless SDFX_CONV_FIND=0 (immediate mode,
         # the heuristic pick). Same box, round 4: RGB phase 39.8 -> 42.5 it/s (the VAE's large maps), latent phase unchanged.
         torch.backends.cudnn.benchmark = os.environ.get("SDFX_CONV_FIND", "1") == "1"
+        # ... without MIOpen's NAIVE reference solvers among the candidates it times: on the VAE's 512^2 maps one trial of them takes
+        # 40-55 ms, 12 s of the start-up in all (profiles/r05_bench_kernel_stats_sd15.csv: naive_conv_ab_nonpacked_*); they never win
+        for v in ("FWD", "BWD", "WRW"):
+            os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + v, "0")
         dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
