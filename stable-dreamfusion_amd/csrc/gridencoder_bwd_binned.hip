@@ -53,7 +53,7 @@ static_assert(kMaxBucketsPerLevel <= kBinThreads, "K1 scans the bucket histogram
 constexpr uint32_t kReduceThreads = SDFX_BUCKET_LOG2 >= 12 ? 128 : 256;   // (float tables: per-wave private accumulators must fit the LDS)
 constexpr uint32_t kItemsPerSplit = 131072;              // a bucket holding more items than this is reduced by several workgroups
 constexpr uint32_t kItemsPerSplitCoarse = 65536;         // ... for levels of few buckets, each of which gets a large share of the batch
-constexpr uint32_t kCoarseBuckets = 128;
+constexpr uint32_t kCoarseBuckets = 128u >> (SDFX_BUCKET_LOG2 - 11);   // (levels of at most 2^18 rows, whatever the bucket size)
 constexpr uint32_t kMaxSplits = 512;
 constexpr uint32_t kNoSharedAcc = 0xFFFFFFFFu;
 
