@@ -436,7 +436,7 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::
 //     overlap gains, and the list stores still cost 13 % with nobody waiting for them: they are throughput, not latency
 //     (profiles/r05_xcd_timeline_k1_pipelined_loop_variant.txt);
 //   * fewer, longer reservations — 4096-row buckets and / or 1024-sample tiles (half as many atomics, 192-byte runs): K1 unchanged
-//     (907 us) or slower (978-1020 us), K2 twice as slow with 64 KB of accumulators (profiles/r05_scatter_bucket_tile_variants.txt);
+//     (896-920 us) or slower (978-1020 us), K2 385 us with 64 KB of accumulators against 340-366 (profiles/r05_scatter_bucket_tile_variants.txt);
 //     tools/ubench/write_streams.hip says why the runs do not help yet: 96-byte and 192-byte runs write at 2.2-2.4 TB/s, the jump
 //     to 4.8-5.4 TB/s comes at 384 bytes (profiles/r05_write_streams_ubench.txt).
 // (second bound = waves per SIMD: 8, i.e. 4 workgroups per CU, which the 30 KB of LDS allow)
