@@ -35,20 +35,22 @@ DevCtl dev_ctl_host();            // sdfx_core.hip: what sdfx_dev_stamps / sdfx_
     }
 
 #if defined(__HIPCC__)
-__device__ __forceinline__ void stamp_end(const DevCtl& c, unsigned long long t0, uint32_t kernel, uint32_t level, uint32_t tile) {
+__device__ __forceinline__ void stamp_end(const DevCtl& c, unsigned long long t0, uint32_t kernel, uint32_t level, uint32_t tile,
+                                          uint32_t slot) {
     if (!c.stamps || threadIdx.x != 0) return;
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     uint32_t xcc, hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    if (blockIdx.x >= c.cap || kernel < 1u || kernel > 3u) return;
-    unsigned long long* r = c.stamps + 2 + ((unsigned long long)(kernel - 1u) * c.cap + blockIdx.x) * 4;
+    if (slot >= c.cap || kernel < 1u || kernel > 3u) return;
+    unsigned long long* r = c.stamps + 2 + ((unsigned long long)(kernel - 1u) * c.cap + slot) * 4;
     r[0] = t0; r[1] = t1;
     r[2] = (unsigned long long)(kernel | (level << 8) | ((xcc & 15u) << 16)) | ((unsigned long long)hwid << 32);
     r[3] = (unsigned long long)tile | ((unsigned long long)blockIdx.x << 32);
 }
 #define SDFX_STAMP_BEGIN const unsigned long long stamp_t0_ = g_dev_ctl.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
-#define SDFX_STAMP_END(kernel, level, tile) ::sdfx::stamp_end(g_dev_ctl, stamp_t0_, (kernel), (level), (tile));
+#define SDFX_STAMP_END(kernel, level, tile) ::sdfx::stamp_end(g_dev_ctl, stamp_t0_, (kernel), (level), (tile), blockIdx.x);
+#define SDFX_STAMP_END_AT(kernel, level, tile, slot) ::sdfx::stamp_end(g_dev_ctl, stamp_t0_, (kernel), (level), (tile), (slot));
 #define SDFX_ABLATE(bit) ((g_dev_ctl.ablate & (bit)) != 0u)
 #endif
 
@@ -59,6 +61,7 @@ __device__ __forceinline__ void stamp_end(const DevCtl& c, unsigned long long t0
 #define SDFX_DEV_CTL_DEFINE static inline void dev_ctl_sync() {}
 #define SDFX_STAMP_BEGIN
 #define SDFX_STAMP_END(kernel, level, tile)
+#define SDFX_STAMP_END_AT(kernel, level, tile, slot)
 #define SDFX_ABLATE(bit) false
 
 #endif

@@ -31,6 +31,9 @@
 #include "grid_point.h"
 #include "dev_stamps.h"
 
+#include <map>
+#include <mutex>
+
 using namespace sdfx;
 using namespace sdfx::grid;
 
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename 
     else
         bin_tile<HALF, INTERP, ALIGN, HASHGRID, false>(in, grad_table, b0, level, tile, lc, bin, cursors, items, src, hist, gbase, boff, wave_tot,
                                                        &block_total, stage);
-    SDFX_STAMP_END(2u, level, tile)
+    SDFX_STAMP_END_AT(2u, level, tile, level * plan.tiles + tile)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -480,14 +483,17 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename 
 __device__ uint32_t g_spill_totals[2];
 
 // one workgroup per bucket: zero the spill accumulator of an overflowed bucket and raise the launch's `any` flag
+// (`bucket_lo`: first bucket of the launch's group of levels, `flag`: that group's word of `diag` — see the two-group launch below)
 __global__ __launch_bounds__(256) void k_grid_bwd_spill_zero(BinPlan bin, const uint32_t* __restrict__ cursors,
-                                                             unsigned long long* __restrict__ spill_acc, uint32_t* __restrict__ diag) {
+                                                             unsigned long long* __restrict__ spill_acc, uint32_t* __restrict__ diag,
+                                                             uint32_t bucket_lo, uint32_t flag) {
+    const uint32_t gb = blockIdx.x + bucket_lo;
     uint32_t level = 0;
-    while (level + 1 < bin.levels && blockIdx.x >= bin.bucket_first[level + 1]) level++;
-    if (cursors[blockIdx.x] <= bin.cap[level]) return;
-    for (uint32_t i = threadIdx.x; i < kSpillWords; i += 256) spill_acc[(size_t)blockIdx.x * kSpillWords + i] = 0ull;
+    while (level + 1 < bin.levels && gb >= bin.bucket_first[level + 1]) level++;
+    if (cursors[gb] <= bin.cap[level]) return;
+    for (uint32_t i = threadIdx.x; i < kSpillWords; i += 256) spill_acc[(size_t)gb * kSpillWords + i] = 0ull;
     if (threadIdx.x == 0) {
-        diag[0] = 1u;             // some bucket overflowed (benign race: every writer stores 1)
+        diag[flag] = 1u;          // some bucket of the group overflowed (benign race: every writer stores 1)
         atomicAdd(&diag[1], 1u);  // how many (sdfx_grid_encode_backward_binned_stats)
         atomicAdd(&g_spill_totals[0], 1u);
     }
@@ -520,8 +526,8 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_spill(const __half* __
                                                                 uint32_t b1, GridPlan plan, BinPlan bin, BinLevels lv, int grad_layout,
                                                                 const uint32_t* __restrict__ cursors, RowLimit rl, StencilSrc src,
                                                                 unsigned long long* __restrict__ spill_acc,
-                                                                const uint32_t* __restrict__ diag, uint32_t k1_grid) {
-    if (diag[0] == 0u) return;   // no bucket overflowed: nearly every launch of the training loop ends here
+                                                                const uint32_t* __restrict__ diag, uint32_t k1_grid, uint32_t flag) {
+    if (diag[flag] == 0u) return;   // no bucket overflowed: nearly every launch of the training loop ends here
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_spill_totals[1], 1u);
     const RowLimitNow rln = row_limit_now(rl);
     for (uint32_t i = 0; i < kSpillTilesPerGroup; i++) {
@@ -568,15 +574,16 @@ struct ReduceJob {
 
 // workgroup -> (level, bucket, split) and its slice of the bucket's item list; false if there is nothing to do
 template <bool HALF>
-__device__ __forceinline__ bool reduce_job(const BinPlan& bin, const uint32_t* __restrict__ cursors, ReduceJob& j) {
+__device__ __forceinline__ bool reduce_job(const BinPlan& bin, const uint32_t* __restrict__ cursors, ReduceJob& j, uint32_t wg_lo = 0) {
+    const uint32_t wg = blockIdx.x + wg_lo;   // (a launch may cover the workgroups of a group of levels only)
     // (K2's workgroups are launched level by level, coarse to fine. Launching the longest-running ones — the finest levels, 4 items
     // per point — first, so that the short ones fill the tail, was measured this round and is 5 % SLOWER: K2 streams its lists at
     // the HBM read rate — 1.34 GB in 340 us — and the fine levels' workgroups all running at once slow each other, 95 -> 150-170 us
     // apiece: profiles/r05_scatter_k2_per_level.txt)
     uint32_t level = 0;
-    while (level + 1 < bin.levels && blockIdx.x >= bin.split_first[level + 1]) level++;
+    while (level + 1 < bin.levels && wg >= bin.split_first[level + 1]) level++;
     const uint32_t splits = bin.splits[level];
-    const uint32_t local = blockIdx.x - bin.split_first[level];
+    const uint32_t local = wg - bin.split_first[level];
     j.level = level;
     j.bucket = local / splits;
     j.gbucket = bin.bucket_first[level] + j.bucket;
@@ -620,10 +627,10 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
                                                                               const uint32_t* __restrict__ cursors,
                                                                               const Item<true>* __restrict__ items,
                                                                               unsigned long long* __restrict__ shared_acc,
-                                                                              const unsigned long long* __restrict__ spill_acc) {
+                                                                              const unsigned long long* __restrict__ spill_acc, uint32_t wg_lo) {
     __shared__ unsigned long long acc[kBucketRows * 2];  // 32 KiB
     ReduceJob j;
-    if (!reduce_job<true>(bin, cursors, j)) return;
+    if (!reduce_job<true>(bin, cursors, j, wg_lo)) return;
     SDFX_STAMP_BEGIN
     for (uint32_t i = threadIdx.x; i < kBucketRows * 2; i += kReduceThreadsFixed) acc[i] = 0ull;
     __syncthreads();
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
             // |sum| < 2^63 * 2^-24; the double is exact up to 2^53, the float conversion rounds once
             flush_row<true>(grad_table + ((size_t)row0 + row) * 2, fixed_to_float(ia), fixed_to_float(ib));
         }
-        SDFX_STAMP_END(3u, j.level, j.bucket)
+        SDFX_STAMP_END_AT(3u, j.level, j.bucket, blockIdx.x + wg_lo)
         return;
     }
     // Several workgroups share this bucket (a level of few buckets): they add their exact partial sums into a 64-bit
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
         if (spill) v += spill[i];
         if (v) atomicAdd(&gacc[i], v);
     }
-    SDFX_STAMP_END(3u, j.level, j.bucket | (j.split << 16))
+    SDFX_STAMP_END_AT(3u, j.level, j.bucket | (j.split << 16), blockIdx.x + wg_lo)
 }
 
 // K3: one workgroup per bucket of the levels of few buckets; buckets that were reduced by a single workgroup are done already
@@ -940,6 +947,60 @@ const float* k1_level_cost(uint32_t levels) {
     return table;
 }
 
+// ---- K2 of the fine levels beside K1 of the coarse ones -------------------------------------------------------------------------
+// One side stream and two events per device, created at first use (the trainer's eager warm-up iterations come before its graph
+// captures; inside a capture the fork / join below makes the side stream part of the captured graph).
+struct Overlap { hipStream_t side; hipEvent_t fork, join; };
+Overlap* overlap_streams() {
+    if (dev_switch("SDFX_GRIDBWD_OVERLAP", 1) == 0) return nullptr;
+    static std::mutex m;
+    static std::map<int, Overlap> per_device;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(m);
+    auto it = per_device.find(dev);
+    if (it == per_device.end()) {
+        Overlap o{};
+        if (hipStreamCreateWithFlags(&o.side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&o.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&o.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            o = Overlap{};
+        }
+        it = per_device.emplace(dev, o).first;
+    }
+    return it->second.side ? &it->second : nullptr;
+}
+
+// Can the plan be cut into a FINE group (levels >= lvl_split, walked first by every XCD) and a COARSE group (the rest, walked after)?
+// True for the -O grid (16 levels: XCD k walks level 15 - k, then level k). `fine` / `coarse` = the plan restricted to each group.
+// The levels whose buckets are split over several K2 workgroups (shared accumulators, rounded by K3) must all be coarse.
+bool two_level_groups(const GridPlan& p, const BinPlan& bin, uint32_t levels, GridPlan& fine, GridPlan& coarse, uint32_t& lvl_split) {
+    if (levels < 2 || p.tiles == 0) return false;
+    lvl_split = levels / 2;
+    fine = p; coarse = p;
+    for (uint32_t k = 0; k < kXcds; k++) {
+        uint32_t mid = p.end[k];
+        bool seen_coarse = false;
+        for (uint32_t item = p.start[k]; item < p.end[k];) {
+            const uint32_t virt = item / p.tiles, level = p.order[virt];
+            const uint32_t seg_end = (virt + 1) * p.tiles < p.end[k] ? (virt + 1) * p.tiles : p.end[k];
+            if (level >= lvl_split) {
+                if (seen_coarse) return false;            // fine after coarse on this XCD
+            } else if (!seen_coarse) {
+                seen_coarse = true;
+                mid = item;
+            }
+            item = seg_end;
+        }
+        fine.end[k] = mid;
+        coarse.start[k] = mid;
+    }
+    for (uint32_t l = lvl_split; l < levels; l++)
+        if (bin.acc_first[l] != kNoSharedAcc) return false;
+    return true;
+}
+
 // SDFX_GRIDBWD_BALANCE=1 (devtools build): cost-balanced ranges; default: equal tile counts
 bool k1_balance_enabled() {
     return dev_switch("SDFX_GRIDBWD_BALANCE", 0) == 1;
@@ -1063,58 +1124,85 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
         unsigned long long* spill_acc = reinterpret_cast<unsigned long long*>(base + lay.spill_offset);
         uint32_t* diag = reinterpret_cast<uint32_t*>(base + kDiagOffset);
         zero_device(scratch, lay.cleared_bytes, st);  // cursors, diagnostics, shared accumulators
-        const uint32_t grid1 = plan_grid_size(plan);
         BinLevels lv;
         memset(&lv, 0, sizeof(lv));
         for (uint32_t l = 0; l < max_level; l++) lv.lv[l] = make_level_const(offsets_host, l, S, H);
         const int sel = (interp ? 4 : 0) | (align_corners ? 2 : 0) | (gridtype == 0 ? 1 : 0);
-#define SDFX_BIN(HALF_, INTERP_, ALIGN_, HASH_)                                                                                   \
-    hipLaunchKernelGGL((k_grid_bwd_bin<HALF_, INTERP_, ALIGN_, HASH_>), dim3(grid1), dim3(kBinThreads), 0, st,                    \
+#define SDFX_BIN(HALF_, INTERP_, ALIGN_, HASH_, PLAN_, STREAM_)                                                                    \
+    hipLaunchKernelGGL((k_grid_bwd_bin<HALF_, INTERP_, ALIGN_, HASH_>), dim3(plan_grid_size(PLAN_)), dim3(kBinThreads), 0, STREAM_, \
                        static_cast<const typename Elem<HALF_>::type*>(grad), inputs,                                              \
-                       static_cast<typename Elem<HALF_>::type*>(grad_embeddings), B, L, b0, b1, plan, bin, lv, grad_layout,        \
+                       static_cast<typename Elem<HALF_>::type*>(grad_embeddings), B, L, b0, b1, PLAN_, bin, lv, grad_layout,       \
                        cursors, static_cast<Item<HALF_>*>(items), row_limit(), stencil_src())
-#define SDFX_BIN_SEL(HALF_)                                                                                                       \
+#define SDFX_BIN_SEL(HALF_, PLAN_, STREAM_)                                                                                       \
     switch (sel) {                                                                                                                \
-        case 0: SDFX_BIN(HALF_, 0u, false, false); break;                                                                         \
-        case 1: SDFX_BIN(HALF_, 0u, false, true); break;                                                                          \
-        case 2: SDFX_BIN(HALF_, 0u, true, false); break;                                                                          \
-        case 3: SDFX_BIN(HALF_, 0u, true, true); break;                                                                           \
-        case 4: SDFX_BIN(HALF_, 1u, false, false); break;                                                                         \
-        case 5: SDFX_BIN(HALF_, 1u, false, true); break;                                                                          \
-        case 6: SDFX_BIN(HALF_, 1u, true, false); break;                                                                          \
-        default: SDFX_BIN(HALF_, 1u, true, true); break;                                                                          \
+        case 0: SDFX_BIN(HALF_, 0u, false, false, PLAN_, STREAM_); break;                                                         \
+        case 1: SDFX_BIN(HALF_, 0u, false, true, PLAN_, STREAM_); break;                                                          \
+        case 2: SDFX_BIN(HALF_, 0u, true, false, PLAN_, STREAM_); break;                                                          \
+        case 3: SDFX_BIN(HALF_, 0u, true, true, PLAN_, STREAM_); break;                                                           \
+        case 4: SDFX_BIN(HALF_, 1u, false, false, PLAN_, STREAM_); break;                                                         \
+        case 5: SDFX_BIN(HALF_, 1u, false, true, PLAN_, STREAM_); break;                                                          \
+        case 6: SDFX_BIN(HALF_, 1u, true, false, PLAN_, STREAM_); break;                                                          \
+        default: SDFX_BIN(HALF_, 1u, true, true, PLAN_, STREAM_); break;                                                          \
     }
-        if (is_half) {
-            SDFX_BIN_SEL(true)
-            // the spill path: two launches that exit at once unless a bucket overflowed (see the head of the file)
-            hipLaunchKernelGGL(k_grid_bwd_spill_zero, dim3(nbuckets), dim3(256), 0, st, bin, cursors, spill_acc, diag);
-            const uint32_t grid_spill = div_up(grid1, kSpillTilesPerGroup);
-#define SDFX_SPILL(INTERP_, ALIGN_, HASH_)                                                                                        \
-    hipLaunchKernelGGL((k_grid_bwd_spill<INTERP_, ALIGN_, HASH_>), dim3(grid_spill), dim3(kBinThreads), 0, st,                    \
-                       static_cast<const __half*>(grad), inputs, static_cast<__half*>(grad_embeddings), B, L, b0, b1, plan, bin,  \
-                       lv, grad_layout, cursors, row_limit(), stencil_src(), spill_acc, diag, grid1)
+#define SDFX_SPILL(INTERP_, ALIGN_, HASH_, PLAN_, STREAM_, FLAG_)                                                                 \
+    hipLaunchKernelGGL((k_grid_bwd_spill<INTERP_, ALIGN_, HASH_>), dim3(div_up(plan_grid_size(PLAN_), kSpillTilesPerGroup)),      \
+                       dim3(kBinThreads), 0, STREAM_, static_cast<const __half*>(grad), inputs,                                   \
+                       static_cast<__half*>(grad_embeddings), B, L, b0, b1, PLAN_, bin, lv, grad_layout, cursors, row_limit(),    \
+                       stencil_src(), spill_acc, diag, plan_grid_size(PLAN_), FLAG_)
+        // K1 (+ the spill pair, which exits at once unless a bucket overflowed: see the head of the file) and K2 for the levels
+        // [lvl_lo, lvl_hi) of plan PLAN_ on stream STREAM_; FLAG_ = that group's overflow word of `diag`
+        auto half_group_k1 = [&](const GridPlan& gp, hipStream_t stream) { SDFX_BIN_SEL(true, gp, stream) };
+        auto half_group_k2 = [&](const GridPlan& gp, hipStream_t stream, uint32_t lvl_lo, uint32_t lvl_hi, uint32_t flag) {
+            const uint32_t bk_lo = bin.bucket_first[lvl_lo], bk_hi = bin.bucket_first[lvl_hi];
+            const uint32_t wg_lo = bin.split_first[lvl_lo], wg_hi = bin.split_first[lvl_hi];
+            if (bk_hi == bk_lo) return;
+            hipLaunchKernelGGL(k_grid_bwd_spill_zero, dim3(bk_hi - bk_lo), dim3(256), 0, stream, bin, cursors, spill_acc, diag, bk_lo, flag);
             switch (sel) {
-                case 0: SDFX_SPILL(0u, false, false); break;
-                case 1: SDFX_SPILL(0u, false, true); break;
-                case 2: SDFX_SPILL(0u, true, false); break;
-                case 3: SDFX_SPILL(0u, true, true); break;
-                case 4: SDFX_SPILL(1u, false, false); break;
-                case 5: SDFX_SPILL(1u, false, true); break;
-                case 6: SDFX_SPILL(1u, true, false); break;
-                default: SDFX_SPILL(1u, true, true); break;
+                case 0: SDFX_SPILL(0u, false, false, gp, stream, flag); break;
+                case 1: SDFX_SPILL(0u, false, true, gp, stream, flag); break;
+                case 2: SDFX_SPILL(0u, true, false, gp, stream, flag); break;
+                case 3: SDFX_SPILL(0u, true, true, gp, stream, flag); break;
+                case 4: SDFX_SPILL(1u, false, false, gp, stream, flag); break;
+                case 5: SDFX_SPILL(1u, false, true, gp, stream, flag); break;
+                case 6: SDFX_SPILL(1u, true, false, gp, stream, flag); break;
+                default: SDFX_SPILL(1u, true, true, gp, stream, flag); break;
             }
-#undef SDFX_SPILL
-            hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(nsplits), dim3(kReduceThreadsFixed), 0, st,
+            hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(wg_hi - wg_lo), dim3(kReduceThreadsFixed), 0, stream,
                                static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items),
-                               shared_acc, spill_acc);
+                               shared_acc, spill_acc, wg_lo);
+        };
+        if (is_half) {
+            // Two groups of levels when the plan allows (the -O grid: every XCD walks one level of the fine half, then one of the
+            // coarse half): K2 of the FINE half — three quarters of the items, a stream of HBM reads into LDS atomics — runs on a side
+            // stream beside K1 of the COARSE half (a latency chain writing short runs): the two leave each other's resources idle.
+            //   main:  zero, K1(fine) -e1-> K1(coarse), [spill pair], ............. -e2-> K2(coarse), K3
+            //   side:            -e1-> [spill pair], K2(fine) -e2->
+            GridPlan fine, coarse;
+            uint32_t lvl_split = 0;
+            Overlap* ov = two_level_groups(plan, bin, max_level, fine, coarse, lvl_split) ? overlap_streams() : nullptr;
+            if (ov && hipEventRecord(ov->fork, st) != hipSuccess) ov = nullptr;   // (nothing launched yet beyond the zeroing)
+            if (ov) {
+                half_group_k1(fine, st);
+                (void)hipEventRecord(ov->fork, st);
+                (void)hipStreamWaitEvent(ov->side, ov->fork, 0);
+                half_group_k2(fine, ov->side, lvl_split, max_level, 0u);
+                (void)hipEventRecord(ov->join, ov->side);
+                half_group_k1(coarse, st);
+                (void)hipStreamWaitEvent(st, ov->join, 0);
+                half_group_k2(coarse, st, 0u, lvl_split, 2u);
+            } else {
+                half_group_k1(plan, st);
+                half_group_k2(plan, st, 0u, max_level, 0u);
+            }
             if (coarse_buckets)
                 hipLaunchKernelGGL(k_grid_bwd_finish, dim3(coarse_buckets), dim3(256), 0, st, static_cast<__half*>(grad_embeddings),
                                    plan, bin, cursors, shared_acc);
         } else {
-            SDFX_BIN_SEL(false)
+            SDFX_BIN_SEL(false, plan, st)
             hipLaunchKernelGGL(k_grid_bwd_reduce_ticket, dim3(nsplits), dim3(kReduceThreads), kReduceLdsBytes, st,
                                static_cast<float*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<false>*>(items));
         }
+#undef SDFX_SPILL
 #undef SDFX_BIN_SEL
 #undef SDFX_BIN
     }

@@ -123,6 +123,9 @@ if os.environ.get("FWD_LEVELS", "1") == "1":
     print(f"   with the split cut by these measured costs: {timed(fwd, 10):.1f} us per launch")
     report(stamped(fwd), 1, "encode forward, split by the measured per-level costs")
     del os.environ["SDFX_GRID_LEVEL_COST"]
+for ov in (1, 0, 1, 0):
+    with _sdfx.dev_switch(SDFX_GRIDBWD_OVERLAP=ov):
+        print(f"scatter with K2(fine levels) on a side stream beside K1(coarse levels) = {ov}: {timed(bwd, 10):8.1f} us/launch")
 rec = stamped(bwd)
 report(rec, 2, "scatter K1")
 report(rec, 3, "scatter K2")
