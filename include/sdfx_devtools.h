@@ -20,7 +20,7 @@
  *   SDFX_GRID_LEVEL_COST   (string, environment only) "c0,c1,...": cost per tile by level      gridencoder_fwd.hip
  *   SDFX_GRID_NOVEC16      1: one gather per corner in the generic kernels                     gridencoder.hip
  *   SDFX_GRIDBWD_MERGE_RES / _COARSE_SPLIT / _BALANCE / _LEVEL_COST (string)                   gridencoder_bwd_binned.hip
- *   SDFX_GRIDBWD_OVERLAP   1 (default) K2 of the fine levels on a side stream beside K1 of the coarse ones, 0 one stream   gridencoder_bwd_binned.hip
+ *   SDFX_GRIDBWD_OVERLAP   0 (default) one stream, 1 K2 of the fine levels on a side stream beside K1 of the coarse ones (slower)   gridencoder_bwd_binned.hip
  *   SDFX_FIELD_IMPL        0 (default) matrix-core kernels, 1 per-thread v_dot2 kernels        field.hip
  *   SDFX_FIELD_FWD_NAT / _FWD_BLOCKS / _BWD_NAT / _BWD_NB / _BWD_LDSFRAG                      field.hip
  *   SDFX_DEV_ABLATE        bits: parts of k_grid_bwd_bin left out (1 list stores, 2 staging, 4 reservations,   gridencoder_bwd_binned.hip

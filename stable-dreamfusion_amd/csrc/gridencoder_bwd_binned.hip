@@ -952,7 +952,7 @@ const float* k1_level_cost(uint32_t levels) {
 // captures; inside a capture the fork / join below makes the side stream part of the captured graph).
 struct Overlap { hipStream_t side; hipEvent_t fork, join; };
 Overlap* overlap_streams() {
-    if (dev_switch("SDFX_GRIDBWD_OVERLAP", 1) == 0) return nullptr;
+    if (dev_switch("SDFX_GRIDBWD_OVERLAP", 0) == 0) return nullptr;   // product library: never (see the call site)
     static std::mutex m;
     static std::map<int, Overlap> per_device;
     int dev = 0;
@@ -1172,9 +1172,13 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
                                shared_acc, spill_acc, wg_lo);
         };
         if (is_half) {
-            // Two groups of levels when the plan allows (the -O grid: every XCD walks one level of the fine half, then one of the
-            // coarse half): K2 of the FINE half — three quarters of the items, a stream of HBM reads into LDS atomics — runs on a side
-            // stream beside K1 of the COARSE half (a latency chain writing short runs): the two leave each other's resources idle.
+            // MEASUREMENT VARIANT (devtools library, SDFX_GRIDBWD_OVERLAP=1; the product library always takes the one-stream branch
+            // below): two groups of levels when the plan allows (the -O grid: every XCD walks one level of the fine half, then one of
+            // the coarse half), K2 of the FINE half — three quarters of the items, a stream of HBM reads into LDS atomics — on a side
+            // stream beside K1 of the COARSE half (a latency chain writing short runs). Built on the idea that the two leave each
+            // other's resources idle; measured in round 5: they do not — 1352-1395 us against 1180 us per call at B = 3.26 M (K1 span
+            // 900 -> 1104 us, K2 346 -> 569 us: the list reads and the list writes fight over the same HBM), results identical
+            // (profiles/r05_scatter_k1_k2_overlap.txt).
             //   main:  zero, K1(fine) -e1-> K1(coarse), [spill pair], ............. -e2-> K2(coarse), K3
             //   side:            -e1-> [spill pair], K2(fine) -e2->
             GridPlan fine, coarse;
