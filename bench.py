@@ -1039,7 +1039,8 @@ def main():
     # the north_star configuration of the headline: the frozen UNet / VAE on STOCK PyTorch-ROCm ops (MIOpen convolutions, PyTorch's
     # GroupNorm and scaled_dot_product_attention; none of csrc/conv.hip, attention.hip, groupnorm.hip) — same scene, same mix
     stock_prior = None
-    if job.guidance_kind == "sd15_random" and not args.no_nerf_only and not args.no_stock_prior:
+    if job.guidance_kind == "sd15_random" and not args.no_nerf_only and not args.no_stock_prior and world == 1:   # (a 1-GPU reference figure:
+        # MIOpen compiles the UNet's convolution kernels at their first use, two minutes that the N > 1 runs of a scaling sweep do not repeat)
         stock_prior = stock_prior_pass(job, step, plan, timed_pass)
         stage("stock-prior pass done")
     # third figure: the reference's host flow (torch.amp.GradScaler + foreach Adan, no device-side tail, no graph replay,
