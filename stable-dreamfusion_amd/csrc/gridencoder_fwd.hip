@@ -46,12 +46,13 @@ constexpr uint32_t kMaxSegs = 6;       // per XCD
 constexpr uint32_t kGroup = 7;         // points per stencil
 constexpr uint32_t kGroupsPerWave = 9; // 9 x 7 = 63 lanes
 
-struct Seg { uint32_t level, first, count, pad; };   // tiles [first, first + count) of `level`
+struct Seg { uint32_t level, first, count, tpw; };   // tiles [first, first + count) of `level`, `tpw` (>= 1) consecutive tiles per workgroup
 struct FwdPlan {
     LevelConst lv[kMaxLevels];
     Seg seg[kXcds][kMaxSegs];
     uint32_t ntiles[kXcds];   // workgroups of each XCD (sum of its segments)
-    uint32_t vec16;           // table base 16-byte aligned: paired gathers allowed
+    uint32_t vec16;           // bit l: level l gathers an x-pair with ONE 16-byte load (table base 16-byte aligned) + a select; clear: two
+                              // 4-byte gathers — more texture-path work, fewer instructions: right where the level is VALU-bound
     uint32_t slabs;           // 1, or 7 = stencil batch [7, B/7, 3] evaluated with the 7 points of a sample in neighbouring lanes
     uint32_t slab_points;     // B / slabs
     // measurement aid (SDFX_GRID_PLAN=sample_major): every XCD takes 1/8 of the tiles and evaluates ALL levels of a tile before the
@@ -66,7 +67,8 @@ struct FwdPlan {
 constexpr uint32_t kLdsTiles = 16;
 
 // workgroup -> (level, tile) through the XCD's segment list (walked in order); false when there is nothing to do
-__device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint32_t& tile, uint32_t& seg_end) {
+__device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint32_t& tile, uint32_t& seg_end, uint32_t& tpw) {
+    tpw = 1u;
     const uint32_t xcd = blockIdx.x % kXcds;
     uint32_t local = blockIdx.x / kXcds;
     if (p.sample_major) {
@@ -80,13 +82,14 @@ __device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint
 #pragma unroll
     for (uint32_t s = 0; s < kMaxSegs; s++) {
         const Seg sg = p.seg[xcd][s];
-        if (local < sg.count) {
-            level = sg.level; tile = sg.first + local; seg_end = sg.first + sg.count;
+        const uint32_t wgs = (sg.count + sg.tpw - 1u) / (sg.tpw ? sg.tpw : 1u);   // workgroups of the segment
+        if (local < wgs) {
+            level = sg.level; tile = sg.first + local * sg.tpw; seg_end = sg.first + sg.count; tpw = sg.tpw;
             // an LDS-resident level: one workgroup in kLdsTiles takes that many consecutive tiles, the others have nothing to do
             if ((p.lds_mask >> sg.level) & 1u) return local % kLdsTiles == 0;
             return true;
         }
-        local -= sg.count;
+        local -= wgs;
     }
     return false;
 }
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
     using RowT = typename std::conditional<HALF, uint32_t, uint2>::type;
     constexpr uint32_t P = 1;   // points per thread (the loops below are written for any P; 2 and 4 were measured slower)
     constexpr uint32_t P_TILE = P * kTile;
-    uint32_t level, tile0, seg_end;
-    if (!fwd_item(plan, level, tile0, seg_end)) return;
+    uint32_t level, tile0, seg_end, tpw;
+    if (!fwd_item(plan, level, tile0, seg_end, tpw)) return;
     SDFX_STAMP_BEGIN
     // padding rows of a fixed-capacity batch (sdfx_set_row_limit): samples >= row_total[0] are neither read nor written, and a
     // tile of nothing else ends here. (Stencil batches: the sample is the row within the slab; otherwise the row itself.)
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
     // SDFX_GRID_LDS (measurement aid): the level's table in LDS, kLdsTiles tiles per workgroup
     extern __shared__ uint4 lds_tab[];   // dynamic: kLdsBytes when the plan has an LDS-resident level, nothing otherwise
     const bool in_lds = LDS && HALF && ((plan.lds_mask >> level) & 1u);   // (LDS = false: the default kernel, none of this is compiled in)
-    uint32_t tile_end = tile0 + 1;
+    uint32_t tile_end = min(tile0 + tpw, seg_end);   // (tpw > 1: a workgroup walks consecutive tiles of a VALU-bound coarse level)
     if (in_lds) {
         if constexpr (HALF) {
             const uint4* src = reinterpret_cast<const uint4*>(tab);
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
     // Phase 2: every gather of the thread is issued before the first result is touched (4 P in flight per lane, plus the
     // second gathers of x-pairs that straddle two 16-byte blocks)
     RowT v0[P][4], v1[P][4];
-    if (plan.vec16) {
+    if ((plan.vec16 >> level) & 1u) {
         // rows r0 and r1 = row(x + 1) nearly always share an aligned 16-byte block (the hash's x prime is 1, dense
         // levels are x-major): one gather serves both corners of the pair
         uint4 blk[P][4];
@@ -406,8 +409,11 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
             const uint32_t last = u == bu[k + 1] ? bc[k + 1] : T;
             if (last <= first) continue;
             if (ns == kMaxSegs) { p.ntiles[0] = 0xffffffffu; return p; }   // more levels in one range than a Seg list holds: caller falls back
-            p.seg[k][ns++] = {units[u].level, first, last - first, 0u};
-            p.ntiles[k] += last - first;
+            // tiles per workgroup: 1, or SDFX_GRID_TPW (measurement aid) at the levels whose cost is the VALU floor
+            const uint32_t tpw_coarse = [] { const int v = dev_switch("SDFX_GRID_TPW", 1); return (uint32_t)(v < 1 ? 1 : (v > 16 ? 16 : v)); }();
+            const uint32_t tpw = (balance && step > 0.f && lines[units[u].level] <= valu_lines) ? tpw_coarse : 1u;
+            p.seg[k][ns++] = {units[u].level, first, last - first, tpw};
+            p.ntiles[k] += (last - first + tpw - 1u) / tpw;
         }
     }
     return p;
@@ -474,7 +480,12 @@ bool launch_forward_d3c2(const float* inputs, const void* table, const int32_t* 
     FwdPlan plan = make_fwd_plan(offsets_host, max_level, S, H, is_half ? 2u : 4u, B, slabs, step,
                                  dev_switch("SDFX_GRID_BALANCE", 1) == 1, valu_lines);
     if (plan.ntiles[0] == 0xffffffffu) return false;
-    plan.vec16 = (reinterpret_cast<uintptr_t>(table) % 16) == 0 ? 1u : 0u;
+    plan.vec16 = (reinterpret_cast<uintptr_t>(table) % 16) == 0 ? 0xffffffffu : 0u;
+    {   // SDFX_GRID_SCALAR_BELOW = r (measurement aid): levels of resolution < r gather every corner with its own 4-byte load
+        const uint32_t r = (uint32_t)dev_switch("SDFX_GRID_SCALAR_BELOW", 0);
+        for (uint32_t l = 0; l < max_level; l++)
+            if (plan.lv[l].res < r) plan.vec16 &= ~(1u << l);
+    }
     if (dev_switch("SDFX_GRID_PLAN_DEBUG", 0)) {   // one line per XCD: its segments
         for (uint32_t k = 0; k < kXcds; k++) {
             fprintf(stderr, "[grid plan] B=%u slabs=%u step=%g xcd %u: %u workgroups:", B, plan.slabs, (double)step, k, plan.ntiles[k]);

@@ -108,6 +108,18 @@ print(f"samples M = {M} ({views} views), stencil batch B = {B}")
 print(f"encode forward  {timed(fwd):8.1f} us/launch (events, 5 launches)  = {B * 588 / timed(fwd) / 1e3 / 8000:.3f} of 8 TB/s at 588 B/point")
 print(f"scatter (K1+K2+K3+zeroing) {timed(bwd):8.1f} us/launch")
 report(stamped(fwd), 1, "encode forward")
+if os.environ.get("FWD_VARIANTS"):
+    print("== encode forward variants (devtools switches): tiles per workgroup at the VALU-bound levels x 4-byte gathers below a resolution")
+    ref = None
+    for rnd in range(2):
+        for tpw in (1, 2, 4):
+            for below in (0, 160, 600):
+                with _sdfx.dev_switch(SDFX_GRID_TPW=tpw, SDFX_GRID_SCALAR_BELOW=below):
+                    t = timed(fwd, 10)
+                    if ref is None:
+                        ref = out.clone()
+                    same = bool(torch.equal(out.view(torch.int16), ref.view(torch.int16)))
+                print(f"   round {rnd} tpw {tpw} scalar-below {below:4d}: {t:7.1f} us/launch  identical {same}")
 if os.environ.get("FWD_LEVELS", "1") == "1":
     print("== encode forward, ONE level per launch on the whole GPU (SDFX_GRID_ONLY_LEVEL): us per launch, ns per 256-thread tile, relative to level 0")
     iso = []
