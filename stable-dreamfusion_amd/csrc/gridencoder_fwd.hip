@@ -410,8 +410,9 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
             if (last <= first) continue;
             if (ns == kMaxSegs) { p.ntiles[0] = 0xffffffffu; return p; }   // more levels in one range than a Seg list holds: caller falls back
             // tiles per workgroup: 1, or SDFX_GRID_TPW (measurement aid) at the levels whose cost is the VALU floor
-            const uint32_t tpw_coarse = [] { const int v = dev_switch("SDFX_GRID_TPW", 1); return (uint32_t)(v < 1 ? 1 : (v > 16 ? 16 : v)); }();
-            const uint32_t tpw = (balance && step > 0.f && lines[units[u].level] <= valu_lines) ? tpw_coarse : 1u;
+            const uint32_t tpw_coarse = [] { const int v = dev_switch("SDFX_GRID_TPW", 1); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+            const uint32_t tpw_fine = [] { const int v = dev_switch("SDFX_GRID_TPW_FINE", 1); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+            const uint32_t tpw = (balance && step > 0.f && lines[units[u].level] <= valu_lines) ? tpw_coarse : tpw_fine;
             p.seg[k][ns++] = {units[u].level, first, last - first, tpw};
             p.ntiles[k] += (last - first + tpw - 1u) / tpw;
         }

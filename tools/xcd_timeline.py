@@ -112,14 +112,13 @@ if os.environ.get("FWD_VARIANTS"):
     print("== encode forward variants (devtools switches): tiles per workgroup at the VALU-bound levels x 4-byte gathers below a resolution")
     ref = None
     for rnd in range(2):
-        for tpw in (1, 2, 4):
-            for below in (0, 160, 600):
-                with _sdfx.dev_switch(SDFX_GRID_TPW=tpw, SDFX_GRID_SCALAR_BELOW=below):
-                    t = timed(fwd, 10)
-                    if ref is None:
-                        ref = out.clone()
-                    same = bool(torch.equal(out.view(torch.int16), ref.view(torch.int16)))
-                print(f"   round {rnd} tpw {tpw} scalar-below {below:4d}: {t:7.1f} us/launch  identical {same}")
+        for tpw, fine in ((1, 1), (4, 1), (8, 1), (16, 1), (32, 1), (4, 2), (8, 2), (8, 4), (16, 4), (16, 8)):
+            with _sdfx.dev_switch(SDFX_GRID_TPW=tpw, SDFX_GRID_TPW_FINE=fine):
+                t = timed(fwd, 10)
+                if ref is None:
+                    ref = out.clone()
+                same = bool(torch.equal(out.view(torch.int16), ref.view(torch.int16)))
+            print(f"   round {rnd} tiles per workgroup: VALU-bound levels {tpw:2d}, the others {fine}: {t:7.1f} us/launch  identical {same}")
 if os.environ.get("FWD_LEVELS", "1") == "1":
     print("== encode forward, ONE level per launch on the whole GPU (SDFX_GRID_ONLY_LEVEL): us per launch, ns per 256-thread tile, relative to level 0")
     iso = []
