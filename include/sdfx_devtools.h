@@ -17,7 +17,7 @@
  *   SDFX_GRID_PLAN         (string, environment only) "sample_major" (slower)                  gridencoder_fwd.hip
  *   SDFX_GRID_PLAN_DEBUG   print the per-XCD segments                                          gridencoder_fwd.hip
  *   SDFX_GRID_ONLY_LEVEL   l: the hinted forward evaluates level l alone on all eight XCDs     gridencoder_fwd.hip
- *   SDFX_GRID_TPW          1: consecutive tiles per workgroup at the VALU-bound coarse levels  gridencoder_fwd.hip
+ *   SDFX_GRID_TPW / _FINE  8 / 2: consecutive tiles per workgroup at the VALU-bound levels / the others   gridencoder_fwd.hip
  *   SDFX_GRID_SCALAR_BELOW 0: levels of resolution < r gather corners with 4-byte loads        gridencoder_fwd.hip
  *   SDFX_GRID_LEVEL_COST   (string, environment only) "c0,c1,...": cost per tile by level      gridencoder_fwd.hip
  *   SDFX_GRID_NOVEC16      1: one gather per corner in the generic kernels                     gridencoder.hip

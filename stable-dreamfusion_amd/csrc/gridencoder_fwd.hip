@@ -409,9 +409,13 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
             const uint32_t last = u == bu[k + 1] ? bc[k + 1] : T;
             if (last <= first) continue;
             if (ns == kMaxSegs) { p.ntiles[0] = 0xffffffffu; return p; }   // more levels in one range than a Seg list holds: caller falls back
-            // tiles per workgroup: 1, or SDFX_GRID_TPW (measurement aid) at the levels whose cost is the VALU floor
-            const uint32_t tpw_coarse = [] { const int v = dev_switch("SDFX_GRID_TPW", 1); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
-            const uint32_t tpw_fine = [] { const int v = dev_switch("SDFX_GRID_TPW_FINE", 1); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+            // Consecutive tiles per workgroup (round 5): a workgroup's fixed part — kernel arguments, its place in the plan, the
+            // level's constants, start and retire — was a third of a 2.4 us coarse tile. 8 tiles at the levels whose cost is the VALU
+            // floor, 2 at the others: 601-656 -> 480 us per launch at B = 3.26 M on one box (1 / 1: 601-656; 4 / 1: 519-570; 8 / 1:
+            // 501-533; 16 / 1: 507-516; 8 / 2: 480; 16 / 4: 479; profiles/r05_encode_tiles_per_workgroup.txt). SDFX_GRID_TPW /
+            // SDFX_GRID_TPW_FINE: the devtools library's knobs for that A/B.
+            const uint32_t tpw_coarse = [] { const int v = dev_switch("SDFX_GRID_TPW", 8); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+            const uint32_t tpw_fine = [] { const int v = dev_switch("SDFX_GRID_TPW_FINE", 2); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
             const uint32_t tpw = (balance && step > 0.f && lines[units[u].level] <= valu_lines) ? tpw_coarse : tpw_fine;
             p.seg[k][ns++] = {units[u].level, first, last - first, tpw};
             p.ntiles[k] += (last - first + tpw - 1u) / tpw;
