@@ -119,6 +119,20 @@ if os.environ.get("FWD_VARIANTS"):
                     ref = out.clone()
                 same = bool(torch.equal(out.view(torch.int16), ref.view(torch.int16)))
             print(f"   round {rnd} tiles per workgroup: VALU-bound levels {tpw:2d}, the others {fine}: {t:7.1f} us/launch  identical {same}")
+if os.environ.get("FWD_COSTS"):
+    print("== encode forward: the plan's cost model against SDFX_GRID_LEVEL_COST candidates (alternating)")
+    cands = [c for c in os.environ["FWD_COSTS"].split(";") if c]
+    for rnd in range(3):
+        os.environ.pop("SDFX_GRID_LEVEL_COST", None)
+        print(f"   round {rnd} model: {timed(fwd, 10):7.1f} us", end="")
+        for i, c in enumerate(cands):
+            os.environ["SDFX_GRID_LEVEL_COST"] = c
+            print(f"   cand{i}: {timed(fwd, 10):7.1f} us", end="")
+        print()
+    for i, c in enumerate(cands):
+        os.environ["SDFX_GRID_LEVEL_COST"] = c
+        report(stamped(fwd), 1, f"encode forward, SDFX_GRID_LEVEL_COST={c}")
+    os.environ.pop("SDFX_GRID_LEVEL_COST", None)
 if os.environ.get("FWD_LEVELS", "1") == "1":
     print("== encode forward, ONE level per launch on the whole GPU (SDFX_GRID_ONLY_LEVEL): us per launch, ns per 256-thread tile, relative to level 0")
     iso = []
