@@ -19,6 +19,7 @@
  *   SDFX_GRID_ONLY_LEVEL   l: the hinted forward evaluates level l alone on all eight XCDs     gridencoder_fwd.hip
  *   SDFX_GRID_TPW / _FINE  8 / 2: consecutive tiles per workgroup at the VALU-bound levels / the others   gridencoder_fwd.hip
  *   SDFX_GRID_SCALAR_BELOW 0: levels of resolution < r gather corners with 4-byte loads        gridencoder_fwd.hip
+ *   SDFX_GRID_COST_TABLE   1 (default) measured per-tile costs for stencil batches, 0 max(lines, VALU floor)   gridencoder_fwd.hip
  *   SDFX_GRID_LEVEL_COST   (string, environment only) "c0,c1,...": cost per tile by level      gridencoder_fwd.hip
  *   SDFX_GRID_NOVEC16      1: one gather per corner in the generic kernels                     gridencoder.hip
  *   SDFX_GRIDBWD_MERGE_RES / _COARSE_SPLIT / _BALANCE / _LEVEL_COST (string)                   gridencoder_bwd_binned.hip

@@ -328,6 +328,22 @@ double lines_per_wave(double u, bool stencil) {
     return c[15];
 }
 
+// What a tile of a level COSTS in the launch, in the same units, for stencil batches: the per-XCD timeline of one launch at
+// B = 3.26 M (tools/xcd_timeline.py, round 5) corrected the model "max(lines, VALU floor = 97)" level by level — an XCD's finish time
+// over the mean, applied to the levels it walked: the levels around one cell per step (u = 0.95-1.8) are 6-13 % cheaper than
+// their line count says, the levels of u = 0.2-0.7 up to 11 % dearer than the VALU floor. With this table the eight XCDs finish
+// within 5 % of each other (24 % before) and the launch is 4-6 % shorter (profiles/r05_encode_split_by_timeline_costs.txt).
+double stencil_tile_cost(double u) {
+    static const double us[16] = {0.0271, 0.0389, 0.0525, 0.0728, 0.0998, 0.137, 0.190, 0.261, 0.360, 0.499, 0.689, 0.951, 1.315, 1.816, 2.509, 3.465};
+    static const double cost[16] = {98, 98, 98, 98, 98, 102, 108, 108, 106, 114, 146, 158, 185, 228, 260, 281};
+    if (u <= us[0]) return cost[0];
+    if (u >= us[15]) return cost[15];
+    const double lu = log(u);
+    for (int i = 0; i < 15; i++)
+        if (u <= us[i + 1]) return cost[i] + (lu - log(us[i])) / (log(us[i + 1]) - log(us[i])) * (cost[i + 1] - cost[i]);
+    return cost[15];
+}
+
 struct Unit { uint32_t level; double cost; };   // cost per tile
 
 FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uint32_t H, uint32_t elem_bytes, uint32_t B,
@@ -364,7 +380,10 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
     if (!(balance && step > 0.f)) {   // no information: every level costs the same; the order [L-1, 0, L-2, 1, ...] of GridPlan
         for (uint32_t v = 0, lo = 0, hi = levels; v < levels; v++) units[nu++] = {(v & 1u) ? lo++ : --hi, 1.0};
     } else {                          // fine to coarse; a tile costs its gathers or its VALU work, whichever is longer
-        for (uint32_t l = levels; l-- > 0;) units[nu++] = {l, lines[l] > valu_lines ? lines[l] : valu_lines};
+        for (uint32_t l = levels; l-- > 0;) {
+            const double model = lines[l] > valu_lines ? lines[l] : valu_lines;
+            units[nu++] = {l, (slabs == kGroup && dev_switch("SDFX_GRID_COST_TABLE", 1)) ? stencil_tile_cost((double)p.lv[l].res * step) : model};
+        }
     }
 
     // measurement aids (devtools build): SDFX_GRID_ONLY_LEVEL = l: the launch evaluates level l alone, spread over all eight XCDs (what

@@ -39,12 +39,13 @@ def test_every_tile_is_assigned_once(oracle, B, slabs, step, L, half):
 
 
 def test_step_hint_balances_the_modelled_cost(oracle):
-    """With the ray-ordered stencil model a fine level costs ~267 lines per wave and a coarse one the VALU floor (97):
-    equal tile counts would give the XCD holding (L15, L0) twice the load of the one holding (L8, L7)."""
+    """With a step hint the sequence of levels is cut into eight ranges of equal COST. For stencil batches the cost per tile is the
+    table `stencil_tile_cost` of gridencoder_fwd.hip — the model max(lines per wave, VALU floor 97) corrected level by level from the
+    per-XCD timeline of a launch (round 5): a finest-level tile costs 281, a coarse one 98; equal tile counts would give the XCD
+    holding (L15, L0) nearly twice the load of the one holding (L8, L7)."""
     offsets, pls = oracle.grid_offsets(desired_resolution=2048)
     seg, T = _plan(offsets, pls, 16, 1, 1810900, 7, 1 / 591.0)
-    st7 = [7.6, 9.7, 11.8, 14.6, 18.9, 25.9, 36.3, 52.8, 79.9, 106.6, 136.7, 181.3, 212.8, 242.1, 252.8, 267.4]
-    cost = [max(c, 97.0) for c in st7]
+    cost = [98, 98, 98, 98, 98, 102, 108, 108, 106, 114, 146, 158, 185, 228, 260, 281]   # at the levels' u = res / 591: the table's knots
     load = [sum(cost[l] * c for x, l, f, c in seg if x == k) for k in range(8)]
     assert max(load) <= 1.02 * min(load), load
     even, _ = _plan(offsets, pls, 16, 1, 1810900, 7, 0.0)
