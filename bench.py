@@ -816,17 +816,6 @@ def stock_prior_pass(job, step, plan, timed_pass):
         drop_graphs()
 
 
-CHILD_CORES = 16   # host cores set aside for the child runs while the parent times the CPU baseline on the others
-
-
-def _pin_child():
-    """The child runs (host-paced launches: the DMTet stage runs the reference's host flow) keep cores [0, CHILD_CORES) to themselves."""
-    try:
-        os.sched_setaffinity(0, set(range(min(CHILD_CORES, os.cpu_count() or 1))))
-    except (AttributeError, OSError):
-        pass
-
-
 def child_bench(extra, steps, timeout_s=420):
     """One more configuration of BASELINE.json as a CHILD run of this file (its own process: own model, prior and graphs): returns
     (the child's JSON line as a dict | None, seconds, error text)."""
@@ -836,8 +825,7 @@ def child_bench(extra, steps, timeout_s=420):
     t0 = time.perf_counter()
     try:
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s,
-                             env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")},
-                             preexec_fn=_pin_child)
+                             env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
     except subprocess.TimeoutExpired:
         return None, time.perf_counter() - t0, f"timed out after {timeout_s} s"
     line = next((l for l in reversed(out.stdout.decode("utf-8", "replace").splitlines()) if l.startswith("{")), None)
@@ -1263,24 +1251,15 @@ def main():
         except Exception as exc:  # noqa: BLE001
             result["kernels_standalone"] = {"error": f"{type(exc).__name__}: {exc}"}
     # BASELINE configs[3] (`--IF`) and configs[4] (DMTet stage) in the same driver-visible line: two short CHILD runs of this file
-    # (own process each: own model, prior, graphs), one after the other on this GPU — while THIS process, whose GPU work is done,
-    # times the CPU baseline on the host cores (the children keep one host thread busy each)
-    children, child_thread = {}, None
+    # (own process each: own model, prior, graphs), one after the other, while THIS process — its GPU work done, its memory handed
+    # back — waits: nothing else runs on the GPU or on the host cores. (Round 5 first ran them beside the CPU baseline: the
+    # host-paced DMTet stage then measured 19-32 it/s from run to run against 43 alone.)
+    children = None
     if world == 1 and not args.no_children and args.prior == "sd" and args.stage == "nerf":
-        import threading
-
-        def run_children():
-            for key, extra, steps in (("if", ["--prior", "if"], 20), ("dmtet", ["--stage", "dmtet"], 10)):
-                children[key] = child_bench(extra, steps)
         torch.cuda.empty_cache()
-        child_thread = threading.Thread(target=run_children, daemon=True)
-        child_thread.start()
-        try:     # ... and the CPU baseline (this process and its thread-probe children) keeps off the children's cores
-            ncpu = os.cpu_count() or 1
-            if ncpu > 2 * CHILD_CORES:
-                os.sched_setaffinity(0, set(range(CHILD_CORES, ncpu)))
-        except (AttributeError, OSError):
-            pass
+        children = {key: child_bench(extra, steps)
+                    for key, extra, steps in (("if", ["--prior", "if"], 20), ("dmtet", ["--stage", "dmtet"], 10))}
+        stage("child runs (IF, DMTet) done")
     if world == 1 and not args.no_cpu_baseline:
         try:
             cb = cpu_baseline()
@@ -1301,15 +1280,14 @@ def main():
         except Exception as exc:  # noqa: BLE001
             result["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "restated (-O2 port, golden-pinned)",
                                       "sample": f"failed: {type(exc).__name__}: {exc}"}
-    if child_thread is not None:
-        child_thread.join()
+    if children is not None:
         for key, name in (("if", "iters_per_sec_if"), ("dmtet", "iters_per_sec_dmtet")):
             line, secs, err = children.get(key, (None, 0.0, "not run"))
             result[name] = line["value"] if line else None
             result[name + "_config"] = ({"workload": line["config"]["workload"], "guidance": line["config"]["guidance"], "steps": line["steps"],
                                          "ms_per_step": line["ms_per_step"], "train_mode": line.get("train_mode"),
                                          "samples_per_iter": line.get("samples_per_iter"), "child_run_seconds": round(secs, 1),
-                                         "ran": f"child process of this run, alone on the GPU (host cores 0-{CHILD_CORES - 1}) while the parent timed the CPU baseline on the other cores"}
+                                         "ran": "child process of this run, alone on the GPU and on the host (the parent waits)"}
                                         if line else {"error": err, "child_run_seconds": round(secs, 1)})
     print(json.dumps(result))
     if dist is not None:

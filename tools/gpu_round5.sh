@@ -9,6 +9,7 @@
 #   stats      rocprofv3 --kernel-trace --stats of a short default bench -> kernel_stats csv (top rows)
 #   pmc        tools/gpu_profile_round.sh-style FETCH_SIZE / WRITE_SIZE passes (synthetic prior) -> pmc_traffic.json
 #   variants   A/B libraries under ab/ (tools/build_variant.py): scatter timeline + scatter tests on each
+#   mergeres   scatter by SDFX_GRIDBWD_MERGE_RES; fwdvariants: encode forward by tiles per workgroup (devtools switches)
 #   scatter    tools/gridbwd_bench.py 20 (standalone loop of K1 + K2 + K3) on the product library [and on ab/libsdfx_hip_base.so]
 TAG=${1:-r5}; shift
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
@@ -49,6 +50,13 @@ for STEP in "$@"; do
         grep -E "^encode|^scatter|^== scatter|XCD finish" $OUT/xcd_timeline_$lib.txt | cut -c1-200 | tee -a $OUT/summary.txt
         SDFX_LIB=$REPO/ab/libsdfx_hip_$lib.so timeout 600 python -m pytest tests/test_gpu_02_parity.py tests/test_gpu_zz_stress.py tests/test_gpu_00_vs_reference_kernels.py -m gpu -q -p no:cacheprovider -k "grid or scatter or stencil or binned" 2>&1 | tail -3 | cut -c1-300 | tee -a $OUT/summary.txt
       done ;;
+    mergeres)   # K1's run folding by level resolution (devtools SDFX_GRIDBWD_MERGE_RES; product: 640): scatter time, K1 / K2 spans
+      for r in ${MERGE_RES:-0 213 409 640 1023}; do
+        echo "== SDFX_GRIDBWD_MERGE_RES=$r" | tee -a $OUT/summary.txt
+        SDFX_LIB=$DEVLIB SDFX_GRIDBWD_MERGE_RES=$r FWD_LEVELS=0 timeout 300 python tools/xcd_timeline.py ${VIEWS:-2} 0 2>&1 | grep -E "^scatter \\(|^== scatter" | cut -c1-160 | tee -a $OUT/summary.txt
+      done ;;
+    fwdvariants)
+      SDFX_LIB=$DEVLIB FWD_VARIANTS=1 FWD_LEVELS=0 timeout 300 python tools/xcd_timeline.py ${VIEWS:-2} 0 2>&1 | grep -E "tiles per workgroup" | tee -a $OUT/summary.txt ;;
     *) echo "unknown step $STEP" | tee -a $OUT/summary.txt ;;
   esac
 done
