@@ -94,6 +94,11 @@ __device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint
     return false;
 }
 
+// two consecutive rows of a C = 2 table at the alignment of ONE row
+template <bool HALF> struct PairT;
+template <> struct __attribute__((packed, aligned(4))) PairT<true> { uint32_t a, b; };
+template <> struct __attribute__((packed, aligned(8))) PairT<false> { uint2 a, b; };
+
 template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID, bool LDS>
 __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ inputs,
                                                      const typename Elem<HALF>::type* __restrict__ table,
@@ -116,8 +121,12 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
 
     const LevelConst lc = plan.lv[level];
     const bool hashed = HASHGRID && (lc.flags & 1u);
+    const bool dense = (lc.flags & 1u) == 0u && lc.res >= 2u && !(LDS && HALF && ((plan.lds_mask >> level) & 1u));   // every stride fits: rows never wrap (a one-vertex level and the LDS measurement aid keep the block gathers)
     const bool pow2 = (lc.flags & 2u) != 0u;
     const T* tab = table + (size_t)lc.row0 * C;
+    // a row's address = the level's (uniform) base + a 32-bit byte offset: the load takes its base from scalar registers and ONE vector
+    // register of offset (a level of 2^32 bytes or more goes to k_grid_forward: launch_forward_d3c2)
+    auto at = [&](uint32_t row) -> const char* { return reinterpret_cast<const char*>(tab) + (uint32_t)(row * (uint32_t)(C * sizeof(T))); };
     // SDFX_GRID_LDS (measurement aid): the level's table in LDS, kLdsTiles tiles per workgroup
     extern __shared__ uint4 lds_tab[];   // dynamic: kLdsBytes when the plan has an LDS-resident level, nothing otherwise
     const bool in_lds = LDS && HALF && ((plan.lds_mask >> level) & 1u);   // (LDS = false: the default kernel, none of this is compiled in)
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
     // Phase 1: cell, weights and the row indices of the 4 x-pairs of every point (no memory access)
     float ax[P][2], ay[P][2], az[P][2];
     uint32_t r0[P][4], r1[P][4];
-    bool oob[P];
+    bool oob[P], xstep[P], xfar[P];
 #pragma unroll
     for (uint32_t j = 0; j < P; j++) {
         oob[j] = xin[j][0] < 0 || xin[j][0] > 1 || xin[j][1] < 0 || xin[j][1] > 1 || xin[j][2] < 0 || xin[j][2] > 1;  // gridencoder.cu:105
@@ -209,7 +218,9 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
         ax[j][0] = 1 - pos[0]; ax[j][1] = pos[0];
         ay[j][0] = 1 - pos[1]; ay[j][1] = pos[1];
         az[j][0] = 1 - pos[2]; az[j][1] = pos[2];
-        uint32_t yz[4];   // (y, z) part of the row index for the four (y, z) corners (gridencoder.cu:45-79)
+        // rows of the four (y, z) corners' x-pairs (gridencoder.cu:45-79). The level's kind is a property of the workgroup: two
+        // straight-line versions behind ONE uniform branch (as selects on a uniform condition every corner paid both the xor and
+        // the add, plus the select: 16 of the ~270 vector instructions of a tile)
         {
             const uint32_t fy = hashed ? 2654435761u : lc.m1, fz = hashed ? 805459861u : lc.m2;
             uint32_t ty[2], tz[2];
@@ -220,67 +231,120 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
                 ty[0] = pg[1] * fy; ty[1] = pn[1] * fy;
                 tz[0] = pg[2] * fz; tz[1] = pn[2] * fz;
             }
+            if (hashed) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) yz[k] = hashed ? (ty[k & 1] ^ tz[k >> 1]) : (ty[k & 1] + tz[k >> 1]);
-        }
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t yz = ty[k & 1] ^ tz[k >> 1];
+                    r0[j][k] = wrap(pg[0] ^ yz);
+                    r1[j][k] = wrap(pn[0] ^ yz);
+                }
+            } else if (dense) {   // x + y res + z res^2 < res^3 <= size (make_level_const): nothing to wrap, and r1 = r0 + 1 unless
+                                  // x is the grid's last vertex (x + 1 clamped: r1 = r0). r0 here = the FIRST row of the two-row load
+                                  // of Phase 2: the pair's own r0, or at the last vertex the row before it — never past the table
+                const uint32_t xb = pg[0] - (pn[0] == pg[0] ? 1u : 0u);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            r0[j][k] = wrap(hashed ? (pg[0] ^ yz[k]) : (pg[0] + yz[k]));
-            r1[j][k] = wrap(hashed ? (pn[0] ^ yz[k]) : (pn[0] + yz[k]));
+                for (int k = 0; k < 4; k++) {
+                    r0[j][k] = xb + (ty[k & 1] + tz[k >> 1]);
+                    r1[j][k] = r0[j][k] + 1u;
+                }
+            } else {   // a tiled grid whose strides do not fit: the dense index wrapped (gridencoder.cu:61-79 without the hash)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t yz = ty[k & 1] + tz[k >> 1];
+                    r0[j][k] = wrap(pg[0] + yz);
+                    r1[j][k] = wrap(pn[0] + yz);
+                }
+            }
         }
+        xstep[j] = pn[0] != pg[0];                                   // (false only at the grid's last vertex)
+        xfar[j] = ((pg[0] ^ pn[0]) & wmask) >= RB;                   // hashed power-of-two levels: r0 ^ r1 = (x ^ (x + 1)) & mask for all four pairs
     }
 
     // Phase 2: every gather of the thread is issued before the first result is touched (4 P in flight per lane, plus the
     // second gathers of x-pairs that straddle two 16-byte blocks)
     RowT v0[P][4], v1[P][4];
-    if ((plan.vec16 >> level) & 1u) {
+    if (dense) {
+        // a dense level is x-major: the pair's rows are consecutive — ONE 2-row load at the row's own alignment (gfx950 takes a
+        // dwordx2 at 4-byte alignment), nothing to pick from a block and never a second gather. At the grid's last vertex both
+        // corners are the load's SECOND row (see Phase 1)
+        PairT<HALF> pr[P][4];
+#pragma unroll
+        for (uint32_t j = 0; j < P; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) pr[j][k] = *reinterpret_cast<const PairT<HALF>*>(at(r0[j][k]));
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < P; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v0[j][k] = xstep[j] ? pr[j][k].a : pr[j][k].b;
+                v1[j][k] = pr[j][k].b;
+            }
+        }
+    } else if ((plan.vec16 >> level) & 1u) {
         // rows r0 and r1 = row(x + 1) nearly always share an aligned 16-byte block (the hash's x prime is 1, dense
         // levels are x-major): one gather serves both corners of the pair
-        uint4 blk[P][4];
+        // Does a pair straddle two blocks? At a hashed level of power-of-two size r0 ^ r1 = (x ^ (x + 1)) & mask for all four pairs of
+        // a point: ONE test and one masked branch around its four second gathers (BY_POINT); otherwise pair by pair. Two copies of
+        // the block behind a uniform branch, so that neither pays for the other's test.
+        auto gather16 = [&](auto by_point) {
+            constexpr bool BY_POINT = decltype(by_point)::value;
+            auto pair_far = [&](uint32_t j, int k) -> bool { return BY_POINT ? xfar[j] : ((r0[j][k] ^ r1[j][k]) >= RB); };
+            uint4 blk[P][4];
 #pragma unroll
-        for (uint32_t j = 0; j < P; j++) {
+            for (uint32_t j = 0; j < P; j++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (in_lds) blk[j][k] = lds_tab[r0[j][k] >> 2];
-                else blk[j][k] = *reinterpret_cast<const uint4*>(tab + (size_t)(r0[j][k] & ~(RB - 1)) * C);
-            }
-        }
-        RowT extra[P][4];
-#pragma unroll
-        for (uint32_t j = 0; j < P; j++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if ((r0[j][k] ^ r1[j][k]) >= RB) {
-                    if constexpr (HALF) {
-                        if (in_lds) extra[j][k] = reinterpret_cast<const uint32_t*>(lds_tab)[r1[j][k]];
-                        else extra[j][k] = *reinterpret_cast<const RowT*>(tab + (size_t)r1[j][k] * C);
-                    } else {
-                        extra[j][k] = *reinterpret_cast<const RowT*>(tab + (size_t)r1[j][k] * C);
-                    }
+                for (int k = 0; k < 4; k++) {
+                    if (in_lds) blk[j][k] = lds_tab[r0[j][k] >> 2];
+                    else blk[j][k] = *reinterpret_cast<const uint4*>(at(r0[j][k] & ~(RB - 1)));
                 }
             }
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < P; j++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
+            RowT extra[P][4];
+            auto second = [&](uint32_t j, int k) {
                 if constexpr (HALF) {
-                    v0[j][k] = pick4(blk[j][k], r0[j][k] & 3u);
-                    v1[j][k] = pick4(blk[j][k], r1[j][k] & 3u);
+                    if (in_lds) extra[j][k] = reinterpret_cast<const uint32_t*>(lds_tab)[r1[j][k]];
+                    else extra[j][k] = *reinterpret_cast<const RowT*>(at(r1[j][k]));
                 } else {
-                    v0[j][k] = (r0[j][k] & 1u) ? make_uint2(blk[j][k].z, blk[j][k].w) : make_uint2(blk[j][k].x, blk[j][k].y);
-                    v1[j][k] = (r1[j][k] & 1u) ? make_uint2(blk[j][k].z, blk[j][k].w) : make_uint2(blk[j][k].x, blk[j][k].y);
+                    extra[j][k] = *reinterpret_cast<const RowT*>(at(r1[j][k]));
                 }
-                if ((r0[j][k] ^ r1[j][k]) >= RB) v1[j][k] = extra[j][k];
+            };
+#pragma unroll
+            for (uint32_t j = 0; j < P; j++) {
+                if constexpr (BY_POINT) {
+                    if (xfar[j]) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) second(j, k);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (pair_far(j, k)) second(j, k);
+                }
             }
-        }
+#pragma unroll
+            for (uint32_t j = 0; j < P; j++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if constexpr (HALF) {
+                        v0[j][k] = pick4(blk[j][k], r0[j][k] & 3u);
+                        v1[j][k] = pick4(blk[j][k], r1[j][k] & 3u);
+                    } else {
+                        v0[j][k] = (r0[j][k] & 1u) ? make_uint2(blk[j][k].z, blk[j][k].w) : make_uint2(blk[j][k].x, blk[j][k].y);
+                        v1[j][k] = (r1[j][k] & 1u) ? make_uint2(blk[j][k].z, blk[j][k].w) : make_uint2(blk[j][k].x, blk[j][k].y);
+                    }
+                    if (pair_far(j, k)) v1[j][k] = extra[j][k];
+                }
+            }
+        };
+        if (hashed && !need_mod) gather16(std::true_type{});
+        else gather16(std::false_type{});
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < P; j++) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                v0[j][k] = *reinterpret_cast<const RowT*>(tab + (size_t)r0[j][k] * C);
-                v1[j][k] = *reinterpret_cast<const RowT*>(tab + (size_t)r1[j][k] * C);
+                v0[j][k] = *reinterpret_cast<const RowT*>(at(r0[j][k]));
+                v1[j][k] = *reinterpret_cast<const RowT*>(at(r1[j][k]));
             }
         }
     }
@@ -333,15 +397,19 @@ double lines_per_wave(double u, bool stencil) {
 // over the mean, applied to the levels it walked: the levels around one cell per step (u = 0.95-1.8) are 6-13 % cheaper than
 // their line count says, the levels of u = 0.2-0.7 up to 11 % dearer than the VALU floor. With this table the eight XCDs finish
 // within 5 % of each other (24 % before) and the launch is 4-6 % shorter (profiles/r05_encode_split_by_timeline_costs.txt).
-double stencil_tile_cost(double u) {
+// Second pass after the kernel's dense levels got their two-row loads and the hashed ones lost a few instructions
+// (profiles/r05_encode_dense_levels.txt): a dense level's tile costs 0.71 of the table's entry, the hashed entries below u = 1 moved
+// by 1-7 %.
+double stencil_tile_cost(double u, bool dense) {
     static const double us[16] = {0.0271, 0.0389, 0.0525, 0.0728, 0.0998, 0.137, 0.190, 0.261, 0.360, 0.499, 0.689, 0.951, 1.315, 1.816, 2.509, 3.465};
-    static const double cost[16] = {98, 98, 98, 98, 98, 102, 108, 108, 106, 114, 146, 158, 185, 228, 260, 281};
-    if (u <= us[0]) return cost[0];
-    if (u >= us[15]) return cost[15];
+    static const double cost[16] = {98, 98, 98, 98, 98, 91, 101, 109, 108, 114, 141, 151, 180, 233, 265, 281};
+    const double k = dense ? 0.71 : 1.0;
+    if (u <= us[0]) return k * cost[0];
+    if (u >= us[15]) return k * cost[15];
     const double lu = log(u);
     for (int i = 0; i < 15; i++)
-        if (u <= us[i + 1]) return cost[i] + (lu - log(us[i])) / (log(us[i + 1]) - log(us[i])) * (cost[i + 1] - cost[i]);
-    return cost[15];
+        if (u <= us[i + 1]) return k * (cost[i] + (lu - log(us[i])) / (log(us[i + 1]) - log(us[i])) * (cost[i + 1] - cost[i]));
+    return k * cost[15];
 }
 
 struct Unit { uint32_t level; double cost; };   // cost per tile
@@ -382,7 +450,7 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
     } else {                          // fine to coarse; a tile costs its gathers or its VALU work, whichever is longer
         for (uint32_t l = levels; l-- > 0;) {
             const double model = lines[l] > valu_lines ? lines[l] : valu_lines;
-            units[nu++] = {l, (slabs == kGroup && dev_switch("SDFX_GRID_COST_TABLE", 1)) ? stencil_tile_cost((double)p.lv[l].res * step) : model};
+            units[nu++] = {l, (slabs == kGroup && dev_switch("SDFX_GRID_COST_TABLE", 1)) ? stencil_tile_cost((double)p.lv[l].res * step, (p.lv[l].flags & 1u) == 0u && p.lv[l].res >= 2u) : model};
         }
     }
 
@@ -504,11 +572,14 @@ bool launch_forward_d3c2(const float* inputs, const void* table, const int32_t* 
     FwdPlan plan = make_fwd_plan(offsets_host, max_level, S, H, is_half ? 2u : 4u, B, slabs, step,
                                  dev_switch("SDFX_GRID_BALANCE", 1) == 1, valu_lines);
     if (plan.ntiles[0] == 0xffffffffu) return false;
+    for (uint32_t l = 0; l < max_level; l++)   // the kernel addresses a level's rows by 32-bit byte offsets
+        if ((uint64_t)plan.lv[l].size * (is_half ? 4u : 8u) >= (1ull << 32)) return false;
     plan.vec16 = (reinterpret_cast<uintptr_t>(table) % 16) == 0 ? 0xffffffffu : 0u;
     {   // SDFX_GRID_SCALAR_BELOW = r (measurement aid): levels of resolution < r gather every corner with its own 4-byte load
         const uint32_t r = (uint32_t)dev_switch("SDFX_GRID_SCALAR_BELOW", 0);
+        const uint32_t from = (uint32_t)dev_switch("SDFX_GRID_SCALAR_FROM", 0);   // ... and levels of resolution >= from (0: none)
         for (uint32_t l = 0; l < max_level; l++)
-            if (plan.lv[l].res < r) plan.vec16 &= ~(1u << l);
+            if (plan.lv[l].res < r || (from && plan.lv[l].res >= from)) plan.vec16 &= ~(1u << l);
     }
     if (dev_switch("SDFX_GRID_PLAN_DEBUG", 0)) {   // one line per XCD: its segments
         for (uint32_t k = 0; k < kXcds; k++) {

@@ -41,11 +41,11 @@ def test_every_tile_is_assigned_once(oracle, B, slabs, step, L, half):
 def test_step_hint_balances_the_modelled_cost(oracle):
     """With a step hint the sequence of levels is cut into eight ranges of equal COST. For stencil batches the cost per tile is the
     table `stencil_tile_cost` of gridencoder_fwd.hip — the model max(lines per wave, VALU floor 97) corrected level by level from the
-    per-XCD timeline of a launch (round 5): a finest-level tile costs 281, a coarse one 98; equal tile counts would give the XCD
-    holding (L15, L0) nearly twice the load of the one holding (L8, L7)."""
+    per-XCD timeline of a launch (round 5): a finest-level tile costs 281, a tile of a dense level (0-4 of this grid: two-row
+    loads) 0.71 * 98; equal tile counts would give the XCD holding L15 several times the load of the one holding L0-L2."""
     offsets, pls = oracle.grid_offsets(desired_resolution=2048)
     seg, T = _plan(offsets, pls, 16, 1, 1810900, 7, 1 / 591.0)
-    cost = [98, 98, 98, 98, 98, 102, 108, 108, 106, 114, 146, 158, 185, 228, 260, 281]   # at the levels' u = res / 591: the table's knots
+    cost = [0.71 * 98] * 5 + [91, 101, 109, 108, 114, 141, 151, 180, 233, 265, 281]   # at the levels' u = res / 591: the table's knots
     load = [sum(cost[l] * c for x, l, f, c in seg if x == k) for k in range(8)]
     assert max(load) <= 1.02 * min(load), load
     even, _ = _plan(offsets, pls, 16, 1, 1810900, 7, 0.0)

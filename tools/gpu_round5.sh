@@ -55,6 +55,11 @@ for STEP in "$@"; do
         echo "== SDFX_GRIDBWD_MERGE_RES=$r" | tee -a $OUT/summary.txt
         SDFX_LIB=$DEVLIB SDFX_GRIDBWD_MERGE_RES=$r FWD_LEVELS=0 timeout 300 python tools/xcd_timeline.py ${VIEWS:-2} 0 2>&1 | grep -E "^scatter \\(|^== scatter" | cut -c1-160 | tee -a $OUT/summary.txt
       done ;;
+    fwdscalar)
+      SDFX_LIB=$DEVLIB FWD_SCALAR=${FWD_SCALAR:-0,100000} FWD_LEVELS=0 timeout 300 python tools/xcd_timeline.py ${VIEWS:-2} 0 2>&1 | grep -E "scalar below|every level alone" | tee -a $OUT/summary.txt ;;
+    fwdscalarfrom)
+      SDFX_LIB=$DEVLIB FWD_LEVELS=0 timeout 300 python tools/xcd_timeline.py ${VIEWS:-2} 0 2>&1 | grep -v "amdgpu.ids" > $OUT/xcd_timeline_scalar_from.txt
+      grep -E "round [0-9] from|XCD finish|4-byte gathers" $OUT/xcd_timeline_scalar_from.txt | cut -c1-220 | tee -a $OUT/summary.txt ;;
     fwdvariants)
       SDFX_LIB=$DEVLIB FWD_VARIANTS=1 FWD_LEVELS=0 timeout 300 python tools/xcd_timeline.py ${VIEWS:-2} 0 2>&1 | grep -E "tiles per workgroup" | tee -a $OUT/summary.txt ;;
     *) echo "unknown step $STEP" | tee -a $OUT/summary.txt ;;

@@ -119,6 +119,38 @@ if os.environ.get("FWD_VARIANTS"):
                     ref = out.clone()
                 same = bool(torch.equal(out.view(torch.int16), ref.view(torch.int16)))
             print(f"   round {rnd} tiles per workgroup: VALU-bound levels {tpw:2d}, the others {fine}: {t:7.1f} us/launch  identical {same}")
+if os.environ.get("FWD_SCALAR"):
+    print("== encode forward, every level alone (SDFX_GRID_ONLY_LEVEL) by SDFX_GRID_SCALAR_BELOW (levels of res below it gather each corner with its own 4-byte load): us per launch")
+    rows = {}
+    for thr in [int(v) for v in os.environ["FWD_SCALAR"].split(",")]:
+        rows[thr] = []
+        for l in range(16):
+            with _sdfx.dev_switch(SDFX_GRID_ONLY_LEVEL=l, SDFX_GRID_SCALAR_BELOW=thr):
+                rows[thr].append(timed(fwd, 10))
+        with _sdfx.dev_switch(SDFX_GRID_SCALAR_BELOW=thr):
+            whole = timed(fwd, 10)
+        print(f"   scalar below {thr:6d}: " + " ".join(f"{v:5.1f}" for v in rows[thr]) + f"   | all levels in one launch {whole:.1f}")
+if os.environ.get("FWD_SCALAR_FROM"):
+    print("== encode forward, whole launch: 4-byte gathers at the levels of res >= SDFX_GRID_SCALAR_FROM, with SDFX_GRID_LEVEL_COST (alternating rounds)")
+    cfgs = [c.split(":") for c in os.environ["FWD_SCALAR_FROM"].split(";") if c]   # "from:cost,cost,..." ; cost list may be empty
+    ref = None
+    for rnd in range(3):
+        for frm, cost in cfgs:
+            if cost:
+                os.environ["SDFX_GRID_LEVEL_COST"] = cost
+            with _sdfx.dev_switch(SDFX_GRID_SCALAR_FROM=int(frm)):
+                t = timed(fwd, 10)
+                if ref is None:
+                    ref = out.clone()
+                same = bool(torch.equal(out.view(torch.int16), ref.view(torch.int16)))
+            os.environ.pop("SDFX_GRID_LEVEL_COST", None)
+            print(f"   round {rnd} from {int(frm):5d} costs {cost or 'table'}: {t:7.1f} us/launch identical {same}")
+    for frm, cost in cfgs:
+        if cost:
+            os.environ["SDFX_GRID_LEVEL_COST"] = cost
+        with _sdfx.dev_switch(SDFX_GRID_SCALAR_FROM=int(frm)):
+            report(stamped(fwd), 1, f"encode forward, 4-byte gathers from res {frm}, costs {cost or 'table'}")
+        os.environ.pop("SDFX_GRID_LEVEL_COST", None)
 if os.environ.get("FWD_COSTS"):
     print("== encode forward: the plan's cost model against SDFX_GRID_LEVEL_COST candidates (alternating)")
     cands = [c for c in os.environ["FWD_COSTS"].split(";") if c]
