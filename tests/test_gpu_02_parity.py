@@ -150,6 +150,7 @@ def test_grid_forward_hinted_kernel_bit_exact(oracle, dev, is_half, interp, grid
     pts = np.clip(xyzs[None] + offs[:, None], -1, 1).reshape(-1, 3)               # [7, M, 3]
     x = ((pts + np.float32(1)) / np.float32(2)).astype(np.float32)
     x[3] = [1.5, 0.2, 0.2]; x[11] = [0.3, -0.1, 0.5]                              # outside [0, 1]: zero features
+    x[5] = [1.0, 1.0, 1.0]; x[6] = [0.0, 0.0, 0.0]; x[12] = [1.0, 0.5, 0.0]       # the grid's first and last vertices (dense levels: the two-row load's edge case)
     S = np.log2(pls)
     L, C = 16, 2
     step = 1.0 / 591.0
