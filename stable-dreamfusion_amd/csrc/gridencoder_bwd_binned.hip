@@ -368,7 +368,7 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::
     // write-out: it stays in a register while the histogram is scanned and the items are staged (the round trip of a returning
     // device-scope atomic is a microsecond or two). And an exclusive prefix sum of the histogram = where each bucket's items go in
     // the workgroup's LDS staging area
-    uint32_t my_cnt = 0, my_base = 0, my_boff = 0;
+    uint32_t my_cnt = 0, my_base = 0;
     if (threadIdx.x < nb) {
         my_cnt = hist[threadIdx.x];
         if (my_cnt && !SDFX_ABLATE(4u)) my_base = atomicAdd(&cursors[bucket0 + threadIdx.x], my_cnt);
@@ -379,8 +379,7 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::
         __syncthreads();
         uint32_t woff = 0;
         for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) woff += wave_tot[w];
-        my_boff = woff + incl - my_cnt;
-        if (threadIdx.x < nb) boff[threadIdx.x] = my_boff;
+        if (threadIdx.x < nb) boff[threadIdx.x] = woff + incl - my_cnt;
         if (threadIdx.x == kBinThreads - 1) *block_total = woff + incl;
     }
     __syncthreads();
@@ -393,45 +392,32 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::
     // (exact); float tables add with the reference's float atomics.
     const uint32_t cap = bin.cap[level];
     Item<HALF>* level_items = items + (size_t)bin.item_first[level] * 1024u;
-    // (staging slot -> LDS address by a full-rate 24-bit multiply: slots are < kBinThreads * NIT)
-    auto stage_at = [&](uint32_t slot) -> Item<HALF>& { return *reinterpret_cast<Item<HALF>*>(reinterpret_cast<char*>(stage) + __umul24(slot, (uint32_t)sizeof(Item<HALF>))); };
     if (emit && !SDFX_ABLATE(2u)) {
 #pragma unroll
         for (uint32_t i = 0; i < NIT; i++) {
             if constexpr (HALF) {
                 const uint32_t v0 = c.h[2 * i], v1 = c.h[2 * i + 1];
-                const uint32_t slot_lds = boff[ibucket[i]] + rank[i];
-                stage_at(slot_lds) = make_pair_item(rows[2 * i], split[i] ? rows[2 * i] : rows[2 * i + 1], v0, split[i] ? 0u : v1);
+                stage[boff[ibucket[i]] + rank[i]] = make_pair_item(rows[2 * i], split[i] ? rows[2 * i] : rows[2 * i + 1], v0, split[i] ? 0u : v1);
                 if (split[i]) {   // the second corner goes to its own bucket's list by a one-slot reservation of this lane
                     const uint32_t b1 = rows[2 * i + 1] >> kBucketRowsLog2;
                     const uint32_t slot = atomicAdd(&cursors[bucket0 + b1], 1u);
                     if (slot < cap) level_items[(size_t)b1 * cap + slot] = make_pair_item(rows[2 * i + 1], rows[2 * i + 1], v1, 0u);
                 }
             } else {
-                const uint32_t slot_lds = boff[ibucket[i]] + rank[i];
-                stage_at(slot_lds) = Item<false>::make(rows[i], c.v[i].x, c.v[i].y);
+                stage[boff[ibucket[i]] + rank[i]] = Item<false>::make(rows[i], c.v[i].x, c.v[i].y);
             }
         }
     }
-    // What the write-out needs per bucket, in two words (the reservation's result is first touched here): staging slot k of bucket b
-    // goes to byte gdelta[b] + 12 k of the level's lists — a 32-bit offset on a uniform base: the chunk size bounds a level's lists
-    // below 4 GB (kMaxChunk) — if k < klimit[b], the staging slot at which the bucket's list is full. (64-bit index arithmetic per
-    // ITEM was three quarter-rate multiplies: a fifth of the kernel's vector instructions.) `hist` is dead since the scan read it.
-    uint32_t* const gdelta = gbase;
-    uint32_t* const klimit = hist;
-    if (threadIdx.x < nb) {
-        gdelta[threadIdx.x] = (threadIdx.x * cap + my_base - my_boff) * (uint32_t)sizeof(Item<HALF>);
-        klimit[threadIdx.x] = my_boff + (cap > my_base ? cap - my_base : 0u);
-    }
+    if (threadIdx.x < nb) gbase[threadIdx.x] = my_base;   // (the reservation's result is first touched here)
     __syncthreads();
 
     const uint32_t total = SDFX_ABLATE(3u) ? 0u : *block_total;
-    char* const level_bytes = reinterpret_cast<char*>(level_items);
     for (uint32_t k = threadIdx.x; k < total; k += kBinThreads) {
         const Item<HALF> it = stage[k];
         const uint32_t bucket = it.bucket();
-        if (k < klimit[bucket]) {
-            *reinterpret_cast<Item<HALF>*>(level_bytes + (uint32_t)(gdelta[bucket] + k * (uint32_t)sizeof(Item<HALF>))) = it;
+        const uint32_t slot = gbase[bucket] + (k - boff[bucket]);
+        if (slot < cap) {
+            level_items[(size_t)bucket * cap + slot] = it;
         } else if constexpr (!HALF) {
             T* dst = grad_table + ((size_t)lc.row0 + it.row) * C;
             unsafeAtomicAdd(dst, it.a);
@@ -816,10 +802,6 @@ __global__ __launch_bounds__(kReduceThreads) void k_grid_bwd_reduce_ticket(float
     }
 }
 
-// K1 addresses a level's lists by 32-bit byte offsets: at most 2.5 x 8 x chunk twelve-byte items per level (a float table's few-bucket
-// level) = 240 bytes per sample -> chunks of at most 2^23 samples (2 GB); longer batches take several passes (the loop in the entry point)
-constexpr uint32_t kMaxChunk = 1u << 23;
-
 // host: bucket geometry for a chunk of `chunk` samples
 BinPlan make_bin_plan(const GridPlan& plan, uint32_t levels, uint32_t chunk, bool pair_items, uint64_t* total_items_1024,
                       uint32_t* total_buckets, uint32_t* total_splits, uint32_t* shared_acc_rows = nullptr,
@@ -1106,7 +1088,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
     }
 
     // largest chunk (multiple of 512 samples) whose item lists fit the scratch
-    uint32_t chunk = B < kMaxChunk ? B : kMaxChunk;
+    uint32_t chunk = B;
     {
         const uint32_t gran = kBinThreads * kPointsPerThread;
         chunk = ((chunk + gran - 1) / gran) * gran;
