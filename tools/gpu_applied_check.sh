@@ -7,7 +7,7 @@ ARGS="--no-stock-prior --no-children --no-cpu-baseline --no-kernel-bench --no-ne
 pick() { python -c "
 import json,sys
 d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
-print(sys.argv[2], 'value %.1f applied %s scale %s samples %.0f frac %.3f enc_us %.1f pts %.0f' % (d['value'], d['optimizer_steps_applied'], d['grad_scale'], d['samples_per_iter'], d['roofline']['frac'], d['roofline']['avg_launch_us'], d['roofline']['points_per_launch']))" $1 $2; }
+print(sys.argv[2], 'latent %.1f' % d['phases']['latent']['iters_per_sec'], 'value %.1f applied %s scale %s samples %.0f frac %.3f enc_us %.1f pts %.0f' % (d['value'], d['optimizer_steps_applied'], d['grad_scale'], d['samples_per_iter'], d['roofline']['frac'], d['roofline']['avg_launch_us'], d['roofline']['points_per_launch']))" $1 $2; }
 for i in $(seq 1 $RUNS); do
   timeout 300 python bench.py $ARGS > $OUT/product_$i.json 2> $OUT/product_$i.err; pick $OUT/product_$i.json product_$i | tee -a $OUT/summary.txt
 done
