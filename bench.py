@@ -88,6 +88,7 @@ class KernelTimer:
     def __init__(self):
         self.records = []   # (name, start_event, end_event, algorithmic_bytes)
         self.enabled = False
+        self.cover_host = False   # only the untimed eager pass spins in front of its launches: NOTHING is added to the timed region
 
     def wrap(self, module, fname, name, bytes_fn):
         inner = getattr(module, fname)
@@ -100,7 +101,8 @@ class KernelTimer:
             # the host needs 20-40 us of Python between the two records (argument marshalling of the operator): on an idle stream
             # that time would sit between the start event and the kernel. A short GPU-side spin in front keeps the stream busy
             # while [start, kernel, end] are queued, so the events bracket the kernel alone (what rocprofv3 reports for it)
-            torch.cuda._sleep(HOST_COVER_CYCLES)
+            if timer.cover_host:
+                torch.cuda._sleep(HOST_COVER_CYCLES)
             s.record()
             out = inner(*a, **k)
             e.record()
@@ -993,12 +995,13 @@ def main():
         # launch sizes up to the capacity padding). rocprofv3 sees the replayed kernels directly: profiles/ holds that
         # trace of this command for comparison (tools/gpu_profile_round.sh).
         step.mode = "device"
-        timer.enabled = True
+        del timer.records[:]          # (the timed region's few eager launches — the occupancy refresh — are not part of these figures)
+        timer.enabled = timer.cover_host = True
         n_eager = min(args.steps, 8)
         for j in range(n_eager):
             job.step(i + j)
         job.sync()
-        timer.enabled = False
+        timer.enabled = timer.cover_host = False
         step.mode = "graph"
         roofline_pass = f"{n_eager} eager iterations after the timed region (graph replay hides launches from Python)"
 
