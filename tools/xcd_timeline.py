@@ -174,7 +174,7 @@ if os.environ.get("FWD_LEVELS", "1") == "1":
     tiles = -(-(-(-M // 9) * 64) // 256)
     for l in range(16):
         print(f"   level {l:2d}: {iso[l]:7.1f} us  {1e3 * iso[l] / tiles:6.2f} ns/tile  x{iso[l] / iso[0]:.2f}")
-    print(f"   sum over the levels {sum(iso):.1f} us = {sum(iso) / 8:.1f} us per XCD if split perfectly; all levels in one launch: {timed(fwd, 10):.1f} us")
+    print(f"   sum over the levels {sum(iso):.1f} us (each alone on all eight XCDs, one after the other); all levels in one launch: {timed(fwd, 10):.1f} us")
     print("   as SDFX_GRID_LEVEL_COST: " + ",".join(f"{v / iso[0] * 100:.0f}" for v in iso))
     os.environ["SDFX_GRID_LEVEL_COST"] = ",".join(f"{v / iso[0] * 100:.0f}" for v in iso)
     print(f"   with the split cut by these measured costs: {timed(fwd, 10):.1f} us per launch")
