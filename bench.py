@@ -637,9 +637,6 @@ class GpuJob:
         self.dmtet = args.stage == "dmtet"
         if self.dmtet:
             from sdfx_nerf.options import dmtet_preset
-            from sdfx_nerf.renderer import NeRFRenderer
-            import dmtet_caller                      # tests/dmtet_caller.py: the reference's run_dmtet + mesh regularisers (caller code the
-            dmtet_caller.install(NeRFRenderer)       # package does not ship; /root/reference is absent on the GPU box)
             dmtet_preset(self.opt)                   # main.py:253-260: 512 x 512, t_range [0.02, 0.50]
         self.model = NeRFNetwork(self.opt).to(dev)
         if self.dmtet:
@@ -929,13 +926,27 @@ def main():
         dist.barrier()
     job.sync()
     timer.enabled = True
+    # experiments of DESIGN section 7.1 (never set in a measured run): SDFX_BENCH_SPIN_TIMED=1 puts round 5's GPU-side spin back in
+    # front of the timed region's eager wrapped launches; SDFX_BENCH_TRACE=1 keeps, per step and without a host read, the sample
+    # total and a copy of the optimiser's control block (loss scale, applied / skipped steps) and prints them to stderr afterwards
+    timer.cover_host = os.environ.get("SDFX_BENCH_SPIN_TIMED") == "1"
+    step_trace = [] if (os.environ.get("SDFX_BENCH_TRACE") == "1" and not dry) else None
     samples, marks = 0, []
     t0 = time.perf_counter()
     i = args.warmup
     for name, k in plan:
         job.set_phase(name)
         for _ in range(k):
-            samples += job.step(i)
+            m_step = job.step(i)
+            samples += m_step
+            if step_trace is not None and hasattr(job.step_obj.optimizer, "ctl"):
+                st_ = job.step_obj
+                entry = st_.graphs.get(getattr(st_, "last_key", None))
+                extra = None
+                if entry is not None:     # the replayed graph's loss and the largest |scaled gradient| per parameter tensor
+                    extra = torch.stack([entry[2].float().reshape(())] + [g.detach().abs().max().float() if g is not None
+                                                                           else torch.zeros((), device=dev) for g in entry[4]])
+                step_trace.append((name, st_.global_step, m_step, st_.optimizer.ctl.clone(), extra))
             i += 1
         if len(plan) > 1:
             job.sync()                             # phase boundary: one device synchronisation inside the region
@@ -946,8 +957,14 @@ def main():
         dist.barrier()
     job.sync()
     elapsed_local = time.perf_counter() - t0
-    timer.enabled = False
+    timer.enabled = timer.cover_host = False
     stage("timed region done")
+    if step_trace:
+        for name, gs, m_step, ctl, extra in step_trace:
+            c = ctl.cpu().tolist()
+            x = "" if extra is None else " loss %.4g gradmax " % extra[0].item() + " ".join("%.3g" % v for v in extra[1:].cpu().tolist())
+            print(f"[trace] {name} global_step {gs} samples {m_step} scale {c[0]:g} applied {int(c[2])} skipped {int(c[10])} "
+                  f"norm {c[9]:.4g} clip {c[4]:.4g}{x}", file=sys.stderr)
     applied_in_timed = job.applied() - applied_before
     stats_timed = {k: v - stats_before.get(k, 0) for k, v in getattr(getattr(job, "step_obj", None), "stats", {}).items()}
     host_now = dict(getattr(getattr(job, "step_obj", None), "host_s", {}))
@@ -1156,7 +1173,18 @@ def main():
             "note": "`value` runs the frozen prior on this repository's kernels (outside SURVEY section 8); iters_per_sec_stock_prior is the "
                     "same region with stock PyTorch-ROCm ops, north_star's configuration",
             "miopen_find_mode": bool(torch.backends.cudnn.benchmark), "captured_in_hip_graph": job.train_mode == "graph"},
-        "rays_per_iter": 512 * 512 if args.stage == "dmtet" else 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid, "phase": args.phase}
+        "rays_per_iter": 512 * 512 if args.stage == "dmtet" else 4096, "parallelism": f"independent-prompts x{world}", "occupancy": args.grid, "phase": args.phase,
+        # what this very run did, kept INSIDE `config` because the driver's record keeps this object whole (and only the names of the
+        # other top-level keys): every timed step must have applied its optimiser step; the north_star configuration (frozen prior
+        # on stock PyTorch-ROCm ops) and this repository's own part of the iteration beside the headline
+        "run_record": {
+            "steps": args.steps, "optimizer_steps_applied": applied_in_timed, "all_steps_applied": bool(applied_in_timed == args.steps),
+            "grad_scale": result.get("grad_scale"), "samples_per_iter": round(samples / max(args.steps, 1)),
+            "train_mode": job.train_mode, "graph_stats_timed_region": stats_timed,
+            "iters_per_sec_stock_prior": stock_prior, "iters_per_sec_reference_flow": ref_flow,
+            "iters_per_sec_nerf_only": nerf_only, "ms_nerf_only": nerf_only_ms, "samples_per_iter_nerf_only": nerf_only_samples,
+            "ms_nerf_only_per_million_samples": result.get("ms_nerf_only_per_million_samples"),
+            "phases_iters_per_sec": {k: round(v["iters_per_sec"], 2) for k, v in phases.items()}}}
     try:   # the dispatch assumption behind the level-per-XCD plans (include/sdfx.h): 1 = workgroup b runs on XCD (b + c) mod 8
         import _sdfx
         result["xcd_round_robin"] = int(_sdfx.lib().sdfx_xcd_round_robin())

@@ -174,10 +174,13 @@ uint64_t sdfx_compact_rays_scratch_bytes(uint32_t n);
  *                           (in the reference's meshgrid order n = (x H + y) H + z) or, when NULL, from Philox4x32-10 keyed
  *                           by (seed, cascade) with counter n. The density of point m is then the new value of cell m.
  *   sdfx_occupancy_update   grid = max(grid * decay, sigmas) where grid >= 0 (renderer.py:1137-1139); stats[0] += sum,
- *                           stats[1] += count of those cells (doubles; zeroed first when reset_stats != 0).
+ *                           stats[1] += count of those cells (doubles; zeroed first when reset_stats != 0). `stats` holds
+ *                           sdfx_occupancy_stats_doubles() doubles, zero before the first use: behind the two totals sit the
+ *                           per-workgroup partials, added up in a fixed order (the mean is bit-reproducible).
  *   sdfx_occupancy_pack     bitfield = packbits(grid, min(stats[0] / stats[1], density_thresh)) (renderer.py:1140-1147,
  *                           raymarching.cu:267-300); mean_out[0] (optional) = the mean, for reporting.
  */
+uint32_t sdfx_occupancy_stats_doubles(void);
 int sdfx_occupancy_points(uint32_t H, double bound_cascade, const float* noise, uint64_t seed, uint32_t cascade, float* xyzs,
                           sdfx_stream_t stream);
 int sdfx_occupancy_update(float* density_grid_cascade, const float* sigmas, uint32_t n_cells, float decay, double* stats,
@@ -468,7 +471,9 @@ int sdfx_entropy_backward(const float* weights, uint32_t capacity, const int32_t
  *   ctl    float32[sdfx_adan_ctl_words()]:  [0] loss scale (set before first use)  [1] growth tracker
  *          [2] optimiser steps applied  [3] 1/scale  [4] clip factor  [5] 1 = this iteration overflowed
  *          [6..8] bias corrections  [9] unscaled gradient norm  [10] iterations skipped
- *   stats  float64[2], zero before the first use: sum of squares of all (scaled) gradients, non-finite count
+ *   stats  float64[sdfx_amp_grad_stats_doubles()], zero before the first use: [0] sum of squares of all (scaled) gradients,
+ *          [1] non-finite count, the rest is the kernels' own (per-workgroup partials added up in a fixed order, so that the two
+ *          totals do not depend on the order the workgroups ran in)
  *
  * Per iteration: sdfx_amp_grad_stats over all gradient tensors, sdfx_adan_prepare (also applies
  * GradScaler.update()'s growth/back-off to ctl[0] and clears stats), sdfx_adan_update over all parameter
@@ -477,6 +482,7 @@ int sdfx_entropy_backward(const float* weights, uint32_t capacity, const int32_t
  * arguments, so one launch covers up to 16 tensors.
  */
 uint32_t sdfx_adan_ctl_words(void);
+uint32_t sdfx_amp_grad_stats_doubles(void);
 int sdfx_amp_grad_stats(const float* const* grads, const uint64_t* counts, uint32_t tensors, double* stats,
                         sdfx_stream_t stream);
 int sdfx_adan_prepare(float* ctl, double* stats, float beta1, float beta2, float beta3, float max_grad_norm, float eps,

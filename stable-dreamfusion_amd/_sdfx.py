@@ -115,6 +115,8 @@ _SIGNATURES = {
     "sdfx_conv3x3_scratch_bytes": [_u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _int],
     "sdfx_conv3x3_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _int, _ptr, _ptr, _ptr],
     "sdfx_adan_ctl_words": [],
+    "sdfx_amp_grad_stats_doubles": [],
+    "sdfx_occupancy_stats_doubles": [],
     "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],
     "sdfx_adan_prepare": [_ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _u32, _ptr],
     "sdfx_adan_update": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _f32, _f32, _f32, _f32, _int, _ptr],
@@ -133,6 +135,8 @@ _RESTYPES = {
     "sdfx_linear_scratch_bytes": _u64,
     "sdfx_conv3x3_packed_scratch_bytes": _u64,
     "sdfx_adan_ctl_words": _u32,
+    "sdfx_amp_grad_stats_doubles": _u32,
+    "sdfx_occupancy_stats_doubles": _u32,
 }
 
 _LIB = None

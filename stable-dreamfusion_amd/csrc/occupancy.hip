@@ -11,8 +11,8 @@
 //                  meshgrid index n = (x H + y) H + z — used by the parity tests), or Philox4x32-10 keyed by (seed, cascade)
 //                  with counter n: reproducible for a given seed whatever the launch shape.
 //   k_occ_update   density_grid = max(density_grid * decay, sigma) where density_grid >= 0 (renderer.py:1137-1139), and
-//                  the sum and count of the updated valid cells (for the mean, :1140), reduced per wave, one double
-//                  atomicAdd per workgroup.
+//                  the sum and count of the updated valid cells (for the mean, :1140): per-workgroup partials in fixed slots,
+//                  added up in slot order by the last workgroup to arrive (bit-reproducible: no floating-point atomics).
 //   k_occ_pack     threshold = min(mean, density_thresh) computed ON THE DEVICE from those two numbers (the reference
 //                  reads the mean back with .item(), :1140-1144), then the bit packing of raymarching.cu:267-300.
 #include <hip/hip_runtime.h>
@@ -65,9 +65,16 @@ __global__ __launch_bounds__(256) void k_occ_points(uint32_t H, uint32_t n_cells
     }
 }
 
+// `stats` (float64 words; sdfx_occupancy_stats_doubles() of them): [0] sum, [1] count, [2] arrival ticket of the launch in flight,
+// [3 ...] per-workgroup (sum, count) partials. Each workgroup fills its own slot, the one that arrives last adds the slots in slot
+// order: the mean — and with it the occupancy threshold — is the same bits whatever order the workgroups ran in.
+constexpr uint32_t kOccHeader = 3, kOccMaxBlocks = 2048;
+
 __global__ __launch_bounds__(256) void k_occ_update(float* __restrict__ grid, const float* __restrict__ sigmas, uint32_t n_cells,
                                                      float decay, double* __restrict__ stats) {
     __shared__ double part[2][4];
+    __shared__ double red[2][256];
+    __shared__ int is_last;
     double sum = 0.0, cnt = 0.0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_cells; i += gridDim.x * 256) {
         const float old = grid[i];
@@ -80,9 +87,32 @@ __global__ __launch_bounds__(256) void k_occ_update(float* __restrict__ grid, co
     for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o); cnt += __shfl_down(cnt, o); }
     if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = sum; part[1][threadIdx.x >> 6] = cnt; }
     __syncthreads();
+    double* __restrict__ slots = stats + kOccHeader;
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(stats + 2);
     if (threadIdx.x == 0) {
-        atomicAdd(&stats[0], part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-        atomicAdd(&stats[1], part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        __hip_atomic_store(&slots[2 * blockIdx.x], part[0][0] + part[0][1] + part[0][2] + part[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&slots[2 * blockIdx.x + 1], part[1][0] + part[1][1] + part[1][2] + part[1][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        is_last = atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    double s = 0.0, c = 0.0;
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += 256) {
+        s += __hip_atomic_load(&slots[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c += __hip_atomic_load(&slots[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = c;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[0] += red[0][0];      // the cascades' launches follow one another on the stream
+        stats[1] += red[1][0];
+        *ticket = 0ull;
     }
 }
 
@@ -106,6 +136,8 @@ __global__ __launch_bounds__(256) void k_occ_pack(const float* __restrict__ grid
 
 extern "C" {
 
+uint32_t sdfx_occupancy_stats_doubles(void) { return kOccHeader + 2 * kOccMaxBlocks; }
+
 int sdfx_occupancy_points(uint32_t H, double bound_cascade, const float* noise, uint64_t seed, uint32_t cascade, float* xyzs,
                           sdfx_stream_t stream) {
     SDFX_REQUIRE(xyzs, "occupancy_points: null pointer");
@@ -121,9 +153,9 @@ int sdfx_occupancy_update(float* density_grid_cascade, const float* sigmas, uint
                           sdfx_stream_t stream) {
     SDFX_REQUIRE(density_grid_cascade && sigmas && stats, "occupancy_update: null pointer");
     hipStream_t st = as_stream(stream);
-    if (reset_stats) zero_device(stats, 2 * sizeof(double), st);
+    if (reset_stats) zero_device(stats, kOccHeader * sizeof(double), st);
     if (n_cells == 0) return SDFX_OK;
-    const uint32_t blocks = div_up(n_cells, 256 * 8) < 2048 ? div_up(n_cells, 256 * 8) : 2048;
+    const uint32_t blocks = div_up(n_cells, 256 * 8) < kOccMaxBlocks ? div_up(n_cells, 256 * 8) : kOccMaxBlocks;
     hipLaunchKernelGGL(k_occ_update, dim3(blocks), dim3(256), 0, st, density_grid_cascade, sigmas, n_cells, decay, stats);
     return check_launch("occupancy_update");
 }

@@ -27,11 +27,20 @@ namespace {
 
 constexpr uint32_t kThreads = 256;
 
+// Layout of `stats` (float64 words; sdfx_amp_grad_stats_doubles() of them): [0] sum of squares, [1] non-finite workgroups,
+// [2] arrival ticket of the launch in flight (bit pattern of a uint64), [3 ...] per-workgroup partials (sum, flag) pairs.
+// Every workgroup stores its partial in ITS OWN slot; the workgroup that arrives last adds the slots up in slot order. The two
+// totals are therefore the same bits whatever order the workgroups ran in (a double atomicAdd per workgroup made the low bits of
+// the gradient norm — and with them, once in a long while, the float32 clip factor — depend on timing).
+constexpr uint32_t kStatsHeader = 3;
+constexpr uint32_t kMaxStatBlocks = 512 * 16;   // 512 workgroups per tensor, 16 tensors per launch
+
 // one workgroup's share of one gradient tensor: `nblocks` workgroups stride over it
 __device__ __forceinline__ void grad_stats_body(const float* __restrict__ g, uint64_t n, uint32_t block, uint32_t nblocks,
                                                 double* __restrict__ stats) {
     __shared__ double part[kThreads / 64];
-    __shared__ int bad_any;
+    __shared__ double red[2][kThreads];
+    __shared__ int bad_any, is_last;
     if (threadIdx.x == 0) bad_any = 0;
     __syncthreads();
     double acc = 0.0;
@@ -51,16 +60,39 @@ __device__ __forceinline__ void grad_stats_body(const float* __restrict__ g, uin
             acc += (double)v[k] * (double)v[k];
         }
     }
-    // wave reduction, then one atomic per workgroup
+    // wave reduction (fixed tree), then this workgroup's slot
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if (__ballot(bad) && (threadIdx.x & 63) == 0) bad_any = 1;
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
+    double* __restrict__ slots = stats + kStatsHeader;
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(stats + 2);
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (uint32_t w = 0; w < kThreads / 64; w++) s += part[w];
-        atomicAdd(&stats[0], s);
-        if (bad_any) atomicAdd(&stats[1], 1.0);
+        __hip_atomic_store(&slots[2 * blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&slots[2 * blockIdx.x + 1], bad_any ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        is_last = atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    double s = 0.0, b = 0.0;
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += kThreads) {     // slot order per thread, then a fixed tree
+        s += __hip_atomic_load(&slots[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b += __hip_atomic_load(&slots[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (uint32_t o = kThreads / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[0] += red[0][0];      // launches on one stream run one after the other: a plain read-modify-write
+        stats[1] += red[1][0];
+        *ticket = 0ull;
     }
 }
 
@@ -153,6 +185,8 @@ uint32_t blocks_for(uint64_t n) {
 extern "C" {
 
 uint32_t sdfx_adan_ctl_words(void) { return 16; }
+
+uint32_t sdfx_amp_grad_stats_doubles(void) { return kStatsHeader + 2 * kMaxStatBlocks; }
 
 int sdfx_amp_grad_stats(const float* const* grads, const uint64_t* counts, uint32_t tensors, double* stats,
                         sdfx_stream_t stream) {

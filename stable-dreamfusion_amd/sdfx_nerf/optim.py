@@ -106,7 +106,7 @@ class DeviceAdan:
         dev = self.param_groups[0]["params"][0].device
         self.ctl = torch.zeros(int(S.lib().sdfx_adan_ctl_words()), dtype=torch.float32, device=dev)
         self.ctl[0] = init_scale if amp else 1.0
-        self.stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.stats = torch.zeros(int(S.lib().sdfx_amp_grad_stats_doubles()), dtype=torch.float64, device=dev)
         self.scale = self.ctl[0]
         self.state = {}
         for g in self.param_groups:

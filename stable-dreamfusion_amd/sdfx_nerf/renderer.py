@@ -95,24 +95,14 @@ class NeRFRenderer(nn.Module):
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def run_dmtet(self, rays_o, rays_d, mvp, h, w, **kwargs):
-        """The reference's `run_dmtet` (nerf/renderer.py:862-964) and its mesh regularisers (:179-257) are CALLER code — plain tensor
-        operations around the operators, which SURVEY section 2 leaves to the reference's own file — and are not part of this package.
-        What the package provides for that stage are the operators they call: marching tetrahedra (`self.dmtet_model`, csrc/dmtet.hip)
-        and rasterize / interpolate / antialias with nvdiffrast's signatures (sdfx_nerf/dmtet.py, csrc/raster.hip). With the reference
-        checkout present its own method runs on them; bench.py and the tests, which run where the reference
-        is absent, install the harness copy kept beside the tests (tests/dmtet_caller.py: `install(NeRFRenderer)`)."""
-        caller = getattr(type(self), "_dmtet_caller", None)
-        if caller is None:
-            raise RuntimeError("run_dmtet: no caller installed — use the reference's nerf/renderer.py:862-964 over sdfx_nerf.dmtet's "
-                               "operators (INTEGRATION.md), or tests/dmtet_caller.install(NeRFRenderer)")
-        return caller(self, rays_o, rays_d, mvp, h, w, **kwargs)
+        """One frame of the DMTet stage (what nerf/renderer.py:862-964 returns): sdfx_nerf/dmtet_stage.py."""
+        from . import dmtet_stage
+        return dmtet_stage.run_dmtet(self, rays_o, rays_d, mvp, h, w, **kwargs)
 
     def init_tet(self, mesh=None):
-        """nerf/renderer.py:818-859 (sdf / tet_scale from the density field): caller code like run_dmtet, same arrangement."""
-        caller = getattr(type(self), "_init_tet_caller", None)
-        if caller is None:
-            raise RuntimeError("init_tet: no caller installed (see run_dmtet)")
-        return caller(self, mesh)
+        """sdf / tet_scale from the density field (nerf/renderer.py:818-859): sdfx_nerf/dmtet_stage.py."""
+        from . import dmtet_stage
+        return dmtet_stage.init_tet(self, mesh)
 
     @torch.no_grad()
     def density_blob(self, x):
@@ -311,7 +301,7 @@ class NeRFRenderer(nn.Module):
         H, n = self.grid_size, self.grid_size ** 3
         if self._occ_buffers is None or self._occ_buffers[0].device != device:
             self._occ_buffers = (torch.empty(n, 3, dtype=torch.float32, device=device),
-                                 torch.zeros(2, dtype=torch.float64, device=device),
+                                 torch.zeros(int(S.lib().sdfx_occupancy_stats_doubles()), dtype=torch.float64, device=device),
                                  torch.zeros(1, dtype=torch.float32, device=device))
         pts, stats, mean = self._occ_buffers
         grid = S.check_tensor(self.density_grid, "density_grid", torch.float32)

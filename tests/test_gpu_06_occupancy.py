@@ -83,7 +83,7 @@ def test_update_and_pack_match_the_reference_expressions(oracle, dev, cascades):
     bits_ref = oracle.packbits(new, thresh)
 
     grid = torch.from_numpy(grid0).to(dev)
-    stats = torch.zeros(2, dtype=torch.float64, device=dev)
+    stats = torch.zeros(int(S.lib().sdfx_occupancy_stats_doubles()), dtype=torch.float64, device=dev)
     mean_out = torch.zeros(1, device=dev)
     bitfield = torch.zeros(cascades * n // 8, dtype=torch.uint8, device=dev)
     for cas in range(cascades):

@@ -31,8 +31,6 @@ def rel(a, ref):
 def D():
     importlib.import_module("stable-dreamfusion_amd")
     from sdfx_nerf import dmtet, renderer
-    import dmtet_caller                          # the reference's run_dmtet + mesh regularisers, restated: harness, not product
-    dmtet_caller.install(renderer.NeRFRenderer)
     return dmtet
 
 
