@@ -946,7 +946,7 @@ def main():
                 if entry is not None:     # the replayed graph's loss and the largest |scaled gradient| per parameter tensor
                     extra = torch.stack([entry[2].float().reshape(())] + [g.detach().abs().max().float() if g is not None
                                                                            else torch.zeros((), device=dev) for g in entry[4]])
-                step_trace.append((name, st_.global_step, m_step, st_.optimizer.ctl.clone(), extra))
+                step_trace.append((name, st_.global_step, m_step, st_.optimizer.ctl.clone(), extra, time.perf_counter() - t0))
             i += 1
         if len(plan) > 1:
             job.sync()                             # phase boundary: one device synchronisation inside the region
@@ -960,11 +960,13 @@ def main():
     timer.enabled = timer.cover_host = False
     stage("timed region done")
     if step_trace:
-        for name, gs, m_step, ctl, extra in step_trace:
+        t_prev = 0.0
+        for name, gs, m_step, ctl, extra, t_host in step_trace:
             c = ctl.cpu().tolist()
             x = "" if extra is None else " loss %.4g gradmax " % extra[0].item() + " ".join("%.3g" % v for v in extra[1:].cpu().tolist())
             print(f"[trace] {name} global_step {gs} samples {m_step} scale {c[0]:g} applied {int(c[2])} skipped {int(c[10])} "
-                  f"norm {c[9]:.4g} clip {c[4]:.4g}{x}", file=sys.stderr)
+                  f"norm {c[9]:.4g} clip {c[4]:.4g} host_ms {1e3 * (t_host - t_prev):.2f}{x}", file=sys.stderr)
+            t_prev = t_host
     applied_in_timed = job.applied() - applied_before
     stats_timed = {k: v - stats_before.get(k, 0) for k, v in getattr(getattr(job, "step_obj", None), "stats", {}).items()}
     host_now = dict(getattr(getattr(job, "step_obj", None), "host_s", {}))

@@ -210,6 +210,11 @@ int sdfx_render_infer(const float* rays_o, const float* rays_d, const float* nea
  * segment (xcd, level, first tile, tiles); an XCD walks its segments in order. Returns the number of segments, < 0 on error. */
 int sdfx_grid_forward_plan(const int32_t* offsets_host, uint32_t max_level, float S, uint32_t H, int is_half, uint32_t B,
                            uint32_t slabs, float step, int32_t* segments, uint32_t max_segments, uint32_t* tiles_per_level);
+/* Host-only: costs[l] (l < max_level) = what the plan above prices a tile of level l at, in table lines looked up by a wave: the
+ * model max(distinct lines per wave at the step hint, VALU floor), or — for the one configuration it was measured on, the -O grid at
+ * the iteration's step — that model corrected by a per-XCD timeline; 1.0 for every level without a step hint. Returns max_level. */
+int sdfx_grid_forward_level_costs(const int32_t* offsets_host, uint32_t max_level, float S, uint32_t H, uint32_t slabs, float step,
+                                  double* costs);
 
 /* Host-only (no GPU work): the per-XCD item ranges the binned backward's first kernel would use for a batch of B points:
  * ranges[2k], ranges[2k + 1] = [start, end) of XCD k over the (virtual level, tile) items in virtual-level-major order,
@@ -479,7 +484,9 @@ int sdfx_entropy_backward(const float* weights, uint32_t capacity, const int32_t
  * GradScaler.update()'s growth/back-off to ctl[0] and clears stats), sdfx_adan_update over all parameter
  * tensors (a no-op when ctl[5] != 0, as GradScaler.step() skips optimizer.step()). The tensor lists are HOST
  * arrays of device pointers / element counts / per-tensor lr and weight decay; they travel in the kernel
- * arguments, so one launch covers up to 16 tensors.
+ * arguments, so one launch covers up to 16 tensors. `half_copies` (NULL, or one entry per tensor, each NULL or a float16 buffer of
+ * that tensor's size): the update also writes half(p) there — the fp16 table the next forward gathers from (gridencoder/grid.py:46-47
+ * casts the whole table every call; an overflowed iteration leaves parameter and copy untouched, so they stay in step).
  */
 uint32_t sdfx_adan_ctl_words(void);
 uint32_t sdfx_amp_grad_stats_doubles(void);
@@ -488,7 +495,7 @@ int sdfx_amp_grad_stats(const float* const* grads, const uint64_t* counts, uint3
 int sdfx_adan_prepare(float* ctl, double* stats, float beta1, float beta2, float beta3, float max_grad_norm, float eps,
                       float growth_factor, float backoff_factor, uint32_t growth_interval, sdfx_stream_t stream);
 int sdfx_adan_update(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_diff,
-                     float* const* exp_avg_sq, float* const* pre_grad, const uint64_t* counts, const float* lrs,
+                     float* const* exp_avg_sq, float* const* pre_grad, void* const* half_copies, const uint64_t* counts, const float* lrs,
                      const float* weight_decays, uint32_t tensors, const float* ctl, float eps, float beta1, float beta2,
                      float beta3, int no_prox, sdfx_stream_t stream);
 

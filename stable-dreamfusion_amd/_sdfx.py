@@ -89,6 +89,7 @@ _SIGNATURES = {
     "sdfx_set_stencil_source": [_ptr, _u32, _f32, _f32, C.c_double],
     "sdfx_grid_backward_plan": [_ptr, _u32, _f32, _u32, _u32, _int, _ptr, _ptr],
     "sdfx_grid_forward_plan": [_ptr, _u32, _f32, _u32, _int, _u32, _u32, _f32, _ptr, _u32, _ptr],
+    "sdfx_grid_forward_level_costs": [_ptr, _u32, _f32, _u32, _u32, _f32, _ptr],
     "sdfx_marching_tets_scratch_bytes": [_u32, _u32],
     "sdfx_marching_tets_count": [_ptr, _ptr, _u32, _ptr, _u32, _ptr, _ptr, _ptr],
     "sdfx_marching_tets_emit": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _u32, _ptr],
@@ -119,7 +120,7 @@ _SIGNATURES = {
     "sdfx_occupancy_stats_doubles": [],
     "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],
     "sdfx_adan_prepare": [_ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _u32, _ptr],
-    "sdfx_adan_update": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _f32, _f32, _f32, _f32, _int, _ptr],
+    "sdfx_adan_update": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _f32, _f32, _f32, _f32, _int, _ptr],
 }
 _RESTYPES = {
     "sdfx_march_rays_train_scratch_bytes": _u64,
@@ -279,3 +280,50 @@ def check_tensor(t: torch.Tensor, name: str, *dtypes) -> torch.Tensor:
 
 def call(name: str, *args) -> None:
     check(getattr(lib(), name)(*args))
+
+
+def half_image(p: torch.Tensor, create: bool = True):
+    """The float16 image of a float32 parameter `p` that the forward kernels gather from — `p.to(torch.half)` of
+    gridencoder/grid.py:46-47 — kept on the tensor object and reused while it is current: (buffer, p._version at the time it was
+    formed). Every PyTorch in-place write to `p` (an optimiser's foreach ops, load_state_dict) bumps `p._version`, so the image is
+    re-formed (into the SAME buffer: captured graphs keep reading it) at the next call; DeviceAdan writes parameters through a raw
+    pointer, which does not touch the version — and rewrites the image in the same kernel (sdfx_adan_update: half_copies), so the
+    two stay in step without a cast launch per iteration. `create` False: only return a current image (None otherwise)."""
+    hit = getattr(p, "_sdfx_half", None)
+    if hit is not None and hit[1] == p._version and hit[0].shape == p.shape and hit[0].device == p.device:
+        return hit[0]
+    if not create:
+        return None
+    buf = hit[0] if (hit is not None and hit[0].shape == p.shape and hit[0].device == p.device) else torch.empty_like(p, dtype=torch.float16)
+    with torch.no_grad():
+        buf.copy_(p.detach())
+    p._sdfx_half = (buf, p._version)
+    return buf
+
+
+class StreamScratch:
+    """Grow-on-demand float32 scratch per (device, stream), for kernels whose every call rewrites what it reads (split-K partials,
+    GroupNorm partial moments). Streams get their own buffer because nothing orders two streams' calls against each other. A buffer
+    that a HIP-graph capture was handed has its address baked into that graph and must outlive it: such a buffer is kept when it is
+    outgrown; one that no capture ever saw is released then. A request the current buffer cannot hold DURING a capture is served
+    from the capturing graph's own pool (it lives and dies with that graph) and is not remembered."""
+
+    def __init__(self):
+        self._bufs = {}    # (device index, stream handle) -> [[buffer, handed to a capture?], ...], the last one current
+
+    def get(self, device, nbytes):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        bufs = self._bufs.setdefault(key, [])
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not bufs or bufs[-1][0].numel() * 4 < nbytes:
+            buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+            if capturing:
+                return buf
+            bufs[:] = [b for b in bufs if b[1]]      # superseded buffers no graph refers to: released
+            bufs.append([buf, False])
+        if capturing:
+            bufs[-1][1] = True
+        return bufs[-1][0]
+
+    def held_bytes(self):
+        return sum(b[0].numel() * 4 for bufs in self._bufs.values() for b in bufs)

@@ -392,6 +392,16 @@ double lines_per_wave(double u, bool stencil) {
     return c[15];
 }
 
+// The measured correction below was taken on ONE configuration: the -O grid (16 levels from 16 to 2048: S = log2(1.3819), so the
+// levels' u = res x step are exactly the table's knots) at the iteration's step (1 / 591 of the unit cube). It is applied to that
+// configuration only (within 20 % of the step); every other grid or step is priced by the model max(lines per wave, VALU floor),
+// which needs no measurement. The plan's price list is readable through sdfx_grid_forward_level_costs (tests/test_grid_plan.py
+// checks the balance property against it, not against a copy of these numbers).
+bool measured_stencil_config(uint32_t levels, float S, uint32_t H, float step) {
+    const double s_ref = log2(2048.0 / 16.0) / 15.0, step_ref = 1.0 / 591.0;
+    return levels == 16 && H == 16 && fabs((double)S - s_ref) < 1e-4 && step > 0.8 * step_ref && step < 1.25 * step_ref;
+}
+
 // What a tile of a level COSTS in the launch, in the same units, for stencil batches: the per-XCD timeline of one launch at
 // B = 3.26 M (tools/xcd_timeline.py, round 5) corrected the model "max(lines, VALU floor = 97)" level by level — an XCD's finish time
 // over the mean, applied to the levels it walked: the levels around one cell per step (u = 0.95-1.8) are 6-13 % cheaper than
@@ -450,7 +460,8 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
     } else {                          // fine to coarse; a tile costs its gathers or its VALU work, whichever is longer
         for (uint32_t l = levels; l-- > 0;) {
             const double model = lines[l] > valu_lines ? lines[l] : valu_lines;
-            units[nu++] = {l, (slabs == kGroup && dev_switch("SDFX_GRID_COST_TABLE", 1)) ? stencil_tile_cost((double)p.lv[l].res * step, (p.lv[l].flags & 1u) == 0u && p.lv[l].res >= 2u) : model};
+            const bool table = slabs == kGroup && measured_stencil_config(levels, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1);
+            units[nu++] = {l, table ? stencil_tile_cost((double)p.lv[l].res * step, (p.lv[l].flags & 1u) == 0u && p.lv[l].res >= 2u) : model};
         }
     }
 
@@ -503,7 +514,9 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
             // SDFX_GRID_TPW_FINE: the devtools library's knobs for that A/B.
             const uint32_t tpw_coarse = [] { const int v = dev_switch("SDFX_GRID_TPW", 8); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
             const uint32_t tpw_fine = [] { const int v = dev_switch("SDFX_GRID_TPW_FINE", 2); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
-            const uint32_t tpw = (balance && step > 0.f && lines[units[u].level] <= valu_lines) ? tpw_coarse : tpw_fine;
+            // (an LDS-resident level — the SDFX_GRID_LDS measurement aid — has its own walk of kLdsTiles tiles per workgroup: one tile per plan slot)
+            const uint32_t tpw = ((p.lds_mask >> units[u].level) & 1u) ? 1u
+                                 : (balance && step > 0.f && lines[units[u].level] <= valu_lines) ? tpw_coarse : tpw_fine;
             p.seg[k][ns++] = {units[u].level, first, last - first, tpw};
             p.ntiles[k] += (last - first + tpw - 1u) / tpw;
         }
@@ -598,6 +611,23 @@ bool launch_forward_d3c2(const float* inputs, const void* table, const int32_t* 
 
 }  // namespace grid
 }  // namespace sdfx
+
+// Host-only: the cost per tile the plan prices level l at (costs[l], l < max_level; the unit is one table line looked up by a wave) —
+// the measured table for the configuration it was measured on, the model max(lines, VALU floor) otherwise, 1.0 without a step hint.
+extern "C" int sdfx_grid_forward_level_costs(const int32_t* offsets_host, uint32_t max_level, float S, uint32_t H, uint32_t slabs,
+                                             float step, double* costs) {
+    if (!offsets_host || !costs || max_level < 1 || max_level > kMaxLevels) return -1;
+    const double valu_lines = (double)dev_switch("SDFX_GRID_VALU_LINES", 97);
+    const bool balance = dev_switch("SDFX_GRID_BALANCE", 1) == 1;
+    for (uint32_t l = 0; l < max_level; l++) {
+        const LevelConst c = make_level_const(offsets_host, l, S, H);
+        if (!(balance && step > 0.f)) { costs[l] = 1.0; continue; }
+        const double lines = lines_per_wave((double)c.res * step, slabs == kGroup);
+        const bool table = slabs == kGroup && measured_stencil_config(max_level, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1);
+        costs[l] = table ? stencil_tile_cost((double)c.res * step, (c.flags & 1u) == 0u && c.res >= 2u) : (lines > valu_lines ? lines : valu_lines);
+    }
+    return (int)max_level;
+}
 
 // Host-only: the per-XCD work list the forward would use, 4 integers per segment (xcd, level, first tile, tiles);
 // returns the number of segments (<= max_segments), tiles per level in *tiles_per_level.

@@ -106,6 +106,7 @@ struct TensorList {
     float* v[kMaxTensors];
     float* n[kMaxTensors];
     float* prev[kMaxTensors];
+    __half* half_copy[kMaxTensors];   // optional: float16 image of the parameter, rewritten with every update (nullptr: none)
     uint64_t count[kMaxTensors];
     float lr[kMaxTensors], wd[kMaxTensors];
     uint32_t first[kMaxTensors + 1];
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(kThreads) void k_adan_update(TensorList tl, const f
     float* __restrict__ v = tl.v[t];
     float* __restrict__ nn = tl.n[t];
     float* __restrict__ prev = tl.prev[t];
+    __half* __restrict__ hc = tl.half_copy[t];
     const uint64_t n = tl.count[t];
     h.lr = tl.lr[t];
     h.wd = tl.wd[t];
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void k_adan_update(TensorList tl, const f
     const uint64_t stride = (uint64_t)nblocks * kThreads * 4;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                            reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(nn) |
-                           reinterpret_cast<uintptr_t>(prev)) & 15) == 0;
+                           reinterpret_cast<uintptr_t>(prev) | (reinterpret_cast<uintptr_t>(hc) << 1)) & 15) == 0;
     for (uint64_t i = ((uint64_t)block * kThreads + threadIdx.x) * 4; i < n; i += stride) {
         if (aligned && i + 4 <= n) {
             float4 P = *reinterpret_cast<float4*>(p + i);
@@ -164,13 +166,20 @@ __global__ __launch_bounds__(kThreads) void k_adan_update(TensorList tl, const f
             adan_one(P.z, G.z, M.z, V.z, N.z, R.z, unscale, first, bc1, bc2, bc3, h);
             adan_one(P.w, G.w, M.w, V.w, N.w, R.w, unscale, first, bc1, bc2, bc3, h);
             *reinterpret_cast<float4*>(p + i) = P;
+            if (hc) {   // the table the next forward gathers from: embeddings.to(half) (gridencoder/grid.py:46-47), formed here instead of by a cast launch
+                union { __half2 h2[2]; uint2 u; } pk;
+                pk.h2[0] = __floats2half2_rn(P.x, P.y); pk.h2[1] = __floats2half2_rn(P.z, P.w);
+                *reinterpret_cast<uint2*>(hc + i) = pk.u;
+            }
             *reinterpret_cast<float4*>(m + i) = M;
             *reinterpret_cast<float4*>(v + i) = V;
             *reinterpret_cast<float4*>(nn + i) = N;
             *reinterpret_cast<float4*>(prev + i) = R;
         } else {
-            for (uint32_t k = 0; k < 4 && i + k < n; k++)
+            for (uint32_t k = 0; k < 4 && i + k < n; k++) {
                 adan_one(p[i + k], g[i + k], m[i + k], v[i + k], nn[i + k], prev[i + k], unscale, first, bc1, bc2, bc3, h);
+                if (hc) hc[i + k] = __float2half_rn(p[i + k]);
+            }
         }
     }
 }
@@ -222,7 +231,7 @@ int sdfx_adan_prepare(float* ctl, double* stats, float beta1, float beta2, float
 }
 
 int sdfx_adan_update(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_diff,
-                     float* const* exp_avg_sq, float* const* pre_grad, const uint64_t* counts, const float* lrs,
+                     float* const* exp_avg_sq, float* const* pre_grad, void* const* half_copies, const uint64_t* counts, const float* lrs,
                      const float* weight_decays, uint32_t tensors, const float* ctl, float eps, float beta1, float beta2,
                      float beta3, int no_prox, sdfx_stream_t stream) {
     SDFX_REQUIRE(ctl && (tensors == 0 || (params && grads && exp_avg && exp_avg_diff && exp_avg_sq && pre_grad && counts && lrs &&
@@ -240,6 +249,7 @@ int sdfx_adan_update(float* const* params, const float* const* grads, float* con
             const uint32_t k = tl.tensors++;
             tl.p[k] = params[t]; tl.g[k] = grads[t]; tl.m[k] = exp_avg[t]; tl.v[k] = exp_avg_diff[t];
             tl.n[k] = exp_avg_sq[t]; tl.prev[k] = pre_grad[t];
+            tl.half_copy[k] = half_copies ? static_cast<__half*>(half_copies[t]) : nullptr;
             tl.count[k] = counts[t]; tl.lr[k] = lrs[t]; tl.wd[k] = weight_decays[t];
             tl.first[k] = blocks;
             blocks += blocks_for(counts[t]);

@@ -100,35 +100,54 @@ __device__ __forceinline__ Raw load_raw(const RenderArgs& a, uint32_t i, bool va
 // w + kRayWaves, ...; each shades its chunk and scans it locally; the chunk products meet in LDS, every wave rebuilds the
 // transmittance at its chunk's start by multiplying the earlier products IN ORDER (the same association as the serial walk, so
 // the same bits), and the ray sums are added chunk by chunk in order by wave 0.
-template <uint32_t kRayWaves>
-__global__ __launch_bounds__(kRayWaves * 64) void k_render_train_fwd(RenderArgs a, float* __restrict__ weights,
+// kRays > 1 (measurement variant, SDFX_RENDER_RAYS): kRays rays share one workgroup — kRays groups of kRayWaves sibling waves, each
+// group walking its own ray exactly as above; the groups only share the barriers, so every group loops to the longest ray's round
+// count (its extra rounds find no valid sample). Fewer, fatter workgroups; per-ray arithmetic and its order are unchanged.
+template <uint32_t kRayWaves, uint32_t kRays>
+__global__ __launch_bounds__(kRays * kRayWaves * 64) void k_render_train_fwd(RenderArgs a, float* __restrict__ weights,
                                                                    float* __restrict__ weights_sum, float* __restrict__ depth,
                                                                    float* __restrict__ image, float* __restrict__ ray_sums) {
-    constexpr uint32_t kRayThreads = kRayWaves * 64;
-    if (blockIdx.x >= a.n_rays) {   // padding rows [total, cap) belong to no ray: zero weight
+    constexpr uint32_t kRayThreads = kRayWaves * 64, kGroupThreads = kRays * kRayThreads;
+    const uint32_t ray_blocks = (a.n_rays + kRays - 1) / kRays;
+    if (blockIdx.x >= ray_blocks) {   // padding rows [total, cap) belong to no ray: zero weight
         const uint32_t total = (uint32_t)a.total_p[0];
-        for (uint32_t i = total + (blockIdx.x - a.n_rays) * kRayThreads + threadIdx.x; i < a.cap; i += kPadBlocks * kRayThreads) weights[i] = 0.f;
+        for (uint32_t i = total + (blockIdx.x - ray_blocks) * kGroupThreads + threadIdx.x; i < a.cap; i += kPadBlocks * kGroupThreads) weights[i] = 0.f;
         return;
     }
-    __shared__ float prod[2][kRayWaves];          // chunk products of the current round (double-buffered across rounds)
-    __shared__ float part[kRayWaves][7];          // per-wave partial ray sums
-    const uint32_t n = blockIdx.x;
+    __shared__ float prod_s[kRays][2][kRayWaves];   // chunk products of the current round (double-buffered across rounds)
+    __shared__ float part_s[kRays][kRayWaves][7];   // per-wave partial ray sums
+    __shared__ uint32_t rounds_s[kRays];
+    const uint32_t rg = kRays > 1 ? threadIdx.x / kRayThreads : 0u;      // this thread's ray within the workgroup
+    const uint32_t tr = kRays > 1 ? threadIdx.x % kRayThreads : threadIdx.x;
+    float (&prod)[2][kRayWaves] = prod_s[rg];
+    float (&part)[kRayWaves][7] = part_s[rg];
+    const uint32_t n = blockIdx.x * kRays + rg;
     const int lane = lane_id();
-    const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t offset = (uint32_t)a.rays[n * 2], count = (uint32_t)a.rays[n * 2 + 1];
-    if (count == 0 || offset + count > a.cap) {   // raymarching.cu:521-528 (the reference's weights are zero-initialised)
-        for (uint32_t k = threadIdx.x; k < count && offset + k < a.cap; k += kRayThreads) weights[offset + k] = 0.f;
-        if (threadIdx.x == 0) {
+    const uint32_t wv = tr >> 6;
+    const bool in_range = n < a.n_rays;
+    uint32_t offset = in_range ? (uint32_t)a.rays[n * 2] : 0u, count = in_range ? (uint32_t)a.rays[n * 2 + 1] : 0u;
+    bool live_ray = in_range;
+    if (in_range && (count == 0 || offset + count > a.cap)) {   // raymarching.cu:521-528 (the reference's weights are zero-initialised)
+        for (uint32_t k = tr; k < count && offset + k < a.cap; k += kRayThreads) weights[offset + k] = 0.f;
+        if (tr == 0) {
             weights_sum[n] = 0; depth[n] = 0; image[n * 3 + 0] = 0; image[n * 3 + 1] = 0; image[n * 3 + 2] = 0;
             ray_sums[n * 2 + 0] = 0; ray_sums[n * 2 + 1] = 0;
         }
-        return;
+        if (kRays == 1) return;
+        live_ray = false; count = 0; offset = 0;      // (its waves keep the other rays' barriers company)
     }
     const int mode = shading_mode(a);
     const float ratio = a.ratio_p[0];
-    const Vec3 l = ray_light(a.rays_o, a.light_off, n);
+    const Vec3 l = ray_light(a.rays_o, a.light_off, in_range ? n : 0u);
     const bool lamb = mode == kLambertian;
-    const uint32_t n_chunks = (count + kWave - 1) / kWave, rounds = (n_chunks + kRayWaves - 1) / kRayWaves;
+    const uint32_t n_chunks = (count + kWave - 1) / kWave;
+    uint32_t rounds = (n_chunks + kRayWaves - 1) / kRayWaves;
+    if (kRays > 1) {
+        if (tr == 0) rounds_s[rg] = rounds;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < kRays; q++) rounds = max(rounds, rounds_s[q]);
+    }
 
     float T_round = 1.0f;                          // transmittance at the start of the round's first chunk (same in every wave)
     float r = 0, g = 0, b = 0, ws = 0, d = 0, ent = 0, ori = 0;
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(kRayWaves * 64) void k_render_train_fwd(RenderArgs 
         part[wv][0] = r; part[wv][1] = g; part[wv][2] = b; part[wv][3] = ws; part[wv][4] = d; part[wv][5] = ent; part[wv][6] = ori;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tr == 0 && live_ray) {
         float acc[7];
 #pragma unroll
         for (int q = 0; q < 7; q++) {
@@ -193,47 +212,63 @@ __global__ __launch_bounds__(kRayWaves * 64) void k_render_train_fwd(RenderArgs 
     }
 }
 
-template <uint32_t kRayWaves>
-__global__ __launch_bounds__(kRayWaves * 64) void k_render_train_bwd(RenderArgs a, const float* __restrict__ weights_sum,
+template <uint32_t kRayWaves, uint32_t kRays>
+__global__ __launch_bounds__(kRays * kRayWaves * 64) void k_render_train_bwd(RenderArgs a, const float* __restrict__ weights_sum,
                                                                    const float* __restrict__ depth, const float* __restrict__ image,
                                                                    const float* __restrict__ g_weights_sum,
                                                                    const float* __restrict__ g_depth, const float* __restrict__ g_image,
                                                                    const float* __restrict__ g_ray_sums, float* __restrict__ dsigma7,
                                                                    float* __restrict__ dalbedo) {
-    constexpr uint32_t kRayThreads = kRayWaves * 64;
+    constexpr uint32_t kRayThreads = kRayWaves * 64, kGroupThreads = kRays * kRayThreads;
     const size_t cap = a.cap;
     auto zero_row = [&](uint32_t i) {
 #pragma unroll
         for (uint32_t s = 0; s < 7; s++) dsigma7[s * cap + i] = 0.f;
         dalbedo[(size_t)i * 3 + 0] = 0.f; dalbedo[(size_t)i * 3 + 1] = 0.f; dalbedo[(size_t)i * 3 + 2] = 0.f;
     };
-    if (blockIdx.x >= a.n_rays) {
+    const uint32_t ray_blocks = (a.n_rays + kRays - 1) / kRays;
+    if (blockIdx.x >= ray_blocks) {
         const uint32_t total = (uint32_t)a.total_p[0];
-        for (uint32_t i = total + (blockIdx.x - a.n_rays) * kRayThreads + threadIdx.x; i < a.cap; i += kPadBlocks * kRayThreads) zero_row(i);
+        for (uint32_t i = total + (blockIdx.x - ray_blocks) * kGroupThreads + threadIdx.x; i < a.cap; i += kPadBlocks * kGroupThreads) zero_row(i);
         return;
     }
-    __shared__ float prod[2][kRayWaves];
-    __shared__ float tot[2][kRayWaves][5];        // chunk totals of (w c_r, w c_g, w c_b, w, w t)
-    const uint32_t n = blockIdx.x;
+    __shared__ float prod_s[kRays][2][kRayWaves];
+    __shared__ float tot_s[kRays][2][kRayWaves][5];        // chunk totals of (w c_r, w c_g, w c_b, w, w t)
+    __shared__ uint32_t rounds_s[kRays];
+    const uint32_t rg = kRays > 1 ? threadIdx.x / kRayThreads : 0u;
+    const uint32_t tr = kRays > 1 ? threadIdx.x % kRayThreads : threadIdx.x;
+    float (&prod)[2][kRayWaves] = prod_s[rg];
+    float (&tot)[2][kRayWaves][5] = tot_s[rg];
+    const uint32_t n = blockIdx.x * kRays + rg;
     const int lane = lane_id();
-    const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t offset = (uint32_t)a.rays[n * 2], count = (uint32_t)a.rays[n * 2 + 1];
-    if (count == 0 || offset + count > a.cap) {          // raymarching.cu:630: no gradient for such a ray
-        for (uint32_t k = threadIdx.x; k < count && offset + k < a.cap; k += kRayThreads) zero_row(offset + k);
-        return;
+    const uint32_t wv = tr >> 6;
+    const bool in_range = n < a.n_rays;
+    uint32_t offset = in_range ? (uint32_t)a.rays[n * 2] : 0u, count = in_range ? (uint32_t)a.rays[n * 2 + 1] : 0u;
+    if (in_range && (count == 0 || offset + count > a.cap)) {          // raymarching.cu:630: no gradient for such a ray
+        for (uint32_t k = tr; k < count && offset + k < a.cap; k += kRayThreads) zero_row(offset + k);
+        if (kRays == 1) return;
+        count = 0; offset = 0;
     }
     const int mode = shading_mode(a);
     const float ratio = a.ratio_p[0];
-    const Vec3 l = ray_light(a.rays_o, a.light_off, n);
+    const uint32_t ns = in_range ? n : 0u;     // (a ray slot past the last ray reads ray 0's scalars and uses none of them)
+    const Vec3 l = ray_light(a.rays_o, a.light_off, ns);
 
-    const float gi0 = g_image[n * 3 + 0], gi1 = g_image[n * 3 + 1], gi2 = g_image[n * 3 + 2];
-    const float gws = g_weights_sum[n], gd = g_depth ? g_depth[n] : 0.f;
-    const float g_ent = g_ray_sums ? g_ray_sums[n * 2 + 0] : 0.f, g_ori = g_ray_sums ? g_ray_sums[n * 2 + 1] : 0.f;
-    const float r_final = image[n * 3 + 0], g_final = image[n * 3 + 1], b_final = image[n * 3 + 2];
-    const float ws_final = weights_sum[n], d_final = depth[n];
+    const float gi0 = g_image[ns * 3 + 0], gi1 = g_image[ns * 3 + 1], gi2 = g_image[ns * 3 + 2];
+    const float gws = g_weights_sum[ns], gd = g_depth ? g_depth[ns] : 0.f;
+    const float g_ent = g_ray_sums ? g_ray_sums[ns * 2 + 0] : 0.f, g_ori = g_ray_sums ? g_ray_sums[ns * 2 + 1] : 0.f;
+    const float r_final = image[ns * 3 + 0], g_final = image[ns * 3 + 1], b_final = image[ns * 3 + 2];
+    const float ws_final = weights_sum[ns], d_final = depth[ns];
 
     const bool lamb = mode == kLambertian;
-    const uint32_t n_chunks = (count + kWave - 1) / kWave, rounds = (n_chunks + kRayWaves - 1) / kRayWaves;
+    const uint32_t n_chunks = (count + kWave - 1) / kWave;
+    uint32_t rounds = (n_chunks + kRayWaves - 1) / kRayWaves;
+    if (kRays > 1) {
+        if (tr == 0) rounds_s[rg] = rounds;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < kRays; q++) rounds = max(rounds, rounds_s[q]);
+    }
     float T_round = 1.0f, acc_round[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // state at the start of the round's first chunk
     Raw nxt = load_raw(a, offset + wv * kWave + (uint32_t)lane, wv * kWave + (uint32_t)lane < count, lamb);
     for (uint32_t rd = 0; rd < rounds; rd++) {
@@ -312,11 +347,28 @@ __global__ __launch_bounds__(kRayWaves * 64) void k_render_train_bwd(RenderArgs 
     }
 }
 
-// sibling waves per ray (SDFX_RENDER_WAVES = 1, 2, 4, 8; measurement aid — every value gives the same results up to the order
-// in which the ray sums are added)
-int ray_waves() {
-    const int v = [] { const int w = dev_switch("SDFX_RENDER_WAVES", 2); return (w == 1 || w == 4 || w == 8) ? w : 2; }();
-    return v;
+// Launch shape: sibling waves per ray x rays per workgroup. Measured on the GPU clock at 4096 rays (tools/render_fit.py, replayed graphs;
+// profiles/r06_render_rays_per_workgroup.txt), t = fixed + marginal x samples:
+//     2 waves, 1 ray  (rounds 3-5)   forward 5.6 us + 11.7 us / Msample   backward 9.5 + 18.4
+//     1 wave, 4 rays                 forward 5.1 + 11.7                   backward 6.1 + 21.0
+//     2 waves, 2 / 4 rays            forward 6.0 / 6.7 + 12 / 11.4        backward 8.5 / 9.4 + 18.6 / 19.6
+//     4 waves, 1 / 2 rays            forward 8.0 / 11.4 + 10.1 / 9.8      backward 14.3 / 17.2 + 16.6 / 17.4
+// A 64-thread workgroup per ray is what costs the backward its fixed part (4160 workgroups that each read their ray's scalars, run
+// two barriers per round and retire); four rays in a 256-thread workgroup, one wave each, cut it by a third and lose a sixth of the
+// streaming rate (a ray's chunks are walked by one wave again). The iteration runs at ~120 samples per ray (0.5 M samples), where the
+// second shape is 4 % / 11 % faster; from ~290 samples per ray on the first one wins: chosen by the launch's samples per ray. Results
+// are identical up to the order in which a ray's chunk sums are added. SDFX_RENDER_WAVES / SDFX_RENDER_RAYS (devtools library) force a shape.
+constexpr uint32_t kWideRaySamples = 256;   // mean samples per ray (capacity / rays) above which the two-wave-per-ray shape is used
+void launch_shape(uint32_t capacity, uint32_t n_rays, int& waves, int& rays) {
+    const int w = dev_switch("SDFX_RENDER_WAVES", 0), r = dev_switch("SDFX_RENDER_RAYS", 0);
+    if (w || r) {
+        waves = (w == 1 || w == 4 || w == 8) ? w : 2;
+        rays = (r == 2 || r == 4) ? r : 1;
+        return;
+    }
+    const bool wide = (uint64_t)capacity > (uint64_t)kWideRaySamples * n_rays;
+    waves = wide ? 2 : 1;
+    rays = wide ? 1 : 4;
 }
 
 int fill_args(RenderArgs& a, const float* sigma7, const float* albedo, const float* dirs, const float* ts, const int32_t* rays,
@@ -345,12 +397,20 @@ int sdfx_render_train_forward(const float* sigma7, const float* albedo, const fl
     if (n_rays == 0) return SDFX_OK;   // (capacity 0 = a view without samples: every ray has count 0 and gets zero outputs)
     RenderArgs a;
     fill_args(a, sigma7, albedo, dirs, ts, rays, rays_o, light_offset, ratio, mode_dev, mode, epsilon, T_thresh, capacity, n_rays, total);
-    switch (ray_waves()) {
-        case 1: hipLaunchKernelGGL(k_render_train_fwd<1>, dim3(n_rays + kPadBlocks), dim3(64), 0, as_stream(stream), a, weights, weights_sum, depth, image, ray_sums); break;
-        case 8: hipLaunchKernelGGL(k_render_train_fwd<8>, dim3(n_rays + kPadBlocks), dim3(512), 0, as_stream(stream), a, weights, weights_sum, depth, image, ray_sums); break;
-        case 4: hipLaunchKernelGGL(k_render_train_fwd<4>, dim3(n_rays + kPadBlocks), dim3(256), 0, as_stream(stream), a, weights, weights_sum, depth, image, ray_sums); break;
-        default: hipLaunchKernelGGL(k_render_train_fwd<2>, dim3(n_rays + kPadBlocks), dim3(128), 0, as_stream(stream), a, weights, weights_sum, depth, image, ray_sums); break;
-    }
+#define SDFX_RFWD(RW_, RR_) hipLaunchKernelGGL((k_render_train_fwd<RW_, RR_>), dim3(div_up(n_rays, RR_) + kPadBlocks), dim3(RR_ * RW_ * 64), 0, \
+                                              as_stream(stream), a, weights, weights_sum, depth, image, ray_sums)
+    int rw, rr;
+    launch_shape(capacity, n_rays, rw, rr);
+    if (rr == 2 && rw == 2) SDFX_RFWD(2, 2);
+    else if (rr == 4 && rw == 2) SDFX_RFWD(2, 4);
+    else if (rr == 2 && rw == 1) SDFX_RFWD(1, 2);
+    else if (rr == 4 && rw == 1) SDFX_RFWD(1, 4);
+    else if (rr == 2 && rw == 4) SDFX_RFWD(4, 2);
+    else if (rw == 1) SDFX_RFWD(1, 1);
+    else if (rw == 4) SDFX_RFWD(4, 1);
+    else if (rw == 8) SDFX_RFWD(8, 1);
+    else SDFX_RFWD(2, 1);
+#undef SDFX_RFWD
     return check_launch("render_train_forward");
 }
 
@@ -367,14 +427,20 @@ int sdfx_render_train_backward(const float* sigma7, const float* albedo, const f
     if (capacity == 0 || n_rays == 0) return SDFX_OK;
     RenderArgs a;
     fill_args(a, sigma7, albedo, dirs, ts, rays, rays_o, light_offset, ratio, mode_dev, mode, epsilon, T_thresh, capacity, n_rays, total);
-#define SDFX_RBWD(RW_) hipLaunchKernelGGL(k_render_train_bwd<RW_>, dim3(n_rays + kPadBlocks), dim3(RW_ * 64), 0, as_stream(stream), a, \
-                                          weights_sum, depth, image, grad_weights_sum, grad_depth, grad_image, grad_ray_sums, dsigma7, dalbedo)
-    switch (ray_waves()) {
-        case 1: SDFX_RBWD(1); break;
-        case 4: SDFX_RBWD(4); break;
-        case 8: SDFX_RBWD(8); break;
-        default: SDFX_RBWD(2); break;
-    }
+#define SDFX_RBWD(RW_, RR_) hipLaunchKernelGGL((k_render_train_bwd<RW_, RR_>), dim3(div_up(n_rays, RR_) + kPadBlocks), dim3(RR_ * RW_ * 64), 0, \
+                                              as_stream(stream), a, weights_sum, depth, image, grad_weights_sum, grad_depth, grad_image,  \
+                                              grad_ray_sums, dsigma7, dalbedo)
+    int rw, rr;
+    launch_shape(capacity, n_rays, rw, rr);
+    if (rr == 2 && rw == 2) SDFX_RBWD(2, 2);
+    else if (rr == 4 && rw == 2) SDFX_RBWD(2, 4);
+    else if (rr == 2 && rw == 1) SDFX_RBWD(1, 2);
+    else if (rr == 4 && rw == 1) SDFX_RBWD(1, 4);
+    else if (rr == 2 && rw == 4) SDFX_RBWD(4, 2);
+    else if (rw == 1) SDFX_RBWD(1, 1);
+    else if (rw == 4) SDFX_RBWD(4, 1);
+    else if (rw == 8) SDFX_RBWD(8, 1);
+    else SDFX_RBWD(2, 1);
 #undef SDFX_RBWD
     return check_launch("render_train_backward");
 }

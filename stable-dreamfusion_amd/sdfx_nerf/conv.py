@@ -14,21 +14,13 @@ import torch.nn.functional as F
 import _devswitch
 
 _FUSED = _devswitch.get("SDFX_CONV", 1)
-_SCRATCH = {}   # (device index, stream) -> [float32 scratch buffers, the last one current]: for split-K partials, grown on demand (every call rewrites what it reads)
+import _sdfx as _S
+
+_SCRATCH = _S.StreamScratch()   # per (device, stream) float32 scratch, grown on demand (_sdfx.StreamScratch: what is kept, what is released)
 
 
 def _scratch(device, nbytes):
-    """Per (device, stream) scratch. An outgrown buffer is kept alive beside its replacement (as _gridencoder._BINNED_SCRATCH does): a
-    HIP graph captured while it was current has its address baked in and may be replayed later; streams get their own buffer because
-    nothing orders two streams' calls against each other."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    bufs = _SCRATCH.setdefault(key, [])
-    if not bufs or bufs[-1].numel() * 4 < nbytes:
-        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        if torch.cuda.is_current_stream_capturing():
-            return buf          # memory of the graph being captured: it lives and dies with that graph, so it is not kept for later calls
-        bufs.append(buf)
-    return bufs[-1]
+    return _SCRATCH.get(device, nbytes)
 
 
 def conv_ok(x, weight, bias=None, residual=None, stride=1) -> bool:

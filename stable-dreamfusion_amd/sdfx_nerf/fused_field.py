@@ -52,7 +52,9 @@ class _fused_field(Function):
         L = offsets.shape[0] - 1
         C = embeddings.shape[1]
         S = np.log2(per_level_scale)
-        emb = embeddings.to(torch.half).contiguous()             # autocast: fp16 table (grid.py:46-47)
+        # autocast: fp16 table (grid.py:46-47: embeddings.to(torch.half) every call). The image is kept while it is current
+        # (_sdfx.half_image): with the device-side optimiser, whose update kernel rewrites it, no cast is launched at all
+        emb = _sdfx.half_image(embeddings) if (embeddings.dtype == torch.float32 and embeddings.is_contiguous()) else embeddings.to(torch.half).contiguous()
         enc = torch.empty(L, B, C, device=x.device, dtype=torch.half)
         packed = torch.empty(_field.packed_words(), dtype=torch.int32, device=x.device)
         _field.pack(w1.detach().float().contiguous(), b1.detach().float().contiguous(), w2.detach().float().contiguous(),

@@ -196,7 +196,7 @@ class NeRFNetwork(NeRFRenderer):
         packed = torch.empty(_field.packed_words(), dtype=torch.int32, device=dev)
         _field.pack(*[t.detach().float().contiguous() for t in (n[0].weight, n[0].bias, n[1].weight, n[1].bias, n[2].weight, n[2].bias)],
                     packed)
-        emb = self.encoder.embeddings.detach().to(torch.half).contiguous()          # autocast: fp16 table (grid.py:46-47)
+        emb = S.half_image(self.encoder.embeddings)          # autocast: fp16 table (grid.py:46-47), kept while current
         f = dict(dtype=torch.float32, device=dev)
         ws, depth, image = torch.empty(N, **f), torch.empty(N, **f), torch.empty(N, 3, **f)
         counter = torch.empty(1, dtype=torch.int32, device=dev)

@@ -144,8 +144,18 @@ class DeviceAdan:
         S.call("sdfx_adan_prepare", S.ptr(self.ctl), S.ptr(self.stats), b1, b2, b3, self.max_grad_norm, self.eps,
                self.growth[0], self.growth[1], self.growth[2], st)
         state = [self.state[p] for _, p in todo]
+        # float16 images of parameters the forward keeps (_sdfx.half_image: the hash table): rewritten by the update kernel itself —
+        # this write goes through a raw pointer and leaves p._version alone, so whoever holds an image must have it refreshed here
+        halves = []
+        for _, p in todo:
+            hit = getattr(p, "_sdfx_half", None)
+            ok = hit is not None and hit[0].shape == p.shape and hit[0].device == p.device and hit[0].is_contiguous()
+            if ok and hit[1] != p._version:      # a PyTorch write since the image was formed: re-form it first (same buffer)
+                S.half_image(p)
+            halves.append(hit[0] if ok else None)
+        half_ptrs = (C.c_void_p * n)(*[None if h is None else h.data_ptr() for h in halves])
         S.call("sdfx_adan_update", ptrs([p for _, p in todo]), grads, ptrs([s_[0] for s_ in state]), ptrs([s_[1] for s_ in state]),
-               ptrs([s_[2] for s_ in state]), ptrs([s_[3] for s_ in state]), counts,
+               ptrs([s_[2] for s_ in state]), ptrs([s_[3] for s_ in state]), half_ptrs, counts,
                (C.c_float * n)(*[g["lr"] for g, _ in todo]), (C.c_float * n)(*[g["weight_decay"] for g, _ in todo]), n,
                S.ptr(self.ctl), self.eps, b1, b2, b3, int(self.no_prox), st)
 

@@ -3,7 +3,7 @@
 `update_extra_interval` steps, shading schedule, render, SDS loss, entropy / orientation
 regularisers, AMP backward, optimiser step.
 
-Three ways of driving the same arithmetic (`mode`, default from SDFX_TRAIN_MODE, else "graph"):
+Three ways of driving the same arithmetic (`mode`; default "graph" — in a devtools session, `SDFX_DEV=1`, SDFX_TRAIN_MODE overrides it):
 
   "reference"  the reference's host flow: torch.amp.GradScaler + Adan behind the Optimizer interface; the
                host reads back the sample total, found_inf and nothing else. ~270 launches per iteration, each

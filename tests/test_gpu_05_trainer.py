@@ -62,6 +62,41 @@ def test_device_adan_matches_foreach_adan(dev):
     assert devopt.skipped_steps() == 2 and devopt.get_scale() == scale
 
 
+def test_device_adan_keeps_the_half_image_of_a_parameter_current(dev):
+    """_sdfx.half_image(p) == p.to(torch.half) at every moment: rewritten by k_adan_update when DeviceAdan steps (a raw-pointer write
+    that leaves p._version alone), left alone with the parameter on an overflowed iteration, re-formed into the same buffer after a
+    PyTorch in-place write (which bumps the version)."""
+    optim = _mods()
+    import _sdfx as S
+    g = torch.Generator().manual_seed(9)
+    shapes = [(1000003, 2), (64, 32)]                       # an odd row count: the unaligned tail of the float4 path
+    ps = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.1).to(dev)) for s in shapes]
+    opt = optim.DeviceAdan([{"params": ps, "lr": 5e-2}], eps=1e-8, weight_decay=2e-5, max_grad_norm=5.0, amp=True, init_scale=1024.0)
+    img = S.half_image(ps[0])
+    assert img.dtype == torch.float16 and torch.equal(img, ps[0].detach().half())
+    assert S.half_image(ps[1], create=False) is None        # nobody asked for an image of the second tensor: none is kept
+    for it in range(4):
+        before = ps[0].detach().clone()
+        for p in ps:
+            p.grad = (torch.randn(p.shape, generator=g) * 1e-3).to(dev) * 1024.0
+        if it == 2:
+            ps[1].grad[3, 5] = float("inf")                 # overflowed iteration: neither the parameter nor its image moves
+        opt.step()
+        assert S.half_image(ps[0]) is img                   # same buffer (captured graphs keep reading it), no re-cast
+        assert torch.equal(img, ps[0].detach().half())
+        assert (it == 2) == bool(torch.equal(before, ps[0].detach()))
+    with torch.no_grad():
+        ps[0].mul_(0.5)                                     # a PyTorch write: the image is stale until asked for again
+    assert S.half_image(ps[0], create=False) is None
+    assert S.half_image(ps[0]) is img and torch.equal(img, ps[0].detach().half())
+    ps[0].grad = (torch.randn(ps[0].shape, generator=g) * 1e-3).to(dev) * opt.get_scale()
+    ps[1].grad = torch.zeros_like(ps[1])
+    with torch.no_grad():
+        ps[0].add_(1e-3)                                    # stale again when the optimiser steps: it re-forms, then keeps it current
+    opt.step()
+    assert torch.equal(S.half_image(ps[0]), ps[0].detach().half())
+
+
 def _make(dev, mode, seed=0, hw=32):
     importlib.import_module("stable-dreamfusion_amd")
     from sdfx_nerf.guidance import synthetic_prior

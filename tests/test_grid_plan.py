@@ -38,19 +38,35 @@ def test_every_tile_is_assigned_once(oracle, B, slabs, step, L, half):
     assert sum(per_xcd) == L * T
 
 
-def test_step_hint_balances_the_modelled_cost(oracle):
-    """With a step hint the sequence of levels is cut into eight ranges of equal COST. For stencil batches the cost per tile is the
-    table `stencil_tile_cost` of gridencoder_fwd.hip — the model max(lines per wave, VALU floor 97) corrected level by level from the
-    per-XCD timeline of a launch (round 5): a finest-level tile costs 281, a tile of a dense level (0-4 of this grid: two-row
-    loads) 0.71 * 98; equal tile counts would give the XCD holding L15 several times the load of the one holding L0-L2."""
-    offsets, pls = oracle.grid_offsets(desired_resolution=2048)
-    seg, T = _plan(offsets, pls, 16, 1, 1810900, 7, 1 / 591.0)
-    cost = [0.71 * 98] * 5 + [91, 101, 109, 108, 114, 141, 151, 180, 233, 265, 281]   # at the levels' u = res / 591: the table's knots
+def _costs(offsets, pls, L, slabs, step):
+    off = (C.c_int32 * len(offsets))(*[int(v) for v in offsets])
+    out = (C.c_double * L)()
+    assert S.lib().sdfx_grid_forward_level_costs(off, L, float(np.log2(pls)), 16, slabs, step, out) == L
+    return np.array(out[:])
+
+
+@pytest.mark.parametrize("desired,step", [(2048, 1 / 591.0), (2048, 1 / 300.0), (1024, 1 / 591.0), (4096, 1 / 1182.0)])
+def test_step_hint_balances_the_plans_own_cost(oracle, desired, step):
+    """With a step hint the sequence of levels is cut into eight ranges of equal COST, whatever the grid and the step: the loads of
+    the eight XCDs, priced with the plan's own price list (sdfx_grid_forward_level_costs), are within 2 % of each other, while equal
+    tile counts (no hint) leave them a factor apart. The price list itself: never below the VALU floor of a dense level's tile,
+    non-decreasing towards the fine levels once above it, and — away from the one configuration the measured correction was taken on
+    (the -O grid at the iteration's step) — exactly the model max(lines per wave, 97)."""
+    offsets, pls = oracle.grid_offsets(desired_resolution=desired)
+    seg, T = _plan(offsets, pls, 16, 1, 1810900, 7, step)
+    cost = _costs(offsets, pls, 16, 7, step)
     load = [sum(cost[l] * c for x, l, f, c in seg if x == k) for k in range(8)]
     assert max(load) <= 1.02 * min(load), load
     even, _ = _plan(offsets, pls, 16, 1, 1810900, 7, 0.0)
     load_even = [sum(cost[l] * c for x, l, f, c in even if x == k) for k in range(8)]
-    assert max(load_even) > 1.5 * min(load_even)
+    assert max(load_even) > 1.3 * min(load_even)             # (1.46 - 2.9 over these grids and steps)
+    assert (cost >= 0.7 * 97).all() and cost[-1] > 2 * cost[0]
+    fine = cost[cost > 1.2 * 97]
+    assert (np.diff(fine) >= -1e-9).all()                     # past the VALU floor the price follows the line count upwards
+    measured = desired == 2048 and abs(step * 591 - 1) < 0.2
+    if not measured:
+        assert (cost >= 97 - 1e-9).all() and (cost[:3] == 97).all()    # the model: VALU floor at the coarse end, lines beyond
+    assert (_costs(offsets, pls, 16, 7, 0.0) == 1.0).all()    # no hint: every level the same
 
 
 @pytest.mark.parametrize("B", [1, 511, 4096 * 7, 1810900, 3150000])

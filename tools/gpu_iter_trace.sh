@@ -16,8 +16,15 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "")
 idx = [i for i, r in enumerate(rows) if "k_adan_update" in r["Kernel_Name"]]
 print("kernels", len(rows), "optimiser steps", len(idx))
-# the iteration between the 8th and the 9th optimiser update of the timed region's tail
-a, b = idx[-6] + 1, idx[-5] + 1
+# a REPLAYED iteration of the timed region: bench.py ends with an eager kernel-timing pass whose launches are preceded by
+# at::cuda::spin_kernel — take the last iteration before the first of those that holds neither a spin nor an occupancy refresh
+spin = [i for i, r in enumerate(rows) if "spin_kernel" in r["Kernel_Name"]]
+last = len(idx) - 2
+if spin:
+    last = max(k for k in range(len(idx) - 1) if idx[k + 1] < spin[0]) - 1
+while last > 0 and any("k_occ_points" in r["Kernel_Name"] for r in rows[idx[last] + 1:idx[last + 1] + 1]):
+    last -= 1
+a, b = idx[last] + 1, idx[last + 1] + 1
 t0 = int(rows[a]["Start_Timestamp"])
 busy = 0
 prev_end = t0
@@ -40,10 +47,11 @@ if occ:
     for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
         print("   %8.1f us  x%-3d %s" % (t, n, k))
 ends = [int(rows[i]["End_Timestamp"]) for i in idx]
-periods = [(ends[k + 1] - ends[k]) / 1e3 for k in range(len(ends) - 12, len(ends) - 1)]
-idle = [(int(rows[idx[k] + 1]["Start_Timestamp"]) - ends[k]) / 1e3 for k in range(len(ends) - 12, len(ends) - 1)]
-print("iteration period (optimiser update to optimiser update), last 11: median %.1f us; idle before the first kernel of an iteration: median %.1f us"
+hi = last + 1
+periods = [(ends[k + 1] - ends[k]) / 1e3 for k in range(max(hi - 11, 0), hi)]
+idle = [(int(rows[idx[k] + 1]["Start_Timestamp"]) - ends[k]) / 1e3 for k in range(max(hi - 11, 0), hi)]
+print("iteration period (optimiser update to optimiser update), the 11 replayed iterations before it: median %.1f us; idle before the first kernel of an iteration: median %.1f us"
       % (sorted(periods)[len(periods) // 2], sorted(idle)[len(idle) // 2]))
 PY
-tail -22 $OUT/iteration_trace.txt
+tail -8 $OUT/iteration_trace.txt
 find $OUT/prof -type f -size +1M -delete 2>/dev/null

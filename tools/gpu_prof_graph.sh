@@ -5,7 +5,7 @@ OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-SDFX_BENCH_TRACE=1 SDFX_TRAIN_MODE=$MODE timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-bench > $OUT/prof.log 2>&1
+SDFX_DEV=1 SDFX_BENCH_TRACE=1 SDFX_TRAIN_MODE=$MODE timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-bench > $OUT/prof.log 2>&1
 echo "rocprof exit $?"
 grep -E "trace|value" $OUT/prof.log | cut -c1-160
 python3 - <<PY

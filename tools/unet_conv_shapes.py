@@ -2,6 +2,7 @@
 """Every convolution the SD-1.5 UNet restatement runs (batch 2, 64 x 64 latents), timed alone on the GPU clock: shape, FLOPs, us,
 TFLOP/s — the size of the opportunity a hand-written MFMA implicit GEMM would have."""
 import importlib, os, sys, collections
+os.environ["SDFX_DEV"] = "1"       # a devtools session: the Python package reads SDFX_* switches only then (_devswitch.py)
 os.environ["SDFX_CONV"] = "0"      # every convolution through F.conv2d (what this tool times); csrc/conv.hip has tools/conv_bench.py
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
