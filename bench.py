@@ -914,9 +914,18 @@ def main():
         job.prime(name)
         stage(f"phase {name} primed")
     job.set_phase(plan[0][0])
+    # the warm-up steps run with the measurement apparatus of the timed region switched on (its records are dropped): the first
+    # timing-event pair, and whatever else a process creates lazily at first use, is paid for here — in the first process on a fresh
+    # box the first timed step was 7 ms longer than in every later process (profiles/r06_first_process_step_times.txt)
+    timer.enabled = not dry
+    if not dry:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record(); torch.cuda._sleep(1000); ev[1].record()
     for i in range(args.warmup):
         job.step(i)
     job.sync()
+    timer.enabled = False
+    del timer.records[:]
     applied_before = job.applied()
     stats_before = dict(getattr(getattr(job, "step_obj", None), "stats", {}))
     host_before = dict(getattr(getattr(job, "step_obj", None), "host_s", {}))
@@ -1115,7 +1124,7 @@ def main():
     # requests at 64 B, MI355X_MICROARCH.md "HBM"). The file stores, per kernel, the counters AND the work of the launches they
     # were averaged over (`points_per_launch`); traffic is scaled per point to the launch size this run reports, so that
     # `traffic`, `algorithmic_bytes_per_launch` and `avg_launch_us` describe the same launch. null when the file is absent.
-    traffic_file = next((f for f in ("profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
+    traffic_file = next((f for f in ("profiles/r06_pmc_traffic.json", "profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
                          if os.path.exists(os.path.join(ROOT, f))), None)
     pmc = {}
     if traffic_file:

@@ -225,13 +225,17 @@ __global__ __launch_bounds__(256) void k_march_count_wave(const float* __restric
 // Offsets = exclusive prefix sum of the counts in ray order, starting from counter[0]; the
 // total is added to counter[0] (the reference's atomicAdd bookkeeping, raymarching.cu:470-474,
 // made deterministic). Single workgroup; N is a few thousand rays on the training path.
-__global__ __launch_bounds__(1024) void k_scan_counts(int32_t* __restrict__ rays, uint32_t N,
-                                                       int32_t* __restrict__ counter) {
-    __shared__ uint32_t wave_tot[16];
+__global__ __launch_bounds__(256) void k_scan_counts(int32_t* __restrict__ rays, uint32_t N,
+                                                      int32_t* __restrict__ counter) {
+    // 256 threads: the prefetched counting pass runs on a side stream BESIDE the training kernels, and a 1024-thread workgroup needs
+    // 16 free wave slots on one CU at once — beside k_grid_fwd it sat in the queue for up to 120 us (profiles/r06_iteration_trace_*);
+    // four waves find room at once, and 16 rounds of 256 rays cost the same few microseconds as 4 rounds of 1024
+    constexpr uint32_t kScanThreads = 256, kScanWaves = kScanThreads / 64;
+    __shared__ uint32_t wave_tot[kScanWaves];
     const int lane = lane_id();
     const int wid = (int)(threadIdx.x >> 6);
     uint32_t base = (uint32_t)counter[0];
-    for (uint32_t start = 0; start < N; start += 1024) {
+    for (uint32_t start = 0; start < N; start += kScanThreads) {
         const uint32_t i = start + threadIdx.x;
         const uint32_t c = i < N ? (uint32_t)rays[i * 2 + 1] : 0u;
         const uint32_t incl = wave_incl_sum_u32(c, lane);
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(int32_t* __restrict__ rays
         __syncthreads();
         uint32_t woff = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < 16; w++) {
+        for (int w = 0; w < (int)kScanWaves; w++) {
             const uint32_t v = wave_tot[w];
             if (w < wid) woff += v;
             tot += v;
@@ -733,7 +737,7 @@ int sdfx_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
 #endif
             hipLaunchKernelGGL(k_march_count_wave, dim3(div_up((uint64_t)N * kWave, 256)), dim3(256), 0, st, rays_o, rays_d, grid,
                                p, max_steps, N, nears, fars, noises, rays, scratch);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, rays, N, counter);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(256), 0, st, rays, N, counter);
         return check_launch("march_rays_train(count)");
     }
     SDFX_REQUIRE(dirs && ts, "march_rays_train: dirs/ts must be given together with xyzs");

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Standalone launch loop of the hash-grid encode forward (timing per implementation switch, and for rocprofv3 --pmc).
-usage: python tools/encode_bench.py [uniform|ray|stencil] [f16|f32] [launches] [impl,balance,hint ...]
-  uniform  2^21 uniform random points (the occupancy refresh's shape)
+usage: python tools/encode_bench.py [uniform|morton|ray|stencil] [f16|f32] [launches] [impl,balance,hint ...]
+  uniform  2^21 uniform random points
+  morton   the occupancy refresh's own batch: the 2^21 jittered cell centres of the 128^3 grid in Morton order (sdfx_occupancy_points);
+           hint = 1 describes it to the encoder as ordered points one cell (1 / 128 of the cube) apart
   ray      the samples of one 4096-ray view through S-grid-init, in ray order
   stencil  those samples and their six finite-difference neighbours, batched [7, M, 3] as the iteration does
 Each variant = the switches SDFX_GRID_FWD / SDFX_GRID_BALANCE of the DEVTOOLS library (-1 = default; run with
@@ -25,6 +27,10 @@ g = torch.Generator().manual_seed(3)
 table = (torch.randn(int(offsets_np[-1]), 2, generator=g) * 0.1).to(dev).to(dt)
 if kind == "uniform":
     x = torch.rand(1 << 21, 3, generator=g).to(dev)
+elif kind == "morton":
+    pts = torch.empty(1 << 21, 3, dtype=torch.float32, device=dev)
+    _sdfx.call("sdfx_occupancy_points", 128, 1.0, None, 1234, 0, _sdfx.ptr(pts), _sdfx.stream())
+    x = ((pts + 1) / 2).contiguous()
 else:
     bf = synth.s_grid_init()[2]
     o, d = synth.s_rays(0)
@@ -51,7 +57,7 @@ for rnd in range(3):            # rounds interleaved so that clock / thermal dri
             else:
                 _sdfx.lib().sdfx_dev_unset(name.encode())
         slabs = 7 if (hint and kind == "stencil") else 1
-        step = STEP if (hint and kind != "uniform") else 0.0
+        step = (1.0 / 128.0 if kind == "morton" else STEP) if (hint and kind != "uniform") else 0.0
         out = torch.empty(16, B, 2, device=dev, dtype=dt)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for i in range(n + 2):

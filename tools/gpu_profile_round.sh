@@ -15,6 +15,10 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
 echo "stats exit $?" | tee $OUT/summary.txt
 tail -1 $OUT/stats.log | cut -c1-300 | tee -a $OUT/summary.txt
+# the same pass with the synthetic prior: this repository's kernels only (what the PMC passes below run); kept under its own name
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_synth -o bench -- $PMC_CMD > $OUT/stats_synth.log 2>&1
+echo "stats (synthetic prior) exit $?" | tee -a $OUT/summary.txt
+cp $OUT/stats_synth/bench_kernel_stats.csv $OUT/kernel_stats_synthetic_prior.csv 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- $PMC_CMD > $OUT/pmc_$C.log 2>&1
   echo "pmc $C exit $?" | tee -a $OUT/summary.txt
