@@ -242,8 +242,11 @@ int sdfx_grid_encode_forward(const float* inputs, const void* embeddings, const 
  *   slabs  1, or 7: the B points are 7 slabs of B/7 points and points i, i + B/7, ..., i + 6B/7 are the finite-difference
  *          stencil of one sample (x, x +- e along each axis; nerf/network_grid.py:81-96 evaluated in one call). The seven
  *          points are then processed by neighbouring lanes, which share table lines at every level.
- *   step   expected distance, in input units ([0,1]), between consecutive points of a slab when they are consecutive
- *          samples of a ray (dt_min / (2 bound)); 0 = unknown. Drives the per-XCD split of the levels (cost model).
+ *   step   > 0: expected distance, in input units ([0,1]), between consecutive points of a slab when they are consecutive
+ *          samples of a ray (dt_min / (2 bound)); < 0: consecutive points walk a space-filling curve through a regular grid of
+ *          points |step| apart, so that 64 consecutive points are a 4 x 4 x 4 block (the Morton-ordered cell centres of the
+ *          occupancy refresh: step = -1 / grid size); 0 = unknown. step > 0 drives the per-XCD split of the levels (cost model);
+ *          step < 0 selects the hinted kernel with an even split.
  */
 int sdfx_grid_encode_forward_hint(const float* inputs, const void* embeddings, const int32_t* offsets,
                              const int32_t* offsets_host, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
@@ -484,17 +487,19 @@ int sdfx_entropy_backward(const float* weights, uint32_t capacity, const int32_t
  * GradScaler.update()'s growth/back-off to ctl[0] and clears stats), sdfx_adan_update over all parameter
  * tensors (a no-op when ctl[5] != 0, as GradScaler.step() skips optimizer.step()). The tensor lists are HOST
  * arrays of device pointers / element counts / per-tensor lr and weight decay; they travel in the kernel
- * arguments, so one launch covers up to 16 tensors. `half_copies` (NULL, or one entry per tensor, each NULL or a float16 buffer of
+ * arguments, so one launch covers up to 16 tensors. `grad_is_half` (NULL: none): entry t != 0 says gradient t is stored as float16
+ * (the hash table's gradient as the scatter leaves it; float16 -> float32 is exact, so the update equals the one its float32 copy
+ * would give). `half_copies` (NULL, or one entry per tensor, each NULL or a float16 buffer of
  * that tensor's size): the update also writes half(p) there — the fp16 table the next forward gathers from (gridencoder/grid.py:46-47
  * casts the whole table every call; an overflowed iteration leaves parameter and copy untouched, so they stay in step).
  */
 uint32_t sdfx_adan_ctl_words(void);
 uint32_t sdfx_amp_grad_stats_doubles(void);
-int sdfx_amp_grad_stats(const float* const* grads, const uint64_t* counts, uint32_t tensors, double* stats,
+int sdfx_amp_grad_stats(const void* const* grads, const uint8_t* grad_is_half, const uint64_t* counts, uint32_t tensors, double* stats,
                         sdfx_stream_t stream);
 int sdfx_adan_prepare(float* ctl, double* stats, float beta1, float beta2, float beta3, float max_grad_norm, float eps,
                       float growth_factor, float backoff_factor, uint32_t growth_interval, sdfx_stream_t stream);
-int sdfx_adan_update(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_diff,
+int sdfx_adan_update(float* const* params, const void* const* grads, const uint8_t* grad_is_half, float* const* exp_avg, float* const* exp_avg_diff,
                      float* const* exp_avg_sq, float* const* pre_grad, void* const* half_copies, const uint64_t* counts, const float* lrs,
                      const float* weight_decays, uint32_t tensors, const float* ctl, float eps, float beta1, float beta2,
                      float beta3, int no_prox, sdfx_stream_t stream);

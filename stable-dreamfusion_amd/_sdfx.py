@@ -118,9 +118,9 @@ _SIGNATURES = {
     "sdfx_adan_ctl_words": [],
     "sdfx_amp_grad_stats_doubles": [],
     "sdfx_occupancy_stats_doubles": [],
-    "sdfx_amp_grad_stats": [_ptr, _ptr, _u32, _ptr, _ptr],
+    "sdfx_amp_grad_stats": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr],
     "sdfx_adan_prepare": [_ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _u32, _ptr],
-    "sdfx_adan_update": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _f32, _f32, _f32, _f32, _int, _ptr],
+    "sdfx_adan_update": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _f32, _f32, _f32, _f32, _int, _ptr],
 }
 _RESTYPES = {
     "sdfx_march_rays_train_scratch_bytes": _u64,

@@ -485,9 +485,10 @@ int sdfx_grid_encode_forward_hint(const float* inputs, const void* embeddings, c
     SDFX_REQUIRE(aligned_for(embeddings, C, eb) && aligned_for(outputs, C, eb) && (!dy_dx || aligned_for(dy_dx, C, eb)),
                  "grid_encode_forward: embeddings/outputs/dy_dx must be aligned to min(16, C*sizeof(elem)) bytes");
     if (B == 0) return SDFX_OK;
-    // the D = 3, C = 2 kernel (gridencoder_fwd.hip) where the caller described its batch (a step hint); a batch without a
-    // hint (e.g. the 2^21 jittered cell centres of the occupancy refresh) keeps k_grid_forward, which is 6 % faster there
-    if (D == 3 && C == 2 && !dy_dx && fast_forward_enabled() && (step > 0.f || slabs > 1) &&
+    // the D = 3, C = 2 kernel (gridencoder_fwd.hip) where the caller described its batch (a step hint: ray-ordered samples, or —
+    // round 6, step < 0 — points in space-filling-curve order such as the occupancy refresh's 2^21 Morton-ordered cell centres:
+    // 478 -> 410 us with the even split, profiles/r06_refresh_encode_morton.txt); a batch without any hint keeps k_grid_forward
+    if (D == 3 && C == 2 && !dy_dx && fast_forward_enabled() && (step != 0.f || slabs > 1) &&
         launch_forward_d3c2(inputs, embeddings, offsets_host, outputs, B, L, max_level, S, H, gridtype, align_corners, interp,
                             is_half, out_layout, slabs, step, as_stream(stream))) {
         return check_launch("grid_encode_forward");

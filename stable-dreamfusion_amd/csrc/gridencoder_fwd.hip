@@ -433,7 +433,7 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
     for (uint32_t l = 0; l < levels; l++) {
         p.lv[l] = make_level_const(offsets_host, l, S, H);
         const LevelConst& c = p.lv[l];
-        lines[l] = lines_per_wave((double)c.res * step, slabs == kGroup);
+        lines[l] = lines_per_wave((double)c.res * fabs((double)step), slabs == kGroup);
     }
     p.slabs = slabs == kGroup && B % kGroup == 0 ? kGroup : 1u;
     p.slab_points = B / p.slabs;
@@ -455,12 +455,17 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
     // ---- the sequence of levels and what a tile of each costs ----
     Unit units[kMaxLevels];
     uint32_t nu = 0;
-    if (!(balance && step > 0.f)) {   // no information: every level costs the same; the order [L-1, 0, L-2, 1, ...] of GridPlan
+    // step < 0 — points in space-filling-curve order (64 consecutive points = a 4 x 4 x 4 block of a regular grid; the occupancy refresh)
+    // — is NOT priced: a line-count model of such blocks (rows shared in y and z: all but the three finest levels at the VALU floor)
+    // was built and its balanced split measured 628 us against 404 us for the even fine / coarse pairing below (and 474 us for
+    // k_grid_forward; profiles/r06_refresh_encode_morton.txt): the fine hashed levels cost what their L1 misses cost, not what their
+    // distinct lines suggest. The pairing [L-1, 0, L-2, 1, ...] gives every XCD one fine and one coarse level, which is about even.
+    if (!(balance && step > 0.f)) {   // no (usable) information: every level costs the same; the order [L-1, 0, L-2, 1, ...] of GridPlan
         for (uint32_t v = 0, lo = 0, hi = levels; v < levels; v++) units[nu++] = {(v & 1u) ? lo++ : --hi, 1.0};
     } else {                          // fine to coarse; a tile costs its gathers or its VALU work, whichever is longer
         for (uint32_t l = levels; l-- > 0;) {
             const double model = lines[l] > valu_lines ? lines[l] : valu_lines;
-            const bool table = slabs == kGroup && measured_stencil_config(levels, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1);
+            const bool table = slabs == kGroup && step > 0.f && measured_stencil_config(levels, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1);
             units[nu++] = {l, table ? stencil_tile_cost((double)p.lv[l].res * step, (p.lv[l].flags & 1u) == 0u && p.lv[l].res >= 2u) : model};
         }
     }
@@ -515,7 +520,9 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
             const uint32_t tpw_coarse = [] { const int v = dev_switch("SDFX_GRID_TPW", 8); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
             const uint32_t tpw_fine = [] { const int v = dev_switch("SDFX_GRID_TPW_FINE", 2); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
             // (an LDS-resident level — the SDFX_GRID_LDS measurement aid — has its own walk of kLdsTiles tiles per workgroup: one tile per plan slot)
+            // (curve-ordered batches: 8 tiles per workgroup at every level — 439 / 428 / 420 / 409 us for 1 / 2 / 4 / 8, same process)
             const uint32_t tpw = ((p.lds_mask >> units[u].level) & 1u) ? 1u
+                                 : step < 0.f ? tpw_coarse
                                  : (balance && step > 0.f && lines[units[u].level] <= valu_lines) ? tpw_coarse : tpw_fine;
             p.seg[k][ns++] = {units[u].level, first, last - first, tpw};
             p.ntiles[k] += (last - first + tpw - 1u) / tpw;
@@ -623,7 +630,7 @@ extern "C" int sdfx_grid_forward_level_costs(const int32_t* offsets_host, uint32
         const LevelConst c = make_level_const(offsets_host, l, S, H);
         if (!(balance && step > 0.f)) { costs[l] = 1.0; continue; }
         const double lines = lines_per_wave((double)c.res * step, slabs == kGroup);
-        const bool table = slabs == kGroup && measured_stencil_config(max_level, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1);
+        const bool table = slabs == kGroup && step > 0.f && measured_stencil_config(max_level, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1);
         costs[l] = table ? stencil_tile_cost((double)c.res * step, (c.flags & 1u) == 0u && c.res >= 2u) : (lines > valu_lines ? lines : valu_lines);
     }
     return (int)max_level;

@@ -35,8 +35,35 @@ constexpr uint32_t kThreads = 256;
 constexpr uint32_t kStatsHeader = 3;
 constexpr uint32_t kMaxStatBlocks = 512 * 16;   // 512 workgroups per tensor, 16 tensors per launch
 
+// four consecutive gradient elements from i on (elements past n: 0), float32 or float16 storage; the float16 -> float32 conversion is
+// exact, so a half gradient gives the same update as its float32 copy would
+template <bool GHALF>
+__device__ __forceinline__ void load_grad4(const void* __restrict__ gv, uint64_t i, uint64_t n, float v[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if constexpr (GHALF) {
+        const __half* g = static_cast<const __half*>(gv);
+        if (i + 4 <= n && (reinterpret_cast<uintptr_t>(g + i) & 7) == 0) {
+            union { uint2 u; __half2 h2[2]; } q;
+            q.u = *reinterpret_cast<const uint2*>(g + i);
+            const float2 a = __half22float2(q.h2[0]), b = __half22float2(q.h2[1]);
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+        } else {
+            for (uint32_t k = 0; k < 4 && i + k < n; k++) v[k] = __half2float(g[i + k]);
+        }
+    } else {
+        const float* g = static_cast<const float*>(gv);
+        if (i + 4 <= n && (reinterpret_cast<uintptr_t>(g + i) & 15) == 0) {
+            const float4 q = *reinterpret_cast<const float4*>(g + i);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            for (uint32_t k = 0; k < 4 && i + k < n; k++) v[k] = g[i + k];
+        }
+    }
+}
+
 // one workgroup's share of one gradient tensor: `nblocks` workgroups stride over it
-__device__ __forceinline__ void grad_stats_body(const float* __restrict__ g, uint64_t n, uint32_t block, uint32_t nblocks,
+template <bool GHALF>
+__device__ __forceinline__ void grad_stats_body(const void* __restrict__ g, uint64_t n, uint32_t block, uint32_t nblocks,
                                                 double* __restrict__ stats) {
     __shared__ double part[kThreads / 64];
     __shared__ double red[2][kThreads];
@@ -45,19 +72,19 @@ __device__ __forceinline__ void grad_stats_body(const float* __restrict__ g, uin
     __syncthreads();
     double acc = 0.0;
     bool bad = false;
-    const uint64_t stride = (uint64_t)nblocks * kThreads * 4;
-    for (uint64_t i = ((uint64_t)block * kThreads + threadIdx.x) * 4; i < n; i += stride) {
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (i + 4 <= n && (reinterpret_cast<uintptr_t>(g + i) & 15) == 0) {
-            const float4 q = *reinterpret_cast<const float4*>(g + i);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
-            for (uint32_t k = 0; k < 4 && i + k < n; k++) v[k] = g[i + k];
-        }
+    // 16 bytes per lane and step: four floats, or eight halves (two load_grad4 whose 8-byte loads the compiler merges)
+    constexpr uint32_t kPer = GHALF ? 8 : 4;
+    const uint64_t stride = (uint64_t)nblocks * kThreads * kPer;
+    for (uint64_t i = ((uint64_t)block * kThreads + threadIdx.x) * kPer; i < n; i += stride) {
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            bad |= !(fabsf(v[k]) <= 3.402823466e38f);  // inf or nan
-            acc += (double)v[k] * (double)v[k];
+        for (uint32_t q = 0; q < kPer; q += 4) {
+            float v[4];
+            load_grad4<GHALF>(g, i + q, n, v);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                bad |= !(fabsf(v[k]) <= 3.402823466e38f);  // inf or nan
+                acc += (double)v[k] * (double)v[k];
+            }
         }
     }
     // wave reduction (fixed tree), then this workgroup's slot
@@ -100,7 +127,10 @@ __device__ __forceinline__ void grad_stats_body(const float* __restrict__ g, uin
 // needs no side buffer), workgroup b belongs to the tensor t with first[t] <= b < first[t + 1].
 constexpr uint32_t kMaxTensors = 16;
 struct TensorList {
-    const float* g[kMaxTensors];
+    // the gradient: float32, or float16 where bit t of g_half is set (the hash table's gradient as the scatter leaves it: read as
+    // it is, instead of through a 24 MB -> 48 MB conversion launch)
+    const void* g[kMaxTensors];
+    uint32_t g_half;
     float* p[kMaxTensors];
     float* m[kMaxTensors];
     float* v[kMaxTensors];
@@ -121,7 +151,8 @@ __device__ __forceinline__ uint32_t tensor_of_block(const TensorList& tl, uint32
 
 __global__ __launch_bounds__(kThreads) void k_grad_stats(TensorList tl, double* __restrict__ stats) {
     const uint32_t t = tensor_of_block(tl, blockIdx.x);
-    grad_stats_body(tl.g[t], tl.count[t], blockIdx.x - tl.first[t], tl.first[t + 1] - tl.first[t], stats);
+    if ((tl.g_half >> t) & 1u) grad_stats_body<true>(tl.g[t], tl.count[t], blockIdx.x - tl.first[t], tl.first[t + 1] - tl.first[t], stats);
+    else grad_stats_body<false>(tl.g[t], tl.count[t], blockIdx.x - tl.first[t], tl.first[t + 1] - tl.first[t], stats);
 }
 
 // (control-block layout, overflow / clip / bias-correction bookkeeping and the per-element update: optim_math.h, shared
@@ -134,11 +165,10 @@ __global__ void k_adan_prepare(float* __restrict__ ctl, double* __restrict__ sta
     stats[1] = 0.0;
 }
 
-__global__ __launch_bounds__(kThreads) void k_adan_update(TensorList tl, const float* __restrict__ ctl, AdanHyper h) {
-    if (ctl[5] != 0.f) return;  // overflowed iteration: GradScaler.step() skips optimizer.step()
-    const uint32_t t = tensor_of_block(tl, blockIdx.x);
+template <bool GHALF>
+__device__ __forceinline__ void adan_update_body(const TensorList& tl, uint32_t t, const float* __restrict__ ctl, AdanHyper h) {
     float* __restrict__ p = tl.p[t];
-    const float* __restrict__ g = tl.g[t];
+    const void* __restrict__ g = tl.g[t];
     float* __restrict__ m = tl.m[t];
     float* __restrict__ v = tl.v[t];
     float* __restrict__ nn = tl.n[t];
@@ -152,19 +182,20 @@ __global__ __launch_bounds__(kThreads) void k_adan_update(TensorList tl, const f
     const bool first = ctl[2] == 1.0f;
     const float bc1 = ctl[6], bc2 = ctl[7], bc3 = ctl[8];
     const uint64_t stride = (uint64_t)nblocks * kThreads * 4;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) |
                            reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(nn) |
                            reinterpret_cast<uintptr_t>(prev) | (reinterpret_cast<uintptr_t>(hc) << 1)) & 15) == 0;
     for (uint64_t i = ((uint64_t)block * kThreads + threadIdx.x) * 4; i < n; i += stride) {
+        float G[4];
+        load_grad4<GHALF>(g, i, n, G);
         if (aligned && i + 4 <= n) {
             float4 P = *reinterpret_cast<float4*>(p + i);
-            const float4 G = *reinterpret_cast<const float4*>(g + i);
             float4 M = *reinterpret_cast<float4*>(m + i), V = *reinterpret_cast<float4*>(v + i);
             float4 N = *reinterpret_cast<float4*>(nn + i), R = *reinterpret_cast<float4*>(prev + i);
-            adan_one(P.x, G.x, M.x, V.x, N.x, R.x, unscale, first, bc1, bc2, bc3, h);
-            adan_one(P.y, G.y, M.y, V.y, N.y, R.y, unscale, first, bc1, bc2, bc3, h);
-            adan_one(P.z, G.z, M.z, V.z, N.z, R.z, unscale, first, bc1, bc2, bc3, h);
-            adan_one(P.w, G.w, M.w, V.w, N.w, R.w, unscale, first, bc1, bc2, bc3, h);
+            adan_one(P.x, G[0], M.x, V.x, N.x, R.x, unscale, first, bc1, bc2, bc3, h);
+            adan_one(P.y, G[1], M.y, V.y, N.y, R.y, unscale, first, bc1, bc2, bc3, h);
+            adan_one(P.z, G[2], M.z, V.z, N.z, R.z, unscale, first, bc1, bc2, bc3, h);
+            adan_one(P.w, G[3], M.w, V.w, N.w, R.w, unscale, first, bc1, bc2, bc3, h);
             *reinterpret_cast<float4*>(p + i) = P;
             if (hc) {   // the table the next forward gathers from: embeddings.to(half) (gridencoder/grid.py:46-47), formed here instead of by a cast launch
                 union { __half2 h2[2]; uint2 u; } pk;
@@ -177,11 +208,18 @@ __global__ __launch_bounds__(kThreads) void k_adan_update(TensorList tl, const f
             *reinterpret_cast<float4*>(prev + i) = R;
         } else {
             for (uint32_t k = 0; k < 4 && i + k < n; k++) {
-                adan_one(p[i + k], g[i + k], m[i + k], v[i + k], nn[i + k], prev[i + k], unscale, first, bc1, bc2, bc3, h);
+                adan_one(p[i + k], G[k], m[i + k], v[i + k], nn[i + k], prev[i + k], unscale, first, bc1, bc2, bc3, h);
                 if (hc) hc[i + k] = __float2half_rn(p[i + k]);
             }
         }
     }
+}
+
+__global__ __launch_bounds__(kThreads) void k_adan_update(TensorList tl, const float* __restrict__ ctl, AdanHyper h) {
+    if (ctl[5] != 0.f) return;  // overflowed iteration: GradScaler.step() skips optimizer.step()
+    const uint32_t t = tensor_of_block(tl, blockIdx.x);
+    if ((tl.g_half >> t) & 1u) adan_update_body<true>(tl, t, ctl, h);
+    else adan_update_body<false>(tl, t, ctl, h);
 }
 
 uint32_t blocks_for(uint64_t n) {
@@ -197,7 +235,7 @@ uint32_t sdfx_adan_ctl_words(void) { return 16; }
 
 uint32_t sdfx_amp_grad_stats_doubles(void) { return kStatsHeader + 2 * kMaxStatBlocks; }
 
-int sdfx_amp_grad_stats(const float* const* grads, const uint64_t* counts, uint32_t tensors, double* stats,
+int sdfx_amp_grad_stats(const void* const* grads, const uint8_t* grad_is_half, const uint64_t* counts, uint32_t tensors, double* stats,
                         sdfx_stream_t stream) {
     SDFX_REQUIRE(stats && (tensors == 0 || (grads && counts)), "amp_grad_stats: null pointer");
     for (uint32_t t0 = 0; t0 < tensors; t0 += kMaxTensors) {
@@ -209,6 +247,7 @@ int sdfx_amp_grad_stats(const float* const* grads, const uint64_t* counts, uint3
             SDFX_REQUIRE(grads[t], "amp_grad_stats: null gradient pointer");
             const uint32_t k = tl.tensors++;
             tl.g[k] = grads[t];
+            if (grad_is_half && grad_is_half[t]) tl.g_half |= 1u << k;
             tl.count[k] = counts[t];
             tl.first[k] = blocks;
             // every workgroup ends in one double atomic on the same two words: keep their number small
@@ -230,7 +269,7 @@ int sdfx_adan_prepare(float* ctl, double* stats, float beta1, float beta2, float
     return check_launch("adan_prepare");
 }
 
-int sdfx_adan_update(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_diff,
+int sdfx_adan_update(float* const* params, const void* const* grads, const uint8_t* grad_is_half, float* const* exp_avg, float* const* exp_avg_diff,
                      float* const* exp_avg_sq, float* const* pre_grad, void* const* half_copies, const uint64_t* counts, const float* lrs,
                      const float* weight_decays, uint32_t tensors, const float* ctl, float eps, float beta1, float beta2,
                      float beta3, int no_prox, sdfx_stream_t stream) {
@@ -248,6 +287,7 @@ int sdfx_adan_update(float* const* params, const float* const* grads, float* con
                          "adan_update: null tensor pointer");
             const uint32_t k = tl.tensors++;
             tl.p[k] = params[t]; tl.g[k] = grads[t]; tl.m[k] = exp_avg[t]; tl.v[k] = exp_avg_diff[t];
+            if (grad_is_half && grad_is_half[t]) tl.g_half |= 1u << k;
             tl.n[k] = exp_avg_sq[t]; tl.prev[k] = pre_grad[t];
             tl.half_copy[k] = half_copies ? static_cast<__half*>(half_copies[t]) : nullptr;
             tl.count[k] = counts[t]; tl.lr[k] = lrs[t]; tl.wd[k] = weight_decays[t];

@@ -65,6 +65,7 @@ class _fused_field(Function):
             _gridencoder.grid_encode_forward(inputs, emb, offsets, enc, B, 3, C, L, L, S, base_resolution, None, gridtype,
                                              align_corners, interp, 0, slabs, step)
             _field.forward(enc, 0, None if src else x, packed, B, blob_density, blob_radius, sigma, albedo)
+        ctx.emb_param = embeddings       # (the Parameter object itself: DeviceAdan.half_grads marks it, see backward)
         ctx.src = None if src is None else src[1:]
         if src is not None:
             inputs = x.new_empty(0)      # placeholders: the backward forms the batch from x as well
@@ -95,6 +96,13 @@ class _fused_field(Function):
                             db2, dw3, db3)
             _gridencoder.grid_encode_backward(denc, None if ctx.src else inputs, grad_emb, offsets, grad_emb, B, 3, C, L, L, S, H, None,
                                               None, gridtype, align_corners, interp, 0)
+        # Under DeviceAdan.half_grads() the table's gradient goes to the optimiser as the scatter left it — float16 — instead of back to
+        # autograd, which converts it to the parameter's float32 first (a 24 MB -> 48 MB launch, read once by the optimiser step)
+        par = ctx.emb_param
+        if getattr(par, "_sdfx_take_half_grad", False) and par.dtype == torch.float32:
+            prev = getattr(par, "_sdfx_half_grad", None)
+            par._sdfx_half_grad = grad_emb if prev is None else prev.add_(grad_emb)
+            grad_emb = None
         return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 12
 
 

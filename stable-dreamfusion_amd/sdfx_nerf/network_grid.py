@@ -104,13 +104,17 @@ class NeRFNetwork(NeRFRenderer):
         self.register_buffer("_fd_offsets", torch.tensor([[e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]],
                                                          dtype=torch.float32), persistent=False)
 
-    def common_forward(self, x, slabs=1, ray_ordered=False):
+    accepts_curve_step = True    # density(x, curve_step=...): see common_forward
+
+    def common_forward(self, x, slabs=1, ray_ordered=False, curve_step=0.0):
         """`slabs` = 7: x is the [7, N, 3] batch of a finite-difference stencil; `ray_ordered`: consecutive rows are
-        consecutive samples of a ray. Both only steer the encoder's work split (same values either way)."""
+        consecutive samples of a ray; `curve_step` > 0: the rows walk a space-filling curve through a regular grid of points that far
+        apart in world units (the occupancy refresh's Morton-ordered cell centres). All of them only steer the encoder's work split
+        (include/sdfx.h, sdfx_grid_encode_forward_hint; same values either way)."""
         if _FUSED and _ff.supported(self.encoder, self.sigma_net, x, self.opt.density_activation, self.max_level):
             shape = x.shape[:-1]
             # sample spacing in the encoder's unit cube: dt_min = 2 sqrt(3) / max_steps (raymarching.cu:385) over 2 bound
-            step = (3.0 ** 0.5) / (self.opt.max_steps * self.bound) if ray_ordered else 0.0
+            step = (3.0 ** 0.5) / (self.opt.max_steps * self.bound) if ray_ordered else -float(curve_step) / (2 * self.bound)
             sigma, albedo = _ff.fused_field(x.reshape(-1, 3), self.encoder, self.sigma_net, self.bound,
                                             self.opt.blob_density, self.opt.blob_radius, slabs, step)
             return sigma.view(*shape), albedo.view(*shape, 3)
@@ -237,8 +241,8 @@ class NeRFNetwork(NeRFRenderer):
                 color = albedo * lambertian.unsqueeze(-1)
         return sigma, color, normal
 
-    def density(self, x):
-        sigma, albedo = self.common_forward(x)
+    def density(self, x, curve_step=0.0):
+        sigma, albedo = self.common_forward(x, curve_step=curve_step)
         return {"sigma": sigma, "albedo": albedo}
 
     def background(self, d):

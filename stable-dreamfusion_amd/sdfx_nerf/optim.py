@@ -121,25 +121,56 @@ class DeviceAdan:
     def zero_grad(self):
         for p in self.parameters():
             p.grad = None
+            if getattr(p, "_sdfx_half_grad", None) is not None:
+                p._sdfx_half_grad = None
+
+    class _HalfGrads:
+        def __init__(self, params):
+            self.params = params
+
+        def __enter__(self):
+            for p in self.params:
+                p._sdfx_take_half_grad = True
+            return self
+
+        def __exit__(self, *exc):
+            for p in self.params:
+                p._sdfx_take_half_grad = False
+            return False
+
+    def half_grads(self):
+        """`with opt.half_grads(): loss.backward()` — inside, an operator of this package whose parameter gradient is born in float16 (the
+        hash table's: the scatter of sdfx_nerf/fused_field.py) hands it to THIS optimiser as it is (`p._sdfx_half_grad`) instead of
+        returning it to autograd, which would convert it to the parameter's float32 (a 24 MB -> 48 MB launch per iteration) before
+        step() reads it once. step() takes the float16 gradient directly (exact conversion in the kernels: the same update).
+        `p.grad` stays None for such a parameter, so the context belongs around a backward that only this optimiser consumes."""
+        return DeviceAdan._HalfGrads(self.parameters())
 
     @torch.no_grad()
     def step(self):
         import ctypes as C
         S = self._S
         st = S.stream()
-        todo = []
+        todo, gts = [], []
         for g in self.param_groups:
             for p in g["params"]:
-                if p.grad is None:
+                hg = getattr(p, "_sdfx_half_grad", None)
+                if hg is not None and p.grad is not None:       # both kinds arrived: fold the float16 one into the float32 one
+                    p.grad.add_(hg.to(p.grad.dtype))
+                    p._sdfx_half_grad = hg = None
+                gt = hg if hg is not None else p.grad
+                if gt is None:
                     continue
-                if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
-                    raise RuntimeError("DeviceAdan: gradients must be contiguous float32")
+                if gt.dtype not in (torch.float32, torch.float16) or not gt.is_contiguous() or gt.numel() != p.numel():
+                    raise RuntimeError("DeviceAdan: gradients must be contiguous float32 (or float16 handed over under half_grads())")
                 todo.append((g, p))
+                gts.append(gt)
         n = len(todo)
         ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
-        grads = ptrs([p.grad for _, p in todo])
+        grads = ptrs(gts)
+        is_half = (C.c_uint8 * n)(*[int(gt.dtype == torch.float16) for gt in gts])
         counts = (C.c_uint64 * n)(*[p.numel() for _, p in todo])
-        S.call("sdfx_amp_grad_stats", grads, counts, n, S.ptr(self.stats), st)
+        S.call("sdfx_amp_grad_stats", grads, is_half, counts, n, S.ptr(self.stats), st)
         b1, b2, b3 = self.betas
         S.call("sdfx_adan_prepare", S.ptr(self.ctl), S.ptr(self.stats), b1, b2, b3, self.max_grad_norm, self.eps,
                self.growth[0], self.growth[1], self.growth[2], st)
@@ -154,7 +185,7 @@ class DeviceAdan:
                 S.half_image(p)
             halves.append(hit[0] if ok else None)
         half_ptrs = (C.c_void_p * n)(*[None if h is None else h.data_ptr() for h in halves])
-        S.call("sdfx_adan_update", ptrs([p for _, p in todo]), grads, ptrs([s_[0] for s_ in state]), ptrs([s_[1] for s_ in state]),
+        S.call("sdfx_adan_update", ptrs([p for _, p in todo]), grads, is_half, ptrs([s_[0] for s_ in state]), ptrs([s_[1] for s_ in state]),
                ptrs([s_[2] for s_ in state]), ptrs([s_[3] for s_ in state]), half_ptrs, counts,
                (C.c_float * n)(*[g["lr"] for g, _ in todo]), (C.c_float * n)(*[g["weight_decay"] for g, _ in todo]), n,
                S.ptr(self.ctl), self.eps, b1, b2, b3, int(self.no_prox), st)

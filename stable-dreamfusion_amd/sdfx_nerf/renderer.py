@@ -312,7 +312,9 @@ class NeRFRenderer(nn.Module):
             nz = None if noise is None else S.check_tensor(noise[cas].to(device=device, dtype=torch.float32).contiguous(), "noise",
                                                            torch.float32)
             S.call("sdfx_occupancy_points", H, float(bound), S.ptr(nz), seed, cas, S.ptr(pts), S.stream())
-            sigmas = self.density(pts)["sigma"].reshape(-1).detach().float().contiguous()
+            # (the points are the grid's cell centres in Morton order, 2 bound_c / H apart: told to a field that takes the hint)
+            hint = {"curve_step": 2.0 * bound / H} if getattr(self, "accepts_curve_step", False) else {}
+            sigmas = self.density(pts, **hint)["sigma"].reshape(-1).detach().float().contiguous()
             S.call("sdfx_occupancy_update", grid.data_ptr() + cas * n * 4, S.ptr(sigmas), n, float(decay), S.ptr(stats),
                    int(cas == 0), S.stream())
         S.call("sdfx_occupancy_pack", S.ptr(grid), self.cascade * n, S.ptr(stats), float(self.density_thresh),

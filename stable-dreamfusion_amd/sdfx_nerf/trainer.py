@@ -252,16 +252,17 @@ class TrainStep:
         with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
             loss = self.train_step((xyzs, dirs, ts, self.cur_rays, self.n_valid, self.cur_total), shading, as_latent, bg_kind,
                                    split=True)
-        if isinstance(loss, tuple):
-            scale = self.optimizer.scale         # 0-dim view of the optimiser's control block, read at execution time
-            torch.autograd.backward(list(loss), [scale.to(t.dtype) if t.dtype != scale.dtype else scale for t in loss])
-            with torch.no_grad():
-                total = loss[0].float()
-                for t in loss[1:]:
-                    total = total + t.float()
-        else:
-            (loss * self.optimizer.scale).backward()
-            total = loss.detach()
+        with self.optimizer.half_grads():        # the table's float16 gradient goes straight to the optimiser kernels (sdfx_nerf/optim.py)
+            if isinstance(loss, tuple):
+                scale = self.optimizer.scale         # 0-dim view of the optimiser's control block, read at execution time
+                torch.autograd.backward(list(loss), [scale.to(t.dtype) if t.dtype != scale.dtype else scale for t in loss])
+                with torch.no_grad():
+                    total = loss[0].float()
+                    for t in loss[1:]:
+                        total = total + t.float()
+            else:
+                (loss * self.optimizer.scale).backward()
+                total = loss.detach()
         self.optimizer.step()
         return total
 
@@ -363,7 +364,8 @@ class TrainStep:
             loss = self._stage_train(marched, *key[1:6])
         # (the gradient buffers of this graph are kept reachable for diagnostics: Python's p.grad only names the
         # buffers of the most recent capture)
-        self.graphs[key] = (g1, g2, loss, marched, [p.grad for p in self.optimizer.parameters()])
+        self.graphs[key] = (g1, g2, loss, marched, [p.grad if p.grad is not None else getattr(p, "_sdfx_half_grad", None)
+                                                    for p in self.optimizer.parameters()])
         self.graph_uses[key] = 0
         self._priming.add(key)
         self.stats["captures"] += 1

@@ -21,7 +21,7 @@ def _plan(offsets, pls, L, half, B, slabs, step):
 
 
 @pytest.mark.parametrize("B", [1, 100, 4096 * 7, 1810900, 1 << 21])
-@pytest.mark.parametrize("slabs,step", [(1, 0.0), (7, 0.0), (1, 1 / 591.0), (7, 1 / 591.0), (7, 1e-5), (7, 0.05)])
+@pytest.mark.parametrize("slabs,step", [(1, 0.0), (7, 0.0), (1, 1 / 591.0), (7, 1 / 591.0), (7, 1e-5), (7, 0.05), (1, -1 / 128.0)])
 @pytest.mark.parametrize("L,half", [(16, 1), (16, 0), (9, 1), (1, 1)])
 def test_every_tile_is_assigned_once(oracle, B, slabs, step, L, half):
     offsets, pls = oracle.grid_offsets(desired_resolution=2048)
@@ -67,6 +67,16 @@ def test_step_hint_balances_the_plans_own_cost(oracle, desired, step):
     if not measured:
         assert (cost >= 97 - 1e-9).all() and (cost[:3] == 97).all()    # the model: VALU floor at the coarse end, lines beyond
     assert (_costs(offsets, pls, 16, 7, 0.0) == 1.0).all()    # no hint: every level the same
+
+
+def test_space_filling_curve_hint_takes_the_even_pairing(oracle):
+    """step < 0 (64 consecutive points = a 4 x 4 x 4 block of a regular grid: the occupancy refresh's Morton-ordered cell centres) goes
+    to the hinted kernel unpriced: every level costs the same and every XCD gets the same number of tiles."""
+    offsets, pls = oracle.grid_offsets(desired_resolution=2048)
+    assert (_costs(offsets, pls, 16, 1, -1 / 128.0) == 1.0).all()
+    seg, T = _plan(offsets, pls, 16, 1, 1 << 21, 1, -1 / 128.0)
+    per_xcd = [int(seg[seg[:, 0] == k, 3].sum()) for k in range(8)]
+    assert max(per_xcd) - min(per_xcd) <= 1 and sum(per_xcd) == 16 * T
 
 
 @pytest.mark.parametrize("B", [1, 511, 4096 * 7, 1810900, 3150000])

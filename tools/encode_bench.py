@@ -57,7 +57,7 @@ for rnd in range(3):            # rounds interleaved so that clock / thermal dri
             else:
                 _sdfx.lib().sdfx_dev_unset(name.encode())
         slabs = 7 if (hint and kind == "stencil") else 1
-        step = (1.0 / 128.0 if kind == "morton" else STEP) if (hint and kind != "uniform") else 0.0
+        step = (-1.0 / 128.0 if kind == "morton" else STEP) if (hint and kind != "uniform") else 0.0
         out = torch.empty(16, B, 2, device=dev, dtype=dt)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for i in range(n + 2):
