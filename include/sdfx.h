@@ -347,6 +347,12 @@ int sdfx_field_stencil_points(const float* xyzs, uint32_t M, float epsilon, floa
                               sdfx_stream_t stream);
 int sdfx_field_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                     uint32_t* packed, sdfx_stream_t stream);
+/* sdfx_set_albedo_rows(rows): until reset with 0, the `albedo` output of sdfx_field_forward and the `dalbedo` input of
+ * sdfx_field_backward hold only the FIRST `rows` rows of the batch (this thread's calls): albedo is not stored for the rows behind them
+ * and their d-albedo is taken as zero. A 7-point stencil batch [7, M, ...] needs the albedo of its M base samples only.
+ * sdfx_field_albedo_rows_ok(B, enc_layout): 1 when both calls honour it for such a batch (the [L, B, 2]-layout kernels). */
+void sdfx_set_albedo_rows(uint32_t rows);
+int sdfx_field_albedo_rows_ok(uint32_t B, int enc_layout);
 int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const uint32_t* packed, uint32_t B,
                        float blob_density, float blob_radius, float* sigma, float* albedo, sdfx_stream_t stream);
 int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const uint32_t* packed, uint32_t B,

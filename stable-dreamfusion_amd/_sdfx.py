@@ -86,6 +86,8 @@ _SIGNATURES = {
     "sdfx_entropy_forward": [_ptr, _u32, _ptr, _ptr, _ptr],
     "sdfx_entropy_backward": [_ptr, _u32, _ptr, _ptr, _ptr, _ptr],
     "sdfx_set_row_limit": [_ptr, _u32],
+    "sdfx_set_albedo_rows": [_u32],
+    "sdfx_field_albedo_rows_ok": [_u32, _int],
     "sdfx_set_stencil_source": [_ptr, _u32, _f32, _f32, C.c_double],
     "sdfx_grid_backward_plan": [_ptr, _u32, _f32, _u32, _u32, _int, _ptr, _ptr],
     "sdfx_grid_forward_plan": [_ptr, _u32, _f32, _u32, _int, _u32, _u32, _f32, _ptr, _u32, _ptr],
@@ -204,6 +206,24 @@ class stencil_source:
     def __exit__(self, *exc):
         if self.xyzs is not None:
             lib().sdfx_set_stencil_source(None, 0, 0.0, 0.0, 0.0)
+        return False
+
+
+class albedo_rows:
+    """`with albedo_rows(n): ...` — sdfx_set_albedo_rows around the field calls inside (include/sdfx.h): their albedo / d-albedo buffers
+    hold the first n rows of the batch only. n = 0 / None: no-op."""
+
+    def __init__(self, rows):
+        self.rows = int(rows or 0)
+
+    def __enter__(self):
+        if self.rows:
+            lib().sdfx_set_albedo_rows(self.rows)
+        return self
+
+    def __exit__(self, *exc):
+        if self.rows:
+            lib().sdfx_set_albedo_rows(0)
         return False
 
 

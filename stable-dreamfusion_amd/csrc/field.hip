@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
                                                                                    const float* __restrict__ dsigma,
                                                                                    const float* __restrict__ dalbedo,
                                                                                    uint32_t* __restrict__ denc, float* __restrict__ partials,
-                                                                                   RowLimit rl, StencilSrc src) {
+                                                                                   RowLimit rl, StencilSrc src, uint32_t alb_rows) {
     constexpr uint32_t TS = 128 * NB;
     constexpr uint32_t kFB = TS * kTrPitch;                  // bytes of one feature block [TS samples][32 features]
     constexpr uint32_t kD3 = 5 * kFB, kD3Pitch = 8;          // d h3 (4 features): [TS][4 halves] behind the five blocks
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 2 : 1) void k_field_backward_na
     // every operand through a buffer descriptor: 32-bit offsets (the level stride p B 4 rides in the scalar offset: no 64-bit
     // address arithmetic per load), and a dead lane's out-of-range offset reads 0 — no masking afterwards
     const __amdgpu_buffer_rsrc_t denc_buf = out_buffer(denc, (uint64_t)B * (kIn / 2) * 4), enc_buf = in_buffer(enc, (uint64_t)B * (kIn / 2) * 4),
-                                 ds_buf = in_buffer(dsigma, (uint64_t)B * 4), da_buf = in_buffer(dalbedo, (uint64_t)B * 12),
+                                 ds_buf = in_buffer(dsigma, (uint64_t)B * 4), da_buf = in_buffer(dalbedo, (uint64_t)alb_rows * 12),   // rows >= alb_rows: out of range, read as 0 (sdfx_set_albedo_rows)
                                  px_buf = src.xyzs ? in_buffer(src.xyzs, (uint64_t)src.M * 12) : in_buffer(x, (uint64_t)B * 12);
     const uint32_t ntiles = (B + TS - 1) / TS;
     auto next_live = [&](uint32_t tl) {
@@ -516,7 +516,7 @@ template <int NB>
 __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* __restrict__ enc, const float* __restrict__ x,
                                                                  const uint32_t* __restrict__ P, uint32_t B, float blob_density,
                                                                  float inv_2r2, float* __restrict__ sigma, float* __restrict__ albedo,
-                                                                 RowLimit rl, StencilSrc src) {
+                                                                 RowLimit rl, StencilSrc src, uint32_t alb_rows) {
     constexpr uint32_t TS = 128 * NB, kFwdFrags = fW3T;   // fragments of W1, W2, W3
     __shared__ uint4 sfrag[kFwdFrags * 64];
     __shared__ float sbias[kBiasPad];
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(kThreads) void k_field_forward_nat(const uint32_t* 
     // two dependent reads of the row limit, then its feature loads, and ended with the coordinate load: four exposed latencies
     // for ~0.5 us of arithmetic.
     const RowLimitNow rn = row_limit_now(rl);
-    const __amdgpu_buffer_rsrc_t sig_buf = out_buffer(sigma, (uint64_t)B * 4), alb_buf = out_buffer(albedo, (uint64_t)B * 12),
+    const __amdgpu_buffer_rsrc_t sig_buf = out_buffer(sigma, (uint64_t)B * 4), alb_buf = out_buffer(albedo, (uint64_t)alb_rows * 12),   // rows >= alb_rows: the store is dropped
                                  enc_buf = in_buffer(enc, (uint64_t)B * (kIn / 2) * 4),
                                  px_buf = src.xyzs ? in_buffer(src.xyzs, (uint64_t)src.M * 12) : in_buffer(x, (uint64_t)B * 12);
     const uint32_t ntiles = (B + TS - 1) / TS;
@@ -742,6 +742,12 @@ int sdfx_field_pack(const float* w1, const float* b1, const float* w2, const flo
     return check_launch("field_pack");
 }
 
+// 1 when sdfx_field_forward AND sdfx_field_backward of a batch of B rows in this layout run the kernels that honour sdfx_set_albedo_rows
+// (buffer descriptors sized to the albedo rows: out-of-range stores are dropped, loads read 0)
+int sdfx_field_albedo_rows_ok(uint32_t B, int enc_layout) {
+    return (enc_layout == 0 && B < kNatMaxRows && !use_dot2() && native_forward() > 0 && dev_switch("SDFX_FIELD_BWD_NAT", 1) != 0) ? 1 : 0;
+}
+
 int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const uint32_t* packed, uint32_t B,
                        float blob_density, float blob_radius, float* sigma, float* albedo, sdfx_stream_t stream) {
     SDFX_REQUIRE(enc && packed && sigma && albedo, "field_forward: null pointer");
@@ -751,6 +757,9 @@ int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const ui
     SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_forward: features misaligned");
     SDFX_REQUIRE(blob_radius > 0, "field_forward: blob_radius must be positive");
     if (B == 0) return SDFX_OK;
+    const uint32_t alb_rows = albedo_rows() ? (albedo_rows() < B ? albedo_rows() : B) : B;
+    SDFX_REQUIRE(alb_rows == B || sdfx_field_albedo_rows_ok(B, enc_layout), "field_forward: albedo for the first %u of %u rows only needs the "
+                 "[L, B, 2]-layout kernels (sdfx_field_albedo_rows_ok)", alb_rows, B);
 #ifdef SDFX_DEVTOOLS
     if (use_dot2()) {
         hipLaunchKernelGGL(k_field_forward, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
@@ -766,10 +775,10 @@ int sdfx_field_forward(const void* enc, int enc_layout, const float* x, const ui
         const uint32_t tiles = div_up(B, 128u * nb), blocks = tiles < cap ? tiles : cap;
         if (nb == 2)
             hipLaunchKernelGGL(k_field_forward_nat<2>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), static_cast<const uint32_t*>(enc), x,
-                               packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src());
+                               packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src(), alb_rows);
         else
             hipLaunchKernelGGL(k_field_forward_nat<1>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), static_cast<const uint32_t*>(enc), x,
-                               packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src());
+                               packed, B, blob_density, 1.0f / (2 * blob_radius * blob_radius), sigma, albedo, row_limit(), stencil_src(), alb_rows);
     } else {
         hipLaunchKernelGGL(k_field_forward_mma, dim3(div_up(B, kThreads)), dim3(kThreads), 0, as_stream(stream),
                            static_cast<const uint32_t*>(enc), enc_layout, x, packed, B, blob_density,
@@ -790,6 +799,9 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
     SDFX_REQUIRE((reinterpret_cast<uintptr_t>(enc) % (enc_layout ? 16 : 4)) == 0, "field_backward: features misaligned");
     SDFX_REQUIRE(blob_radius > 0, "field_backward: blob_radius must be positive");
     hipStream_t st = as_stream(stream);
+    const uint32_t alb_rows = albedo_rows() ? (albedo_rows() < B ? albedo_rows() : B) : B;
+    SDFX_REQUIRE(alb_rows == B || sdfx_field_albedo_rows_ok(B, enc_layout), "field_backward: d-albedo for the first %u of %u rows only needs the "
+                 "[L, B, 2]-layout kernels (sdfx_field_albedo_rows_ok)", alb_rows, B);
     const int lds_frags = dev_switch("SDFX_FIELD_BWD_LDSFRAG", 1) != 0;
     const bool native = dev_switch("SDFX_FIELD_BWD_NAT", 1) != 0;
     const int nb = dev_switch("SDFX_FIELD_BWD_NB", 1) == 2 ? 2 : 1;
@@ -811,7 +823,7 @@ int sdfx_field_backward(const void* enc, int enc_layout, const float* x, const u
                 const RowLimit rlim = row_limit();
 #define SDFX_NAT(LDSF_, NB_)                                                                                                       \
     hipLaunchKernelGGL((k_field_backward_nat<LDSF_, NB_>), dim3(nblocks), dim3(kThreads), 0, st, ep, x, packed, B, blob_density, i2, \
-                       dsigma, dalbedo, dp, scratch, rlim, stencil_src())
+                       dsigma, dalbedo, dp, scratch, rlim, stencil_src(), alb_rows)
                 if (nb == 2) { if (lds_frags) SDFX_NAT(1, 2); else SDFX_NAT(0, 2); }
                 else { if (lds_frags) SDFX_NAT(1, 1); else SDFX_NAT(0, 1); }
 #undef SDFX_NAT

@@ -63,6 +63,11 @@ struct StencilSrc {
 };
 StencilSrc stencil_src();   // the calling thread's current setting
 
+// sdfx_set_albedo_rows: the field kernels' albedo / d-albedo buffers hold only the first `rows` rows of the batch (0: all of them).
+// A 7-point stencil batch needs the albedo of its M base samples only: the other six slabs' albedo was written (36 MB per launch at
+// 0.5 M samples) for nobody, and their d-albedo — zeros the slice's backward had to create — read for nothing.
+uint32_t albedo_rows();     // the calling thread's current setting
+
 // Zero `bytes` (a multiple of 4) of device memory with a KERNEL. hipMemsetAsync is avoided on purpose: captured into
 // a HIP graph it becomes a memset node, and the 5 MB one of the binned scatter did not clear its whole range on
 // replay (ROCm 7.2): accumulators kept sums from earlier iterations until the table gradient overflowed.

@@ -35,6 +35,9 @@ RowLimit row_limit() { return g_row_limit; }
 static thread_local StencilSrc g_stencil_src = {nullptr, 0, 0.f, 0.f, 0.f};
 StencilSrc stencil_src() { return g_stencil_src; }
 
+static thread_local uint32_t g_albedo_rows = 0;
+uint32_t albedo_rows() { return g_albedo_rows; }
+
 #ifdef SDFX_DEVTOOLS
 namespace {
 std::mutex g_dev_mutex;
@@ -137,6 +140,8 @@ void sdfx_dev_unset(const char* name) {   // back to the environment / the defau
 const char* sdfx_last_error(void) { return sdfx::g_err; }
 
 void sdfx_set_row_limit(const int32_t* total, uint32_t period) { sdfx::g_row_limit = {total, period}; }
+
+void sdfx_set_albedo_rows(uint32_t rows) { sdfx::g_albedo_rows = rows; }
 
 void sdfx_set_stencil_source(const float* xyzs, uint32_t M, float epsilon, float bound, double two_bound) {
     // PyTorch divides a tensor by a Python scalar as a multiplication with the reciprocal formed in DOUBLE precision and then

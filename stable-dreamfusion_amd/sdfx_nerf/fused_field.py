@@ -28,7 +28,7 @@ class _fused_field(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, x, embeddings, offsets, w1, b1, w2, b2, w3, b3, bound, per_level_scale, base_resolution, gridtype,
-                align_corners, interp, blob_density, blob_radius, slabs, step, stencil_eps=0.0, row_total=None):
+                align_corners, interp, blob_density, blob_radius, slabs, step, stencil_eps=0.0, row_total=None, base_albedo=False):
         x = x.float().contiguous()
         # row_total (int32 [1], device): the live rows of a fixed-capacity sample buffer; the kernels below skip the padding
         # behind it (include/sdfx.h, sdfx_set_row_limit) instead of evaluating the field on zeros
@@ -60,8 +60,12 @@ class _fused_field(Function):
         _field.pack(w1.detach().float().contiguous(), b1.detach().float().contiguous(), w2.detach().float().contiguous(),
                     b2.detach().float().contiguous(), w3.detach().float().contiguous(), b3.detach().float().contiguous(), packed)
         sigma = torch.empty(B, dtype=torch.float32, device=x.device)
-        albedo = torch.empty(B, 3, dtype=torch.float32, device=x.device)
-        with _sdfx.row_limit(*limit), _sdfx.stencil_source(*(src or (None, 0.0, 0.0))):
+        # base_albedo: a stencil batch whose consumer wants the albedo of the M base samples only (the shading of network_grid.py:108-130
+        # uses the centre point's): the kernels then neither store the other six slabs' albedo nor read a gradient for it
+        # (sdfx_set_albedo_rows) — the [7 M, 3] tensor, and the zero-filled gradient the slice albedo[:M] used to cost, are gone
+        alb_rows = x.shape[0] if (base_albedo and stencil_eps > 0 and _sdfx.lib().sdfx_field_albedo_rows_ok(B, 0)) else 0
+        albedo = torch.empty(alb_rows or B, 3, dtype=torch.float32, device=x.device)
+        with _sdfx.row_limit(*limit), _sdfx.stencil_source(*(src or (None, 0.0, 0.0))), _sdfx.albedo_rows(alb_rows):
             _gridencoder.grid_encode_forward(inputs, emb, offsets, enc, B, 3, C, L, L, S, base_resolution, None, gridtype,
                                              align_corners, interp, 0, slabs, step)
             _field.forward(enc, 0, None if src else x, packed, B, blob_density, blob_radius, sigma, albedo)
@@ -70,6 +74,7 @@ class _fused_field(Function):
         if src is not None:
             inputs = x.new_empty(0)      # placeholders: the backward forms the batch from x as well
         ctx.limit = limit
+        ctx.alb_rows = alb_rows
         ctx.save_for_backward(x, inputs, offsets, enc, packed)
         ctx.meta = (B, C, L, S, base_resolution, gridtype, align_corners, interp, blob_density, blob_radius, tuple(emb.shape))
         return sigma, albedo
@@ -78,7 +83,7 @@ class _fused_field(Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, dsigma, dalbedo):
         if ctx.meta is None:
-            return (None,) * 21
+            return (None,) * 22
         x, inputs, offsets, enc, packed = ctx.saved_tensors
         B, C, L, S, H, gridtype, align_corners, interp, blob_density, blob_radius, emb_shape = ctx.meta
         dev = x.device
@@ -91,7 +96,7 @@ class _fused_field(Function):
         dw3, db3 = torch.empty(4, 64, **f32), torch.empty(4, **f32)
         grad_emb = torch.zeros(emb_shape, dtype=torch.half, device=dev)
         src = (None, 0.0, 0.0) if ctx.src is None else (x,) + ctx.src
-        with _sdfx.row_limit(*ctx.limit), _sdfx.stencil_source(*src):
+        with _sdfx.row_limit(*ctx.limit), _sdfx.stencil_source(*src), _sdfx.albedo_rows(ctx.alb_rows):
             _field.backward(enc, 0, None if ctx.src else x, packed, B, blob_density, blob_radius, dsigma, dalbedo, denc, dw1, db1, dw2,
                             db2, dw3, db3)
             _gridencoder.grid_encode_backward(denc, None if ctx.src else inputs, grad_emb, offsets, grad_emb, B, 3, C, L, L, S, H, None,
@@ -103,7 +108,7 @@ class _fused_field(Function):
             prev = getattr(par, "_sdfx_half_grad", None)
             par._sdfx_half_grad = grad_emb if prev is None else prev.add_(grad_emb)
             grad_emb = None
-        return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 12
+        return (None, grad_emb, None, dw1, db1, dw2, db2, dw3, db3) + (None,) * 13
 
 
 def supported(encoder, sigma_net, x, density_activation, max_level) -> bool:
@@ -113,14 +118,16 @@ def supported(encoder, sigma_net, x, density_activation, max_level) -> bool:
             and sigma_net.net[0].bias is not None)
 
 
-def fused_field(x, encoder, sigma_net, bound, blob_density, blob_radius, slabs=1, step=0.0, stencil_eps=0.0, row_total=None):
+def fused_field(x, encoder, sigma_net, bound, blob_density, blob_radius, slabs=1, step=0.0, stencil_eps=0.0, row_total=None,
+                base_albedo=False):
     """`slabs`, `step`: locality hints for the encoder (include/sdfx.h, sdfx_grid_encode_forward_hint): slabs = 7 when x is the
     [7, N, 3] batch of a finite-difference stencil, step = distance between consecutive ray samples in the unit cube.
     `stencil_eps` > 0: x is [N, 3] and the field is evaluated on its 7-point stencil batch (outputs [7 N], [7 N, 3]).
     `row_total`: int32 device tensor [1] — only the first row_total[0] samples are live (fixed-capacity buffers); the outputs and
-    gradients of the rows behind them are left unwritten."""
+    gradients of the rows behind them are left unwritten. `base_albedo` (with `stencil_eps`): albedo is returned for the N base
+    samples only ([N, 3]; rows [0, N) of what the full call returns)."""
     n = sigma_net.net
     return _fused_field.apply(x, encoder.embeddings, encoder.offsets, n[0].weight, n[0].bias, n[1].weight, n[1].bias,
                               n[2].weight, n[2].bias, bound, encoder.per_level_scale, encoder.base_resolution,
                               encoder.gridtype_id, encoder.align_corners, encoder.interp_id, blob_density, blob_radius,
-                              int(slabs), float(step), float(stencil_eps), row_total)
+                              int(slabs), float(step), float(stencil_eps), row_total, bool(base_albedo))

@@ -174,12 +174,14 @@ class NeRFNetwork(NeRFRenderer):
             step = (3.0 ** 0.5) / (self.opt.max_steps * self.bound)
             live = total if (_ROW_LIMIT and torch.is_tensor(total) and total.dtype == torch.int32 and total.is_cuda) else None
             sigma_all, albedo_all = _ff.fused_field(x.reshape(-1, 3), self.encoder, self.sigma_net, self.bound, self.opt.blob_density,
-                                                    self.opt.blob_radius, 7, step, stencil_eps=1e-2, row_total=live)
+                                                    self.opt.blob_radius, 7, step, stencil_eps=1e-2, row_total=live, base_albedo=True)
         else:
             neigh = (x.unsqueeze(0) + self._fd_offsets.unsqueeze(1)).clamp(-self.bound, self.bound)
             pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)
             sigma_all, albedo_all = self.common_forward(pts, slabs=7, ray_ordered=True)
-        return _fs.fused_render(sigma_all, albedo_all[:x.shape[0]], dirs, ts, rays, rays_o, light_offset, ratio, shading, total, T_thresh)
+        # (a slice — even the whole range — costs its backward a zero fill and a copy: only taken when the field returned all 7 slabs' albedo)
+        albedo0 = albedo_all if albedo_all.shape[0] == x.shape[0] else albedo_all[:x.shape[0]]
+        return _fs.fused_render(sigma_all, albedo0, dirs, ts, rays, rays_o, light_offset, ratio, shading, total, T_thresh)
 
     def infer_fused_available(self, shading, light_d=None):
         """The persistent inference kernel (csrc/infer.hip) covers 'albedo' shading of the -O field under fp16 autocast."""

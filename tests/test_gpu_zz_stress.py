@@ -367,3 +367,46 @@ def test_binned_scatter_overflow_in_chunks_and_level_major_gradients(oracle, dev
     lbc = np.ascontiguousarray(gr.reshape(n, 16, 2).transpose(1, 0, 2))
     lm, _ = _scatter_half(dev, x, lbc, offsets, pls, 1 << 20, layout=0)
     assert torch.equal(lm, one)
+
+
+def test_base_albedo_equals_the_first_slab_of_the_full_call(dev):
+    """fused_field(..., stencil_eps, base_albedo=True) — albedo stored and differentiated for the M base samples only
+    (sdfx_set_albedo_rows: the buffer descriptors of the field kernels end behind row M) — against the full [7 M, 3] call whose
+    consumer slices [:M]: identical sigma and albedo, identical table / MLP gradients, with and without a row limit."""
+    importlib.import_module("stable-dreamfusion_amd")
+    import _sdfx
+    from sdfx_nerf import fused_field as ff
+    from sdfx_nerf.network_grid import NeRFNetwork
+    from sdfx_nerf.options import default_opt
+    torch.manual_seed(3)
+    model = NeRFNetwork(default_opt()).to(dev)
+    with torch.no_grad():
+        model.encoder.embeddings.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(2)
+    M = 40000
+    x = (torch.rand(M, 3, generator=g) * 1.6 - 0.8).to(dev)
+    gs, ga = torch.randn(7 * M, generator=g).to(dev), torch.randn(M, 3, generator=g).to(dev)
+    assert _sdfx.lib().sdfx_field_albedo_rows_ok(7 * M, 0) == 1
+    for live in (None, 33333):
+        total = None if live is None else torch.tensor([live], dtype=torch.int32, device=dev)
+        n_live = M if live is None else live
+        gs_l, ga_l = gs.clone(), ga.clone()
+        if live is not None:
+            gs_l[(torch.arange(7 * M, device=dev) % M) >= live] = 0
+            ga_l[live:] = 0
+        outs = []
+        for base in (False, True):
+            for p in model.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.float16):
+                sigma, albedo = ff.fused_field(x, model.encoder, model.sigma_net, model.bound, 5.0, 0.2, 7, 3.0 ** 0.5 / 1024, stencil_eps=1e-2,
+                                               row_total=total, base_albedo=base)
+            assert albedo.shape[0] == (M if base else 7 * M)
+            ((sigma * gs_l).sum() + (albedo[:M] * ga_l).sum()).backward()
+            keep = (torch.arange(7 * M, device=dev) % M) < n_live
+            outs.append((sigma.detach()[keep].clone(), albedo.detach()[:n_live].clone(), model.encoder.embeddings.grad.clone(),
+                         [p.grad.clone() for p in model.sigma_net.parameters()]))
+        (s0, a0, t0, w0), (s1, a1, t1, w1) = outs
+        assert torch.equal(s0, s1) and torch.equal(a0, a1)
+        assert torch.equal(t0, t1)
+        assert all(torch.equal(u, v) for u, v in zip(w0, w1))
