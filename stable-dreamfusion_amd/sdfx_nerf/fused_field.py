@@ -22,6 +22,8 @@ import _devswitch
 
 # the [7, M, 3] finite-difference stencil batch formed inside the kernels (sdfx_set_stencil_source) instead of by k_stencil_points
 _STENCIL_SOURCE = _devswitch.get("SDFX_STENCIL_SOURCE", 1)
+# the float16 image of the table kept while current and rewritten by the Adan kernel (_sdfx.half_image); 0: cast at every call (grid.py:46-47)
+_HALF_IMAGE = _devswitch.get("SDFX_HALF_IMAGE", 1)
 
 
 class _fused_field(Function):
@@ -54,7 +56,8 @@ class _fused_field(Function):
         S = np.log2(per_level_scale)
         # autocast: fp16 table (grid.py:46-47: embeddings.to(torch.half) every call). The image is kept while it is current
         # (_sdfx.half_image): with the device-side optimiser, whose update kernel rewrites it, no cast is launched at all
-        emb = _sdfx.half_image(embeddings) if (embeddings.dtype == torch.float32 and embeddings.is_contiguous()) else embeddings.to(torch.half).contiguous()
+        emb = (_sdfx.half_image(embeddings) if (_HALF_IMAGE and embeddings.dtype == torch.float32 and embeddings.is_contiguous())
+               else embeddings.to(torch.half).contiguous())
         enc = torch.empty(L, B, C, device=x.device, dtype=torch.half)
         packed = torch.empty(_field.packed_words(), dtype=torch.int32, device=x.device)
         _field.pack(w1.detach().float().contiguous(), b1.detach().float().contiguous(), w2.detach().float().contiguous(),

@@ -30,6 +30,8 @@ _FUSED_SHADE = _devswitch.get("SDFX_FUSED_SHADE", 1)
 _FUSED_RENDER = _devswitch.get("SDFX_FUSED_RENDER", 1)
 # test-time frames: march + field + compositing + compaction of nerf/renderer.py:759-794 in one persistent kernel (csrc/infer.hip)
 _FUSED_INFER = _devswitch.get("SDFX_FUSED_INFER", 1)
+# albedo of a stencil batch stored / differentiated for its base samples only (csrc/field.hip: sdfx_set_albedo_rows)
+_BASE_ALBEDO = _devswitch.get("SDFX_BASE_ALBEDO", 1)
 # The background MLP (4096 rays x 1.4 k MACs) is evaluated in float32 even under autocast: its gradient is the image
 # gradient times the loss scale, un-attenuated by compositing weights, and is what overflows fp16 first — in half it
 # caps the loss scale ~64x lower (field gradients underflow) and costs a GradScaler skip every ~12 iterations.
@@ -174,7 +176,7 @@ class NeRFNetwork(NeRFRenderer):
             step = (3.0 ** 0.5) / (self.opt.max_steps * self.bound)
             live = total if (_ROW_LIMIT and torch.is_tensor(total) and total.dtype == torch.int32 and total.is_cuda) else None
             sigma_all, albedo_all = _ff.fused_field(x.reshape(-1, 3), self.encoder, self.sigma_net, self.bound, self.opt.blob_density,
-                                                    self.opt.blob_radius, 7, step, stencil_eps=1e-2, row_total=live, base_albedo=True)
+                                                    self.opt.blob_radius, 7, step, stencil_eps=1e-2, row_total=live, base_albedo=bool(_BASE_ALBEDO))
         else:
             neigh = (x.unsqueeze(0) + self._fd_offsets.unsqueeze(1)).clamp(-self.bound, self.bound)
             pts = torch.cat([x.unsqueeze(0), neigh], dim=0).reshape(-1, 3)

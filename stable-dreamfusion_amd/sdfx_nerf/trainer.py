@@ -44,6 +44,7 @@ _FUSED_STAGE = _devswitch.get("SDFX_FUSED_STAGE", 1)
 _FUSED_HEAD = _devswitch.get("SDFX_FUSED_HEAD", 1)
 _PREFETCH = _devswitch.get("SDFX_PREFETCH", 1)      # counting pass of the next iteration on a second stream
 _STEP_SYNC = _devswitch.get("SDFX_STEP_SYNC", 0)    # debugging aid: device-wide synchronisation after every step
+_HALF_GRADS = _devswitch.get("SDFX_HALF_GRADS", 1)  # the table's float16 gradient handed to DeviceAdan as it is (optim.DeviceAdan.half_grads)
 
 # layout of the per-iteration scalar block
 _SC_AMBIENT, _SC_BG, _SC_WF, _SC_WS, _SC_WB, _SC_ENTROPY, _SC_MODE, _SC_WORDS = 0, 1, 4, 5, 6, 7, 8, 12
@@ -252,7 +253,9 @@ class TrainStep:
         with torch.autocast("cuda", dtype=torch.float16, enabled=opt.fp16):
             loss = self.train_step((xyzs, dirs, ts, self.cur_rays, self.n_valid, self.cur_total), shading, as_latent, bg_kind,
                                    split=True)
-        with self.optimizer.half_grads():        # the table's float16 gradient goes straight to the optimiser kernels (sdfx_nerf/optim.py)
+        import contextlib
+        # the table's float16 gradient goes straight to the optimiser kernels (sdfx_nerf/optim.py)
+        with (self.optimizer.half_grads() if _HALF_GRADS else contextlib.nullcontext()):
             if isinstance(loss, tuple):
                 scale = self.optimizer.scale         # 0-dim view of the optimiser's control block, read at execution time
                 torch.autograd.backward(list(loss), [scale.to(t.dtype) if t.dtype != scale.dtype else scale for t in loss])
