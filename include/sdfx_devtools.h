@@ -18,6 +18,8 @@
  *   SDFX_GRID_PLAN_DEBUG   print the per-XCD segments                                          gridencoder_fwd.hip
  *   SDFX_GRID_ONLY_LEVEL   l: the hinted forward evaluates level l alone on all eight XCDs     gridencoder_fwd.hip
  *   SDFX_GRID_TPW / _FINE  8 / 2: consecutive tiles per workgroup at the VALU-bound levels / the others   gridencoder_fwd.hip
+ *   SDFX_GRID_PAIR         1 (default) half tables: two levels per wave (k_grid_fwd_pair), 0 one level per workgroup   gridencoder_fwd.hip
+ *   SDFX_GRID_TPW_PAIR     2: consecutive tiles per workgroup of the pair plan                  gridencoder_fwd.hip
  *   SDFX_GRID_SCALAR_BELOW 0: levels of resolution < r gather corners with 4-byte loads        gridencoder_fwd.hip
  *   SDFX_GRID_SCALAR_FROM  0: ... and levels of resolution >= r (0: none); dense levels always take their two-row loads
  *   SDFX_GRID_COST_TABLE   1 (default) measured per-tile costs for stencil batches, 0 max(lines, VALU floor)   gridencoder_fwd.hip

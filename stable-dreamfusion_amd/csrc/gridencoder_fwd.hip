@@ -46,7 +46,10 @@ constexpr uint32_t kMaxSegs = 6;       // per XCD
 constexpr uint32_t kGroup = 7;         // points per stencil
 constexpr uint32_t kGroupsPerWave = 9; // 9 x 7 = 63 lanes
 
-struct Seg { uint32_t level, first, count, tpw; };   // tiles [first, first + count) of `level`, `tpw` (>= 1) consecutive tiles per workgroup
+constexpr uint32_t kNoLevel = 0xffffffffu;
+// tiles [first, first + count) of `level`, `tpw` (>= 1) consecutive tiles per workgroup. A PAIR plan (FwdPlan::pair) evaluates a second
+// level, `level2` (kNoLevel: none), on the same tiles in the same waves (k_grid_fwd_pair)
+struct Seg { uint32_t level, first, count, tpw, level2; };
 struct FwdPlan {
     LevelConst lv[kMaxLevels];
     Seg seg[kXcds][kMaxSegs];
@@ -63,12 +66,17 @@ struct FwdPlan {
     // into LDS by a workgroup that then walks kLdsTiles tiles of that level, gathering with ds_read instead of through the
     // texture-address path — north_star's "LDS staging", measured in profiles/r03_encode_lds_levels.txt
     uint32_t lds_mask, lds_bytes;
+    // Round 6: every wave evaluates TWO levels of its tile — a fine one and a coarse one, (L-1, 0), (L-2, 1), ... — with the fine
+    // level's gathers in flight while it forms the coarse level's rows (k_grid_fwd_pair; half tables). The units of the level sequence
+    // are then these pairs, an XCD's L2 holds the two tables of the pair it is walking, and the coordinates of a tile are formed once
+    // for both levels.
+    uint32_t pair;
 };
 constexpr uint32_t kLdsTiles = 16;
 
 // workgroup -> (level, tile) through the XCD's segment list (walked in order); false when there is nothing to do
-__device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint32_t& tile, uint32_t& seg_end, uint32_t& tpw) {
-    tpw = 1u;
+__device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint32_t& tile, uint32_t& seg_end, uint32_t& tpw, uint32_t& level2) {
+    tpw = 1u; level2 = kNoLevel;
     const uint32_t xcd = blockIdx.x % kXcds;
     uint32_t local = blockIdx.x / kXcds;
     if (p.sample_major) {
@@ -84,7 +92,7 @@ __device__ __forceinline__ bool fwd_item(const FwdPlan& p, uint32_t& level, uint
         const Seg sg = p.seg[xcd][s];
         const uint32_t wgs = (sg.count + sg.tpw - 1u) / (sg.tpw ? sg.tpw : 1u);   // workgroups of the segment
         if (local < wgs) {
-            level = sg.level; tile = sg.first + local * sg.tpw; seg_end = sg.first + sg.count; tpw = sg.tpw;
+            level = sg.level; tile = sg.first + local * sg.tpw; seg_end = sg.first + sg.count; tpw = sg.tpw; level2 = sg.level2;
             // an LDS-resident level: one workgroup in kLdsTiles takes that many consecutive tiles, the others have nothing to do
             if ((p.lds_mask >> sg.level) & 1u) return local % kLdsTiles == 0;
             return true;
@@ -111,8 +119,8 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
     using RowT = typename std::conditional<HALF, uint32_t, uint2>::type;
     constexpr uint32_t P = 1;   // points per thread (the loops below are written for any P; 2 and 4 were measured slower)
     constexpr uint32_t P_TILE = P * kTile;
-    uint32_t level, tile0, seg_end, tpw;
-    if (!fwd_item(plan, level, tile0, seg_end, tpw)) return;
+    uint32_t level, tile0, seg_end, tpw, level2_unused;
+    if (!fwd_item(plan, level, tile0, seg_end, tpw, level2_unused)) return;
     SDFX_STAMP_BEGIN
     // padding rows of a fixed-capacity batch (sdfx_set_row_limit): samples >= row_total[0] are neither read nor written, and a
     // tile of nothing else ends here. (Stencil batches: the sample is the row within the slab; otherwise the row itself.)
@@ -368,6 +376,338 @@ __global__ __launch_bounds__(kTile) void k_grid_fwd(const float* __restrict__ in
     SDFX_STAMP_END(1u, level, tile0)
 }
 
+// ---- two levels per wave (round 6) ---------------------------------------------------------------------------------------
+// What the per-level counters say (profiles/r06_encode_levels_pmc.txt): a wave of a fine hashed level spends 0.6 of its cycles parked
+// on its gathers while its SIMD issues vector instructions a third of the time, a wave of a coarse level the other way round — and
+// with one level per XCD at a time the two never share a CU. Mixing them workgroup by workgroup does not help (measured, see the
+// head of the file: the fine workgroups end up holding the wave slots). Here the mix is inside every wave: the fine level's rows are
+// formed and its gathers issued, THEN the coarse level's rows are formed and its loads issued (vector memory returns in order:
+// the fine level's data is complete when `vmcnt` has dropped to the coarse level's count), then the two are reduced and stored in that
+// order. Same arithmetic per level as k_grid_fwd, bit for bit; the coordinates of the tile are formed once.
+struct LevelKind {   // wave-uniform properties of a level (scalar registers)
+    LevelConst lc;
+    const char* tab;
+    uint32_t wmask;
+    bool hashed, dense, need_mod, mul24, vec16;
+};
+template <bool HASHGRID>
+__device__ __forceinline__ LevelKind level_kind(const FwdPlan& plan, const __half* table, uint32_t level) {
+    LevelKind k;
+    k.lc = plan.lv[level];
+    k.hashed = HASHGRID && (k.lc.flags & 1u);
+    k.dense = (k.lc.flags & 1u) == 0u && k.lc.res >= 2u;
+    k.need_mod = (k.lc.flags & 3u) == 1u;
+    k.mul24 = (k.lc.flags & 4u) != 0u;
+    k.vec16 = ((plan.vec16 >> level) & 1u) != 0u;
+    k.wmask = (k.lc.flags & 2u) ? k.lc.size - 1u : 0xffffffffu;
+    k.tab = reinterpret_cast<const char*>(table + (size_t)k.lc.row0 * 2);
+    return k;
+}
+// A level's KIND decides the shape of its loads, and a value loaded in one arm of a branch and used after the join is copied at the
+// join — which waits for it. So the kinds of the two levels are template parameters of the tile loop (one uniform dispatch per
+// workgroup): between the issue of a level's loads and their use there is no join that merges them.
+enum : uint32_t {
+    kKindDense = 0,    // every stride fits: x-major rows that never wrap — one two-row load per x-pair
+    kKindHash16 = 1,   // hashed, power-of-two size, 16-byte aligned table: one 16-byte block per pair, ONE straddle test per point
+    kKindOther = 2,    // anything else (unaligned tables, sizes that need a modulo, tiled grids with truncated strides, one-vertex levels):
+                       // k_grid_fwd's general code, values picked as soon as loaded
+    kKindNone = 3,     // no second level
+};
+__device__ __forceinline__ uint32_t kind_of(const LevelKind& k) {
+    if (k.dense) return kKindDense;
+    if (k.hashed && !k.need_mod && k.vec16) return kKindHash16;
+    return kKindOther;
+}
+
+// cell, weights and the y / z terms of the rows (k_grid_fwd's Phase 1)
+struct Located { uint32_t pg[3], pn[3], ty[2], tz[2]; };
+template <uint32_t INTERP, bool ALIGN>
+__device__ __forceinline__ void locate(const LevelKind& k, const float xin[3], float pos[3], Located& o) {
+    const LevelConst& lc = k.lc;
+    float deriv;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        grid_locate_axis(xin[d], lc.res, ALIGN, INTERP, pos[d], deriv, o.pg[d]);
+        o.pg[d] = min(o.pg[d], lc.res - 1u);
+        o.pn[d] = min(o.pg[d] + 1u, lc.res - 1u);
+    }
+    (void)deriv;
+    const uint32_t fy = k.hashed ? 2654435761u : lc.m1, fz = k.hashed ? 805459861u : lc.m2;
+    if (k.mul24) {
+        o.ty[0] = __umul24(o.pg[1], fy & 0xFFFFFFu); o.ty[1] = __umul24(o.pn[1], fy & 0xFFFFFFu);
+        o.tz[0] = __umul24(o.pg[2], fz & 0xFFFFFFu); o.tz[1] = __umul24(o.pn[2], fz & 0xFFFFFFu);
+    } else {
+        o.ty[0] = o.pg[1] * fy; o.ty[1] = o.pn[1] * fy;
+        o.tz[0] = o.pg[2] * fz; o.tz[1] = o.pn[2] * fz;
+    }
+}
+__device__ __forceinline__ uint32_t reduce8(const float pos[3], const uint32_t v0[4], const uint32_t v1[4]) {
+    const float ax[2] = {1 - pos[0], pos[0]}, ay[2] = {1 - pos[1], pos[1]}, az[2] = {1 - pos[2], pos[2]};
+    Acc2<true> acc;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {   // corner order of gridencoder.cu:168-195 (x fastest); weights ((1 * a_x) * a_y) * a_z
+        const float wy = ay[c & 1], wz = az[c >> 1];
+        acc.add(((1 * ax[0]) * wy) * wz, v0[c]);
+        acc.add(((1 * ax[1]) * wy) * wz, v1[c]);
+    }
+    return __builtin_bit_cast(uint32_t, acc.acc);
+}
+
+template <uint32_t KIND> struct PointLevel;
+
+template <> struct PointLevel<kKindNone> {
+    template <uint32_t INTERP, bool ALIGN> __device__ __forceinline__ void start(const LevelKind&, const float*) {}
+    __device__ __forceinline__ uint32_t reduce(const LevelKind&) const { return 0u; }
+};
+
+template <> struct PointLevel<kKindDense> {   // 12 registers while the loads are in flight
+    PairT<true> pr[4];
+    float pos[3];
+    bool xstep;
+    template <uint32_t INTERP, bool ALIGN> __device__ __forceinline__ void start(const LevelKind& k, const float xin[3]) {
+        Located o;
+        locate<INTERP, ALIGN>(k, xin, pos, o);
+        // r1 = r0 + 1 unless x is the grid's last vertex (x + 1 clamped: r1 = r0): the load then starts one row earlier and both corners
+        // are its SECOND row — never past the table
+        const uint32_t xb = o.pg[0] - (o.pn[0] == o.pg[0] ? 1u : 0u);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            pr[c] = *reinterpret_cast<const PairT<true>*>(k.tab + (uint32_t)((xb + (o.ty[c & 1] + o.tz[c >> 1])) * 4u));
+        xstep = o.pn[0] != o.pg[0];
+    }
+    __device__ __forceinline__ uint32_t reduce(const LevelKind&) const {
+        uint32_t v0[4], v1[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { v0[c] = xstep ? pr[c].a : pr[c].b; v1[c] = pr[c].b; }
+        return reduce8(pos, v0, v1);
+    }
+};
+
+template <> struct PointLevel<kKindHash16> {   // 25 registers while the loads are in flight
+    uint4 blk[4];
+    uint32_t extra[4];
+    float pos[3];
+    uint32_t sel;   // bits 2c, 2c+1 = r0[c] & 3; 8+2c, 9+2c = r1[c] & 3; bit 16 = the pairs straddle two blocks
+    template <uint32_t INTERP, bool ALIGN> __device__ __forceinline__ void start(const LevelKind& k, const float xin[3]) {
+        Located o;
+        locate<INTERP, ALIGN>(k, xin, pos, o);
+        uint32_t r0[4], r1[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t yz = o.ty[c & 1] ^ o.tz[c >> 1];
+            r0[c] = (o.pg[0] ^ yz) & k.wmask;
+            r1[c] = (o.pn[0] ^ yz) & k.wmask;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) blk[c] = *reinterpret_cast<const uint4*>(k.tab + (uint32_t)((r0[c] & ~3u) * 4u));
+        // r0 ^ r1 = (x ^ (x + 1)) & mask for all four pairs of the point: one test, one masked branch around the four second gathers
+        const bool far = ((o.pg[0] ^ o.pn[0]) & k.wmask) >= 4u;
+        if (far) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) extra[c] = *reinterpret_cast<const uint32_t*>(k.tab + (uint32_t)(r1[c] * 4u));
+        }
+        sel = far ? (1u << 16) : 0u;
+#pragma unroll
+        for (int c = 0; c < 4; c++) sel |= ((r0[c] & 3u) << (2 * c)) | ((r1[c] & 3u) << (8 + 2 * c));
+    }
+    __device__ __forceinline__ uint32_t reduce(const LevelKind&) const {
+        uint32_t v0[4], v1[4];
+        const bool far = (sel >> 16) & 1u;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            // (the block as four opaque VALUES: left as members of *this, the compiler folds pick4's selects into ONE load from a
+            // computed address — which pins the whole struct in scratch memory)
+            uint4 b = blk[c];
+            asm("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+            v0[c] = pick4(b, (sel >> (2 * c)) & 3u);
+            v1[c] = pick4(b, (sel >> (8 + 2 * c)) & 3u);
+            if (far) v1[c] = extra[c];
+        }
+        return reduce8(pos, v0, v1);
+    }
+};
+
+template <> struct PointLevel<kKindOther> {   // the general code: the eight rows as soon as they are loaded (11 registers afterwards)
+    uint32_t v0[4], v1[4];
+    float pos[3];
+    template <uint32_t INTERP, bool ALIGN> __device__ __forceinline__ void start(const LevelKind& k, const float xin[3]) {
+        const LevelConst& lc = k.lc;
+        Located o;
+        locate<INTERP, ALIGN>(k, xin, pos, o);
+        auto wrap = [&](uint32_t idx) -> uint32_t {
+            idx &= k.wmask;
+            if (k.need_mod) idx %= lc.size;
+            return idx;
+        };
+        auto at = [&](uint32_t row) -> const char* { return k.tab + (uint32_t)(row * 4u); };
+        if (k.dense) {
+            const uint32_t xb = o.pg[0] - (o.pn[0] == o.pg[0] ? 1u : 0u);
+            PairT<true> pr[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) pr[c] = *reinterpret_cast<const PairT<true>*>(at(xb + (o.ty[c & 1] + o.tz[c >> 1])));
+#pragma unroll
+            for (int c = 0; c < 4; c++) { v0[c] = o.pn[0] != o.pg[0] ? pr[c].a : pr[c].b; v1[c] = pr[c].b; }
+            return;
+        }
+        uint32_t r0[4], r1[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t yz = k.hashed ? (o.ty[c & 1] ^ o.tz[c >> 1]) : (o.ty[c & 1] + o.tz[c >> 1]);
+            r0[c] = wrap(k.hashed ? (o.pg[0] ^ yz) : (o.pg[0] + yz));
+            r1[c] = wrap(k.hashed ? (o.pn[0] ^ yz) : (o.pn[0] + yz));
+        }
+        if (k.vec16) {
+            uint4 blk[4];
+            uint32_t extra[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) blk[c] = *reinterpret_cast<const uint4*>(at(r0[c] & ~3u));
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                extra[c] = 0u;
+                if ((r0[c] ^ r1[c]) >= 4u) extra[c] = *reinterpret_cast<const uint32_t*>(at(r1[c]));
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                v0[c] = pick4(blk[c], r0[c] & 3u);
+                v1[c] = (r0[c] ^ r1[c]) >= 4u ? extra[c] : pick4(blk[c], r1[c] & 3u);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                v0[c] = *reinterpret_cast<const uint32_t*>(at(r0[c]));
+                v1[c] = *reinterpret_cast<const uint32_t*>(at(r1[c]));
+            }
+        }
+    }
+    __device__ __forceinline__ uint32_t reduce(const LevelKind&) const { return reduce8(pos, v0, v1); }
+};
+
+// the tiles of one workgroup at the levels of kinds KA and KB
+template <uint32_t INTERP, bool ALIGN, uint32_t KA, uint32_t KB>
+__device__ __forceinline__ void pair_tiles(const float* __restrict__ inputs, __half* __restrict__ outputs, uint32_t B, uint32_t L,
+                                           const FwdPlan& plan, int out_layout, uint32_t n_live, const StencilSrc& src, const LevelKind& ka,
+                                           const LevelKind& kb, uint32_t level, uint32_t level2, uint32_t tile0, uint32_t tile_end) {
+    for (uint32_t tile = tile0; tile < tile_end; tile++) {
+        // ---- slot of this thread -> point (k_grid_fwd's map) ----
+        const uint32_t slot = tile * kTile + threadIdx.x;
+        {
+            const uint32_t first_slot = tile * kTile;
+            const uint32_t first = plan.slabs == kGroup ? (first_slot >> 6) * kGroupsPerWave : first_slot;
+            if (first >= n_live) continue;
+        }
+        uint32_t pt, sk = 0, sm = 0;
+        bool live;
+        if (plan.slabs == kGroup) {
+            const uint32_t lane = slot & 63u, g = lane / kGroup;
+            const uint32_t sample = (slot >> 6) * kGroupsPerWave + g;
+            live = lane < kGroup * kGroupsPerWave && sample < n_live;
+            sk = lane - g * kGroup;
+            sm = sample;
+            pt = sk * plan.slab_points + sample;
+        } else {
+            live = slot < n_live;
+            pt = slot;
+            if (src.xyzs) { sk = stencil_slab(slot < B ? slot : 0u, src.M); sm = (slot < B ? slot : 0u) - sk * src.M; }
+        }
+        if (!live) { pt = 0; sk = 0; sm = 0; }
+        float xin[3];
+        if (src.xyzs) {
+            const float x[3] = {src.xyzs[(size_t)sm * 3], src.xyzs[(size_t)sm * 3 + 1], src.xyzs[(size_t)sm * 3 + 2]};
+            float p[3];
+            stencil_world(src, sk, x, p);
+#pragma unroll
+            for (int d = 0; d < 3; d++) xin[d] = (p[d] + src.bound) * src.inv;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; d++) xin[d] = inputs[(size_t)pt * 3 + d];
+        }
+        const bool oob = xin[0] < 0 || xin[0] > 1 || xin[1] < 0 || xin[1] > 1 || xin[2] < 0 || xin[2] > 1;  // gridencoder.cu:105
+        auto out_of = [&](uint32_t lv) -> __half* {
+            return out_layout == 0 ? outputs + ((size_t)lv * B + pt) * 2 : outputs + ((size_t)pt * L + lv) * 2;
+        };
+
+        // Both levels' loads in flight together when the second level is a dense one (12 registers of loads: 63 in all, 8 waves per
+        // SIMD); two hashed levels would need 87 registers that way, so those are evaluated one after the other (they are the middle
+        // of the level sequence, where neither level waits much for its gathers) and share the tile's coordinates only.
+#ifndef SDFX_PAIR_OVERLAP_HASH
+#define SDFX_PAIR_OVERLAP_HASH 0   // measurement aid: 1 = two hashed levels in flight together as well (build with -DSDFX_PAIR_WAVES=5)
+#endif
+        constexpr bool kOverlap = KB == kKindDense || (SDFX_PAIR_OVERLAP_HASH && KB == kKindHash16);
+        PointLevel<KA> qa;
+        PointLevel<KB> qb;
+        qa.template start<INTERP, ALIGN>(ka, xin);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kOverlap) {
+            qb.template start<INTERP, ALIGN>(kb, xin);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const uint32_t r = qa.reduce(ka);
+            if (live) *reinterpret_cast<uint32_t*>(out_of(level)) = oob ? 0u : r;
+        }
+        if constexpr (KB != kKindNone) {
+            if constexpr (!kOverlap) {
+                __builtin_amdgcn_sched_barrier(0);
+                qb.template start<INTERP, ALIGN>(kb, xin);
+            }
+            const uint32_t r = qb.reduce(kb);
+            if (live) *reinterpret_cast<uint32_t*>(out_of(level2)) = oob ? 0u : r;
+        }
+    }
+}
+
+#ifndef SDFX_PAIR_WAVES
+#define SDFX_PAIR_WAVES 8   // waves per SIMD the register allocation aims at (measurement aid: -DSDFX_PAIR_WAVES=8 / 6 / 5)
+#endif
+template <uint32_t INTERP, bool ALIGN, bool HASHGRID>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(SDFX_PAIR_WAVES, SDFX_PAIR_WAVES)))
+void k_grid_fwd_pair(const float* __restrict__ inputs, const __half* __restrict__ table, __half* __restrict__ outputs, uint32_t B,
+                     uint32_t L, FwdPlan plan, int out_layout, const int32_t* __restrict__ row_total, StencilSrc src) {
+    uint32_t level, tile0, seg_end, tpw, level2;
+    if (!fwd_item(plan, level, tile0, seg_end, tpw, level2)) return;
+    SDFX_STAMP_BEGIN
+    const uint32_t n_rows = plan.slabs == kGroup ? plan.slab_points : B;
+    const uint32_t n_live = row_total ? min(n_rows, (uint32_t)row_total[0]) : n_rows;
+    const bool two = level2 != kNoLevel;   // (uniform; an odd level count leaves one level alone)
+    const LevelKind ka = level_kind<HASHGRID>(plan, table, level);
+    const LevelKind kb = level_kind<HASHGRID>(plan, table, two ? level2 : level);
+    const uint32_t tile_end = min(tile0 + tpw, seg_end);
+    const uint32_t kind_a = kind_of(ka) == kKindHash16 ? kKindHash16 : kKindOther, kind_b = two ? kind_of(kb) : kKindNone;
+#define SDFX_PAIR_CASE(KA_, KB_)                                                                                                     \
+    if (kind_a == KA_ && kind_b == KB_)                                                                                              \
+        pair_tiles<INTERP, ALIGN, KA_, KB_>(inputs, outputs, B, L, plan, out_layout, n_live, src, ka, kb, level, level2, tile0, tile_end);
+#ifndef SDFX_PAIR_COMBOS
+#define SDFX_PAIR_COMBOS 0xFF
+#endif
+    if (false) {}
+#if SDFX_PAIR_COMBOS & 1
+    else SDFX_PAIR_CASE(kKindHash16, kKindDense)
+#endif
+#if SDFX_PAIR_COMBOS & 2
+    else SDFX_PAIR_CASE(kKindHash16, kKindHash16)
+#endif
+#if SDFX_PAIR_COMBOS & 4
+    else SDFX_PAIR_CASE(kKindHash16, kKindOther)
+#endif
+#if SDFX_PAIR_COMBOS & 8
+    else SDFX_PAIR_CASE(kKindHash16, kKindNone)
+#endif
+#if SDFX_PAIR_COMBOS & 16
+    else SDFX_PAIR_CASE(kKindOther, kKindDense)
+#endif
+#if SDFX_PAIR_COMBOS & 32
+    else SDFX_PAIR_CASE(kKindOther, kKindHash16)
+#endif
+#if SDFX_PAIR_COMBOS & 64
+    else SDFX_PAIR_CASE(kKindOther, kKindOther)
+#endif
+#if SDFX_PAIR_COMBOS & 128
+    else SDFX_PAIR_CASE(kKindOther, kKindNone)
+#endif
+#undef SDFX_PAIR_CASE
+    SDFX_STAMP_END(1u, level, tile0)
+}
+
 // ---- host: the plan -------------------------------------------------------------------------------------------------
 
 // Distinct 128-byte table lines per wave (64 lanes: 9 samples x 7 stencil points, or 64 consecutive samples) as a
@@ -422,7 +762,17 @@ double stencil_tile_cost(double u, bool dense) {
     return k * cost[15];
 }
 
-struct Unit { uint32_t level; double cost; };   // cost per tile
+struct Unit { uint32_t level; double cost; uint32_t level2; };   // cost per tile (pair plans: of both levels)
+
+// what the plan prices a tile of level l at (the measured table on its configuration, the model elsewhere, 1 without a usable hint)
+double level_tile_cost(const LevelConst& c, uint32_t levels, float S, uint32_t H, uint32_t slabs, float step, bool balance, double valu_lines) {
+    if (!(balance && step > 0.f)) return 1.0;
+    const double lines = lines_per_wave((double)c.res * fabs((double)step), slabs == kGroup);
+    const bool table = slabs == kGroup && measured_stencil_config(levels, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1);
+    return table ? stencil_tile_cost((double)c.res * step, (c.flags & 1u) == 0u && c.res >= 2u) : (lines > valu_lines ? lines : valu_lines);
+}
+
+bool pair_plan_enabled(uint32_t elem_bytes) { return elem_bytes == 2 && dev_switch("SDFX_GRID_PAIR", 1) == 1; }
 
 FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uint32_t H, uint32_t elem_bytes, uint32_t B,
                       uint32_t slabs, float step, bool balance, double valu_lines) {
@@ -460,21 +810,32 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
     // was built and its balanced split measured 628 us against 404 us for the even fine / coarse pairing below (and 474 us for
     // k_grid_forward; profiles/r06_refresh_encode_morton.txt): the fine hashed levels cost what their L1 misses cost, not what their
     // distinct lines suggest. The pairing [L-1, 0, L-2, 1, ...] gives every XCD one fine and one coarse level, which is about even.
-    if (!(balance && step > 0.f)) {   // no (usable) information: every level costs the same; the order [L-1, 0, L-2, 1, ...] of GridPlan
-        for (uint32_t v = 0, lo = 0, hi = levels; v < levels; v++) units[nu++] = {(v & 1u) ? lo++ : --hi, 1.0};
-    } else {                          // fine to coarse; a tile costs its gathers or its VALU work, whichever is longer
-        for (uint32_t l = levels; l-- > 0;) {
-            const double model = lines[l] > valu_lines ? lines[l] : valu_lines;
-            const bool table = slabs == kGroup && step > 0.f && measured_stencil_config(levels, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1);
-            units[nu++] = {l, table ? stencil_tile_cost((double)p.lv[l].res * step, (p.lv[l].flags & 1u) == 0u && p.lv[l].res >= 2u) : model};
+    p.pair = (pair_plan_enabled(elem_bytes) && !p.sample_major && !p.lds_mask) ? 1u : 0u;
+    if (p.pair) {
+        // units = (fine, coarse) pairs from both ends of the level sequence, (L-1, 0), (L-2, 1), ..., an odd count's middle level alone;
+        // a pair's tile is priced at the sum of its levels' prices (what the overlap inside the wave takes off is about the same
+        // share for every pair of the -O grid: profiles/r06_encode_pair_timeline.txt)
+        for (uint32_t lo = 0, hi = levels; lo < hi;) {
+            --hi;
+            const double ch = level_tile_cost(p.lv[hi], levels, S, H, slabs, step, balance, valu_lines);
+            if (lo < hi) {
+                units[nu++] = {hi, ch + level_tile_cost(p.lv[lo], levels, S, H, slabs, step, balance, valu_lines), lo};
+                lo++;
+            } else {
+                units[nu++] = {hi, ch, kNoLevel};
+            }
         }
+    } else if (!(balance && step > 0.f)) {   // no (usable) information: every level costs the same; the order [L-1, 0, L-2, 1, ...] of GridPlan
+        for (uint32_t v = 0, lo = 0, hi = levels; v < levels; v++) units[nu++] = {(v & 1u) ? lo++ : --hi, 1.0, kNoLevel};
+    } else {                          // fine to coarse; a tile costs its gathers or its VALU work, whichever is longer
+        for (uint32_t l = levels; l-- > 0;) units[nu++] = {l, level_tile_cost(p.lv[l], levels, S, H, slabs, step, balance, valu_lines), kNoLevel};
     }
 
     // measurement aids (devtools build): SDFX_GRID_ONLY_LEVEL = l: the launch evaluates level l alone, spread over all eight XCDs (what
     // a tile of that level costs with the whole GPU on it: tools/xcd_timeline.py); SDFX_GRID_LEVEL_COST = "c0,c1,...": cost per tile by level
     {
         const int only = dev_switch("SDFX_GRID_ONLY_LEVEL", -1);
-        if (only >= 0 && (uint32_t)only < levels) { units[0] = {(uint32_t)only, 1.0}; nu = 1; }
+        if (only >= 0 && (uint32_t)only < levels) { units[0] = {(uint32_t)only, 1.0, kNoLevel}; nu = 1; }
         if (const char* e = dev_string("SDFX_GRID_LEVEL_COST")) {
             double c[kMaxLevels];
             uint32_t n = 0;
@@ -485,8 +846,10 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
                 c[n++] = v;
                 e = (*end == ',') ? end + 1 : end;
             }
-            for (uint32_t u = 0; u < nu; u++)
+            for (uint32_t u = 0; u < nu; u++) {
                 if (units[u].level < n && c[units[u].level] > 0) units[u].cost = c[units[u].level];
+                if (units[u].level2 != kNoLevel && units[u].level2 < n && c[units[u].level2] > 0) units[u].cost += c[units[u].level2];
+            }
         }
     }
 
@@ -521,10 +884,13 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
             const uint32_t tpw_fine = [] { const int v = dev_switch("SDFX_GRID_TPW_FINE", 2); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
             // (an LDS-resident level — the SDFX_GRID_LDS measurement aid — has its own walk of kLdsTiles tiles per workgroup: one tile per plan slot)
             // (curve-ordered batches: 8 tiles per workgroup at every level — 439 / 428 / 420 / 409 us for 1 / 2 / 4 / 8, same process)
-            const uint32_t tpw = ((p.lds_mask >> units[u].level) & 1u) ? 1u
+            // (pair plans: a workgroup's tile is two levels' worth of work — SDFX_GRID_TPW_PAIR consecutive tiles)
+            const uint32_t tpw_pair = [] { const int v = dev_switch("SDFX_GRID_TPW_PAIR", 2); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+            const uint32_t tpw = p.pair ? tpw_pair
+                                 : ((p.lds_mask >> units[u].level) & 1u) ? 1u
                                  : step < 0.f ? tpw_coarse
                                  : (balance && step > 0.f && lines[units[u].level] <= valu_lines) ? tpw_coarse : tpw_fine;
-            p.seg[k][ns++] = {units[u].level, first, last - first, tpw};
+            p.seg[k][ns++] = {units[u].level, first, last - first, tpw, units[u].level2};
             p.ntiles[k] += (last - first + tpw - 1u) / tpw;
         }
     }
@@ -553,6 +919,13 @@ void launch(const float* inputs, const void* table, void* outputs, uint32_t B, u
     dev_ctl_sync();
 #define SDFX_FWD(INTERP_, ALIGN_, HASH_)                                                                               \
     do {                                                                                                               \
+        if constexpr (HALF) {                                                                                          \
+            if (plan.pair) {                                                                                           \
+                hipLaunchKernelGGL((k_grid_fwd_pair<INTERP_, ALIGN_, HASH_>), dim3(grid), dim3(kTile), 0, st, inputs,  \
+                                   static_cast<const __half*>(table), static_cast<__half*>(outputs), B, L, plan, out_layout, row_total, src); \
+                break;                                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
         if (plan.lds_mask)                                                                                             \
             hipLaunchKernelGGL((k_grid_fwd<HALF, INTERP_, ALIGN_, HASH_, true>), dim3(grid), dim3(kTile), plan.lds_bytes, st, inputs,   \
                                static_cast<const T*>(table), static_cast<T*>(outputs), B, L, plan, out_layout, row_total, src);         \
@@ -606,7 +979,8 @@ bool launch_forward_d3c2(const float* inputs, const void* table, const int32_t* 
             fprintf(stderr, "[grid plan] B=%u slabs=%u step=%g xcd %u: %u workgroups:", B, plan.slabs, (double)step, k, plan.ntiles[k]);
             for (uint32_t sgi = 0; sgi < kMaxSegs; sgi++) {
                 const Seg& sg = plan.seg[k][sgi];
-                if (sg.count) fprintf(stderr, "  L%u[%u,+%u)", sg.level, sg.first, sg.count);
+                if (sg.count && sg.level2 != kNoLevel) fprintf(stderr, "  L%u+L%u[%u,+%u)", sg.level, sg.level2, sg.first, sg.count);
+                else if (sg.count) fprintf(stderr, "  L%u[%u,+%u)", sg.level, sg.first, sg.count);
             }
             fprintf(stderr, "\n");
         }
@@ -628,10 +1002,7 @@ extern "C" int sdfx_grid_forward_level_costs(const int32_t* offsets_host, uint32
     const bool balance = dev_switch("SDFX_GRID_BALANCE", 1) == 1;
     for (uint32_t l = 0; l < max_level; l++) {
         const LevelConst c = make_level_const(offsets_host, l, S, H);
-        if (!(balance && step > 0.f)) { costs[l] = 1.0; continue; }
-        const double lines = lines_per_wave((double)c.res * step, slabs == kGroup);
-        const bool table = slabs == kGroup && step > 0.f && measured_stencil_config(max_level, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1);
-        costs[l] = table ? stencil_tile_cost((double)c.res * step, (c.flags & 1u) == 0u && c.res >= 2u) : (lines > valu_lines ? lines : valu_lines);
+        costs[l] = level_tile_cost(c, max_level, S, H, slabs, step, balance, valu_lines);
     }
     return (int)max_level;
 }
@@ -655,6 +1026,11 @@ extern "C" int sdfx_grid_forward_plan(const int32_t* offsets_host, uint32_t max_
             if (n == max_segments) return -2;
             int32_t* o = segments + 4 * n++;
             o[0] = (int32_t)k; o[1] = (int32_t)sg.level; o[2] = (int32_t)sg.first; o[3] = (int32_t)sg.count;
+            if (sg.level2 != kNoLevel) {   // a pair plan's segment: the same tiles at the partner level
+                if (n == max_segments) return -2;
+                int32_t* o2 = segments + 4 * n++;
+                o2[0] = (int32_t)k; o2[1] = (int32_t)sg.level2; o2[2] = (int32_t)sg.first; o2[3] = (int32_t)sg.count;
+            }
         }
     }
     return (int)n;
