@@ -762,6 +762,22 @@ double stencil_tile_cost(double u, bool dense) {
     return k * cost[15];
 }
 
+// What a tile of a PAIR costs on the configuration of measured_stencil_config, by the fine level's u = res x step (knots = levels 8-15 of
+// the -O grid, whose partners are levels 7-0): mean workgroup time of the pair in one launch at B = 3.26 M (tools/pair_ab.py,
+// profiles/r06_encode_pair_plan.txt), in the units of the per-level table. Against the sum of the two levels' prices the pairs of two
+// hashed levels (8+7 ... 11+4) come out 3-12 % dearer, the fine + dense pairs within 1.5 %: with the sum the XCDs finished 13-15 % of the
+// span apart, with this table 3 %.
+double stencil_pair_cost(double u_fine) {
+    static const double us[8] = {0.360, 0.499, 0.689, 0.951, 1.315, 1.816, 2.509, 3.465};
+    static const double cost[8] = {243, 229, 239, 236, 261, 300, 330, 350};
+    if (u_fine <= us[0]) return cost[0];
+    if (u_fine >= us[7]) return cost[7];
+    const double lu = log(u_fine);
+    for (int i = 0; i < 7; i++)
+        if (u_fine <= us[i + 1]) return cost[i] + (lu - log(us[i])) / (log(us[i + 1]) - log(us[i])) * (cost[i + 1] - cost[i]);
+    return cost[7];
+}
+
 struct Unit { uint32_t level; double cost; uint32_t level2; };   // cost per tile (pair plans: of both levels)
 
 // what the plan prices a tile of level l at (the measured table on its configuration, the model elsewhere, 1 without a usable hint)
@@ -770,6 +786,23 @@ double level_tile_cost(const LevelConst& c, uint32_t levels, float S, uint32_t H
     const double lines = lines_per_wave((double)c.res * fabs((double)step), slabs == kGroup);
     const bool table = slabs == kGroup && measured_stencil_config(levels, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1);
     return table ? stencil_tile_cost((double)c.res * step, (c.flags & 1u) == 0u && c.res >= 2u) : (lines > valu_lines ? lines : valu_lines);
+}
+
+// ... and a tile of the pair (hi, lo) of a pair plan. The measured table on its configuration; elsewhere a model of what the table shows:
+// the coarse partner's work hides behind the fine level's gathers, so a pair costs its fine level's lines (x 1.3: the L1 misses of a fine
+// hashed level, the correction the per-level table also carries) or the vector work of two levels (2.42 VALU floors = 235 line units),
+// whichever is longer. Against the measured pairs of the -O grid this is within 6 % (235, 235, 235, 236, 277, 315, 329, 348 for
+// 243, 229, 239, 236, 261, 300, 330, 350); the plain sum of the two levels' prices left the XCDs 31 % of the span apart (454 us where
+// the table gives 371 and one level per workgroup 424: profiles/r06_encode_pair_plan.txt).
+double pair_tile_cost(const LevelConst& hi, const LevelConst& lo, uint32_t levels, float S, uint32_t H, uint32_t slabs, float step, bool balance,
+                      double valu_lines) {
+    if (!(balance && step > 0.f)) return 2.0;
+    if (slabs == kGroup && measured_stencil_config(levels, S, H, step) && dev_switch("SDFX_GRID_COST_TABLE", 1))
+        return stencil_pair_cost((double)hi.res * step);
+    const double lh = lines_per_wave((double)hi.res * fabs((double)step), slabs == kGroup);
+    const double ll = lines_per_wave((double)lo.res * fabs((double)step), slabs == kGroup);
+    const double gathers = 1.3 * (lh > ll ? lh : ll), valu = 2.42 * valu_lines;
+    return gathers > valu ? gathers : valu;
 }
 
 bool pair_plan_enabled(uint32_t elem_bytes) { return elem_bytes == 2 && dev_switch("SDFX_GRID_PAIR", 1) == 1; }
@@ -819,7 +852,7 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
             --hi;
             const double ch = level_tile_cost(p.lv[hi], levels, S, H, slabs, step, balance, valu_lines);
             if (lo < hi) {
-                units[nu++] = {hi, ch + level_tile_cost(p.lv[lo], levels, S, H, slabs, step, balance, valu_lines), lo};
+                units[nu++] = {hi, pair_tile_cost(p.lv[hi], p.lv[lo], levels, S, H, slabs, step, balance, valu_lines), lo};
                 lo++;
             } else {
                 units[nu++] = {hi, ch, kNoLevel};
@@ -1003,6 +1036,15 @@ extern "C" int sdfx_grid_forward_level_costs(const int32_t* offsets_host, uint32
     for (uint32_t l = 0; l < max_level; l++) {
         const LevelConst c = make_level_const(offsets_host, l, S, H);
         costs[l] = level_tile_cost(c, max_level, S, H, slabs, step, balance, valu_lines);
+    }
+    // a pair plan (half tables) prices PAIRS: the fine level of a pair is listed at the pair's price less its partner's, so that
+    // sum(costs[l] x tiles) over an XCD's segments is what the plan balanced
+    if (pair_plan_enabled(2u)) {
+        for (uint32_t lo = 0, hi = max_level; lo + 1 < hi; lo++) {
+            --hi;
+            costs[hi] = pair_tile_cost(make_level_const(offsets_host, hi, S, H), make_level_const(offsets_host, lo, S, H), max_level, S, H, slabs, step,
+                                       balance, valu_lines) - costs[lo];
+        }
     }
     return (int)max_level;
 }

@@ -38,6 +38,20 @@ def test_every_tile_is_assigned_once(oracle, B, slabs, step, L, half):
     assert sum(per_xcd) == L * T
 
 
+@pytest.mark.parametrize("L", [16, 9, 2, 1])
+@pytest.mark.parametrize("slabs,step", [(7, 1 / 591.0), (1, 0.0), (1, -1 / 128.0)])
+def test_half_tables_are_planned_in_pairs(oracle, L, slabs, step):
+    """Half tables: every wave evaluates a fine level and its coarse partner — (L-1, 0), (L-2, 1), ... — on the same tiles
+    (k_grid_fwd_pair), so the two levels of a pair have the same segments on the same XCDs; an odd level count leaves the middle level
+    alone. Float tables keep one level per workgroup (any segmentation)."""
+    offsets, pls = oracle.grid_offsets(desired_resolution=2048)
+    seg, T = _plan(offsets, pls, L, 1, 1810900, slabs, step)
+    by_level = {l: sorted((int(x), int(f), int(c)) for x, ll, f, c in seg if ll == l) for l in range(L)}
+    for lo in range(L // 2):
+        assert by_level[lo] == by_level[L - 1 - lo], (lo, by_level[lo], by_level[L - 1 - lo])
+    assert all(sum(c for _, _, c in v) == T for v in by_level.values())
+
+
 def _costs(offsets, pls, L, slabs, step):
     off = (C.c_int32 * len(offsets))(*[int(v) for v in offsets])
     out = (C.c_double * L)()
@@ -61,11 +75,13 @@ def test_step_hint_balances_the_plans_own_cost(oracle, desired, step):
     load_even = [sum(cost[l] * c for x, l, f, c in even if x == k) for k in range(8)]
     assert max(load_even) > 1.3 * min(load_even)             # (1.46 - 2.9 over these grids and steps)
     assert (cost >= 0.7 * 97).all() and cost[-1] > 2 * cost[0]
-    fine = cost[cost > 1.2 * 97]
-    assert (np.diff(fine) >= -1e-9).all()                     # past the VALU floor the price follows the line count upwards
     measured = desired == 2048 and abs(step * 591 - 1) < 0.2
     if not measured:
+        fine = cost[cost > 1.2 * 97]
+        assert (np.diff(fine) >= -1e-9).all()                 # past the VALU floor the price follows the line count upwards
         assert (cost >= 97 - 1e-9).all() and (cost[:3] == 97).all()    # the model: VALU floor at the coarse end, lines beyond
+    else:                                                     # (the measured pair table: a fine level is listed at its pair's price less the partner's)
+        assert (np.diff(cost[10:]) > 0).all()
     assert (_costs(offsets, pls, 16, 7, 0.0) == 1.0).all()    # no hint: every level the same
 
 

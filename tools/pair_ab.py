@@ -44,7 +44,8 @@ def fwd():
 
 def timed(fn, k=n):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fn(); fn()
+    for _ in range(25):          # ~10 ms of launches: the clocks are up again after a host-side pause (stamp read-back, plan switch)
+        fn()
     s.record()
     for _ in range(k):
         fn()
@@ -85,31 +86,33 @@ def report(rec, title):
 
 
 print(f"samples M = {M} ({views} views), stencil batch B = {B}")
-tpws = [int(v) for v in os.environ.get("PAIR_TPW", "1,2,4").split(",")]
-variants = [("one level per workgroup (k_grid_fwd)", dict(SDFX_GRID_PAIR=0))] + \
-           [(f"two levels per wave, {t} tiles per workgroup", dict(SDFX_GRID_PAIR=1, SDFX_GRID_TPW_PAIR=t)) for t in tpws]
+tpws = [int(v) for v in os.environ.get("PAIR_TPW", "2").split(",")]
+cands = [c for c in os.environ.get("PAIR_COSTS", "").split(";") if c]
+variants = [("one level per workgroup (k_grid_fwd)", dict(SDFX_GRID_PAIR=0), None)] + \
+           [(f"two levels per wave, {t} tiles per workgroup", dict(SDFX_GRID_PAIR=1, SDFX_GRID_TPW_PAIR=t), None) for t in tpws] + \
+           [("two levels per wave, pairs priced by the model (sum of the levels' prices)", dict(SDFX_GRID_PAIR=1, SDFX_GRID_COST_TABLE=0), None)] + \
+           [(f"two levels per wave, SDFX_GRID_LEVEL_COST candidate {i}", dict(SDFX_GRID_PAIR=1), c) for i, c in enumerate(cands)]
 ref = None
-times = {name: [] for name, _ in variants}
+times = {name: [] for name, _, _ in variants}
 for rnd in range(3):
-    for name, sw in variants:
+    for name, sw, cost in variants:
+        if cost:
+            os.environ["SDFX_GRID_LEVEL_COST"] = cost
         with _sdfx.dev_switch(**sw):
             t = timed(fwd)
             if ref is None:
                 ref = out.clone()
             same = bool(torch.equal(out.view(torch.int16), ref.view(torch.int16)))
             out.zero_()
+        os.environ.pop("SDFX_GRID_LEVEL_COST", None)
         times[name].append(t)
         print(f"   round {rnd} {name}: {t:7.1f} us/launch = {B * 588 / t / 1e3 / 8000:.3f} of 8 TB/s  identical to the first: {same}", flush=True)
-for name, _ in variants:
+for name, _, _ in variants:
     print(f"{name}: min {min(times[name]):.1f} us  ({B * 588 / min(times[name]) / 1e3 / 8000:.3f} of 8 TB/s at 588 B/point)")
-best = min(tpws, key=lambda t: min(times[f"two levels per wave, {t} tiles per workgroup"]))
-with _sdfx.dev_switch(SDFX_GRID_PAIR=0):
-    report(stamped(fwd), "one level per workgroup")
-with _sdfx.dev_switch(SDFX_GRID_PAIR=1, SDFX_GRID_TPW_PAIR=best):
-    report(stamped(fwd), f"two levels per wave, {best} tiles per workgroup")
-    for i, c in enumerate([c for c in os.environ.get("PAIR_COSTS", "").split(";") if c]):
-        os.environ["SDFX_GRID_LEVEL_COST"] = c
-        ts = [timed(fwd) for _ in range(3)]
-        print(f"== pair plan with SDFX_GRID_LEVEL_COST={c}: {min(ts):.1f} us ({[round(t) for t in ts]})")
-        report(stamped(fwd), f"pair plan, costs candidate {i}")
+if os.environ.get("PAIR_TIMELINE", "1") == "1":
+    for name, sw, cost in variants:
+        if cost:
+            os.environ["SDFX_GRID_LEVEL_COST"] = cost
+        with _sdfx.dev_switch(**sw):
+            report(stamped(fwd), name)
         os.environ.pop("SDFX_GRID_LEVEL_COST", None)
