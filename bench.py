@@ -1145,7 +1145,7 @@ def main():
         return total / units * units_this_run, units
 
     enc = ksum.get("grid_encode_forward") or {"GBps": 0.0, "avg_us": 0.0, "launches": 0, "bytes": 0}
-    enc_kernel, pmc_key = "k_grid_fwd<half> (7-point stencil batches of the iteration)", "k_grid_fwd"
+    enc_kernel, pmc_key = "k_grid_fwd_pair (two levels per wave; 7-point stencil batches of the iteration)", "k_grid_fwd"
     if not enc["launches"] and ksum.get("grid_encode_forward_unhinted"):     # DMTet stage: one un-hinted encode of the visible points
         enc, enc_kernel = ksum["grid_encode_forward_unhinted"], "k_grid_forward<3, 2, half> (surface points of the rasterised mesh, no hint)"
         pmc_key = "k_grid_forward"

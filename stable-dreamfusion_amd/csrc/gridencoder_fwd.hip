@@ -630,7 +630,8 @@ __device__ __forceinline__ void pair_tiles(const float* __restrict__ inputs, __h
         // SIMD); two hashed levels would need 87 registers that way, so those are evaluated one after the other (they are the middle
         // of the level sequence, where neither level waits much for its gathers) and share the tile's coordinates only.
 #ifndef SDFX_PAIR_OVERLAP_HASH
-#define SDFX_PAIR_OVERLAP_HASH 0   // measurement aid: 1 = two hashed levels in flight together as well (build with -DSDFX_PAIR_WAVES=5)
+#define SDFX_PAIR_OVERLAP_HASH 0   // measurement aid: 1 = two hashed levels in flight together as well (build with -DSDFX_PAIR_WAVES=5:
+                                   // 388 us against 386 us for this kernel on the same box, profiles/r06_encode_pair_plan.txt)
 #endif
         constexpr bool kOverlap = KB == kKindDense || (SDFX_PAIR_OVERLAP_HASH && KB == kKindHash16);
         PointLevel<KA> qa;
