@@ -377,8 +377,10 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::
         const uint32_t incl = wave_incl_sum_u32(my_cnt, lane);
         if (lane == (int)kWave - 1) wave_tot[threadIdx.x >> 6] = incl;
         __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) woff += wave_tot[w];
+        uint32_t woff = 0;   // totals of the waves below this one: every thread reads all of them at once, no loop of dependent LDS reads
+#pragma unroll                // (with the scan on the DPP network instead of six ds_bpermute round trips: K1 span 834-841 -> 807 us at
+                              // B = 3.26 M, same box, profiles/r06_scatter_k1_scan_and_order.txt)
+        for (uint32_t w = 0; w + 1 < kBinThreads / 64; w++) woff += w < (threadIdx.x >> 6) ? wave_tot[w] : 0u;
         if (threadIdx.x < nb) boff[threadIdx.x] = woff + incl - my_cnt;
         if (threadIdx.x == kBinThreads - 1) *block_total = woff + incl;
     }
@@ -442,6 +444,10 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::
 //     (896-920 us) or slower (978-1020 us), K2 385 us with 64 KB of accumulators against 340-366 (profiles/r05_scatter_bucket_tile_variants.txt);
 //     tools/ubench/write_streams.hip says why the runs do not help yet: 96-byte and 192-byte runs write at 2.2-2.4 TB/s, the jump
 //     to 4.8-5.4 TB/s comes at 384 bytes (profiles/r05_write_streams_ubench.txt).
+//   * round 6: the VALUES of the items (weights, products, run folding, rounding) computed after the histogram and the reservation
+//     atomics instead of before, so that the returning atomics fly behind them (56 registers): K1 span 838-855 us against 804-806 us
+//     for this order on the same box; an XCD's two levels walked tile by tile instead of one after the other, and 2 / 4 items per
+//     workgroup: no change (profiles/r06_scatter_k1_scan_and_order.txt, r06_scatter_k1_interleave_tpw.txt).
 // (second bound = waves per SIMD: 8, i.e. 4 workgroups per CU, which the 30 KB of LDS allow)
 template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
 __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,

@@ -222,12 +222,19 @@ __device__ __forceinline__ float wave_last(float v) {
 // sum over the wave in every lane
 __device__ __forceinline__ float wave_total(float v) { return wave_last(wave_incl_sum(v, 0)); }
 
+// the same scan on integers (was a chain of six ds_bpermute_b32 round trips)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t u = __shfl_up(v, o, kWave);
-        if (lane >= o) v += u;
-    }
+    (void)lane;
+    v += dpp_u32<0x111, 0xf>(0u, v);   // row_shr:1
+    v += dpp_u32<0x112, 0xf>(0u, v);   // row_shr:2
+    v += dpp_u32<0x114, 0xf>(0u, v);   // row_shr:4
+    v += dpp_u32<0x118, 0xf>(0u, v);   // row_shr:8
+    v += dpp_u32<0x142, 0xa>(0u, v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_u32<0x143, 0xc>(0u, v);   // row_bcast:31 into rows 2 and 3
     return v;
 }
 
