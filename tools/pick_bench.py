@@ -15,6 +15,7 @@ for line in sys.stdin:
     print("  if", d.get("iters_per_sec_if"), (d.get("iters_per_sec_if_config") or {}).get("error"), "dmtet", d.get("iters_per_sec_dmtet"),
           (d.get("iters_per_sec_dmtet_config") or {}).get("error"))
     print("  roofline frac", round(r.get("frac", 0), 4), "enc_us", round(r.get("avg_launch_us", 0), 1), "points", round(r.get("points_per_launch") or 0),
+          "eager frac", round(r.get("eager_frac") or 0, 4), "eager us", round(r.get("eager_avg_launch_us") or 0, 1),
           "gather", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in (r.get("gather") or {}).items() if k in ("ta_busy_frac", "frac")})
     print("  kernels_in_step", {k: v.get("avg_us") for k, v in d.get("kernels_in_step", {}).items() if isinstance(v, dict)})
     rc = d.get("roofline_composite", {})
