@@ -91,6 +91,7 @@ class KernelTimer:
         self.cover_host = False   # only the untimed eager pass spins in front of its launches: NOTHING is added to the timed region
         self.contexts = {}        # the sdfx_set_row_limit / sdfx_set_stencil_source settings in force (recorded by install_timers)
         self.last_launch = {}     # name -> (callable, args, kwargs, contexts) of the last timed launch: replayed in a graph afterwards
+        self.replay_names = {"grid_encode_forward"}   # ... kept for these names only, and dropped once replayed
 
     def wrap(self, module, fname, name, bytes_fn):
         inner = getattr(module, fname)
@@ -109,7 +110,10 @@ class KernelTimer:
             out = inner(*a, **k)
             e.record()
             timer.records.append((name, s, e, bytes_fn(*a, **k)))
-            timer.last_launch[name] = (inner, a, k, dict(timer.contexts), bytes_fn(*a, **k))
+            if name in timer.replay_names:   # (detached: a kept autograd graph — its AccumulateGrad nodes on this stream — breaks the
+                det = lambda v: v.detach() if isinstance(v, torch.Tensor) else v   # next graph capture: capture_end segfaults)
+                timer.last_launch[name] = (inner, tuple(det(v) for v in a), {kk: det(v) for kk, v in k.items()}, dict(timer.contexts),
+                                           bytes_fn(*a, **k))
             if os.environ.get("SDFX_BENCH_DEBUG_LAUNCHES") and name.startswith("grid_encode_forward"):
                 rl = timer.contexts.get("row_limit")
                 print(f"[bench] {name}: B = {a[4]}, row limit total = {int(rl.total[0]) if rl is not None and rl.total is not None else None}, "
@@ -1077,7 +1081,8 @@ def main():
         step.mode = "graph"
         roofline_pass = f"{n_eager} eager iterations after the timed region (graph replay hides launches from Python)"
         try:   # the encode of the LAST of those iterations once more, as launches of a replayed graph (see replay_last_launch)
-            enc_replayed = replay_last_launch(timer, "grid_encode_forward")
+            enc_replayed = None if os.environ.get("SDFX_BENCH_NO_REPLAY") else replay_last_launch(timer, "grid_encode_forward")
+            timer.last_launch.clear(); timer.contexts.clear()
         except Exception as exc:  # noqa: BLE001 — the eager figures stand
             print(f"[bench] encode replay failed: {exc}", file=sys.stderr)
             enc_replayed = None

@@ -849,14 +849,18 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
         // units = (fine, coarse) pairs from both ends of the level sequence, (L-1, 0), (L-2, 1), ..., an odd count's middle level alone;
         // a pair's tile is priced at the sum of its levels' prices (what the overlap inside the wave takes off is about the same
         // share for every pair of the -O grid: profiles/r06_encode_pair_timeline.txt)
-        for (uint32_t lo = 0, hi = levels; lo < hi;) {
+        // SDFX_GRID_PAIR_MIDDLE = 0 (measurement aid): only a DENSE level is paired; the hashed levels left over in the middle of the
+        // sequence go one level per workgroup (their two 2 MiB tables would fill an XCD's 4 MiB L2)
+        const bool pair_hashed = dev_switch("SDFX_GRID_PAIR_MIDDLE", 1) == 1;
+        uint32_t lo = 0, hi = levels;
+        while (lo < hi) {
             --hi;
-            const double ch = level_tile_cost(p.lv[hi], levels, S, H, slabs, step, balance, valu_lines);
-            if (lo < hi) {
+            const bool lo_dense = lo < hi && (p.lv[lo].flags & 1u) == 0u && p.lv[lo].res >= 2u;
+            if (lo < hi && (pair_hashed || lo_dense)) {
                 units[nu++] = {hi, pair_tile_cost(p.lv[hi], p.lv[lo], levels, S, H, slabs, step, balance, valu_lines), lo};
                 lo++;
             } else {
-                units[nu++] = {hi, ch, kNoLevel};
+                units[nu++] = {hi, level_tile_cost(p.lv[hi], levels, S, H, slabs, step, balance, valu_lines), kNoLevel};
             }
         }
     } else if (!(balance && step > 0.f)) {   // no (usable) information: every level costs the same; the order [L-1, 0, L-2, 1, ...] of GridPlan
@@ -920,7 +924,7 @@ FwdPlan make_fwd_plan(const int32_t* offsets_host, uint32_t levels, float S, uin
             // (curve-ordered batches: 8 tiles per workgroup at every level — 439 / 428 / 420 / 409 us for 1 / 2 / 4 / 8, same process)
             // (pair plans: a workgroup's tile is two levels' worth of work — SDFX_GRID_TPW_PAIR consecutive tiles)
             const uint32_t tpw_pair = [] { const int v = dev_switch("SDFX_GRID_TPW_PAIR", 2); return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
-            const uint32_t tpw = p.pair ? tpw_pair
+            const uint32_t tpw = (p.pair && units[u].level2 != kNoLevel) ? tpw_pair
                                  : ((p.lds_mask >> units[u].level) & 1u) ? 1u
                                  : step < 0.f ? tpw_coarse
                                  : (balance && step > 0.f && lines[units[u].level] <= valu_lines) ? tpw_coarse : tpw_fine;

@@ -91,7 +91,10 @@ cands = [c for c in os.environ.get("PAIR_COSTS", "").split(";") if c]
 variants = [("one level per workgroup (k_grid_fwd)", dict(SDFX_GRID_PAIR=0), None)] + \
            [(f"two levels per wave, {t} tiles per workgroup", dict(SDFX_GRID_PAIR=1, SDFX_GRID_TPW_PAIR=t), None) for t in tpws] + \
            [("two levels per wave, pairs priced by the model (sum of the levels' prices)", dict(SDFX_GRID_PAIR=1, SDFX_GRID_COST_TABLE=0), None)] + \
-           [(f"two levels per wave, SDFX_GRID_LEVEL_COST candidate {i}", dict(SDFX_GRID_PAIR=1), c) for i, c in enumerate(cands)]
+           [(f"two levels per wave, SDFX_GRID_LEVEL_COST candidate {i}", dict(SDFX_GRID_PAIR=1), c) for i, c in enumerate(cands)] + \
+           ([("dense levels paired, the hashed middle levels one per workgroup", dict(SDFX_GRID_PAIR=1, SDFX_GRID_PAIR_MIDDLE=0), None)] +
+            [(f"dense levels paired, middle levels single, cost candidate {i}", dict(SDFX_GRID_PAIR=1, SDFX_GRID_PAIR_MIDDLE=0), c)
+             for i, c in enumerate(c for c in os.environ.get("PAIR_MIDDLE_COSTS", "").split(";") if c)] if os.environ.get("PAIR_MIDDLE") else [])
 ref = None
 times = {name: [] for name, _, _ in variants}
 for rnd in range(3):
