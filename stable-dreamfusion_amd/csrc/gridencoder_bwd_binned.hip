@@ -46,7 +46,10 @@ SDFX_DEV_CTL_DEFINE   // devtools build: per-workgroup timestamps, ablation bits
 #endif
 constexpr uint32_t kBucketRowsLog2 = SDFX_BUCKET_LOG2;
 constexpr uint32_t kBucketRows = 1u << kBucketRowsLog2;  // rows per bucket (16 KiB of float2 accumulators)
-constexpr uint32_t kMaxBucketsPerLevel = 512;            // levels up to 2^20 rows
+#ifndef SDFX_MAX_BUCKETS
+#define SDFX_MAX_BUCKETS 512   // measurement aid: -DSDFX_MAX_BUCKETS=256 -DSDFX_BIN_THREADS=256 builds K1 with 256-sample tiles (levels up to 2^19 rows)
+#endif
+constexpr uint32_t kMaxBucketsPerLevel = SDFX_MAX_BUCKETS;   // levels up to 2^20 rows
 #ifndef SDFX_BIN_THREADS
 #define SDFX_BIN_THREADS 512   // measurement aid: -DSDFX_BIN_THREADS=1024 builds K1 with 1024-sample tiles (half as many reservations per item)
 #endif
@@ -343,6 +346,14 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::
 
     Contrib<HALF> c;
     tile_compute<HALF, INTERP, ALIGN, HASHGRID, MERGE>(in, b0, tile, lc, src, c);
+#ifdef SDFX_K1_PAD   // measurement aid (tools/build_variant.py ... -DSDFX_K1_PAD=n): n more full-rate vector instructions per thread and level,
+    {                // results unchanged — does K1's time follow its vector instruction count? (profiles/r06_scatter_k1_valu_pad.txt)
+        uint32_t pad = c.rows[0];
+#pragma unroll
+        for (int i = 0; i < SDFX_K1_PAD; i++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad));
+        c.rows[0] = pad - (uint32_t)SDFX_K1_PAD;
+    }
+#endif
     const uint32_t (&rows)[NCORN] = c.rows;
     const bool emit = c.emit;
     // items of this lane: one per corner (float tables) or one per x-pair of corners (half tables, see Item<true>)
@@ -448,6 +459,12 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::
 //     atomics instead of before, so that the returning atomics fly behind them (56 registers): K1 span 838-855 us against 804-806 us
 //     for this order on the same box; an XCD's two levels walked tile by tile instead of one after the other, and 2 / 4 items per
 //     workgroup: no change (profiles/r06_scatter_k1_scan_and_order.txt, r06_scatter_k1_interleave_tpw.txt).
+//   * round 6, what bounds it (profiles/r06_scatter_k1_bound.txt): 410 vector instructions per wave and level = 0.8 of the SIMD cycles
+//     of its span — 64 dummy instructions more (-DSDFX_K1_PAD) cost 2-3 %, 128 cost 5-7 %: the chain leaves ~20 % of the vector issue
+//     unused and no more; 256-sample tiles (8 workgroups of 4 waves per CU, -DSDFX_BIN_THREADS=256 -DSDFX_MAX_BUCKETS=256) live as long
+//     as 512-sample ones: 1046 against 800 us; and the list stores: a 64-byte sector that two runs share leaves the L2 before the second
+//     run arrives 7 times in 10 (17.4 M of 39.3 M sectors written back twice, 3.8 M partial requests, 4 x the write-request stalls of
+//     a dense stream) — the L2 combines writes over a short window only, whatever the store's cache-policy bits.
 // (second bound = waves per SIMD: 8, i.e. 4 workgroups per CU, which the 30 KB of LDS allow)
 template <bool HALF, uint32_t INTERP, bool ALIGN, bool HASHGRID>
 __global__ __launch_bounds__(kBinThreads, 8) void k_grid_bwd_bin(const typename Elem<HALF>::type* __restrict__ grad,

@@ -25,7 +25,8 @@ struct Item { uint32_t a, b, c; };
 enum Mode { BUCKETED = 0, ALIGNED32 = 1, DENSE = 2, GRANULES = 3 };
 
 // run: items per (tile, bucket) visit; a tile visits kItems / run buckets, rotating through the 256 with the tile index
-template <int MODE>
+// NT: 0 = plain stores, 1 = __builtin_nontemporal_store (global_store ... nt), 2 = sc1 (system-scope write-through hint), 3 = sc0 sc1 nt
+template <int MODE, int NT = 0>
 __global__ __launch_bounds__(kThreads) void k_write(Item* __restrict__ out, uint32_t tiles, uint64_t cap, uint32_t run, int flat,
                                                      uint64_t pool_granules) {
     // (level, tile) of this workgroup
@@ -58,19 +59,24 @@ __global__ __launch_bounds__(kThreads) void k_write(Item* __restrict__ out, uint
             if (MODE == BUCKETED) slot += 3;                      // lists start wherever: not line aligned
             dst = level_base + (uint64_t)bucket * cap + slot;
         }
-        out[dst] = it;
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 v3 = {it.a, it.b, it.c};
+        if (NT == 0) out[dst] = it;
+        else if (NT == 1) asm volatile("global_store_dwordx3 %0, %1, off nt" :: "v"(out + dst), "v"(v3) : "memory");
+        else if (NT == 2) asm volatile("global_store_dwordx3 %0, %1, off sc1" :: "v"(out + dst), "v"(v3) : "memory");
+        else asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1 nt" :: "v"(out + dst), "v"(v3) : "memory");
     }
 }
 
-template <int MODE>
+template <int MODE, int NT = 0>
 float run_mode(Item* buf, uint32_t tiles, uint64_t cap, uint32_t run, int flat, uint64_t pool_granules) {
     const uint32_t grid = 2 * tiles * 8;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_write<MODE>), dim3(grid), dim3(kThreads), 0, 0, buf, tiles, cap, run, flat, pool_granules);
+    for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_write<MODE, NT>), dim3(grid), dim3(kThreads), 0, 0, buf, tiles, cap, run, flat, pool_granules);
     hipEventRecord(a);
     const int n = 5;
-    for (int i = 0; i < n; i++) hipLaunchKernelGGL((k_write<MODE>), dim3(grid), dim3(kThreads), 0, 0, buf, tiles, cap, run, flat, pool_granules);
+    for (int i = 0; i < n; i++) hipLaunchKernelGGL((k_write<MODE, NT>), dim3(grid), dim3(kThreads), 0, 0, buf, tiles, cap, run, flat, pool_granules);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
@@ -98,6 +104,15 @@ int main(int argc, char** argv) {
             {"bucketed   run 128 (1.5 KB)", BUCKETED, 128}, {"aligned32  run  32 (384 B)", ALIGNED32, 32}, {"aligned32  run  64 (768 B)", ALIGNED32, 64},
             {"dense      24 KB per tile", DENSE, 0},      {"granules   384 B anywhere", GRANULES, 0},
         };
+        if (argc > 2) {   // cache-policy variants of K1's pattern (any second argument)
+            const char* pol[] = {"plain", "nt", "sc1", "sc0 sc1 nt"};
+            for (uint32_t run : {8u, 16u, 32u}) {
+                float ms[4] = {run_mode<BUCKETED, 0>(buf, tiles, cap, run, flat, pool), run_mode<BUCKETED, 1>(buf, tiles, cap, run, flat, pool),
+                               run_mode<BUCKETED, 2>(buf, tiles, cap, run, flat, pool), run_mode<BUCKETED, 3>(buf, tiles, cap, run, flat, pool)};
+                for (int q = 0; q < 4; q++) printf("%s  bucketed run %3u (%4u B)  stores %-11s %8.1f us  %6.2f TB/s\n", map, run, run * 12, pol[q], ms[q] * 1e3, gb / ms[q]);
+            }
+            continue;
+        }
         for (auto& r : rows) {
             float ms = 0;
             switch (r.mode) {
