@@ -365,6 +365,7 @@ __device__ __forceinline__ void bin_tile(const TileIn& in, typename Elem<HALF>::
         if constexpr (HALF) {
             ibucket[i] = rows[2 * i] >> kBucketRowsLog2;
             split[i] = (rows[2 * i + 1] >> kBucketRowsLog2) != ibucket[i];   // the pair straddles two buckets (dense levels, rarely)
+            if constexpr (kBucketRowsLog2 > 12) split[i] = split[i] || ((rows[2 * i] ^ rows[2 * i + 1]) >> 12) != 0u;   // (12 bits in the item)
         } else {
             ibucket[i] = rows[i] >> kBucketRowsLog2;
             split[i] = false;
@@ -588,6 +589,7 @@ __global__ __launch_bounds__(kBinThreads) void k_grid_bwd_spill(const __half* __
 constexpr uint32_t kReduceThreadsFixed = SDFX_REDUCE_THREADS;
 constexpr uint32_t kReduceWaves = kReduceThreads / 64;
 constexpr uint32_t kReduceLdsBytes = kReduceWaves * kBucketRows * (sizeof(float2) + 1);
+constexpr uint32_t kReduceFixedLdsBytes = SDFX_BUCKET_LOG2 > 12 ? kBucketRows * 2 * (uint32_t)sizeof(unsigned long long) : 0u;   // (dynamic part)
 
 struct ReduceJob {
     uint32_t level, bucket, gbucket, split, used, begin, end, cap;
@@ -651,7 +653,11 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
                                                                               const Item<true>* __restrict__ items,
                                                                               unsigned long long* __restrict__ shared_acc,
                                                                               const unsigned long long* __restrict__ spill_acc, uint32_t wg_lo) {
+#if SDFX_BUCKET_LOG2 > 12
+    extern __shared__ __align__(16) unsigned long long acc[];   // 128 KiB at 8192 rows: one workgroup per CU (launched with kReduceFixedLdsBytes)
+#else
     __shared__ unsigned long long acc[kBucketRows * 2];  // 32 KiB
+#endif
     ReduceJob j;
     if (!reduce_job<true>(bin, cursors, j, wg_lo)) return;
     SDFX_STAMP_BEGIN
@@ -1104,6 +1110,9 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
     const uint32_t eb = is_half ? 2 : 4;
     {   // K2 needs more than the 64 KiB of LDS a kernel gets without asking
         static bool lds_ok = [] {
+            if (kReduceFixedLdsBytes && hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_bwd_reduce_fixed),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReduceFixedLdsBytes) != hipSuccess)
+                return false;
             return hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_bwd_reduce_ticket),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReduceLdsBytes) == hipSuccess;
         }();
@@ -1190,7 +1199,7 @@ int sdfx_grid_encode_backward_binned(const void* grad, const float* inputs, cons
                 case 6: SDFX_SPILL(1u, true, false, gp, stream, flag); break;
                 default: SDFX_SPILL(1u, true, true, gp, stream, flag); break;
             }
-            hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(wg_hi - wg_lo), dim3(kReduceThreadsFixed), 0, stream,
+            hipLaunchKernelGGL(k_grid_bwd_reduce_fixed, dim3(wg_hi - wg_lo), dim3(kReduceThreadsFixed), kReduceFixedLdsBytes, stream,
                                static_cast<__half*>(grad_embeddings), plan, bin, cursors, static_cast<const Item<true>*>(items),
                                shared_acc, spill_acc, wg_lo);
         };
