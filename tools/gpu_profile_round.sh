@@ -82,5 +82,33 @@ long = [i for i, r in enumerate(rows) if "copyBuffer" in r["Kernel_Name"] and in
 for i in long[-4:]:
     print("  long copy %.0f us, stream %s; prev: %s | next: %s" % ((int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3, rows[i].get("Stream_Id", rows[i].get("Queue_Id", "?")), rows[i-1]["Kernel_Name"][:40], rows[i+1]["Kernel_Name"][:40]))
 PY
+# bench.py's roofline figure against THIS trace: the bench re-runs its last stencil encode as 10 back-to-back launches of a replayed graph
+# (6 replays: 60 launches in a row, nothing between them) — the same launches are in the kernel trace of the same process
+python3 - <<PY | tee $OUT/encode_replay_in_trace.txt | tee -a $OUT/summary.txt
+import csv, json
+for tag, trace, log in (("default (SD-1.5-shaped prior)", "$OUT/stats/bench_kernel_trace.csv", "$OUT/stats.log"), ("synthetic prior", "$OUT/stats_synth/bench_kernel_trace.csv", "$OUT/stats_synth.log")):
+    try:
+        rows = list(csv.DictReader(open(trace)))
+    except OSError:
+        continue
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    best, cur = [], []
+    for r in rows:
+        if "k_grid_fwd" in r["Kernel_Name"]:
+            cur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        else:
+            if len(cur) > len(best): best = cur
+            cur = []
+    if len(cur) > len(best): best = cur
+    line = None
+    for l in open(log):
+        if l.startswith("{"): line = l
+    rf = json.loads(line)["roofline"] if line else {}
+    d = sorted(best[-50:]) if best else [0.0]
+    print("%s: longest streak of consecutive encode launches in the rocprofv3 kernel trace: n = %d, last 50: median %.1f us, min %.1f, max %.1f" % (tag, len(best), d[len(d) // 2], d[0], d[-1]))
+    if rf:
+        print("   the same process's bench line: roofline.avg_launch_us %.1f at %.0f points per launch -> frac %.4f; trace median -> %.1f ps per point = %.4f of 8 TB/s at 588 B per point"
+              % (rf["avg_launch_us"], rf["points_per_launch"], rf["frac"], d[len(d) // 2] * 1e6 / rf["points_per_launch"], 588.0 * rf["points_per_launch"] / (d[len(d) // 2] * 1e-6) / 8e12))
+PY
 find $OUT -type f -size +1M -delete 2>/dev/null
 du -sh $OUT
