@@ -665,7 +665,10 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
     __syncthreads();
 
     const uint32_t row0 = plan.off[j.level];
-    constexpr uint32_t kUnroll = 8;  // independent loads in flight per thread
+#ifndef SDFX_REDUCE_UNROLL
+#define SDFX_REDUCE_UNROLL 8   // measurement aid
+#endif
+    constexpr uint32_t kUnroll = SDFX_REDUCE_UNROLL;  // independent loads in flight per thread
     const Item<true>* src = items + (size_t)bin.item_first[j.level] * 1024u + (size_t)j.bucket * j.cap;
     for (uint32_t base = j.begin; base < j.end; base += kUnroll * kReduceThreadsFixed) {
         Item<true> it[kUnroll];
@@ -694,6 +697,10 @@ __global__ __launch_bounds__(kReduceThreadsFixed) void k_grid_bwd_reduce_fixed(_
 #pragma unroll
         for (uint32_t u = 0; u < kUnroll; u++) {
             if (!have[u]) continue;
+            if (SDFX_ABLATE(128u)) {   // measurement: the list stream alone — the items are consumed, nothing is added (wrong sums)
+                if ((it[u].rows ^ it[u].val0 ^ it[u].val1) == 0x9E3779B9u) atomicAdd(&acc[0], 1ull);
+                continue;
+            }
             add(it[u].val0, it[u].row0());
             if (it[u].val1 & 0x7FFF7FFFu) add(it[u].val1, it[u].row1());
         }
