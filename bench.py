@@ -90,7 +90,7 @@ class KernelTimer:
         self.enabled = False
         self.cover_host = False   # only the untimed eager pass spins in front of its launches: NOTHING is added to the timed region
         self.contexts = {}        # the sdfx_set_row_limit / sdfx_set_stencil_source settings in force (recorded by install_timers)
-        self.last_launch = {}     # name -> (callable, args, kwargs, contexts) of the last timed launch: replayed in a graph afterwards
+        self.last_launch = {}     # name -> [(callable, args, kwargs, contexts, bytes)] of the timed launches: one is replayed in a graph afterwards
         self.replay_names = {"grid_encode_forward"}   # ... kept for these names only, and dropped once replayed
 
     def wrap(self, module, fname, name, bytes_fn):
@@ -112,8 +112,11 @@ class KernelTimer:
             timer.records.append((name, s, e, bytes_fn(*a, **k)))
             if name in timer.replay_names:   # (detached: a kept autograd graph — its AccumulateGrad nodes on this stream — breaks the
                 det = lambda v: v.detach() if isinstance(v, torch.Tensor) else v   # next graph capture: capture_end segfaults)
-                timer.last_launch[name] = (inner, tuple(det(v) for v in a), {kk: det(v) for kk, v in k.items()}, dict(timer.contexts),
-                                           bytes_fn(*a, **k))
+                rl, ss = timer.contexts.get("row_limit"), timer.contexts.get("stencil_source")   # snapshots: both are rewritten by the next iteration
+                snap = {"row_limit": (rl.total.clone() if rl is not None and rl.total is not None else None, rl.period if rl is not None else 0),
+                        "stencil_source": ((ss.xyzs.clone() if ss.xyzs is not None else None, ss.epsilon, ss.bound) if ss is not None else (None, 0.0, 0.0))}
+                timer.last_launch.setdefault(name, []).append((inner, tuple(det(v) for v in a), {kk: det(v) for kk, v in k.items()},
+                                                               snap, bytes_fn(*a, **k)))
             if os.environ.get("SDFX_BENCH_DEBUG_LAUNCHES") and name.startswith("grid_encode_forward"):
                 rl = timer.contexts.get("row_limit")
                 print(f"[bench] {name}: B = {a[4]}, row limit total = {int(rl.total[0]) if rl is not None and rl.total is not None else None}, "
@@ -204,19 +207,22 @@ def install_timers(timer):
 
 
 def replay_last_launch(timer, name, launches=10, replays=5):
-    """(us per launch, algorithmic bytes) of the last eager launch recorded under `name`, run again as `launches` back-to-back copies
-    inside a REPLAYED HIP graph under the same row limit and stencil source — the kernel on the GPU's clock, as the captured
-    iteration runs it (an eager launch runs on a stream that idles between the host's submissions). None if nothing was recorded."""
+    """(us per launch, algorithmic bytes) of ONE eager launch recorded under `name` — the one whose size is closest to the MEAN size of
+    the pass's launches (a view's sample count varies four-fold, and a small batch runs less efficiently per point than a large one:
+    neither the last nor the largest launch is representative) — run again as `launches` back-to-back copies inside a REPLAYED HIP
+    graph under the same row limit and stencil source: the kernel on the GPU's clock, as the captured iteration runs it (an eager
+    launch runs on a stream that idles between the host's submissions). None if nothing was recorded."""
     import _sdfx
-    rec = timer.last_launch.get(name)
-    if not rec:
+    recs = timer.last_launch.get(name)
+    if not recs:
         return None
+    mean = sum(r[4] for r in recs) / len(recs)
+    rec = min(recs, key=lambda r: abs(r[4] - mean))
     inner, a, k, ctx, nbytes = rec
-    rl, ss = ctx.get("row_limit"), ctx.get("stencil_source")
+    (rl_total, rl_period), (ss_xyzs, ss_eps, ss_bound) = ctx["row_limit"], ctx["stencil_source"]
 
     def fn():
-        with _sdfx.row_limit(rl.total if rl else None, rl.period if rl else 0), \
-                _sdfx.stencil_source(ss.xyzs if ss else None, ss.epsilon if ss else 0.0, ss.bound if ss else 0.0):
+        with _sdfx.row_limit(rl_total, rl_period), _sdfx.stencil_source(ss_xyzs, ss_eps, ss_bound):
             inner(*a, **k)
 
     return graph_time_us(fn, launches=launches, replays=replays), nbytes
@@ -1080,7 +1086,7 @@ def main():
         timer.enabled = timer.cover_host = False
         step.mode = "graph"
         roofline_pass = f"{n_eager} eager iterations after the timed region (graph replay hides launches from Python)"
-        try:   # the encode of the LAST of those iterations once more, as launches of a replayed graph (see replay_last_launch)
+        try:   # the encode launch of mean size among those iterations once more, as launches of a replayed graph (see replay_last_launch)
             enc_replayed = None if os.environ.get("SDFX_BENCH_NO_REPLAY") else replay_last_launch(timer, "grid_encode_forward")
             timer.last_launch.clear(); timer.contexts.clear()
         except Exception as exc:  # noqa: BLE001 — the eager figures stand
@@ -1278,7 +1284,7 @@ def main():
         enc = dict(enc, avg_us=us, GBps=nbytes / (us * 1e-6) / 1e9, bytes=nbytes * enc["launches"])
         enc_points = nbytes / 588.0
         traffic, pmc_points = scaled_traffic(pmc_key, enc_points, 64.0)
-        enc_measured_in = ("the stencil encode of the last of " + roofline_pass + ", run again as 10 back-to-back launches of a replayed HIP graph "
+        enc_measured_in = ("the stencil encode launch closest to the mean size of " + roofline_pass + ", run again as 10 back-to-back launches of a replayed HIP graph "
                          "(5 replays, HIP events around them): the kernel on the GPU's clock, as the captured iteration runs it; eager_* = HIP "
                          "events around the eager launches of that pass")
     sec = enc["avg_us"] * 1e-6
